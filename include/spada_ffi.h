@@ -1,0 +1,192 @@
+/*
+ * spada_ffi.h -- C ABI of libspada_spgemm.so, the MI355X (gfx950) SpGEMM engine that replaces
+ * spada-sim's simulated multiply/merge dataflow.
+ *
+ * The reference (tsinghua-ideal/spada-sim) is a binary crate with no FFI of its own.  The seam this
+ * ABI replaces is the one src/main.rs drives (all citations into /root/reference/src):
+ *
+ *   CsrMatStorage::init_with_gemm(GEMM) -> (A, B)        storage.rs:214-239   inputs: three Vecs per matrix
+ *   Simulator::new(cfg.., &mut A, &mut B, &mut psum, ..) simulator.rs:431-507 borrows A/B for its lifetime
+ *   Simulator::execute(&mut self)                        simulator.rs:509-890 blocking, single thread
+ *   Simulator::get_exec_result() -> Vec<CsrRow>          simulator.rs:1034-1062
+ *   get_exec_cycle / get_{a,b,c}_mat_stat / get_cache_stat   simulator.rs:1008-1032
+ *   GEMM::from_mat (square ? A*A : A*A^T)                gemm.rs:41-53
+ *   load_mm_mat (scipy mmread(...).tocsr())              py2rust.rs:62-97
+ *   parse_config (13 required JSON keys)                 frontend.rs:8-23, :77-85
+ *
+ * Conventions
+ *   - plain C, no C++ or torch types; `usize` == uint64_t; values are f64.
+ *   - every function returns SPADA_OK (0) or a positive error code; the message is available from
+ *     spada_last_error() (thread local).  Nothing throws or aborts across the boundary.
+ *   - inputs are BORROWED (the caller keeps its Vec<f64>/Vec<usize> alive between the symbolic and the
+ *     numeric call, as Simulator<'a> borrows A and B); outputs are CALLER-ALLOCATED between the two
+ *     phases, so no memory crosses allocators.
+ *   - a context is bound to one GPU and is not thread safe; calls block until the result is complete.
+ *   - there is NO CPU fallback: without a usable gfx950 device spada_create() fails with
+ *     SPADA_ERR_NO_DEVICE and every compute entry point fails with SPADA_ERR_STATE.
+ *   - column indices are narrowed to 32 bit on the device (cols < 2^32 is checked); the host ABI
+ *     stays 64 bit to match `usize`.
+ */
+#ifndef SPADA_FFI_H
+#define SPADA_FFI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPADA_ABI_VERSION 1
+
+enum spada_status {
+    SPADA_OK = 0,
+    SPADA_ERR_INVALID = 1,      /* bad argument / malformed CSR */
+    SPADA_ERR_NO_DEVICE = 2,    /* no HIP device, or not gfx950 */
+    SPADA_ERR_HIP = 3,          /* a HIP runtime call failed */
+    SPADA_ERR_OOM = 4,
+    SPADA_ERR_IO = 5,           /* file could not be opened / read */
+    SPADA_ERR_PARSE = 6,        /* MatrixMarket / JSON syntax, missing config key */
+    SPADA_ERR_STATE = 7,        /* call sequence violated (numeric before symbolic, ...) */
+    SPADA_ERR_UNSUPPORTED = 8   /* e.g. cols >= 2^32, array-format .mtx, NN workload */
+};
+
+/* CsrMatStorage.{indptr, indices, data} (storage.rs:150-160) viewed without copying. */
+typedef struct spada_csr_view {
+    uint64_t rows, cols, nnz;
+    const uint64_t *indptr;   /* rows + 1 */
+    const uint64_t *indices;  /* nnz, ascending and unique inside a row */
+    const double *data;       /* nnz */
+} spada_csr_view;
+
+/* Per-row accumulator used by the numeric phase (BASELINE.json configs[2] compares the two). */
+enum spada_accumulator {
+    SPADA_ACC_LDS_HASH = 0,   /* LDS hash accumulator + rank sort (default) */
+    SPADA_ACC_SORT_MERGE = 1  /* expand to LDS, bitonic sort by column, segmented sum */
+};
+
+typedef struct spada_options {
+    uint32_t struct_size;     /* = sizeof(spada_options) */
+    int32_t device;           /* HIP device ordinal; -1 = current device */
+    int32_t accumulator;      /* enum spada_accumulator */
+    int32_t flags;            /* reserved, 0 */
+} spada_options;
+
+#define SPADA_N_BINS 12
+
+/* Replaces get_exec_cycle / get_*_mat_stat (simulator.rs:1008-1032) with measured quantities. */
+typedef struct spada_stats {
+    uint64_t rows;            /* C rows computed by the last call (row range length) */
+    uint64_t a_nnz;           /* A nonzeros inside the row range */
+    uint64_t b_nnz;
+    uint64_t nprod;           /* sum over those A nonzeros of nnz(B row) */
+    uint64_t c_nnz;
+    uint64_t bytes_read;      /* algorithmic: (m+1)*8 + a_nnz*12 + a_nnz*16 + nprod*12    */
+    uint64_t bytes_write;     /* algorithmic: (m+1)*8 + c_nnz*12 */
+    double ms_symbolic_call;  /* hipEvent time of the whole symbolic call on the engine stream */
+    double ms_numeric_call;   /* hipEvent time of the whole numeric call */
+    double ms_row_stats;      /* phases (hipEvents on the engine stream) */
+    double ms_binning;
+    double ms_symbolic;
+    double ms_scan;
+    double ms_numeric;
+    uint64_t sym_bin_rows[SPADA_N_BINS];   /* rows per symbolic bin */
+    uint64_t num_bin_rows[SPADA_N_BINS];   /* rows per numeric bin */
+    uint64_t spill_rows;      /* rows that took the global-memory (spill) path */
+    uint64_t workspace_bytes; /* device scratch owned by the context */
+} spada_stats;
+
+typedef struct spada_ctx spada_ctx;          /* engine context: one GPU, one stream, scratch */
+typedef struct spada_dev_csr spada_dev_csr;  /* CSR resident in HBM (u64 indptr, u32 indices, f64 data) */
+typedef struct spada_host_csr spada_host_csr;/* CSR owned by the library on the host */
+
+/* ---- diagnostics ------------------------------------------------------------------------- */
+const char *spada_last_error(void);
+int spada_abi_version(void);
+/* number of usable gfx950 devices; 0 when none (never fails) */
+int spada_device_count(void);
+
+/* ---- engine life cycle (replaces Simulator::new / drop, simulator.rs:431-507) ---------------- */
+int spada_create(const spada_options *opts, spada_ctx **out);
+void spada_destroy(spada_ctx *ctx);
+
+/* ---- host-pointer two-phase SpGEMM: the drop-in seam ---------------------------------------
+ * symbolic: uploads A and B (B may alias A), computes nnz(C) -> *nnz_c.      [execute(), 1st half]
+ * numeric : fills c_indptr (A.rows + 1), c_indices (nnz_c), c_data (nnz_c)   [execute() + get_exec_result()]
+ * C rows are ascending, columns ascending and unique, explicit zeros kept (simulator.rs:1034-1062). */
+int spada_spgemm_symbolic(spada_ctx *ctx, const spada_csr_view *a, const spada_csr_view *b, uint64_t *nnz_c);
+int spada_spgemm_numeric(spada_ctx *ctx, uint64_t *c_indptr, uint64_t *c_indices, double *c_data);
+
+/* ---- device-resident SpGEMM (inputs already in HBM; what bench.py times) ---------------------
+ * Row range [row_begin, row_end) of A selects the A-row block of this GPU (scheduler.rs:296-379
+ * issues disjoint row blocks; B is replicated).  Outputs are device pointers supplied by the caller:
+ * d_c_indptr  : uint64_t[row_end - row_begin + 1], offsets local to the block (starts at 0)
+ * d_c_indices : uint32_t[nnz_c]     d_c_data : double[nnz_c]                                   */
+int spada_dev_csr_upload(spada_ctx *ctx, const spada_csr_view *m, spada_dev_csr **out);
+void spada_dev_csr_free(spada_ctx *ctx, spada_dev_csr *m);
+int spada_dev_spgemm_symbolic(spada_ctx *ctx, const spada_dev_csr *a, const spada_dev_csr *b,
+                              uint64_t row_begin, uint64_t row_end, uint64_t *nnz_c);
+int spada_dev_spgemm_numeric(spada_ctx *ctx, void *d_c_indptr, void *d_c_indices, void *d_c_data);
+/* Convenience for callers without their own device allocator: device buffers owned by the context,
+ * valid until the next symbolic call.  d_* receive device pointers. */
+int spada_dev_spgemm_numeric_owned(spada_ctx *ctx, void **d_c_indptr, void **d_c_indices, void **d_c_data);
+/* copy a finished block back: widens indices to u64 (usize) on the device, then D2H */
+int spada_dev_download_c(spada_ctx *ctx, const void *d_c_indptr, const void *d_c_indices, const void *d_c_data,
+                         uint64_t rows, uint64_t nnz_c, uint64_t *c_indptr, uint64_t *c_indices, double *c_data);
+
+int spada_get_stats(const spada_ctx *ctx, spada_stats *out);
+
+/* ---- host-side ingest (CPU only, usable without a GPU) -------------------------------------- */
+/* load_mm_mat (py2rust.rs:62-97): <dir>/<name>.mtx -> canonical CSR as scipy mmread(...).tocsr() */
+int spada_mtx_read(const char *path, spada_host_csr **out);
+/* C writer (the reference never persists C): coordinate real general, 1-based */
+int spada_mtx_write(const char *path, const spada_csr_view *m);
+int spada_host_csr_from_view(const spada_csr_view *m, spada_host_csr **out);   /* deep copy */
+int spada_host_csr_view(const spada_host_csr *m, spada_csr_view *out);
+void spada_host_csr_free(spada_host_csr *m);
+/* sorted CSR of A^T (gemm.rs:46) */
+int spada_transpose(const spada_csr_view *a, spada_host_csr **out);
+/* GEMM::from_mat (gemm.rs:41-53): square -> *b_out = NULL and *b_is_a = 1; else *b_out = A^T */
+int spada_from_mat(const spada_csr_view *a, spada_host_csr **b_out, int *b_is_a);
+/* structural validation used by every entry point: monotone indptr, indices < cols, ascending unique */
+int spada_csr_validate(const spada_csr_view *m);
+
+/* A-row block boundaries balanced on the prefix sum of per-row products.
+ * bounds has nparts + 1 entries, bounds[0] = 0, bounds[nparts] = A.rows. */
+int spada_partition_rows(const spada_csr_view *a, const spada_csr_view *b, uint32_t nparts, uint64_t *bounds);
+/* sum over A nonzeros of nnz(B row) for rows [row_begin, row_end) */
+int spada_count_products(const spada_csr_view *a, const spada_csr_view *b, uint64_t row_begin, uint64_t row_end,
+                         uint64_t *nprod);
+
+/* ---- synthetic workloads (deterministic, SplitMix64 counter based) ---------------- */
+enum spada_gen_kind {
+    SPADA_GEN_RMAT = 0,          /* p0 = scale, p1 = edge factor; (a,b,c,d) = (.57,.19,.19,.05) */
+    SPADA_GEN_WEBBASE_LIKE = 1,  /* p0 = rows (0 -> 1000005), p1 = nnz target (0 -> 3105536) */
+    SPADA_GEN_COP20K_LIKE = 2,   /* p0 = rows (0 -> 121192) */
+    SPADA_GEN_CAGE12_LIKE = 3,   /* p0 = rows (0 -> 130228) */
+    SPADA_GEN_MC2DEPI_LIKE = 4,  /* p0 = rows (0 -> 525825) */
+    SPADA_GEN_UNIFORM = 5        /* p0 = rows, p1 = nnz per row (Erdos-Renyi rows) */
+};
+int spada_generate(int kind, uint64_t p0, uint64_t p1, uint64_t seed, spada_host_csr **out);
+
+/* ---- configuration (frontend.rs:8-23, :77-85) ------------------------------------------------ */
+typedef struct spada_config {
+    char ss_filepath[1024];
+    char nn_filepath[1024];
+    uint64_t pe_num, at_num, lane_num, cache_size, word_byte;
+    uint64_t block_shape[2];
+    uint64_t mem_latency, cache_latency;
+    float freq;
+    uint64_t channel;
+    float bandwidth_per_channel;
+    /* optional engine keys (absent -> defaults): "gpus", "accumulator", "repeat" */
+    uint32_t gpus;
+    int32_t accumulator;
+    uint32_t repeat;
+} spada_config;
+int spada_config_parse(const char *path, spada_config *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPADA_FFI_H */

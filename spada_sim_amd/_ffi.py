@@ -1,0 +1,115 @@
+"""ctypes binding of libspada_spgemm.so (include/spada_ffi.h).
+
+The library is the product; this module only declares its entry points.  It fails loudly when
+the shared object is missing -- there is no Python or CPU stand-in for the HIP path.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libspada_spgemm.so")
+
+SPADA_N_BINS = 12
+
+u64 = ctypes.c_uint64
+u64p = ctypes.POINTER(ctypes.c_uint64)
+f64p = ctypes.POINTER(ctypes.c_double)
+vp = ctypes.c_void_p
+
+STATUS_NAMES = {0: "OK", 1: "INVALID", 2: "NO_DEVICE", 3: "HIP", 4: "OOM", 5: "IO", 6: "PARSE", 7: "STATE",
+                8: "UNSUPPORTED"}
+
+
+class SpadaError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"SPADA_ERR_{STATUS_NAMES.get(code, code)}: {msg}")
+        self.code = code
+
+
+class CsrView(ctypes.Structure):
+    _fields_ = [("rows", u64), ("cols", u64), ("nnz", u64), ("indptr", u64p), ("indices", u64p), ("data", f64p)]
+
+
+class Options(ctypes.Structure):
+    _fields_ = [("struct_size", ctypes.c_uint32), ("device", ctypes.c_int32), ("accumulator", ctypes.c_int32),
+                ("flags", ctypes.c_int32)]
+
+
+class Stats(ctypes.Structure):
+    _fields_ = [("rows", u64), ("a_nnz", u64), ("b_nnz", u64), ("nprod", u64), ("c_nnz", u64),
+                ("bytes_read", u64), ("bytes_write", u64),
+                ("ms_symbolic_call", ctypes.c_double), ("ms_numeric_call", ctypes.c_double),
+                ("ms_row_stats", ctypes.c_double), ("ms_binning", ctypes.c_double),
+                ("ms_symbolic", ctypes.c_double), ("ms_scan", ctypes.c_double), ("ms_numeric", ctypes.c_double),
+                ("sym_bin_rows", u64 * SPADA_N_BINS), ("num_bin_rows", u64 * SPADA_N_BINS),
+                ("spill_rows", u64), ("workspace_bytes", u64)]
+
+    def as_dict(self):
+        d = {}
+        for name, _ in self._fields_:
+            v = getattr(self, name)
+            d[name] = list(v) if hasattr(v, "__len__") else v
+        return d
+
+
+class Config(ctypes.Structure):
+    _fields_ = [("ss_filepath", ctypes.c_char * 1024), ("nn_filepath", ctypes.c_char * 1024),
+                ("pe_num", u64), ("at_num", u64), ("lane_num", u64), ("cache_size", u64), ("word_byte", u64),
+                ("block_shape", u64 * 2), ("mem_latency", u64), ("cache_latency", u64),
+                ("freq", ctypes.c_float), ("channel", u64), ("bandwidth_per_channel", ctypes.c_float),
+                ("gpus", ctypes.c_uint32), ("accumulator", ctypes.c_int32), ("repeat", ctypes.c_uint32)]
+
+
+# name -> (restype, argtypes); every symbol include/spada_ffi.h declares
+SIGNATURES = {
+    "spada_last_error": (ctypes.c_char_p, []),
+    "spada_abi_version": (ctypes.c_int, []),
+    "spada_device_count": (ctypes.c_int, []),
+    "spada_create": (ctypes.c_int, [ctypes.POINTER(Options), ctypes.POINTER(vp)]),
+    "spada_destroy": (None, [vp]),
+    "spada_spgemm_symbolic": (ctypes.c_int, [vp, ctypes.POINTER(CsrView), ctypes.POINTER(CsrView), u64p]),
+    "spada_spgemm_numeric": (ctypes.c_int, [vp, u64p, u64p, f64p]),
+    "spada_dev_csr_upload": (ctypes.c_int, [vp, ctypes.POINTER(CsrView), ctypes.POINTER(vp)]),
+    "spada_dev_csr_free": (None, [vp, vp]),
+    "spada_dev_spgemm_symbolic": (ctypes.c_int, [vp, vp, vp, u64, u64, u64p]),
+    "spada_dev_spgemm_numeric": (ctypes.c_int, [vp, vp, vp, vp]),
+    "spada_dev_spgemm_numeric_owned": (ctypes.c_int, [vp, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp)]),
+    "spada_dev_download_c": (ctypes.c_int, [vp, vp, vp, vp, u64, u64, u64p, u64p, f64p]),
+    "spada_get_stats": (ctypes.c_int, [vp, ctypes.POINTER(Stats)]),
+    "spada_mtx_read": (ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(vp)]),
+    "spada_mtx_write": (ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(CsrView)]),
+    "spada_host_csr_from_view": (ctypes.c_int, [ctypes.POINTER(CsrView), ctypes.POINTER(vp)]),
+    "spada_host_csr_view": (ctypes.c_int, [vp, ctypes.POINTER(CsrView)]),
+    "spada_host_csr_free": (None, [vp]),
+    "spada_transpose": (ctypes.c_int, [ctypes.POINTER(CsrView), ctypes.POINTER(vp)]),
+    "spada_from_mat": (ctypes.c_int, [ctypes.POINTER(CsrView), ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_int)]),
+    "spada_csr_validate": (ctypes.c_int, [ctypes.POINTER(CsrView)]),
+    "spada_partition_rows": (ctypes.c_int, [ctypes.POINTER(CsrView), ctypes.POINTER(CsrView), ctypes.c_uint32, u64p]),
+    "spada_count_products": (ctypes.c_int, [ctypes.POINTER(CsrView), ctypes.POINTER(CsrView), u64, u64, u64p]),
+    "spada_generate": (ctypes.c_int, [ctypes.c_int, u64, u64, u64, ctypes.POINTER(vp)]),
+    "spada_config_parse": (ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(Config)]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load the shared library (once).  Raises ImportError if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C spada_sim_amd/csrc`).  spada_sim_amd has no fallback path.")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise SpadaError(rc, lib().spada_last_error().decode("utf-8", "replace"))

@@ -1,0 +1,568 @@
+// Device half of libspada_spgemm.so: engine context, HBM-resident CSR, the two-phase SpGEMM pipeline
+// and its C ABI (include/spada_ffi.h).  The seam it replaces is Simulator::new / execute /
+// get_exec_result of the reference (simulator.rs:431-507, :509-890, :1034-1062).
+//
+// There is no CPU fallback in this file: every compute entry point needs a gfx950 device.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <vector>
+
+#include "spada_internal.hpp"
+#include "spgemm_kernels.hip.hpp"
+
+using namespace spada;
+
+#define HIP_TRY(expr)                                                                                      \
+    do {                                                                                                   \
+        hipError_t e_ = (expr);                                                                            \
+        if (e_ != hipSuccess)                                                                              \
+            return fail(e_ == hipErrorOutOfMemory ? SPADA_ERR_OOM : SPADA_ERR_HIP, "%s failed: %s (%s:%d)", \
+                        #expr, hipGetErrorString(e_), __FILE__, __LINE__);                                 \
+    } while (0)
+
+struct spada_dev_csr {
+    uint64_t rows = 0, cols = 0, nnz = 0;
+    uint64_t *ptr = nullptr;
+    uint32_t *idx = nullptr;
+    double *val = nullptr;
+    DevCsrView view() const { return DevCsrView{ptr, idx, val}; }
+};
+
+namespace {
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    // grow-only; newly allocated memory is zeroed when `zero` is set (returns whether it reallocated)
+    int ensure(size_t bytes, bool zero, hipStream_t s, size_t *accounted)
+    {
+        if (bytes <= cap) return SPADA_OK;
+        if (p) {
+            HIP_TRY(hipStreamSynchronize(s));
+            HIP_TRY(hipFree(p));
+            *accounted -= cap;
+            p = nullptr;
+            cap = 0;
+        }
+        size_t want = bytes + bytes / 4 + 256;
+        HIP_TRY(hipMalloc(&p, want));
+        cap = want;
+        *accounted += cap;
+        if (zero) HIP_TRY(hipMemsetAsync(p, 0, cap, s));
+        return SPADA_OK;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <class T>
+    T *as() const { return (T *)p; }
+};
+
+// device counter block, zeroed at the start of every symbolic call
+struct Counters {
+    uint32_t sym_counts[SPADA_N_BINS];
+    uint32_t sym_cursor[SPADA_N_BINS];
+    uint32_t num_counts[SPADA_N_BINS];
+    uint32_t num_cursor[SPADA_N_BINS];
+    unsigned long long totals[2];   // nprod, a_nnz of the row range
+};
+
+enum { EV_SYM_BEGIN, EV_STATS, EV_BINNED, EV_SYM, EV_SCAN, EV_NUM_BEGIN, EV_NUM_END, EV_COUNT };
+
+int pow2_ceil_log2(double x)
+{
+    int l = 0;
+    while ((double)(1 << l) < x && l < 6) ++l;
+    return l;
+}
+
+}  // namespace
+
+struct spada_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int accumulator = SPADA_ACC_LDS_HASH;
+    hipEvent_t ev[EV_COUNT] = {};
+    // state carried from symbolic to numeric
+    bool have_symbolic = false;
+    const spada_dev_csr *A = nullptr, *B = nullptr;
+    uint64_t r0 = 0;
+    uint32_t nrows = 0;
+    uint64_t nnz_c = 0;
+    uint32_t h_sym_counts[SPADA_N_BINS] = {}, h_num_counts[SPADA_N_BINS] = {};
+    // workspace
+    size_t ws_bytes = 0;
+    DevBuf row_nprod, row_nnzc, row_bin, sym_rows, num_rows, counters, cptr, tile_sums, bitmaps, slabs;
+    DevBuf own_idx, own_val, own_ptr, wide_idx;
+    uint64_t spill_slabs = 0, spill_cols = 0;
+    Counters *h_counters = nullptr;   // pinned
+    uint64_t *h_u64 = nullptr;        // pinned
+    // matrices uploaded by the host-pointer API
+    spada_dev_csr *hA = nullptr, *hB = nullptr;
+    spada_stats stats = {};
+};
+
+namespace {
+
+template <class K>
+int allow_lds(K kernel, size_t bytes)
+{
+    HIP_TRY(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return SPADA_OK;
+}
+
+constexpr size_t sym_lds(int G, int LOG_T) { return 128 + (size_t)((G < 256 ? 256 : G) / G) * 4 * (1u << LOG_T); }
+constexpr size_t num_lds(int G, int LOG_T) { return 128 + (size_t)((G < 256 ? 256 : G) / G) * 16 * (1u << LOG_T); }
+
+template <int G, int LOG_T>
+int launch_sym(spada_ctx *c, uint32_t off, uint32_t n, int log2S)
+{
+    if (!n) return SPADA_OK;
+    constexpr int BLOCK = G < 256 ? 256 : G;
+    constexpr int RPB = BLOCK / G;
+    const uint32_t grid = (n + RPB - 1) / RPB;
+    if (log2S > 6) log2S = 6;
+    while ((1 << log2S) > G) --log2S;
+    hipLaunchKernelGGL((k_sym_hash<G, LOG_T>), dim3(grid), dim3(BLOCK), sym_lds(G, LOG_T), c->stream, c->A->view(),
+                       c->B->view(), c->r0, c->sym_rows.as<uint32_t>() + off, n, log2S, c->row_nnzc.as<uint32_t>());
+    HIP_TRY(hipGetLastError());
+    return SPADA_OK;
+}
+
+template <int G, int LOG_T>
+int launch_num(spada_ctx *c, uint32_t off, uint32_t n, int log2S, uint32_t *c_idx, double *c_val)
+{
+    if (!n) return SPADA_OK;
+    constexpr int BLOCK = G < 256 ? 256 : G;
+    constexpr int RPB = BLOCK / G;
+    const uint32_t grid = (n + RPB - 1) / RPB;
+    if (log2S > 6) log2S = 6;
+    while ((1 << log2S) > G) --log2S;
+    hipLaunchKernelGGL((k_num_hash<G, LOG_T>), dim3(grid), dim3(BLOCK), num_lds(G, LOG_T), c->stream, c->A->view(),
+                       c->B->view(), c->r0, c->num_rows.as<uint32_t>() + off, n, log2S, c->cptr.as<uint64_t>(), c_idx,
+                       c_val);
+    HIP_TRY(hipGetLastError());
+    return SPADA_OK;
+}
+
+int ensure_spill(spada_ctx *c, uint32_t rows_in_bin, bool need_slabs)
+{
+    const uint64_t cols = c->B->cols;
+    const uint64_t nslab = std::min<uint64_t>(rows_in_bin, 256);
+    const uint64_t words = ((cols + 31) / 32 + 3) & ~3ull;
+    if (c->spill_cols != cols || c->spill_slabs < nslab) {
+        // geometry changed: drop and re-zero
+        c->ws_bytes -= c->bitmaps.cap + c->slabs.cap;
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        c->bitmaps.release();
+        c->slabs.release();
+        c->spill_cols = cols;
+        c->spill_slabs = nslab;
+    }
+    int rc = c->bitmaps.ensure(c->spill_slabs * words * 4, true, c->stream, &c->ws_bytes);
+    if (rc) return rc;
+    if (need_slabs) rc = c->slabs.ensure(c->spill_slabs * cols * 8, true, c->stream, &c->ws_bytes);
+    return rc;
+}
+
+float ev_ms(spada_ctx *c, int a, int b)
+{
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, c->ev[a], c->ev[b]) != hipSuccess) return 0.f;
+    return ms;
+}
+
+int dev_upload(spada_ctx *c, const spada_csr_view *m, spada_dev_csr **out)
+{
+    if (m->cols >= 0xFFFFFFFFull)
+        return fail(SPADA_ERR_UNSUPPORTED, "cols = %llu does not fit the 32-bit device column index",
+                    (unsigned long long)m->cols);
+    if (m->rows >= 0xFFFFFFFFull) return fail(SPADA_ERR_UNSUPPORTED, "rows = %llu >= 2^32", (unsigned long long)m->rows);
+    auto d = std::make_unique<spada_dev_csr>();
+    d->rows = m->rows;
+    d->cols = m->cols;
+    d->nnz = m->nnz;
+    std::vector<uint32_t> idx32(m->nnz);
+    for (uint64_t q = 0; q < m->nnz; ++q) idx32[q] = (uint32_t)m->indices[q];
+    HIP_TRY(hipMalloc((void **)&d->ptr, (m->rows + 1) * 8));
+    if (hipMalloc((void **)&d->idx, std::max<uint64_t>(m->nnz, 1) * 4) != hipSuccess ||
+        hipMalloc((void **)&d->val, std::max<uint64_t>(m->nnz, 1) * 8) != hipSuccess) {
+        (void)hipFree(d->ptr);
+        if (d->idx) (void)hipFree(d->idx);
+        return fail(SPADA_ERR_OOM, "hipMalloc failed for a %llu-nnz matrix", (unsigned long long)m->nnz);
+    }
+    HIP_TRY(hipMemcpyAsync(d->ptr, m->indptr, (m->rows + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    if (m->nnz) {
+        HIP_TRY(hipMemcpyAsync(d->idx, idx32.data(), m->nnz * 4, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(d->val, m->data, m->nnz * 8, hipMemcpyHostToDevice, c->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    *out = d.release();
+    return SPADA_OK;
+}
+
+void dev_free(spada_dev_csr *m)
+{
+    if (!m) return;
+    if (m->ptr) (void)hipFree(m->ptr);
+    if (m->idx) (void)hipFree(m->idx);
+    if (m->val) (void)hipFree(m->val);
+    delete m;
+}
+
+int run_numeric(spada_ctx *c, uint64_t *d_ptr, uint32_t *d_idx, double *d_val)
+{
+    HIP_TRY(hipEventRecord(c->ev[EV_NUM_BEGIN], c->stream));
+    HIP_TRY(hipMemcpyAsync(d_ptr, c->cptr.p, ((size_t)c->nrows + 1) * 8, hipMemcpyDeviceToDevice, c->stream));
+    const uint32_t *cnt = c->h_num_counts;
+    uint32_t off[SPADA_N_BINS + 1];
+    off[0] = 0;
+    for (int b = 0; b < SPADA_N_BINS; ++b) off[b + 1] = off[b] + cnt[b];
+    const double avg_b = c->B->rows ? (double)c->B->nnz / (double)c->B->rows : 1.0;
+    const int log2S = pow2_ceil_log2(avg_b);
+    int rc;
+    if (cnt[1]) {
+        const uint32_t grid = (cnt[1] + 15) / 16;
+        hipLaunchKernelGGL((k_num_copy<16>), dim3(grid), dim3(256), 0, c->stream, c->A->view(), c->B->view(), c->r0,
+                           c->num_rows.as<uint32_t>() + off[1], cnt[1], c->cptr.as<uint64_t>(), d_idx, d_val);
+        HIP_TRY(hipGetLastError());
+    }
+    if ((rc = launch_num<8, 6>(c, off[2], cnt[2], log2S, d_idx, d_val))) return rc;
+    if ((rc = launch_num<32, 8>(c, off[3], cnt[3], log2S, d_idx, d_val))) return rc;
+    if ((rc = launch_num<64, 10>(c, off[4], cnt[4], log2S, d_idx, d_val))) return rc;
+    if ((rc = launch_num<256, 12>(c, off[5], cnt[5], log2S, d_idx, d_val))) return rc;
+    if ((rc = launch_num<1024, 13>(c, off[6], cnt[6], log2S, d_idx, d_val))) return rc;
+    if (cnt[7]) {
+        if ((rc = ensure_spill(c, cnt[7], true))) return rc;
+        const uint64_t words = ((c->B->cols + 31) / 32 + 3) & ~3ull;
+        const uint32_t grid = (uint32_t)std::min<uint64_t>(cnt[7], c->spill_slabs);
+        hipLaunchKernelGGL(k_num_spill, dim3(grid), dim3(SPILL_BLOCK), 0, c->stream, c->A->view(), c->B->view(), c->r0,
+                           c->num_rows.as<uint32_t>() + off[7], cnt[7], c->bitmaps.as<uint32_t>(), words,
+                           c->slabs.as<double>(), c->B->cols, c->cptr.as<uint64_t>(), d_idx, d_val);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipEventRecord(c->ev[EV_NUM_END], c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->stats.ms_numeric = c->stats.ms_numeric_call = ev_ms(c, EV_NUM_BEGIN, EV_NUM_END);
+    c->stats.workspace_bytes = c->ws_bytes;
+    return SPADA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int spada_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    int ok = 0;
+    for (int d = 0; d < n; ++d) {
+        hipDeviceProp_t p;
+        if (hipGetDeviceProperties(&p, d) == hipSuccess && std::strncmp(p.gcnArchName, "gfx950", 6) == 0) ++ok;
+    }
+    return ok;
+}
+
+int spada_create(const spada_options *opts, spada_ctx **out)
+{
+    if (!out) return fail(SPADA_ERR_INVALID, "spada_create: null out");
+    *out = nullptr;
+    spada_options o{sizeof(spada_options), -1, SPADA_ACC_LDS_HASH, 0};
+    if (opts) {
+        if (opts->struct_size != sizeof(spada_options))
+            return fail(SPADA_ERR_INVALID, "spada_options.struct_size = %u, expected %zu", opts->struct_size,
+                        sizeof(spada_options));
+        o = *opts;
+    }
+    if (o.accumulator != SPADA_ACC_LDS_HASH && o.accumulator != SPADA_ACC_SORT_MERGE)
+        return fail(SPADA_ERR_INVALID, "unknown accumulator %d", o.accumulator);
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n == 0)
+        return fail(SPADA_ERR_NO_DEVICE, "no HIP device visible: this engine has no CPU path");
+    int dev = o.device;
+    if (dev < 0 && hipGetDevice(&dev) != hipSuccess) dev = 0;
+    if (dev >= n) return fail(SPADA_ERR_NO_DEVICE, "device %d requested but only %d visible", dev, n);
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, dev));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(SPADA_ERR_NO_DEVICE, "device %d is %s; the kernels are built for gfx950 (MI355X) only", dev,
+                    prop.gcnArchName);
+    HIP_TRY(hipSetDevice(dev));
+    auto c = std::make_unique<spada_ctx>();
+    c->device = dev;
+    c->accumulator = o.accumulator;
+    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    for (auto &e : c->ev) HIP_TRY(hipEventCreate(&e));
+    HIP_TRY(hipHostMalloc((void **)&c->h_counters, sizeof(Counters), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void **)&c->h_u64, 64, hipHostMallocDefault));
+    int rc;
+    if ((rc = allow_lds(k_sym_hash<8, 6>, sym_lds(8, 6)))) return rc;
+    if ((rc = allow_lds(k_sym_hash<16, 8>, sym_lds(16, 8)))) return rc;
+    if ((rc = allow_lds(k_sym_hash<64, 10>, sym_lds(64, 10)))) return rc;
+    if ((rc = allow_lds(k_sym_hash<256, 12>, sym_lds(256, 12)))) return rc;
+    if ((rc = allow_lds(k_sym_hash<512, 14>, sym_lds(512, 14)))) return rc;
+    if ((rc = allow_lds(k_sym_hash<1024, 15>, sym_lds(1024, 15)))) return rc;
+    if ((rc = allow_lds(k_num_hash<8, 6>, num_lds(8, 6)))) return rc;
+    if ((rc = allow_lds(k_num_hash<32, 8>, num_lds(32, 8)))) return rc;
+    if ((rc = allow_lds(k_num_hash<64, 10>, num_lds(64, 10)))) return rc;
+    if ((rc = allow_lds(k_num_hash<256, 12>, num_lds(256, 12)))) return rc;
+    if ((rc = allow_lds(k_num_hash<1024, 13>, num_lds(1024, 13)))) return rc;
+    *out = c.release();
+    return SPADA_OK;
+}
+
+void spada_destroy(spada_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    dev_free(c->hA);
+    if (c->hB != c->hA) dev_free(c->hB);
+    for (DevBuf *b : {&c->row_nprod, &c->row_nnzc, &c->row_bin, &c->sym_rows, &c->num_rows, &c->counters, &c->cptr,
+                      &c->tile_sums, &c->bitmaps, &c->slabs, &c->own_idx, &c->own_val, &c->own_ptr, &c->wide_idx})
+        b->release();
+    if (c->h_counters) (void)hipHostFree(c->h_counters);
+    if (c->h_u64) (void)hipHostFree(c->h_u64);
+    for (auto &e : c->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int spada_dev_csr_upload(spada_ctx *c, const spada_csr_view *m, spada_dev_csr **out)
+{
+    if (!c) return fail(SPADA_ERR_STATE, "spada_dev_csr_upload: no engine context (no GPU?)");
+    if (!out) return fail(SPADA_ERR_INVALID, "spada_dev_csr_upload: null out");
+    *out = nullptr;
+    int rc = spada_csr_validate(m);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    return dev_upload(c, m, out);
+}
+
+void spada_dev_csr_free(spada_ctx *c, spada_dev_csr *m)
+{
+    if (c) {
+        (void)hipSetDevice(c->device);
+        (void)hipStreamSynchronize(c->stream);
+        if (c->A == m || c->B == m) c->have_symbolic = false;
+    }
+    dev_free(m);
+}
+
+int spada_dev_spgemm_symbolic(spada_ctx *c, const spada_dev_csr *a, const spada_dev_csr *b, uint64_t row_begin,
+                              uint64_t row_end, uint64_t *nnz_c)
+{
+    if (!c) return fail(SPADA_ERR_STATE, "spada_dev_spgemm_symbolic: no engine context (no GPU?)");
+    if (!a || !b || !nnz_c) return fail(SPADA_ERR_INVALID, "spada_dev_spgemm_symbolic: null argument");
+    if (a->cols != b->rows)
+        return fail(SPADA_ERR_INVALID, "inner dimensions differ: A is %llux%llu, B is %llux%llu", (unsigned long long)a->rows,
+                    (unsigned long long)a->cols, (unsigned long long)b->rows, (unsigned long long)b->cols);
+    if (row_begin > row_end || row_end > a->rows) return fail(SPADA_ERR_INVALID, "bad row range");
+    HIP_TRY(hipSetDevice(c->device));
+    c->have_symbolic = false;
+    c->A = a;
+    c->B = b;
+    c->r0 = row_begin;
+    c->nrows = (uint32_t)(row_end - row_begin);
+    c->nnz_c = 0;
+    std::memset(&c->stats, 0, sizeof c->stats);
+    const uint32_t n = c->nrows;
+    hipStream_t s = c->stream;
+    int rc;
+    const size_t n1 = (size_t)n + 1;
+    if ((rc = c->row_nprod.ensure(n1 * 4, false, s, &c->ws_bytes))) return rc;
+    if ((rc = c->row_nnzc.ensure(n1 * 4, false, s, &c->ws_bytes))) return rc;
+    if ((rc = c->row_bin.ensure(n1, false, s, &c->ws_bytes))) return rc;
+    if ((rc = c->sym_rows.ensure(n1 * 4, false, s, &c->ws_bytes))) return rc;
+    if ((rc = c->num_rows.ensure(n1 * 4, false, s, &c->ws_bytes))) return rc;
+    if ((rc = c->cptr.ensure(n1 * 8, false, s, &c->ws_bytes))) return rc;
+    if ((rc = c->counters.ensure(sizeof(Counters), false, s, &c->ws_bytes))) return rc;
+    const uint32_t ntiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+    if ((rc = c->tile_sums.ensure(((size_t)ntiles + 2) * 8, false, s, &c->ws_bytes))) return rc;
+    Counters *dc = c->counters.as<Counters>();
+
+    HIP_TRY(hipEventRecord(c->ev[EV_SYM_BEGIN], s));
+    HIP_TRY(hipMemsetAsync(dc, 0, sizeof(Counters), s));
+    const uint32_t g256 = (n + 255) / 256;
+    if (n) {
+        hipLaunchKernelGGL(k_row_stats, dim3(g256), dim3(256), 0, s, a->ptr, a->idx, b->ptr, c->r0, n,
+                           c->row_nprod.as<uint32_t>(), c->row_nnzc.as<uint32_t>(), c->row_bin.as<uint8_t>(),
+                           dc->sym_counts, dc->totals);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipEventRecord(c->ev[EV_STATS], s));
+    HIP_TRY(hipMemcpyAsync(c->h_counters, dc, sizeof(Counters), hipMemcpyDeviceToHost, s));
+    if (n) {
+        hipLaunchKernelGGL(k_bin_scatter, dim3(g256), dim3(256), 0, s, c->row_bin.as<uint8_t>(), n, dc->sym_counts,
+                           dc->sym_cursor, c->sym_rows.as<uint32_t>());
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipEventRecord(c->ev[EV_BINNED], s));
+    HIP_TRY(hipStreamSynchronize(s));
+    std::memcpy(c->h_sym_counts, c->h_counters->sym_counts, sizeof c->h_sym_counts);
+    const uint64_t nprod = c->h_counters->totals[0], a_nnz = c->h_counters->totals[1];
+
+    {
+        const uint32_t *cnt = c->h_sym_counts;
+        uint32_t off[SPADA_N_BINS + 1];
+        off[0] = 0;
+        for (int k = 0; k < SPADA_N_BINS; ++k) off[k + 1] = off[k] + cnt[k];
+        const double avg_b = b->rows ? (double)b->nnz / (double)b->rows : 1.0;
+        const int log2S = pow2_ceil_log2(avg_b);
+        if ((rc = launch_sym<8, 6>(c, off[2], cnt[2], log2S))) return rc;
+        if ((rc = launch_sym<16, 8>(c, off[3], cnt[3], log2S))) return rc;
+        if ((rc = launch_sym<64, 10>(c, off[4], cnt[4], log2S))) return rc;
+        if ((rc = launch_sym<256, 12>(c, off[5], cnt[5], log2S))) return rc;
+        if ((rc = launch_sym<512, 14>(c, off[6], cnt[6], log2S))) return rc;
+        if ((rc = launch_sym<1024, 15>(c, off[7], cnt[7], log2S))) return rc;
+        if (cnt[8]) {
+            if ((rc = ensure_spill(c, cnt[8], false))) return rc;
+            const uint64_t words = ((b->cols + 31) / 32 + 3) & ~3ull;
+            const uint32_t grid = (uint32_t)std::min<uint64_t>(cnt[8], c->spill_slabs);
+            hipLaunchKernelGGL(k_sym_spill, dim3(grid), dim3(SPILL_BLOCK), 0, s, a->view(), b->view(), c->r0,
+                               c->sym_rows.as<uint32_t>() + off[8], cnt[8], c->bitmaps.as<uint32_t>(), words,
+                               c->row_nnzc.as<uint32_t>());
+            HIP_TRY(hipGetLastError());
+        }
+    }
+    HIP_TRY(hipEventRecord(c->ev[EV_SYM], s));
+
+    // exclusive scan nnzc -> cptr, then classify + bin for the numeric phase
+    hipLaunchKernelGGL(k_scan_tile_sums, dim3(std::max(ntiles, 1u)), dim3(SCAN_BLOCK), 0, s, c->row_nnzc.as<uint32_t>(), n,
+                       c->tile_sums.as<uint64_t>());
+    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(SCAN_BLOCK), 0, s, c->tile_sums.as<uint64_t>(), std::max(ntiles, 1u));
+    hipLaunchKernelGGL(k_scan_apply, dim3(std::max(ntiles, 1u)), dim3(SCAN_BLOCK), 0, s, c->row_nnzc.as<uint32_t>(), n,
+                       c->tile_sums.as<uint64_t>(), std::max(ntiles, 1u), c->cptr.as<uint64_t>());
+    HIP_TRY(hipGetLastError());
+    if (n) {
+        hipLaunchKernelGGL(k_num_classify, dim3(g256), dim3(256), 0, s, a->ptr, c->r0, n, c->row_nprod.as<uint32_t>(),
+                           c->row_nnzc.as<uint32_t>(), c->row_bin.as<uint8_t>(), dc->num_counts);
+        hipLaunchKernelGGL(k_bin_scatter, dim3(g256), dim3(256), 0, s, c->row_bin.as<uint8_t>(), n, dc->num_counts,
+                           dc->num_cursor, c->num_rows.as<uint32_t>());
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipMemcpyAsync(c->h_counters, dc, sizeof(Counters), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(c->h_u64, c->cptr.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipEventRecord(c->ev[EV_SCAN], s));
+    HIP_TRY(hipStreamSynchronize(s));
+    std::memcpy(c->h_num_counts, c->h_counters->num_counts, sizeof c->h_num_counts);
+    c->nnz_c = c->h_u64[0];
+    *nnz_c = c->nnz_c;
+    c->have_symbolic = true;
+
+    spada_stats &st = c->stats;
+    st.rows = n;
+    st.a_nnz = a_nnz;
+    st.b_nnz = b->nnz;
+    st.nprod = nprod;
+    st.c_nnz = c->nnz_c;
+    st.bytes_read = ((uint64_t)n + 1) * 8 + a_nnz * 12 + a_nnz * 16 + nprod * 12;
+    st.bytes_write = ((uint64_t)n + 1) * 8 + c->nnz_c * 12;
+    st.ms_row_stats = ev_ms(c, EV_SYM_BEGIN, EV_STATS);
+    st.ms_binning = ev_ms(c, EV_STATS, EV_BINNED);
+    st.ms_symbolic = ev_ms(c, EV_BINNED, EV_SYM);
+    st.ms_scan = ev_ms(c, EV_SYM, EV_SCAN);
+    st.ms_symbolic_call = ev_ms(c, EV_SYM_BEGIN, EV_SCAN);
+    for (int k = 0; k < SPADA_N_BINS; ++k) {
+        st.sym_bin_rows[k] = c->h_sym_counts[k];
+        st.num_bin_rows[k] = c->h_num_counts[k];
+    }
+    st.spill_rows = c->h_sym_counts[8] + c->h_num_counts[7];
+    st.workspace_bytes = c->ws_bytes;
+    return SPADA_OK;
+}
+
+int spada_dev_spgemm_numeric(spada_ctx *c, void *d_c_indptr, void *d_c_indices, void *d_c_data)
+{
+    if (!c) return fail(SPADA_ERR_STATE, "spada_dev_spgemm_numeric: no engine context (no GPU?)");
+    if (!c->have_symbolic) return fail(SPADA_ERR_STATE, "numeric phase called without a preceding symbolic phase");
+    if (!d_c_indptr || (c->nnz_c && (!d_c_indices || !d_c_data)))
+        return fail(SPADA_ERR_INVALID, "spada_dev_spgemm_numeric: null output pointer");
+    HIP_TRY(hipSetDevice(c->device));
+    return run_numeric(c, (uint64_t *)d_c_indptr, (uint32_t *)d_c_indices, (double *)d_c_data);
+}
+
+int spada_dev_spgemm_numeric_owned(spada_ctx *c, void **d_c_indptr, void **d_c_indices, void **d_c_data)
+{
+    if (!c) return fail(SPADA_ERR_STATE, "spada_dev_spgemm_numeric_owned: no engine context (no GPU?)");
+    if (!c->have_symbolic) return fail(SPADA_ERR_STATE, "numeric phase called without a preceding symbolic phase");
+    if (!d_c_indptr || !d_c_indices || !d_c_data) return fail(SPADA_ERR_INVALID, "null output pointer");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc;
+    if ((rc = c->own_ptr.ensure(((size_t)c->nrows + 1) * 8, false, c->stream, &c->ws_bytes))) return rc;
+    if ((rc = c->own_idx.ensure(std::max<uint64_t>(c->nnz_c, 1) * 4, false, c->stream, &c->ws_bytes))) return rc;
+    if ((rc = c->own_val.ensure(std::max<uint64_t>(c->nnz_c, 1) * 8, false, c->stream, &c->ws_bytes))) return rc;
+    if ((rc = run_numeric(c, c->own_ptr.as<uint64_t>(), c->own_idx.as<uint32_t>(), c->own_val.as<double>()))) return rc;
+    *d_c_indptr = c->own_ptr.p;
+    *d_c_indices = c->own_idx.p;
+    *d_c_data = c->own_val.p;
+    return SPADA_OK;
+}
+
+int spada_dev_download_c(spada_ctx *c, const void *d_c_indptr, const void *d_c_indices, const void *d_c_data, uint64_t rows,
+                         uint64_t nnz_c, uint64_t *c_indptr, uint64_t *c_indices, double *c_data)
+{
+    if (!c) return fail(SPADA_ERR_STATE, "spada_dev_download_c: no engine context (no GPU?)");
+    if (!d_c_indptr || !c_indptr || (nnz_c && (!d_c_indices || !d_c_data || !c_indices || !c_data)))
+        return fail(SPADA_ERR_INVALID, "spada_dev_download_c: null pointer");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpyAsync(c_indptr, d_c_indptr, (rows + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+    if (nnz_c) {
+        int rc = c->wide_idx.ensure(nnz_c * 8, false, c->stream, &c->ws_bytes);
+        if (rc) return rc;
+        const uint32_t grid = (uint32_t)std::min<uint64_t>((nnz_c + 255) / 256, 4096);
+        hipLaunchKernelGGL(k_widen_u32, dim3(grid), dim3(256), 0, c->stream, (const uint32_t *)d_c_indices, nnz_c,
+                           c->wide_idx.as<uint64_t>());
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(c_indices, c->wide_idx.p, nnz_c * 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(c_data, d_c_data, nnz_c * 8, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return SPADA_OK;
+}
+
+int spada_spgemm_symbolic(spada_ctx *c, const spada_csr_view *a, const spada_csr_view *b, uint64_t *nnz_c)
+{
+    if (!c) return fail(SPADA_ERR_STATE, "spada_spgemm_symbolic: no engine context (no GPU?)");
+    if (!a || !b || !nnz_c) return fail(SPADA_ERR_INVALID, "spada_spgemm_symbolic: null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    c->have_symbolic = false;
+    dev_free(c->hA);
+    if (c->hB != c->hA) dev_free(c->hB);
+    c->hA = c->hB = nullptr;
+    int rc = spada_dev_csr_upload(c, a, &c->hA);
+    if (rc) return rc;
+    const bool same = a->indptr == b->indptr && a->indices == b->indices && a->data == b->data && a->rows == b->rows &&
+                      a->cols == b->cols;
+    if (same) c->hB = c->hA;
+    else if ((rc = spada_dev_csr_upload(c, b, &c->hB))) return rc;
+    return spada_dev_spgemm_symbolic(c, c->hA, c->hB, 0, a->rows, nnz_c);
+}
+
+int spada_spgemm_numeric(spada_ctx *c, uint64_t *c_indptr, uint64_t *c_indices, double *c_data)
+{
+    if (!c) return fail(SPADA_ERR_STATE, "spada_spgemm_numeric: no engine context (no GPU?)");
+    if (!c->have_symbolic || !c->hA) return fail(SPADA_ERR_STATE, "numeric phase called without a preceding symbolic phase");
+    void *dp, *di, *dv;
+    int rc = spada_dev_spgemm_numeric_owned(c, &dp, &di, &dv);
+    if (rc) return rc;
+    return spada_dev_download_c(c, dp, di, dv, c->nrows, c->nnz_c, c_indptr, c_indices, c_data);
+}
+
+int spada_get_stats(const spada_ctx *c, spada_stats *out)
+{
+    if (!c || !out) return fail(SPADA_ERR_INVALID, "spada_get_stats: null argument");
+    *out = c->stats;
+    return SPADA_OK;
+}
+
+}  // extern "C"

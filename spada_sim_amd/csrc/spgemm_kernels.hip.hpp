@@ -1,0 +1,678 @@
+// gfx950 (MI355X, CDNA4) kernels of the row-wise expand-scale-merge SpGEMM  C = A * B  on CSR.
+//
+// They replace, as one pipeline, what spada-sim simulates cycle by cycle (citations into
+// /root/reference/src): window fetch of A scalars (scheduler.rs:482-606, storage.rs:279-323), B-fiber
+// streaming (simulator.rs:892-953), the multiplier array (simulator.rs:86-111), sorting network + merge
+// tree (simulator.rs:143-230), psum write-back / partial-fiber merging (simulator.rs:955-983,
+// scheduler.rs:381-480, adder_tree.rs:145-188) and result assembly (simulator.rs:1034-1062).
+//
+// Pipeline:  row_stats -> bin scatter -> symbolic (per bin) -> scan -> classify/bin -> numeric (per bin)
+//   * 64-wide wavefronts throughout; sub-wave groups of 8/16 lanes take small rows so that one
+//     wave keeps 8/4 rows (and their dependent load chains) in flight.
+//   * per-row accumulators live in LDS: open-addressing hash (u32 key, f64 value), ds_cmpst for the
+//     key, ds_add_f64 for the value; column compaction + ordering by a monotone bucket pass with
+//     LDS counters, a group-wide scan and an in-bucket rank, then ascending stores to C.
+//   * rows too large for LDS take the spill path: per-block bitmap / dense f64 slab in HBM with
+//     device-scope atomics, emitted in ascending column order from the bitmap.
+//   * no MFMA: this is irregular gather-accumulate, bounded by memory latency / HBM bandwidth.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "spada_ffi.h"
+
+namespace spada {
+
+constexpr uint32_t EMPTY_KEY = 0xFFFFFFFFu;
+constexpr int WAVE = 64;
+
+struct DevCsrView {
+    const uint64_t *ptr;
+    const uint32_t *idx;
+    const double *val;
+};
+
+// ---- bin definitions (host and device agree through these) -------------------------------------------
+// symbolic bins, by P = products of the row and L = nnz of the A row
+//   0: P == 0 (empty C row)          1: L == 1 (C row = scaled B row, nnz = P; no kernel)
+//   2: P <= 32    G=8    T=64        3: P <= 128   G=16   T=256      4: P <= 512   G=64  T=1024
+//   5: P <= 2048  G=256  T=4096      6: P <= 8192  G=512  T=16384    7: P <= 24576 G=1024 T=32768
+//   8: spill (bitmap in HBM)
+// numeric bins, by n = nnz(C row), P and L
+//   0: n == 0                        1: L == 1 (scaled copy kernel)
+//   2: n <= 32  & P <= 128   G=8  T=64      3: n <= 128 & P <= 1024  G=16  T=256
+//   4: n <= 512 & P <= 8192  G=64 T=1024    5: n <= 2048 & P <= 65536 G=256 T=4096
+//   6: n <= 6144             G=1024 T=8192  7: spill (dense f64 slab in HBM)
+__host__ __device__ inline int sym_bin_of(uint64_t P, uint32_t L)
+{
+    if (P == 0) return 0;
+    if (L == 1) return 1;
+    if (P <= 32) return 2;
+    if (P <= 128) return 3;
+    if (P <= 512) return 4;
+    if (P <= 2048) return 5;
+    if (P <= 8192) return 6;
+    if (P <= 24576) return 7;
+    return 8;
+}
+__host__ __device__ inline int num_bin_of(uint32_t n, uint64_t P, uint32_t L)
+{
+    if (n == 0) return 0;
+    if (L == 1) return 1;
+    int bn = n <= 32 ? 2 : n <= 128 ? 3 : n <= 512 ? 4 : n <= 2048 ? 5 : n <= 6144 ? 6 : 7;
+    int bp = P <= 128 ? 2 : P <= 1024 ? 3 : P <= 8192 ? 4 : P <= 65536 ? 5 : 6;
+    return bn > bp ? bn : bp;
+}
+
+// ---- small helpers -----------------------------------------------------------------------------------
+__device__ inline uint64_t wave_sum_u64(uint64_t v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// Synchronise the G lanes that share one row.  G >= 128 means the group is the whole workgroup.
+// For G <= 64 the group lives inside one wavefront, which executes in lock step; only the LDS
+// traffic has to be ordered.
+template <int G>
+__device__ inline void group_sync()
+{
+    if constexpr (G >= 128) {
+        __syncthreads();
+    } else {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+}
+
+// Sum over the group.  `hdr` is a per-workgroup LDS word used when the group spans several waves.
+template <int G>
+__device__ inline uint32_t group_sum(uint32_t v, uint32_t *hdr)
+{
+    if constexpr (G <= 64) {
+#pragma unroll
+        for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        return v;
+    } else {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        __syncthreads();
+        if (threadIdx.x == 0) *hdr = 0;
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) atomicAdd(hdr, v);
+        __syncthreads();
+        return *hdr;
+    }
+}
+template <int G>
+__device__ inline uint32_t group_min(uint32_t v, uint32_t *hdr)
+{
+    if constexpr (G <= 64) {
+#pragma unroll
+        for (int o = G / 2; o > 0; o >>= 1) v = min(v, (uint32_t)__shfl_xor(v, o));
+        return v;
+    } else {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v = min(v, (uint32_t)__shfl_xor(v, o));
+        __syncthreads();
+        if (threadIdx.x == 0) *hdr = 0xFFFFFFFFu;
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) atomicMin(hdr, v);
+        __syncthreads();
+        return *hdr;
+    }
+}
+template <int G>
+__device__ inline uint32_t group_max(uint32_t v, uint32_t *hdr)
+{
+    if constexpr (G <= 64) {
+#pragma unroll
+        for (int o = G / 2; o > 0; o >>= 1) v = max(v, (uint32_t)__shfl_xor(v, o));
+        return v;
+    } else {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v = max(v, (uint32_t)__shfl_xor(v, o));
+        __syncthreads();
+        if (threadIdx.x == 0) *hdr = 0;
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) atomicMax(hdr, v);
+        __syncthreads();
+        return *hdr;
+    }
+}
+
+// In-place exclusive scan of arr[0..N) by the G lanes of a group; N is a multiple of G.
+// `wtot` = LDS scratch for per-wave totals (>= G/64 words), only used when G > 64.
+template <int G, int N>
+__device__ inline void group_exclusive_scan(uint32_t *arr, int gl, uint32_t *wtot)
+{
+    constexpr int PER = N / G;
+    static_assert(N % G == 0, "scan length must be a multiple of the group size");
+    uint32_t loc[PER];
+    uint32_t tot = 0;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        loc[j] = arr[gl * PER + j];
+        tot += loc[j];
+    }
+    // inclusive scan of `tot` across the lanes of the group
+    uint32_t inc = tot;
+    constexpr int W = G < 64 ? G : 64;
+    const int wl = (G < 64) ? gl : (gl & 63);
+#pragma unroll
+    for (int o = 1; o < W; o <<= 1) {
+        uint32_t t = __shfl_up(inc, o, W);
+        if (wl >= o) inc += t;
+    }
+    uint32_t base = inc - tot;
+    if constexpr (G > 64) {
+        const int w = gl >> 6;
+        __syncthreads();
+        if (wl == 63) wtot[w] = inc;
+        __syncthreads();
+        uint32_t add = 0;
+        for (int k = 0; k < w; ++k) add += wtot[k];
+        base += add;
+    }
+    group_sync<G>();
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        arr[gl * PER + j] = base;
+        base += loc[j];
+    }
+    group_sync<G>();
+}
+
+template <int LOG_T>
+__device__ inline uint32_t hash_slot(uint32_t col)
+{
+    return (col * 0x9E3779B1u) >> (32 - LOG_T);
+}
+
+// ---- 1. row statistics + symbolic binning --------------------------------------------------------------
+// One lane per A row; rows longer than 16 nonzeros are then walked by the whole wave.
+// Coalescing: consecutive lanes read consecutive A row pointers and (for short rows) adjacent A column
+// indices; the B row-pointer pairs are the irregular gather of the path (16 B per A nonzero).
+__global__ __launch_bounds__(256) void k_row_stats(const uint64_t *__restrict__ aptr, const uint32_t *__restrict__ aidx,
+                                                   const uint64_t *__restrict__ bptr, uint64_t r0, uint32_t nrows,
+                                                   uint32_t *__restrict__ row_nprod, uint32_t *__restrict__ row_nnzc,
+                                                   uint8_t *__restrict__ row_bin, uint32_t *__restrict__ bin_counts,
+                                                   unsigned long long *__restrict__ totals /* [0]=nprod [1]=a_nnz */)
+{
+    __shared__ uint32_t s_hist[SPADA_N_BINS];
+    __shared__ unsigned long long s_tot[2];
+    if (threadIdx.x < SPADA_N_BINS) s_hist[threadIdx.x] = 0;
+    if (threadIdx.x < 2) s_tot[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    uint64_t a0 = 0, a1 = 0, P = 0;
+    if (i < nrows) {
+        a0 = aptr[r0 + i];
+        a1 = aptr[r0 + i + 1];
+    }
+    const uint32_t L = (uint32_t)(a1 - a0);
+    const bool is_long = L > 16;
+    if (!is_long) {
+        for (uint64_t q = a0; q < a1; ++q) {
+            uint32_t k = aidx[q];
+            P += bptr[k + 1] - bptr[k];
+        }
+    }
+    unsigned long long mask = __ballot(is_long);
+    while (mask) {
+        const int src = __ffsll((long long)mask) - 1;
+        mask &= mask - 1;
+        const uint64_t sa0 = __shfl(a0, src), sa1 = __shfl(a1, src);
+        uint64_t part = 0;
+        for (uint64_t q = sa0 + lane; q < sa1; q += 64) {
+            uint32_t k = aidx[q];
+            part += bptr[k + 1] - bptr[k];
+        }
+        part = wave_sum_u64(part);
+        if (lane == src) P = part;
+    }
+    if (i < nrows) {
+        const int bin = sym_bin_of(P, L);
+        row_nprod[i] = P > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)P;
+        row_bin[i] = (uint8_t)bin;
+        if (bin == 0) row_nnzc[i] = 0;
+        if (bin == 1) row_nnzc[i] = (uint32_t)P;   // one A nonzero: C row is a scaled copy of one B row
+        atomicAdd(&s_hist[bin], 1u);
+    }
+    uint64_t wp = wave_sum_u64(P), wl = wave_sum_u64((uint64_t)L);
+    if (lane == 0) {
+        atomicAdd(&s_tot[0], (unsigned long long)wp);
+        atomicAdd(&s_tot[1], (unsigned long long)wl);
+    }
+    __syncthreads();
+    if (threadIdx.x < SPADA_N_BINS && s_hist[threadIdx.x]) atomicAdd(&bin_counts[threadIdx.x], s_hist[threadIdx.x]);
+    if (threadIdx.x < 2 && s_tot[threadIdx.x]) atomicAdd(&totals[threadIdx.x], s_tot[threadIdx.x]);
+}
+
+// Scatter row ids into per-bin lists.  bin_counts = histogram (complete), bin_cursor zeroed.
+__global__ __launch_bounds__(256) void k_bin_scatter(const uint8_t *__restrict__ row_bin, uint32_t nrows,
+                                                     const uint32_t *__restrict__ bin_counts,
+                                                     uint32_t *__restrict__ bin_cursor, uint32_t *__restrict__ bin_rows)
+{
+    __shared__ uint32_t s_cnt[SPADA_N_BINS], s_base[SPADA_N_BINS];
+    if (threadIdx.x < SPADA_N_BINS) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    int bin = -1;
+    uint32_t local = 0;
+    if (i < nrows) {
+        bin = row_bin[i];
+        local = atomicAdd(&s_cnt[bin], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < SPADA_N_BINS) {
+        uint32_t off = 0;
+        for (int u = 0; u < (int)threadIdx.x; ++u) off += bin_counts[u];
+        uint32_t c = s_cnt[threadIdx.x];
+        s_base[threadIdx.x] = off + (c ? atomicAdd(&bin_cursor[threadIdx.x], c) : 0u);
+    }
+    __syncthreads();
+    if (bin >= 0) bin_rows[s_base[bin] + local] = i;
+}
+
+// numeric classification: row_bin <- num_bin_of(nnzc, nprod, L) + histogram
+__global__ __launch_bounds__(256) void k_num_classify(const uint64_t *__restrict__ aptr, uint64_t r0, uint32_t nrows,
+                                                      const uint32_t *__restrict__ row_nprod,
+                                                      const uint32_t *__restrict__ row_nnzc, uint8_t *__restrict__ row_bin,
+                                                      uint32_t *__restrict__ bin_counts)
+{
+    __shared__ uint32_t s_hist[SPADA_N_BINS];
+    if (threadIdx.x < SPADA_N_BINS) s_hist[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nrows) {
+        const uint32_t L = (uint32_t)(aptr[r0 + i + 1] - aptr[r0 + i]);
+        const int bin = num_bin_of(row_nnzc[i], row_nprod[i], L);
+        row_bin[i] = (uint8_t)bin;
+        atomicAdd(&s_hist[bin], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < SPADA_N_BINS && s_hist[threadIdx.x]) atomicAdd(&bin_counts[threadIdx.x], s_hist[threadIdx.x]);
+}
+
+// ---- 2. exclusive scan  nnzc[u32] -> cptr[u64]  (three small kernels) -----------------------------------
+constexpr int SCAN_BLOCK = 256;
+constexpr int SCAN_ITEMS = 8;
+constexpr int SCAN_TILE = SCAN_BLOCK * SCAN_ITEMS;
+
+__device__ inline uint64_t block_exclusive_scan_u64(uint64_t v, uint64_t *s_w /*[4]*/, uint64_t *total)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint64_t inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        uint64_t t = __shfl_up(inc, o);
+        if (lane >= o) inc += t;
+    }
+    __syncthreads();
+    if (lane == 63) s_w[w] = inc;
+    __syncthreads();
+    uint64_t add = 0, tot = 0;
+    for (int k = 0; k < SCAN_BLOCK / 64; ++k) {
+        if (k < w) add += s_w[k];
+        tot += s_w[k];
+    }
+    *total = tot;
+    return inc - v + add;
+}
+
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_tile_sums(const uint32_t *__restrict__ in, uint32_t n,
+                                                               uint64_t *__restrict__ tile_sums)
+{
+    __shared__ uint64_t s_w[SCAN_BLOCK / 64];
+    const uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+    uint64_t s = 0;
+#pragma unroll
+    for (int j = 0; j < SCAN_ITEMS; ++j)
+        if (base + j < n) s += in[base + j];
+    uint64_t tot;
+    block_exclusive_scan_u64(s, s_w, &tot);
+    if (threadIdx.x == 0) tile_sums[blockIdx.x] = tot;
+}
+
+// single workgroup: exclusive scan of tile_sums in place, total -> tile_sums[ntiles]
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_tiles(uint64_t *__restrict__ tile_sums, uint32_t ntiles)
+{
+    __shared__ uint64_t s_w[SCAN_BLOCK / 64];
+    uint64_t carry = 0;
+    for (uint32_t b = 0; b < ntiles; b += SCAN_BLOCK) {
+        const uint32_t i = b + threadIdx.x;
+        uint64_t v = i < ntiles ? tile_sums[i] : 0, tot;
+        uint64_t ex = block_exclusive_scan_u64(v, s_w, &tot);
+        if (i < ntiles) tile_sums[i] = carry + ex;
+        carry += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) tile_sums[ntiles] = carry;
+}
+
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_apply(const uint32_t *__restrict__ in, uint32_t n,
+                                                           const uint64_t *__restrict__ tile_sums, uint32_t ntiles,
+                                                           uint64_t *__restrict__ out /* n + 1 */)
+{
+    __shared__ uint64_t s_w[SCAN_BLOCK / 64];
+    const uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+    uint32_t v[SCAN_ITEMS];
+    uint64_t s = 0;
+#pragma unroll
+    for (int j = 0; j < SCAN_ITEMS; ++j) {
+        v[j] = base + j < n ? in[base + j] : 0;
+        s += v[j];
+    }
+    uint64_t tot;
+    uint64_t ex = block_exclusive_scan_u64(s, s_w, &tot) + tile_sums[blockIdx.x];
+#pragma unroll
+    for (int j = 0; j < SCAN_ITEMS; ++j) {
+        if (base + j < n) out[base + j] = ex;
+        ex += v[j];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = tile_sums[ntiles];
+}
+
+// ---- 3. symbolic: LDS hash set per row -------------------------------------------------------------------
+// Group of G lanes per row, T-entry key table per row.  Inside the group, sub-groups of S = 2^log2S lanes
+// take one A nonzero each and stride over its B row (S follows the average B row length, so that short B
+// rows do not idle most of the group and long ones are still read with adjacent lanes on adjacent columns).
+template <int G, int LOG_T>
+__global__ __launch_bounds__((G < 256 ? 256 : G)) void k_sym_hash(DevCsrView A, DevCsrView B, uint64_t r0,
+                                                                   const uint32_t *__restrict__ bin_rows, uint32_t n_bin_rows,
+                                                                   int log2S, uint32_t *__restrict__ row_nnzc)
+{
+    constexpr int T = 1 << LOG_T;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t *hdr = (uint32_t *)smem;                     // 128 B header (group reductions when G > 64)
+    uint32_t *keys = (uint32_t *)(smem + 128) + (threadIdx.x / G) * T;
+    const int gl = threadIdx.x % G;
+    const uint32_t slot = blockIdx.x * ((G < 256 ? 256 : G) / G) + threadIdx.x / G;
+    const bool active = slot < n_bin_rows;
+    for (int s = gl; s < T; s += G) keys[s] = EMPTY_KEY;
+    group_sync<G>();
+    uint32_t cnt = 0, row = 0;
+    if (active) {
+        row = bin_rows[slot];
+        const uint64_t a0 = A.ptr[r0 + row], a1 = A.ptr[r0 + row + 1];
+        const int S = 1 << log2S, sub = gl >> log2S, sl = gl & (S - 1), nsub = G >> log2S;
+        for (uint64_t a = a0 + sub; a < a1; a += nsub) {
+            const uint32_t k = A.idx[a];
+            const uint64_t b0 = B.ptr[k], b1 = B.ptr[k + 1];
+            for (uint64_t q = b0 + sl; q < b1; q += S) {
+                const uint32_t c = B.idx[q];
+                uint32_t h = hash_slot<LOG_T>(c);
+                for (;;) {
+                    const uint32_t old = atomicCAS(&keys[h], EMPTY_KEY, c);
+                    if (old == EMPTY_KEY) { ++cnt; break; }
+                    if (old == c) break;
+                    h = (h + 1) & (T - 1);
+                }
+            }
+        }
+    }
+    cnt = group_sum<G>(cnt, hdr);
+    if (active && gl == 0) row_nnzc[row] = cnt;
+}
+
+// ---- 4. numeric: LDS hash accumulator + ordered emission ---------------------------------------------------
+// LDS per row: keys u32[T] | vals f64[T] | cnt u32[T/2] | list u16[T]   = 16 T bytes.
+template <int G, int LOG_T>
+__global__ __launch_bounds__((G < 256 ? 256 : G)) void k_num_hash(DevCsrView A, DevCsrView B, uint64_t r0,
+                                                                   const uint32_t *__restrict__ bin_rows, uint32_t n_bin_rows,
+                                                                   int log2S, const uint64_t *__restrict__ cptr,
+                                                                   uint32_t *__restrict__ c_idx, double *__restrict__ c_val)
+{
+    constexpr int T = 1 << LOG_T;
+    constexpr int NB = T / 2;
+    constexpr int BLOCK = G < 256 ? 256 : G;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t *hdr = (uint32_t *)smem;   // 128 B: [0..1] reductions, [2..17] wave totals
+    unsigned char *mine = smem + 128 + (size_t)(threadIdx.x / G) * (16 * T);
+    uint32_t *keys = (uint32_t *)mine;
+    double *vals = (double *)(mine + 4 * T);
+    uint32_t *cnt = (uint32_t *)(mine + 12 * T);
+    uint16_t *list = (uint16_t *)(mine + 14 * T);
+    const int gl = threadIdx.x % G;
+    const uint32_t slot = blockIdx.x * (BLOCK / G) + threadIdx.x / G;
+    const bool active = slot < n_bin_rows;
+
+    for (int s = gl; s < T; s += G) {
+        keys[s] = EMPTY_KEY;
+        vals[s] = 0.0;
+    }
+    for (int s = gl; s < NB; s += G) cnt[s] = 0;
+    group_sync<G>();
+
+    uint32_t row = 0;
+    if (active) {
+        row = bin_rows[slot];
+        const uint64_t a0 = A.ptr[r0 + row], a1 = A.ptr[r0 + row + 1];
+        const int S = 1 << log2S, sub = gl >> log2S, sl = gl & (S - 1), nsub = G >> log2S;
+        for (uint64_t a = a0 + sub; a < a1; a += nsub) {
+            const uint32_t k = A.idx[a];
+            const double av = A.val[a];
+            const uint64_t b0 = B.ptr[k], b1 = B.ptr[k + 1];
+            for (uint64_t q = b0 + sl; q < b1; q += S) {
+                const uint32_t c = B.idx[q];
+                const double v = av * B.val[q];          // simulator.rs:100-101
+                uint32_t h = hash_slot<LOG_T>(c);
+                for (;;) {
+                    const uint32_t old = atomicCAS(&keys[h], EMPTY_KEY, c);
+                    if (old == EMPTY_KEY || old == c) break;
+                    h = (h + 1) & (T - 1);
+                }
+                atomicAdd(&vals[h], v);                  // simulator.rs:213-218 (order differs)
+            }
+        }
+    }
+    group_sync<G>();
+
+    // ---- ordered emission: monotone buckets over [kmin, kmax], scan, in-bucket rank ---------------------
+    uint32_t kmin = 0xFFFFFFFFu, kmax = 0;
+    for (int s = gl; s < T; s += G) {
+        const uint32_t k = keys[s];
+        if (k != EMPTY_KEY) {
+            kmin = min(kmin, k);
+            kmax = max(kmax, k);
+        }
+    }
+    kmin = group_min<G>(kmin, hdr);
+    kmax = group_max<G>(kmax, hdr + 1);
+    // rows without any product cannot be here (nnzc > 0), but an inactive group has an empty table
+    const float scale = (kmax >= kmin) ? (float)NB / ((float)(kmax - kmin) + 1.0f) : 0.0f;
+    auto bucket = [&](uint32_t k) -> uint32_t {
+        uint32_t b = (uint32_t)((float)(k - kmin) * scale);
+        return b < (uint32_t)NB ? b : (uint32_t)NB - 1;
+    };
+    for (int s = gl; s < T; s += G) {
+        const uint32_t k = keys[s];
+        if (k != EMPTY_KEY) atomicAdd(&cnt[bucket(k)], 1u);
+    }
+    group_sync<G>();
+    group_exclusive_scan<G, NB>(cnt, gl, hdr + 2);
+    for (int s = gl; s < T; s += G) {
+        const uint32_t k = keys[s];
+        if (k != EMPTY_KEY) {
+            const uint32_t p = atomicAdd(&cnt[bucket(k)], 1u);   // afterwards cnt[b] = end of bucket b
+            list[p] = (uint16_t)s;
+        }
+    }
+    group_sync<G>();
+    if (active) {
+        const uint64_t c0 = cptr[row];
+        const uint32_t n = (uint32_t)(cptr[row + 1] - c0);
+        for (uint32_t p = gl; p < n; p += G) {
+            const uint32_t s = list[p];
+            const uint32_t k = keys[s];
+            const uint32_t b = bucket(k);
+            const uint32_t lo = b ? cnt[b - 1] : 0u, hi = cnt[b];
+            uint32_t r = lo;
+            for (uint32_t j = lo; j < hi; ++j) r += (keys[list[j]] < k) ? 1u : 0u;
+            c_idx[c0 + r] = k;
+            c_val[c0 + r] = vals[s];
+        }
+    }
+}
+
+// ---- 5. numeric, rows with a single A nonzero: C row = a * B row (already ascending) ------------------------
+template <int G>
+__global__ __launch_bounds__(256) void k_num_copy(DevCsrView A, DevCsrView B, uint64_t r0,
+                                                  const uint32_t *__restrict__ bin_rows, uint32_t n_bin_rows,
+                                                  const uint64_t *__restrict__ cptr, uint32_t *__restrict__ c_idx,
+                                                  double *__restrict__ c_val)
+{
+    const uint32_t slot = blockIdx.x * (256 / G) + threadIdx.x / G;
+    const int gl = threadIdx.x % G;
+    if (slot >= n_bin_rows) return;
+    const uint32_t row = bin_rows[slot];
+    const uint64_t a = A.ptr[r0 + row];
+    const uint32_t k = A.idx[a];
+    const double av = A.val[a];
+    const uint64_t b0 = B.ptr[k], b1 = B.ptr[k + 1], c0 = cptr[row];
+    for (uint64_t q = b0 + gl; q < b1; q += G) {
+        c_idx[c0 + (q - b0)] = B.idx[q];
+        c_val[c0 + (q - b0)] = av * B.val[q];
+    }
+}
+
+// ---- 6. spill path: rows whose accumulator does not fit LDS ---------------------------------------------------
+// One persistent workgroup of 1024 lanes per slab; slabs live in HBM (288 GB: a dense f64 row per
+// workgroup is cheap) and are touched with device-scope atomics only, so no L1 line can go stale.
+constexpr int SPILL_BLOCK = 1024;
+
+__device__ inline uint32_t block_sum_u32(uint32_t v, uint32_t *s_w /*[17]*/)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = v;
+    __syncthreads();
+    uint32_t t = 0;
+    for (int k = 0; k < SPILL_BLOCK / 64; ++k) t += s_w[k];
+    return t;
+}
+
+// symbolic: bitmap (1 bit per column) per workgroup; count newly set bits; clear by a second walk.
+__global__ __launch_bounds__(SPILL_BLOCK) void k_sym_spill(DevCsrView A, DevCsrView B, uint64_t r0,
+                                                           const uint32_t *__restrict__ bin_rows, uint32_t n_bin_rows,
+                                                           uint32_t *__restrict__ bitmaps, uint64_t words_per_slab,
+                                                           uint32_t *__restrict__ row_nnzc)
+{
+    __shared__ uint32_t s_w[SPILL_BLOCK / 64 + 1];
+    uint32_t *bm = bitmaps + (uint64_t)blockIdx.x * words_per_slab;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    constexpr int NW = SPILL_BLOCK / 64;
+    for (uint32_t slot = blockIdx.x; slot < n_bin_rows; slot += gridDim.x) {
+        const uint32_t row = bin_rows[slot];
+        const uint64_t a0 = A.ptr[r0 + row], a1 = A.ptr[r0 + row + 1];
+        uint32_t cnt = 0;
+        for (uint64_t a = a0 + wave; a < a1; a += NW) {   // one wave per A nonzero, lanes over the B row
+            const uint32_t k = A.idx[a];
+            const uint64_t b0 = B.ptr[k], b1 = B.ptr[k + 1];
+            for (uint64_t q = b0 + lane; q < b1; q += 64) {
+                const uint32_t c = B.idx[q];
+                const uint32_t bit = 1u << (c & 31);
+                const uint32_t old = atomicOr(&bm[c >> 5], bit);
+                cnt += (old & bit) ? 0u : 1u;
+            }
+        }
+        cnt = block_sum_u32(cnt, s_w);
+        if (threadIdx.x == 0) row_nnzc[row] = cnt;
+        for (uint64_t a = a0 + wave; a < a1; a += NW) {   // clear the touched words again
+            const uint32_t k = A.idx[a];
+            const uint64_t b0 = B.ptr[k], b1 = B.ptr[k + 1];
+            for (uint64_t q = b0 + lane; q < b1; q += 64) atomicAnd(&bm[B.idx[q] >> 5], 0u);
+        }
+        __syncthreads();
+    }
+}
+
+// numeric: dense f64 slab + bitmap per workgroup; emission walks the bitmap in ascending order.
+__global__ __launch_bounds__(SPILL_BLOCK) void k_num_spill(DevCsrView A, DevCsrView B, uint64_t r0,
+                                                           const uint32_t *__restrict__ bin_rows, uint32_t n_bin_rows,
+                                                           uint32_t *__restrict__ bitmaps, uint64_t words_per_slab,
+                                                           double *__restrict__ slabs, uint64_t cols,
+                                                           const uint64_t *__restrict__ cptr, uint32_t *__restrict__ c_idx,
+                                                           double *__restrict__ c_val)
+{
+    __shared__ uint32_t s_w[SPILL_BLOCK / 64 + 1];
+    __shared__ uint32_t s_lo, s_hi;
+    uint32_t *bm = bitmaps + (uint64_t)blockIdx.x * words_per_slab;
+    double *acc = slabs + (uint64_t)blockIdx.x * cols;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    constexpr int NW = SPILL_BLOCK / 64;
+    for (uint32_t slot = blockIdx.x; slot < n_bin_rows; slot += gridDim.x) {
+        const uint32_t row = bin_rows[slot];
+        const uint64_t a0 = A.ptr[r0 + row], a1 = A.ptr[r0 + row + 1];
+        if (threadIdx.x == 0) { s_lo = 0xFFFFFFFFu; s_hi = 0; }
+        __syncthreads();
+        uint32_t wlo = 0xFFFFFFFFu, whi = 0;
+        for (uint64_t a = a0 + wave; a < a1; a += NW) {
+            const uint32_t k = A.idx[a];
+            const double av = A.val[a];
+            const uint64_t b0 = B.ptr[k], b1 = B.ptr[k + 1];
+            for (uint64_t q = b0 + lane; q < b1; q += 64) {
+                const uint32_t c = B.idx[q];
+                const double v = av * B.val[q];
+                atomicAdd(&acc[c], v);
+                atomicOr(&bm[c >> 5], 1u << (c & 31));
+                wlo = min(wlo, c >> 5);
+                whi = max(whi, c >> 5);
+            }
+        }
+        if (wlo != 0xFFFFFFFFu) { atomicMin(&s_lo, wlo); atomicMax(&s_hi, whi); }
+        __threadfence();
+        __syncthreads();
+        const uint64_t c0 = cptr[row];
+        const uint32_t lo = s_lo, hi = s_hi;
+        uint32_t emitted = 0;
+        if (lo != 0xFFFFFFFFu) {
+            for (uint32_t wbase = lo; wbase <= hi; wbase += SPILL_BLOCK) {
+                const uint32_t w = wbase + threadIdx.x;
+                uint32_t bits = (w <= hi) ? atomicExch(&bm[w], 0u) : 0u;
+                const uint32_t pc = __popc(bits);
+                // block exclusive scan of pc
+                uint32_t inc = pc;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    uint32_t t = __shfl_up(inc, o);
+                    if (lane >= o) inc += t;
+                }
+                __syncthreads();
+                if (lane == 63) s_w[wave] = inc;
+                __syncthreads();
+                uint32_t add = 0, tot = 0;
+                for (int k2 = 0; k2 < NW; ++k2) {
+                    if (k2 < wave) add += s_w[k2];
+                    tot += s_w[k2];
+                }
+                uint64_t out = c0 + emitted + add + (inc - pc);
+                while (bits) {
+                    const int b = __ffs((int)bits) - 1;
+                    bits &= bits - 1;
+                    const uint32_t c = (w << 5) + (uint32_t)b;
+                    c_idx[out] = c;
+                    // read-and-reset in one device-scope atomic (served by L2, never by a stale L1 line)
+                    c_val[out] = __longlong_as_double((long long)atomicExch((unsigned long long *)&acc[c], 0ull));
+                    ++out;
+                }
+                emitted += tot;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// widen u32 column indices to the ABI's u64 (usize)
+__global__ __launch_bounds__(256) void k_widen_u32(const uint32_t *__restrict__ in, uint64_t n, uint64_t *__restrict__ out)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        out[i] = in[i];
+}
+
+}  // namespace spada

@@ -1,0 +1,158 @@
+"""GPU (-m gpu): the HIP path, called through the C ABI, against the CPU oracle and the golden vectors.
+
+Bar: C indptr / column indices bit-exact; values within 1e-9 relative (BASELINE.json), with the
+documented cancellation fallback |x - y| <= 1e-9 * sum|a_ik * b_kj| (counted, see conftest.assert_parity)."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, assert_parity, to_oracle
+from oracle import oracle
+from test_oracle_golden import CASES, load_case
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-9
+
+
+def as_csmat(o):
+    import spada_sim_amd as S
+    return S.CsMat((o.rows, o.cols), o.indptr, o.indices, o.data)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_golden_product_cases(engine, name):
+    a, b, exp = load_case(name)
+    ma = as_csmat(a)
+    mb = ma if name in ("rand_sq_300", "skewed_600", "explicit_zero") else as_csmat(b)
+    c = engine.spgemm(ma, mb)
+    ref = oracle.spgemm_sortmerge(a, b)
+    assert_parity(c, ref, a, b, RTOL)
+    assert np.array_equal(c.indices, exp.indices) and np.array_equal(c.indptr, exp.indptr)
+
+
+def test_cari_a_at_through_simulator_interface(engine, matrices_dir):
+    """configs[0]: `accuratesimu spada ss cari config_1mb_row1.json` -> A * A^T (gemm.rs:41-53)."""
+    import spada_sim_amd as S
+    mat = S.load_mm_mat(matrices_dir, "cari")
+    gemm = S.GEMM.from_mat("cari", mat)
+    assert gemm.b.shape == (1200, 400)
+    dram_a, dram_b = S.CsrMatStorage.init_with_gemm(gemm)
+    sim = S.Simulator(2, 16, 8, 1572864, 8, len(dram_b.indptr), [1, 10000000], dram_a, dram_b, None, "Spada",
+                      30, 0, 1.0, 16, 8.0, engine=engine)
+    sim.execute()
+    rows = sim.get_exec_result()
+    g = np.load(os.path.join(GOLDEN, "cari_product.npz"))
+    c = sim.result_matrix()
+    assert len(rows) == 400 and c.nnz() == int(g["nnz"]) == 160000
+    assert np.array_equal(c.indptr, g["indptr"])
+    assert hashlib.sha256(c.indices.tobytes()).hexdigest() == str(g["indices_sha256"])
+    assert np.allclose(rows[0].data[:5], g["row0_head"], rtol=RTOL, atol=0)
+    assert np.allclose(rows[9].data[:5], g["row9_head"], rtol=RTOL, atol=0)
+    assert np.allclose(c.data[g["sample_pos"].astype(np.int64)], g["sample_val"], rtol=RTOL, atol=0)
+    a = to_oracle(gemm.a)
+    ref = oracle.spgemm_spa(a, to_oracle(gemm.b))
+    assert_parity(c, ref, rtol=RTOL)
+    st = engine.stats()
+    assert st["nprod"] == 57760800 and st["c_nnz"] == 160000
+
+
+GEN = [
+    ("uniform_small", 5, 2000, 6, 1),
+    ("rmat_s12", 0, 12, 8, 2),          # power-law rows: hits most LDS bins
+    ("rmat_s14", 0, 14, 16, 3),         # long rows: largest LDS bins + HBM spill path
+    ("webbase_like_50k", 1, 50000, 155000, 4),
+    ("cop20k_like_20k", 2, 20000, 0, 5),
+    ("cage12_like_20k", 3, 20000, 0, 6),
+    ("mc2depi_like", 4, 779 * 40, 0, 7),
+]
+
+
+@pytest.mark.parametrize("name,kind,p0,p1,seed", GEN)
+def test_generated_workloads_match_oracle(engine, name, kind, p0, p1, seed):
+    import spada_sim_amd as S
+    m = S.generate(kind, p0, p1, seed)
+    c = engine.spgemm(m, m)
+    a = to_oracle(m)
+    ref = oracle.spgemm_spa(a, a)
+    nfallback = assert_parity(c, ref, a, a, RTOL)
+    assert nfallback == 0     # positive values: no cancellation
+    st = engine.stats()
+    assert st["nprod"] == oracle.count_products(a, a) and st["c_nnz"] == ref.nnz
+
+
+def test_spill_path_is_exercised(engine):
+    """R-MAT scale 14, degree 16: hub rows exceed every LDS bin (SURVEY 7 hard part 3)."""
+    import spada_sim_amd as S
+    m = S.generate(S.GEN_RMAT, 14, 16, 3)
+    engine.spgemm(m, m)
+    st = engine.stats()
+    assert st["spill_rows"] > 0
+
+
+def test_empty_and_ragged_inputs(engine):
+    import spada_sim_amd as S
+    # all-empty matrix
+    z = S.CsMat((5, 5), np.zeros(6, np.uint64), np.zeros(0, np.uint64), np.zeros(0))
+    c = engine.spgemm(z, z)
+    assert c.nnz() == 0 and np.array_equal(c.indptr, np.zeros(6, np.uint64))
+    # one dense row against a diagonal, the rest empty
+    n = 300
+    indptr = np.zeros(n + 1, np.uint64)
+    indptr[1:] = n
+    a = S.CsMat((n, n), indptr, np.arange(n, dtype=np.uint64), np.linspace(0.5, 1.5, n))
+    d = S.CsMat((n, n), np.arange(n + 1, dtype=np.uint64), np.arange(n, dtype=np.uint64), np.full(n, 2.0))
+    c = engine.spgemm(a, d)
+    ref = oracle.spgemm_sortmerge(to_oracle(a), to_oracle(d))
+    assert_parity(c, ref, rtol=RTOL)
+    # signed values with cancellation: structure exact, values within the cancellation bound
+    rng = np.random.default_rng(5)
+    m = S.generate(S.GEN_UNIFORM, 1500, 12, 9)
+    m.data[:] = rng.uniform(-1, 1, m.nnz())
+    ao = to_oracle(m)
+    assert_parity(engine.spgemm(m, m), oracle.spgemm_spa(ao, ao), ao, ao, RTOL)
+
+
+def test_device_resident_row_blocks_concatenate(engine):
+    """A-row blocks (scheduler.rs:296-379) computed separately concatenate to the full product."""
+    import spada_sim_amd as S
+    m = S.generate(S.GEN_RMAT, 12, 8, 11)
+    ao = to_oracle(m)
+    ref = oracle.spgemm_spa(ao, ao)
+    bounds = S.partition_rows(m, m, 3)
+    d = engine.upload(m)
+    parts = []
+    for r0, r1 in zip(bounds[:-1], bounds[1:]):
+        nnz = engine.symbolic(d, d, r0, r1)
+        p, i, v = engine.numeric_owned()
+        parts.append(engine.download(p, i, v, r1 - r0, nnz, m.shape[1]))
+    engine.free(d)
+    indices = np.concatenate([p.indices for p in parts])
+    data = np.concatenate([p.data for p in parts])
+    lens = np.concatenate([np.diff(p.indptr.astype(np.int64)) for p in parts])
+    assert np.array_equal(np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64), ref.indptr)
+    assert np.array_equal(indices, ref.indices)
+    assert np.all(np.abs(data - ref.data) <= RTOL * np.abs(ref.data))
+
+
+def test_repeatability(engine):
+    """Run twice: identical structure, values within tolerance (LDS atomics add in arbitrary order)."""
+    import spada_sim_amd as S
+    m = S.generate(S.GEN_RMAT, 11, 8, 21)
+    c1 = engine.spgemm(m, m)
+    c2 = engine.spgemm(m, m)
+    assert np.array_equal(c1.indptr, c2.indptr) and np.array_equal(c1.indices, c2.indices)
+    assert np.all(np.abs(c1.data - c2.data) <= 1e-12 * np.abs(c1.data))
+
+
+def test_error_paths(engine):
+    import spada_sim_amd as S
+    a = S.generate(S.GEN_UNIFORM, 50, 3, 1)
+    b = S.CsMat((40, 40), np.zeros(41, np.uint64), np.zeros(0, np.uint64), np.zeros(0))
+    with pytest.raises(S.SpadaError) as e:
+        engine.spgemm(a, b)          # inner dimensions differ
+    assert e.value.code == 1
+    bad = S.CsMat((2, 2), np.array([0, 2, 2], np.uint64), np.array([1, 0], np.uint64), np.array([1.0, 2.0]))
+    with pytest.raises(S.SpadaError):
+        engine.spgemm(bad, bad)      # columns not ascending

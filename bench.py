@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""bench.py -- nnz(C)/s of A*A SpGEMM on MI355X, with roofline and CPU baseline (contract: see DESIGN.md).
+
+One "step" = one complete SpGEMM of the workload: symbolic phase, allocation of C, numeric phase and
+(for N > 1) the allgatherv of the C row blocks.  Inputs (A, B = A) are resident in HBM before the
+timed region starts; the timed region is bracketed by a barrier + torch.cuda.synchronize() on both sides
+and the max over ranks is taken.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--accumulator lds_hash|sort_merge]
+
+N > 1 is launched by the driver through torch.distributed.run (one rank per GPU, RCCL): the A rows are
+split into product-balanced row blocks (one per rank), B is replicated, every rank computes its block
+and the blocks are concatenated on every rank by an allgatherv over xGMI ("scaling": "strong" -- the
+matrix is fixed as N grows).
+
+Workloads: `webbase-1M` (BASELINE.json configs[2], the configuration the metric is quoted on), `cop20k_A`,
+`cage12`, `mc2depi`, `rmat<scale>`.  The SuiteSparse files are not in the image and there is no network:
+if $SPADA_MTX_DIR/<name>.mtx exists it is used, otherwise a seeded surrogate generator with matched
+rows / nnz / degree profile is used and the JSON line says so ("data": "synthetic ...").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 GB/s measured copy ceiling
+
+
+def load_workload(S, name):
+    gens = {
+        "webbase-1M": (S.GEN_WEBBASE_LIKE, 0, 0, 12347),
+        "cop20k_A": (S.GEN_COP20K_LIKE, 0, 0, 12346),
+        "cage12": (S.GEN_CAGE12_LIKE, 0, 0, 12348),
+        "mc2depi": (S.GEN_MC2DEPI_LIKE, 0, 0, 12349),
+    }
+    d = os.environ.get("SPADA_MTX_DIR")
+    if d and os.path.exists(os.path.join(d, name + ".mtx")):
+        return S.load_mm_mat(d, name), f"file {name}.mtx"
+    if name.startswith("rmat"):
+        scale = int(name[4:])
+        return S.generate(S.GEN_RMAT, scale, 16, 22), f"synthetic R-MAT scale {scale} degree 16 seed 22"
+    if name not in gens:
+        raise SystemExit(f"unknown workload {name}")
+    kind, p0, p1, seed = gens[name]
+    return S.generate(kind, p0, p1, seed), f"synthetic surrogate of {name} (seeded generator, no SuiteSparse file in the image)"
+
+
+def cpu_baseline(a, budget_s=15.0):
+    """The oracle's OpenMP SPA variant (kind "port") on a bounded row-prefix sample of the same workload."""
+    from oracle import oracle
+    ao = oracle.Csr(a.shape[0], a.shape[1], a.indptr, a.indices, a.data)
+    nt = oracle.num_threads()
+    # probe on 2 % of the rows to size the sample for ~budget_s seconds
+    rows = a.shape[0]
+    probe = max(1, rows // 50)
+
+    def run(nrows):
+        sub = oracle.Csr(nrows, a.shape[1], a.indptr[:nrows + 1], a.indices[:int(a.indptr[nrows])],
+                         a.data[:int(a.indptr[nrows])])
+        t0 = time.perf_counter()
+        c = oracle.spgemm_spa(sub, ao, n_threads=nt)
+        return time.perf_counter() - t0, c.nnz
+
+    t, _ = run(probe)
+    frac = min(1.0, budget_s / max(t, 1e-6) / 50.0)
+    nrows = max(probe, int(rows * frac))
+    t, nnz = run(nrows)
+    return {"value": nnz / t, "unit": "nnz(C)/s", "cores": nt, "kind": "port",
+            "sample": f"first {nrows} of {rows} A rows ({nnz} nnz(C)) in {t:.2f} s, oracle SPA variant, OpenMP {nt} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="webbase-1M")
+    ap.add_argument("--accumulator", default="lds_hash", choices=["lds_hash", "sort_merge"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import spada_sim_amd as S
+    from spada_sim_amd import parallel
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch N > 1 through torch.distributed.run (one rank per GPU)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    a, data_desc = load_workload(S, args.workload)
+    rows, cols = a.shape
+    eng = S.Engine(device=local_rank, accumulator=S.ACC_SORT_MERGE if args.accumulator == "sort_merge" else S.ACC_LDS_HASH)
+    bounds = S.partition_rows(a, a, world)
+    r0, r1 = bounds[rank], bounds[rank + 1]
+    da = eng.upload(a)                    # A and B = A resident in HBM before the timed region
+    dev = torch.device("cuda", local_rank)
+
+    def step():
+        nnz = eng.symbolic(da, da, r0, r1)
+        c_ptr = torch.empty(r1 - r0 + 1, dtype=torch.int64, device=dev)
+        c_idx = torch.empty(max(nnz, 1), dtype=torch.int32, device=dev)
+        c_val = torch.empty(max(nnz, 1), dtype=torch.float64, device=dev)
+        eng.numeric(c_ptr.data_ptr(), c_idx.data_ptr(), c_val.data_ptr())
+        st = eng.stats()
+        if world > 1:
+            return st, nnz, parallel.allgatherv_c(c_ptr, c_idx[:nnz], c_val[:nnz])
+        return st, nnz, (c_ptr, c_idx, c_val)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    acc = {}
+    for _ in range(args.steps):
+        st, nnz_local, _ = step()
+        for k in ("ms_symbolic_call", "ms_numeric_call", "ms_row_stats", "ms_binning", "ms_symbolic", "ms_scan",
+                  "ms_numeric"):
+            acc[k] = acc.get(k, 0.0) + st[k]
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+        tot = torch.tensor([st["c_nnz"], st["nprod"], st["bytes_read"], st["bytes_write"]], dtype=torch.int64, device=dev)
+        dist.all_reduce(tot)
+        nnz_total, nprod_total = int(tot[0]), int(tot[1])
+    else:
+        nnz_total, nprod_total = st["c_nnz"], st["nprod"]
+
+    if rank == 0:
+        K = args.steps
+        ms_step = elapsed / K * 1e3
+        dev_ms = (acc["ms_symbolic_call"] + acc["ms_numeric_call"]) / K      # rank 0, HIP events on the engine stream
+        achieved = st["bytes_read"] / (dev_ms * 1e-3) / 1e9
+        out = {
+            "metric": "nnz(C)/sec on A*A SpGEMM",
+            "value": nnz_total / (elapsed / K),
+            "unit": "nnz(C)/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": args.warmup,
+            "ms_per_step": ms_step,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": data_desc,
+            "config": {"workload": f"{args.workload} A*A", "rows": rows, "nnz_a": a.nnz(), "products": nprod_total,
+                       "nnz_c": nnz_total, "accumulator": args.accumulator,
+                       "parallelism": f"row-block x{world}, B replicated" + (", allgatherv of C" if world > 1 else "")},
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "SpGEMM pipeline of one step on rank 0 (row_stats, bin_scatter, sym_hash*, scan*, num_classify, "
+                          "num_copy, num_hash*, spill*), device time by HIP events on the engine stream",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "algorithmic_bytes_read": st["bytes_read"],
+                "algorithmic_bytes_write": st["bytes_write"],
+                "device_ms_per_step": dev_ms,
+                "phase_ms": {k: v / K for k, v in acc.items()},
+            },
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(a)
+        print(json.dumps(out))
+    eng.free(da)
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -76,13 +76,6 @@ struct Counters {
 
 enum { EV_SYM_BEGIN, EV_STATS, EV_BINNED, EV_SYM, EV_SCAN, EV_NUM_BEGIN, EV_NUM_END, EV_COUNT };
 
-int pow2_ceil_log2(double x)
-{
-    int l = 0;
-    while ((double)(1 << l) < x && l < 6) ++l;
-    return l;
-}
-
 }  // namespace
 
 struct spada_ctx {
@@ -118,36 +111,33 @@ int allow_lds(K kernel, size_t bytes)
     return SPADA_OK;
 }
 
-constexpr size_t sym_lds(int G, int LOG_T) { return 128 + (size_t)((G < 256 ? 256 : G) / G) * 4 * (1u << LOG_T); }
-constexpr size_t num_lds(int G, int LOG_T) { return 128 + (size_t)((G < 256 ? 256 : G) / G) * 16 * (1u << LOG_T); }
+template <int G, int LOG_T>
+constexpr size_t sym_lds() { return 128 + (size_t)((G <= 64 ? 256 : G) / G) * sym_row_bytes<G, LOG_T>(); }
+template <int G, int LOG_T>
+constexpr size_t num_lds() { return 128 + (size_t)((G <= 64 ? 256 : G) / G) * num_row_bytes<G, LOG_T>(); }
 
 template <int G, int LOG_T>
-int launch_sym(spada_ctx *c, uint32_t off, uint32_t n, int log2S)
+int launch_sym(spada_ctx *c, uint32_t off, uint32_t n)
 {
     if (!n) return SPADA_OK;
-    constexpr int BLOCK = G < 256 ? 256 : G;
+    constexpr int BLOCK = G <= 64 ? 256 : G;
     constexpr int RPB = BLOCK / G;
     const uint32_t grid = (n + RPB - 1) / RPB;
-    if (log2S > 6) log2S = 6;
-    while ((1 << log2S) > G) --log2S;
-    hipLaunchKernelGGL((k_sym_hash<G, LOG_T>), dim3(grid), dim3(BLOCK), sym_lds(G, LOG_T), c->stream, c->A->view(),
-                       c->B->view(), c->r0, c->sym_rows.as<uint32_t>() + off, n, log2S, c->row_nnzc.as<uint32_t>());
+    hipLaunchKernelGGL((k_sym_hash<G, LOG_T>), dim3(grid), dim3(BLOCK), (sym_lds<G, LOG_T>()), c->stream, c->A->view(),
+                       c->B->view(), c->r0, c->sym_rows.as<uint32_t>() + off, n, c->row_nnzc.as<uint32_t>());
     HIP_TRY(hipGetLastError());
     return SPADA_OK;
 }
 
 template <int G, int LOG_T>
-int launch_num(spada_ctx *c, uint32_t off, uint32_t n, int log2S, uint32_t *c_idx, double *c_val)
+int launch_num(spada_ctx *c, uint32_t off, uint32_t n, uint32_t *c_idx, double *c_val)
 {
     if (!n) return SPADA_OK;
-    constexpr int BLOCK = G < 256 ? 256 : G;
+    constexpr int BLOCK = G <= 64 ? 256 : G;
     constexpr int RPB = BLOCK / G;
     const uint32_t grid = (n + RPB - 1) / RPB;
-    if (log2S > 6) log2S = 6;
-    while ((1 << log2S) > G) --log2S;
-    hipLaunchKernelGGL((k_num_hash<G, LOG_T>), dim3(grid), dim3(BLOCK), num_lds(G, LOG_T), c->stream, c->A->view(),
-                       c->B->view(), c->r0, c->num_rows.as<uint32_t>() + off, n, log2S, c->cptr.as<uint64_t>(), c_idx,
-                       c_val);
+    hipLaunchKernelGGL((k_num_hash<G, LOG_T>), dim3(grid), dim3(BLOCK), (num_lds<G, LOG_T>()), c->stream, c->A->view(),
+                       c->B->view(), c->r0, c->num_rows.as<uint32_t>() + off, n, c->cptr.as<uint64_t>(), c_idx, c_val);
     HIP_TRY(hipGetLastError());
     return SPADA_OK;
 }
@@ -155,7 +145,7 @@ int launch_num(spada_ctx *c, uint32_t off, uint32_t n, int log2S, uint32_t *c_id
 int ensure_spill(spada_ctx *c, uint32_t rows_in_bin, bool need_slabs)
 {
     const uint64_t cols = c->B->cols;
-    const uint64_t nslab = std::min<uint64_t>(rows_in_bin, 256);
+    const uint64_t nslab = std::min<uint64_t>(rows_in_bin, 512);
     const uint64_t words = ((cols + 31) / 32 + 3) & ~3ull;
     if (c->spill_cols != cols || c->spill_slabs < nslab) {
         // geometry changed: drop and re-zero
@@ -168,7 +158,7 @@ int ensure_spill(spada_ctx *c, uint32_t rows_in_bin, bool need_slabs)
     }
     int rc = c->bitmaps.ensure(c->spill_slabs * words * 4, true, c->stream, &c->ws_bytes);
     if (rc) return rc;
-    if (need_slabs) rc = c->slabs.ensure(c->spill_slabs * cols * 8, true, c->stream, &c->ws_bytes);
+    if (need_slabs) rc = c->slabs.ensure(c->spill_slabs * words * 4, false, c->stream, &c->ws_bytes);
     return rc;
 }
 
@@ -225,8 +215,6 @@ int run_numeric(spada_ctx *c, uint64_t *d_ptr, uint32_t *d_idx, double *d_val)
     uint32_t off[SPADA_N_BINS + 1];
     off[0] = 0;
     for (int b = 0; b < SPADA_N_BINS; ++b) off[b + 1] = off[b] + cnt[b];
-    const double avg_b = c->B->rows ? (double)c->B->nnz / (double)c->B->rows : 1.0;
-    const int log2S = pow2_ceil_log2(avg_b);
     int rc;
     if (cnt[1]) {
         const uint32_t grid = (cnt[1] + 15) / 16;
@@ -234,18 +222,22 @@ int run_numeric(spada_ctx *c, uint64_t *d_ptr, uint32_t *d_idx, double *d_val)
                            c->num_rows.as<uint32_t>() + off[1], cnt[1], c->cptr.as<uint64_t>(), d_idx, d_val);
         HIP_TRY(hipGetLastError());
     }
-    if ((rc = launch_num<8, 6>(c, off[2], cnt[2], log2S, d_idx, d_val))) return rc;
-    if ((rc = launch_num<32, 8>(c, off[3], cnt[3], log2S, d_idx, d_val))) return rc;
-    if ((rc = launch_num<64, 10>(c, off[4], cnt[4], log2S, d_idx, d_val))) return rc;
-    if ((rc = launch_num<256, 12>(c, off[5], cnt[5], log2S, d_idx, d_val))) return rc;
-    if ((rc = launch_num<1024, 13>(c, off[6], cnt[6], log2S, d_idx, d_val))) return rc;
-    if (cnt[7]) {
-        if ((rc = ensure_spill(c, cnt[7], true))) return rc;
+    if ((rc = launch_num<8, 6>(c, off[2], cnt[2], d_idx, d_val))) return rc;
+    if ((rc = launch_num<16, 7>(c, off[3], cnt[3], d_idx, d_val))) return rc;
+    if ((rc = launch_num<32, 8>(c, off[4], cnt[4], d_idx, d_val))) return rc;
+    if ((rc = launch_num<32, 9>(c, off[5], cnt[5], d_idx, d_val))) return rc;
+    if ((rc = launch_num<64, 10>(c, off[6], cnt[6], d_idx, d_val))) return rc;
+    if ((rc = launch_num<128, 11>(c, off[7], cnt[7], d_idx, d_val))) return rc;
+    if ((rc = launch_num<256, 12>(c, off[8], cnt[8], d_idx, d_val))) return rc;
+    if ((rc = launch_num<1024, 13>(c, off[9], cnt[9], d_idx, d_val))) return rc;
+    if (cnt[NUM_SPILL_BIN]) {
+        const uint32_t nsp = cnt[NUM_SPILL_BIN];
+        if ((rc = ensure_spill(c, nsp, true))) return rc;
         const uint64_t words = ((c->B->cols + 31) / 32 + 3) & ~3ull;
-        const uint32_t grid = (uint32_t)std::min<uint64_t>(cnt[7], c->spill_slabs);
+        const uint32_t grid = (uint32_t)std::min<uint64_t>(nsp, c->spill_slabs);
         hipLaunchKernelGGL(k_num_spill, dim3(grid), dim3(SPILL_BLOCK), 0, c->stream, c->A->view(), c->B->view(), c->r0,
-                           c->num_rows.as<uint32_t>() + off[7], cnt[7], c->bitmaps.as<uint32_t>(), words,
-                           c->slabs.as<double>(), c->B->cols, c->cptr.as<uint64_t>(), d_idx, d_val);
+                           c->num_rows.as<uint32_t>() + off[NUM_SPILL_BIN], nsp, c->bitmaps.as<uint32_t>(),
+                           c->slabs.as<uint32_t>(), words, c->cptr.as<uint64_t>(), d_idx, d_val);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(c->ev[EV_NUM_END], c->stream));
@@ -304,17 +296,20 @@ int spada_create(const spada_options *opts, spada_ctx **out)
     HIP_TRY(hipHostMalloc((void **)&c->h_counters, sizeof(Counters), hipHostMallocDefault));
     HIP_TRY(hipHostMalloc((void **)&c->h_u64, 64, hipHostMallocDefault));
     int rc;
-    if ((rc = allow_lds(k_sym_hash<8, 6>, sym_lds(8, 6)))) return rc;
-    if ((rc = allow_lds(k_sym_hash<16, 8>, sym_lds(16, 8)))) return rc;
-    if ((rc = allow_lds(k_sym_hash<64, 10>, sym_lds(64, 10)))) return rc;
-    if ((rc = allow_lds(k_sym_hash<256, 12>, sym_lds(256, 12)))) return rc;
-    if ((rc = allow_lds(k_sym_hash<512, 14>, sym_lds(512, 14)))) return rc;
-    if ((rc = allow_lds(k_sym_hash<1024, 15>, sym_lds(1024, 15)))) return rc;
-    if ((rc = allow_lds(k_num_hash<8, 6>, num_lds(8, 6)))) return rc;
-    if ((rc = allow_lds(k_num_hash<32, 8>, num_lds(32, 8)))) return rc;
-    if ((rc = allow_lds(k_num_hash<64, 10>, num_lds(64, 10)))) return rc;
-    if ((rc = allow_lds(k_num_hash<256, 12>, num_lds(256, 12)))) return rc;
-    if ((rc = allow_lds(k_num_hash<1024, 13>, num_lds(1024, 13)))) return rc;
+    if ((rc = allow_lds(k_sym_hash<8, 6>, sym_lds<8, 6>()))) return rc;
+    if ((rc = allow_lds(k_sym_hash<16, 8>, sym_lds<16, 8>()))) return rc;
+    if ((rc = allow_lds(k_sym_hash<64, 10>, sym_lds<64, 10>()))) return rc;
+    if ((rc = allow_lds(k_sym_hash<256, 12>, sym_lds<256, 12>()))) return rc;
+    if ((rc = allow_lds(k_sym_hash<512, 14>, sym_lds<512, 14>()))) return rc;
+    if ((rc = allow_lds(k_sym_hash<1024, 15>, sym_lds<1024, 15>()))) return rc;
+    if ((rc = allow_lds(k_num_hash<8, 6>, num_lds<8, 6>()))) return rc;
+    if ((rc = allow_lds(k_num_hash<16, 7>, num_lds<16, 7>()))) return rc;
+    if ((rc = allow_lds(k_num_hash<32, 8>, num_lds<32, 8>()))) return rc;
+    if ((rc = allow_lds(k_num_hash<32, 9>, num_lds<32, 9>()))) return rc;
+    if ((rc = allow_lds(k_num_hash<64, 10>, num_lds<64, 10>()))) return rc;
+    if ((rc = allow_lds(k_num_hash<128, 11>, num_lds<128, 11>()))) return rc;
+    if ((rc = allow_lds(k_num_hash<256, 12>, num_lds<256, 12>()))) return rc;
+    if ((rc = allow_lds(k_num_hash<1024, 13>, num_lds<1024, 13>()))) return rc;
     *out = c.release();
     return SPADA_OK;
 }
@@ -416,14 +411,12 @@ int spada_dev_spgemm_symbolic(spada_ctx *c, const spada_dev_csr *a, const spada_
         uint32_t off[SPADA_N_BINS + 1];
         off[0] = 0;
         for (int k = 0; k < SPADA_N_BINS; ++k) off[k + 1] = off[k] + cnt[k];
-        const double avg_b = b->rows ? (double)b->nnz / (double)b->rows : 1.0;
-        const int log2S = pow2_ceil_log2(avg_b);
-        if ((rc = launch_sym<8, 6>(c, off[2], cnt[2], log2S))) return rc;
-        if ((rc = launch_sym<16, 8>(c, off[3], cnt[3], log2S))) return rc;
-        if ((rc = launch_sym<64, 10>(c, off[4], cnt[4], log2S))) return rc;
-        if ((rc = launch_sym<256, 12>(c, off[5], cnt[5], log2S))) return rc;
-        if ((rc = launch_sym<512, 14>(c, off[6], cnt[6], log2S))) return rc;
-        if ((rc = launch_sym<1024, 15>(c, off[7], cnt[7], log2S))) return rc;
+        if ((rc = launch_sym<8, 6>(c, off[2], cnt[2]))) return rc;
+        if ((rc = launch_sym<16, 8>(c, off[3], cnt[3]))) return rc;
+        if ((rc = launch_sym<64, 10>(c, off[4], cnt[4]))) return rc;
+        if ((rc = launch_sym<256, 12>(c, off[5], cnt[5]))) return rc;
+        if ((rc = launch_sym<512, 14>(c, off[6], cnt[6]))) return rc;
+        if ((rc = launch_sym<1024, 15>(c, off[7], cnt[7]))) return rc;
         if (cnt[8]) {
             if ((rc = ensure_spill(c, cnt[8], false))) return rc;
             const uint64_t words = ((b->cols + 31) / 32 + 3) & ~3ull;
@@ -476,7 +469,7 @@ int spada_dev_spgemm_symbolic(spada_ctx *c, const spada_dev_csr *a, const spada_
         st.sym_bin_rows[k] = c->h_sym_counts[k];
         st.num_bin_rows[k] = c->h_num_counts[k];
     }
-    st.spill_rows = c->h_sym_counts[8] + c->h_num_counts[7];
+    st.spill_rows = c->h_sym_counts[SYM_SPILL_BIN] + c->h_num_counts[NUM_SPILL_BIN];
     st.workspace_bytes = c->ws_bytes;
     return SPADA_OK;
 }

@@ -33,16 +33,19 @@ struct DevCsrView {
 };
 
 // ---- bin definitions (host and device agree through these) -------------------------------------------
-// symbolic bins, by P = products of the row and L = nnz of the A row
+// symbolic bins, by P = products of the row and L = nnz of the A row (table must hold up to P keys)
 //   0: P == 0 (empty C row)          1: L == 1 (C row = scaled B row, nnz = P; no kernel)
 //   2: P <= 32    G=8    T=64        3: P <= 128   G=16   T=256      4: P <= 512   G=64  T=1024
 //   5: P <= 2048  G=256  T=4096      6: P <= 8192  G=512  T=16384    7: P <= 24576 G=1024 T=32768
 //   8: spill (bitmap in HBM)
-// numeric bins, by n = nnz(C row), P and L
+// numeric bins, by n = nnz(C row) (known exactly now), P and L: table T = 2 n_max, G lanes per row,
+// and at most 64 products per lane
 //   0: n == 0                        1: L == 1 (scaled copy kernel)
-//   2: n <= 32  & P <= 128   G=8  T=64      3: n <= 128 & P <= 1024  G=16  T=256
-//   4: n <= 512 & P <= 8192  G=64 T=1024    5: n <= 2048 & P <= 65536 G=256 T=4096
-//   6: n <= 6144             G=1024 T=8192  7: spill (dense f64 slab in HBM)
+//   2: n <= 32   G=8   T=64          3: n <= 64   G=16  T=128         4: n <= 128  G=32  T=256
+//   5: n <= 256  G=32  T=512         6: n <= 512  G=64  T=1024        7: n <= 1024 G=128 T=2048
+//   8: n <= 2048 G=256 T=4096        9: n <= 6144 G=1024 T=8192      10: spill (bitmap-ranked C row in HBM)
+constexpr int NUM_SPILL_BIN = 10;
+constexpr int SYM_SPILL_BIN = 8;
 __host__ __device__ inline int sym_bin_of(uint64_t P, uint32_t L)
 {
     if (P == 0) return 0;
@@ -59,8 +62,9 @@ __host__ __device__ inline int num_bin_of(uint32_t n, uint64_t P, uint32_t L)
 {
     if (n == 0) return 0;
     if (L == 1) return 1;
-    int bn = n <= 32 ? 2 : n <= 128 ? 3 : n <= 512 ? 4 : n <= 2048 ? 5 : n <= 6144 ? 6 : 7;
-    int bp = P <= 128 ? 2 : P <= 1024 ? 3 : P <= 8192 ? 4 : P <= 65536 ? 5 : 6;
+    const int bn = n <= 32 ? 2 : n <= 64 ? 3 : n <= 128 ? 4 : n <= 256 ? 5 : n <= 512 ? 6 : n <= 1024 ? 7 : n <= 2048 ? 8
+                 : n <= 6144 ? 9 : 10;
+    const int bp = P <= 512 ? 2 : P <= 1024 ? 3 : P <= 2048 ? 4 : P <= 4096 ? 6 : P <= 8192 ? 7 : P <= 16384 ? 8 : 9;
     return bn > bp ? bn : bp;
 }
 
@@ -377,21 +381,139 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_apply(const uint32_t *__res
     if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = tile_sums[ntiles];
 }
 
-// ---- 3. symbolic: LDS hash set per row -------------------------------------------------------------------
-// Group of G lanes per row, T-entry key table per row.  Inside the group, sub-groups of S = 2^log2S lanes
-// take one A nonzero each and stride over its B row (S follows the average B row length, so that short B
-// rows do not idle most of the group and long ones are still read with adjacent lanes on adjacent columns).
+// ---- 3. balanced walk over the products of one A row --------------------------------------------------------
+// The G lanes of a group take the row's A nonzeros G at a time: lane j loads (k, a_ik, B.ptr[k], nnz(B_k)),
+// an exclusive scan of the B row lengths gives every product of the chunk a dense index p, and the lanes
+// then stride over p.  The owner of p is found by a branch-free binary search in LDS.  Adjacent lanes read
+// adjacent B entries whenever they fall into the same B row (coalesced 4 B / 8 B loads), every lane has
+// the same number of products whatever the row-length skew, and four independent gathers per lane are in
+// flight before the first LDS atomic.
+// LDS scratch per group: b0 u64[G] | av f64[G] (numeric only) | off u32[G + 2].
+template <int G, bool NUMERIC>
+__host__ __device__ constexpr size_t walk_scratch_bytes()
+{
+    return (size_t)G * 8 + (NUMERIC ? (size_t)G * 8 : 0) + ((size_t)G + 2) * 4;
+}
+
+// exclusive scan of one u32 per lane across the group; *total = group sum
+template <int G>
+__device__ inline uint32_t group_scan_excl(uint32_t v, int gl, uint32_t *wtot, uint32_t *total)
+{
+    constexpr int W = G < 64 ? G : 64;
+    const int wl = (G < 64) ? gl : (gl & 63);
+    uint32_t inc = v;
+#pragma unroll
+    for (int o = 1; o < W; o <<= 1) {
+        uint32_t t = __shfl_up(inc, o, W);
+        if (wl >= o) inc += t;
+    }
+    if constexpr (G <= 64) {
+        *total = __shfl(inc, W - 1, W);
+        return inc - v;
+    } else {
+        const int w = gl >> 6;
+        __syncthreads();
+        if (wl == 63) wtot[w] = inc;
+        __syncthreads();
+        uint32_t add = 0, tot = 0;
+#pragma unroll
+        for (int k = 0; k < G / 64; ++k) {
+            const uint32_t t = wtot[k];
+            if (k < w) add += t;
+            tot += t;
+        }
+        *total = tot;
+        return inc - v + add;
+    }
+}
+
+template <int G, bool NUMERIC, class F>
+__device__ inline void walk_products(const DevCsrView &A, const DevCsrView &B, uint64_t a0, uint64_t a1, int gl,
+                                     unsigned char *scratch, uint32_t *hdr, F &&f)
+{
+    uint64_t *s_b0 = (uint64_t *)scratch;
+    double *s_av = (double *)(scratch + (size_t)G * 8);
+    uint32_t *s_off = (uint32_t *)(scratch + (size_t)G * 8 + (NUMERIC ? (size_t)G * 8 : 0));
+    constexpr int U = 4;
+    for (uint64_t base = a0; base < a1; base += G) {
+        const uint64_t a = base + gl;
+        uint64_t b0 = 0;
+        uint32_t len = 0;
+        double av = 0.0;
+        if (a < a1) {
+            const uint32_t k = A.idx[a];
+            if constexpr (NUMERIC) av = A.val[a];
+            b0 = B.ptr[k];
+            len = (uint32_t)(B.ptr[k + 1] - b0);
+        }
+        const uint32_t maxlen = group_max<G>(len, hdr);
+        uint32_t total;
+        const uint32_t off = group_scan_excl<G>(len, gl, hdr + 2, &total);
+        s_b0[gl] = b0;
+        if constexpr (NUMERIC) s_av[gl] = av;
+        s_off[gl] = off;
+        if (gl == G - 1) s_off[G] = total;
+        group_sync<G>();
+        if (maxlen < (0xFFFFFFFFu / G)) {
+            for (uint32_t p0 = gl; p0 < total; p0 += U * G) {
+                uint32_t c[U];
+                double v[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const uint32_t p = p0 + u * G;
+                    c[u] = EMPTY_KEY;
+                    v[u] = 0.0;
+                    if (p < total) {
+                        int j = 0;
+#pragma unroll
+                        for (int step = G / 2; step >= 1; step >>= 1)
+                            if (s_off[j + step] <= p) j += step;
+                        const uint64_t q = s_b0[j] + (p - s_off[j]);
+                        c[u] = B.idx[q];
+                        if constexpr (NUMERIC) v[u] = s_av[j] * B.val[q];   // simulator.rs:100-101
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    if (c[u] != EMPTY_KEY) f(c[u], v[u]);
+            }
+        } else {
+            // a B row so long that 32-bit product indices of the chunk could wrap: one B row at a time
+            const int cnt = (int)((a1 - base) < (uint64_t)G ? (a1 - base) : (uint64_t)G);
+            for (int j = 0; j < cnt; ++j) {
+                const uint64_t jb0 = s_b0[j];
+                const uint32_t jlen = s_off[j + 1] - s_off[j];   // exact modulo 2^32
+                for (uint32_t t = gl; t < jlen; t += G) {
+                    double v = 0.0;
+                    if constexpr (NUMERIC) v = s_av[j] * B.val[jb0 + t];
+                    f(B.idx[jb0 + t], v);
+                }
+            }
+        }
+        group_sync<G>();
+    }
+}
+
+// ---- 4. symbolic: LDS hash set per row -------------------------------------------------------------------
+// Group of G lanes per row, T-entry key table per row.  LDS: 128 B header | per row: keys u32[T] | walk scratch.
 template <int G, int LOG_T>
-__global__ __launch_bounds__((G < 256 ? 256 : G)) void k_sym_hash(DevCsrView A, DevCsrView B, uint64_t r0,
+__host__ __device__ constexpr size_t sym_row_bytes()
+{
+    return (((size_t)4 << LOG_T) + walk_scratch_bytes<G, false>() + 15) & ~(size_t)15;
+}
+
+template <int G, int LOG_T>
+__global__ __launch_bounds__((G <= 64 ? 256 : G)) void k_sym_hash(DevCsrView A, DevCsrView B, uint64_t r0,
                                                                    const uint32_t *__restrict__ bin_rows, uint32_t n_bin_rows,
-                                                                   int log2S, uint32_t *__restrict__ row_nnzc)
+                                                                   uint32_t *__restrict__ row_nnzc)
 {
     constexpr int T = 1 << LOG_T;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint32_t *hdr = (uint32_t *)smem;                     // 128 B header (group reductions when G > 64)
-    uint32_t *keys = (uint32_t *)(smem + 128) + (threadIdx.x / G) * T;
+    uint32_t *hdr = (uint32_t *)smem;   // 128 B header: [0..1] reductions, [2..17] wave totals
+    unsigned char *mine = smem + 128 + (size_t)(threadIdx.x / G) * sym_row_bytes<G, LOG_T>();
+    uint32_t *keys = (uint32_t *)mine;
     const int gl = threadIdx.x % G;
-    const uint32_t slot = blockIdx.x * ((G < 256 ? 256 : G) / G) + threadIdx.x / G;
+    const uint32_t slot = blockIdx.x * ((G <= 64 ? 256 : G) / G) + threadIdx.x / G;
     const bool active = slot < n_bin_rows;
     for (int s = gl; s < T; s += G) keys[s] = EMPTY_KEY;
     group_sync<G>();
@@ -399,40 +521,40 @@ __global__ __launch_bounds__((G < 256 ? 256 : G)) void k_sym_hash(DevCsrView A, 
     if (active) {
         row = bin_rows[slot];
         const uint64_t a0 = A.ptr[r0 + row], a1 = A.ptr[r0 + row + 1];
-        const int S = 1 << log2S, sub = gl >> log2S, sl = gl & (S - 1), nsub = G >> log2S;
-        for (uint64_t a = a0 + sub; a < a1; a += nsub) {
-            const uint32_t k = A.idx[a];
-            const uint64_t b0 = B.ptr[k], b1 = B.ptr[k + 1];
-            for (uint64_t q = b0 + sl; q < b1; q += S) {
-                const uint32_t c = B.idx[q];
-                uint32_t h = hash_slot<LOG_T>(c);
-                for (;;) {
-                    const uint32_t old = atomicCAS(&keys[h], EMPTY_KEY, c);
-                    if (old == EMPTY_KEY) { ++cnt; break; }
-                    if (old == c) break;
-                    h = (h + 1) & (T - 1);
-                }
+        walk_products<G, false>(A, B, a0, a1, gl, mine + ((size_t)4 << LOG_T), hdr, [&](uint32_t c, double) {
+            uint32_t h = hash_slot<LOG_T>(c);
+            for (;;) {
+                const uint32_t old = atomicCAS(&keys[h], EMPTY_KEY, c);
+                if (old == EMPTY_KEY) { ++cnt; break; }
+                if (old == c) break;
+                h = (h + 1) & (T - 1);
             }
-        }
+        });
     }
     cnt = group_sum<G>(cnt, hdr);
     if (active && gl == 0) row_nnzc[row] = cnt;
 }
 
-// ---- 4. numeric: LDS hash accumulator + ordered emission ---------------------------------------------------
-// LDS per row: keys u32[T] | vals f64[T] | cnt u32[T/2] | list u16[T]   = 16 T bytes.
+// ---- 5. numeric: LDS hash accumulator + ordered emission ---------------------------------------------------
+// LDS per row: keys u32[T] | vals f64[T] | cnt u32[T/2] | list u16[T] | walk scratch.
 template <int G, int LOG_T>
-__global__ __launch_bounds__((G < 256 ? 256 : G)) void k_num_hash(DevCsrView A, DevCsrView B, uint64_t r0,
+__host__ __device__ constexpr size_t num_row_bytes()
+{
+    return (((size_t)16 << LOG_T) + walk_scratch_bytes<G, true>() + 15) & ~(size_t)15;
+}
+
+template <int G, int LOG_T>
+__global__ __launch_bounds__((G <= 64 ? 256 : G)) void k_num_hash(DevCsrView A, DevCsrView B, uint64_t r0,
                                                                    const uint32_t *__restrict__ bin_rows, uint32_t n_bin_rows,
-                                                                   int log2S, const uint64_t *__restrict__ cptr,
+                                                                   const uint64_t *__restrict__ cptr,
                                                                    uint32_t *__restrict__ c_idx, double *__restrict__ c_val)
 {
     constexpr int T = 1 << LOG_T;
     constexpr int NB = T / 2;
-    constexpr int BLOCK = G < 256 ? 256 : G;
+    constexpr int BLOCK = G <= 64 ? 256 : G;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *hdr = (uint32_t *)smem;   // 128 B: [0..1] reductions, [2..17] wave totals
-    unsigned char *mine = smem + 128 + (size_t)(threadIdx.x / G) * (16 * T);
+    unsigned char *mine = smem + 128 + (size_t)(threadIdx.x / G) * num_row_bytes<G, LOG_T>();
     uint32_t *keys = (uint32_t *)mine;
     double *vals = (double *)(mine + 4 * T);
     uint32_t *cnt = (uint32_t *)(mine + 12 * T);
@@ -452,56 +574,50 @@ __global__ __launch_bounds__((G < 256 ? 256 : G)) void k_num_hash(DevCsrView A, 
     if (active) {
         row = bin_rows[slot];
         const uint64_t a0 = A.ptr[r0 + row], a1 = A.ptr[r0 + row + 1];
-        const int S = 1 << log2S, sub = gl >> log2S, sl = gl & (S - 1), nsub = G >> log2S;
-        for (uint64_t a = a0 + sub; a < a1; a += nsub) {
-            const uint32_t k = A.idx[a];
-            const double av = A.val[a];
-            const uint64_t b0 = B.ptr[k], b1 = B.ptr[k + 1];
-            for (uint64_t q = b0 + sl; q < b1; q += S) {
-                const uint32_t c = B.idx[q];
-                const double v = av * B.val[q];          // simulator.rs:100-101
-                uint32_t h = hash_slot<LOG_T>(c);
-                for (;;) {
-                    const uint32_t old = atomicCAS(&keys[h], EMPTY_KEY, c);
-                    if (old == EMPTY_KEY || old == c) break;
-                    h = (h + 1) & (T - 1);
-                }
-                atomicAdd(&vals[h], v);                  // simulator.rs:213-218 (order differs)
+        walk_products<G, true>(A, B, a0, a1, gl, mine + 16 * T, hdr, [&](uint32_t c, double v) {
+            uint32_t h = hash_slot<LOG_T>(c);
+            for (;;) {
+                const uint32_t old = atomicCAS(&keys[h], EMPTY_KEY, c);
+                if (old == EMPTY_KEY || old == c) break;
+                h = (h + 1) & (T - 1);
             }
-        }
+            atomicAdd(&vals[h], v);   // simulator.rs:213-218 (order differs)
+        });
     }
     group_sync<G>();
 
     // ---- ordered emission: monotone buckets over [kmin, kmax], scan, in-bucket rank ---------------------
+    // each lane keeps its T/G table keys in registers for the three passes over the table
+    constexpr int SPL = T / G;
+    uint32_t myk[SPL];
     uint32_t kmin = 0xFFFFFFFFu, kmax = 0;
-    for (int s = gl; s < T; s += G) {
-        const uint32_t k = keys[s];
-        if (k != EMPTY_KEY) {
-            kmin = min(kmin, k);
-            kmax = max(kmax, k);
+#pragma unroll
+    for (int i = 0; i < SPL; ++i) {
+        myk[i] = keys[gl + i * G];
+        if (myk[i] != EMPTY_KEY) {
+            kmin = min(kmin, myk[i]);
+            kmax = max(kmax, myk[i]);
         }
     }
     kmin = group_min<G>(kmin, hdr);
     kmax = group_max<G>(kmax, hdr + 1);
-    // rows without any product cannot be here (nnzc > 0), but an inactive group has an empty table
+    // an inactive group has an empty table (kmin > kmax)
     const float scale = (kmax >= kmin) ? (float)NB / ((float)(kmax - kmin) + 1.0f) : 0.0f;
     auto bucket = [&](uint32_t k) -> uint32_t {
         uint32_t b = (uint32_t)((float)(k - kmin) * scale);
         return b < (uint32_t)NB ? b : (uint32_t)NB - 1;
     };
-    for (int s = gl; s < T; s += G) {
-        const uint32_t k = keys[s];
-        if (k != EMPTY_KEY) atomicAdd(&cnt[bucket(k)], 1u);
-    }
+#pragma unroll
+    for (int i = 0; i < SPL; ++i)
+        if (myk[i] != EMPTY_KEY) atomicAdd(&cnt[bucket(myk[i])], 1u);
     group_sync<G>();
     group_exclusive_scan<G, NB>(cnt, gl, hdr + 2);
-    for (int s = gl; s < T; s += G) {
-        const uint32_t k = keys[s];
-        if (k != EMPTY_KEY) {
-            const uint32_t p = atomicAdd(&cnt[bucket(k)], 1u);   // afterwards cnt[b] = end of bucket b
-            list[p] = (uint16_t)s;
+#pragma unroll
+    for (int i = 0; i < SPL; ++i)
+        if (myk[i] != EMPTY_KEY) {
+            const uint32_t p = atomicAdd(&cnt[bucket(myk[i])], 1u);   // afterwards cnt[b] = end of bucket b
+            list[p] = (uint16_t)(gl + i * G);
         }
-    }
     group_sync<G>();
     if (active) {
         const uint64_t c0 = cptr[row];
@@ -519,7 +635,7 @@ __global__ __launch_bounds__((G < 256 ? 256 : G)) void k_num_hash(DevCsrView A, 
     }
 }
 
-// ---- 5. numeric, rows with a single A nonzero: C row = a * B row (already ascending) ------------------------
+// ---- 6. numeric, rows with a single A nonzero: C row = a * B row (already ascending) ------------------------
 template <int G>
 __global__ __launch_bounds__(256) void k_num_copy(DevCsrView A, DevCsrView B, uint64_t r0,
                                                   const uint32_t *__restrict__ bin_rows, uint32_t n_bin_rows,
@@ -540,103 +656,90 @@ __global__ __launch_bounds__(256) void k_num_copy(DevCsrView A, DevCsrView B, ui
     }
 }
 
-// ---- 6. spill path: rows whose accumulator does not fit LDS ---------------------------------------------------
-// One persistent workgroup of 1024 lanes per slab; slabs live in HBM (288 GB: a dense f64 row per
-// workgroup is cheap) and are touched with device-scope atomics only, so no L1 line can go stale.
+// ---- 7. spill path: rows whose accumulator does not fit LDS ---------------------------------------------------
+// One persistent workgroup of 1024 lanes per row.  Per workgroup, in HBM: a column bitmap (1 bit per column
+// of B) and a per-word prefix-popcount array; both are tiny next to 288 GB and stay L2 resident.  The bitmap
+// gives the row's pattern in ascending order, its prefix popcounts give every column its final position in
+// the C row, and the values are then accumulated with device-scope f64 atomics directly into that (compact,
+// L2-resident) C row -- no dense accumulator, no sort, two walks over the row's products.
+// Words are only ever modified by L2 atomics or by plain stores of this workgroup that are fenced before the
+// next atomic phase; plain loads happen after an agent-scope acquire, so no stale L1 line is ever read.
 constexpr int SPILL_BLOCK = 1024;
+constexpr size_t SPILL_LDS = 128 + walk_scratch_bytes<SPILL_BLOCK, true>();
 
-__device__ inline uint32_t block_sum_u32(uint32_t v, uint32_t *s_w /*[17]*/)
+// This workgroup's plain stores are acknowledged by its XCD's L2 (the vector L1 is write-through) once vmcnt
+// drains; the L2 atomics that follow hit the same L2, so no L2 write-back (`buffer_wbl2`, what __threadfence()
+// would add, flushing every dirty line of the XCD while other workgroups stream C through it) is needed.
+__device__ inline void stores_to_l2() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// pass A of both phases: set the bit of every product column; returns the touched word range [lo, hi]
+__device__ inline void spill_mark(const DevCsrView &A, const DevCsrView &B, uint64_t a0, uint64_t a1,
+                                  unsigned char *smem, uint32_t *hdr, uint32_t *bm, uint32_t *lo, uint32_t *hi)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    uint32_t wlo = 0xFFFFFFFFu, whi = 0;
+    walk_products<SPILL_BLOCK, false>(A, B, a0, a1, threadIdx.x, smem + 128, hdr, [&](uint32_t c, double) {
+        atomicOr(&bm[c >> 5], 1u << (c & 31));
+        wlo = min(wlo, c >> 5);
+        whi = max(whi, c >> 5);
+    });
+    *lo = group_min<SPILL_BLOCK>(wlo, hdr);
+    *hi = group_max<SPILL_BLOCK>(whi, hdr + 1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // drop L1 lines of bm that predate the atomics
     __syncthreads();
-    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = v;
-    __syncthreads();
-    uint32_t t = 0;
-    for (int k = 0; k < SPILL_BLOCK / 64; ++k) t += s_w[k];
-    return t;
 }
 
-// symbolic: bitmap (1 bit per column) per workgroup; count newly set bits; clear by a second walk.
 __global__ __launch_bounds__(SPILL_BLOCK) void k_sym_spill(DevCsrView A, DevCsrView B, uint64_t r0,
                                                            const uint32_t *__restrict__ bin_rows, uint32_t n_bin_rows,
                                                            uint32_t *__restrict__ bitmaps, uint64_t words_per_slab,
                                                            uint32_t *__restrict__ row_nnzc)
 {
-    __shared__ uint32_t s_w[SPILL_BLOCK / 64 + 1];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[SPILL_LDS];
+    uint32_t *hdr = (uint32_t *)smem;
     uint32_t *bm = bitmaps + (uint64_t)blockIdx.x * words_per_slab;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    constexpr int NW = SPILL_BLOCK / 64;
     for (uint32_t slot = blockIdx.x; slot < n_bin_rows; slot += gridDim.x) {
         const uint32_t row = bin_rows[slot];
         const uint64_t a0 = A.ptr[r0 + row], a1 = A.ptr[r0 + row + 1];
+        uint32_t lo, hi;
+        spill_mark(A, B, a0, a1, smem, hdr, bm, &lo, &hi);
         uint32_t cnt = 0;
-        for (uint64_t a = a0 + wave; a < a1; a += NW) {   // one wave per A nonzero, lanes over the B row
-            const uint32_t k = A.idx[a];
-            const uint64_t b0 = B.ptr[k], b1 = B.ptr[k + 1];
-            for (uint64_t q = b0 + lane; q < b1; q += 64) {
-                const uint32_t c = B.idx[q];
-                const uint32_t bit = 1u << (c & 31);
-                const uint32_t old = atomicOr(&bm[c >> 5], bit);
-                cnt += (old & bit) ? 0u : 1u;
+        if (lo != 0xFFFFFFFFu)
+            for (uint32_t w = lo + threadIdx.x; w <= hi; w += SPILL_BLOCK) {
+                cnt += __popc(bm[w]);
+                bm[w] = 0;
             }
-        }
-        cnt = block_sum_u32(cnt, s_w);
+        cnt = group_sum<SPILL_BLOCK>(cnt, hdr);
         if (threadIdx.x == 0) row_nnzc[row] = cnt;
-        for (uint64_t a = a0 + wave; a < a1; a += NW) {   // clear the touched words again
-            const uint32_t k = A.idx[a];
-            const uint64_t b0 = B.ptr[k], b1 = B.ptr[k + 1];
-            for (uint64_t q = b0 + lane; q < b1; q += 64) atomicAnd(&bm[B.idx[q] >> 5], 0u);
-        }
+        stores_to_l2();    // the clears reach L2 before the next row's atomics
         __syncthreads();
     }
 }
 
-// numeric: dense f64 slab + bitmap per workgroup; emission walks the bitmap in ascending order.
 __global__ __launch_bounds__(SPILL_BLOCK) void k_num_spill(DevCsrView A, DevCsrView B, uint64_t r0,
                                                            const uint32_t *__restrict__ bin_rows, uint32_t n_bin_rows,
-                                                           uint32_t *__restrict__ bitmaps, uint64_t words_per_slab,
-                                                           double *__restrict__ slabs, uint64_t cols,
-                                                           const uint64_t *__restrict__ cptr, uint32_t *__restrict__ c_idx,
-                                                           double *__restrict__ c_val)
+                                                           uint32_t *__restrict__ bitmaps, uint32_t *__restrict__ prefixes,
+                                                           uint64_t words_per_slab, const uint64_t *__restrict__ cptr,
+                                                           uint32_t *__restrict__ c_idx, double *__restrict__ c_val)
 {
-    __shared__ uint32_t s_w[SPILL_BLOCK / 64 + 1];
-    __shared__ uint32_t s_lo, s_hi;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[SPILL_LDS];
+    uint32_t *hdr = (uint32_t *)smem;    // [0..1] reductions, [2..17] wave totals
     uint32_t *bm = bitmaps + (uint64_t)blockIdx.x * words_per_slab;
-    double *acc = slabs + (uint64_t)blockIdx.x * cols;
+    uint32_t *pre = prefixes + (uint64_t)blockIdx.x * words_per_slab;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     constexpr int NW = SPILL_BLOCK / 64;
     for (uint32_t slot = blockIdx.x; slot < n_bin_rows; slot += gridDim.x) {
         const uint32_t row = bin_rows[slot];
         const uint64_t a0 = A.ptr[r0 + row], a1 = A.ptr[r0 + row + 1];
-        if (threadIdx.x == 0) { s_lo = 0xFFFFFFFFu; s_hi = 0; }
-        __syncthreads();
-        uint32_t wlo = 0xFFFFFFFFu, whi = 0;
-        for (uint64_t a = a0 + wave; a < a1; a += NW) {
-            const uint32_t k = A.idx[a];
-            const double av = A.val[a];
-            const uint64_t b0 = B.ptr[k], b1 = B.ptr[k + 1];
-            for (uint64_t q = b0 + lane; q < b1; q += 64) {
-                const uint32_t c = B.idx[q];
-                const double v = av * B.val[q];
-                atomicAdd(&acc[c], v);
-                atomicOr(&bm[c >> 5], 1u << (c & 31));
-                wlo = min(wlo, c >> 5);
-                whi = max(whi, c >> 5);
-            }
-        }
-        if (wlo != 0xFFFFFFFFu) { atomicMin(&s_lo, wlo); atomicMax(&s_hi, whi); }
-        __threadfence();
-        __syncthreads();
         const uint64_t c0 = cptr[row];
-        const uint32_t lo = s_lo, hi = s_hi;
-        uint32_t emitted = 0;
+        const uint32_t n = (uint32_t)(cptr[row + 1] - c0);
+        uint32_t lo, hi;
+        spill_mark(A, B, a0, a1, smem, hdr, bm, &lo, &hi);
+        // pass B: prefix popcounts over [lo, hi]; emit the column indices; zero the value row
+        uint32_t running = 0;
         if (lo != 0xFFFFFFFFu) {
             for (uint32_t wbase = lo; wbase <= hi; wbase += SPILL_BLOCK) {
                 const uint32_t w = wbase + threadIdx.x;
-                uint32_t bits = (w <= hi) ? atomicExch(&bm[w], 0u) : 0u;
+                uint32_t bits = (w <= hi) ? bm[w] : 0u;
                 const uint32_t pc = __popc(bits);
-                // block exclusive scan of pc
                 uint32_t inc = pc;
 #pragma unroll
                 for (int o = 1; o < 64; o <<= 1) {
@@ -644,26 +747,39 @@ __global__ __launch_bounds__(SPILL_BLOCK) void k_num_spill(DevCsrView A, DevCsrV
                     if (lane >= o) inc += t;
                 }
                 __syncthreads();
-                if (lane == 63) s_w[wave] = inc;
+                if (lane == 63) hdr[2 + wave] = inc;
                 __syncthreads();
                 uint32_t add = 0, tot = 0;
+#pragma unroll
                 for (int k2 = 0; k2 < NW; ++k2) {
-                    if (k2 < wave) add += s_w[k2];
-                    tot += s_w[k2];
+                    const uint32_t t = hdr[2 + k2];
+                    if (k2 < wave) add += t;
+                    tot += t;
                 }
-                uint64_t out = c0 + emitted + add + (inc - pc);
+                uint32_t out = running + add + (inc - pc);
+                if (w <= hi) pre[w] = out;
                 while (bits) {
                     const int b = __ffs((int)bits) - 1;
                     bits &= bits - 1;
-                    const uint32_t c = (w << 5) + (uint32_t)b;
-                    c_idx[out] = c;
-                    // read-and-reset in one device-scope atomic (served by L2, never by a stale L1 line)
-                    c_val[out] = __longlong_as_double((long long)atomicExch((unsigned long long *)&acc[c], 0ull));
+                    c_idx[c0 + out] = (w << 5) + (uint32_t)b;
                     ++out;
                 }
-                emitted += tot;
+                running += tot;
             }
         }
+        for (uint32_t i = threadIdx.x; i < n; i += SPILL_BLOCK) c_val[c0 + i] = 0.0;
+        stores_to_l2();    // zeros and prefixes are in L2 before any atomic of pass C
+        __syncthreads();
+        // pass C: accumulate every product at its final position
+        walk_products<SPILL_BLOCK, true>(A, B, a0, a1, threadIdx.x, smem + 128, hdr, [&](uint32_t c, double v) {
+            const uint32_t w = c >> 5;
+            const uint32_t pos = pre[w] + __popc(bm[w] & ((1u << (c & 31)) - 1u));
+            atomicAdd(&c_val[c0 + pos], v);
+        });
+        __syncthreads();
+        if (lo != 0xFFFFFFFFu)
+            for (uint32_t w = lo + threadIdx.x; w <= hi; w += SPILL_BLOCK) bm[w] = 0;
+        stores_to_l2();
         __syncthreads();
     }
 }

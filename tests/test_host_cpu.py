@@ -1,0 +1,182 @@
+"""CPU: the host half of libspada_spgemm.so (no GPU needed) -- MatrixMarket ingest against the
+reference loader's outputs, GEMM::from_mat, partitioning, configuration, C-ABI surface."""
+import ctypes
+import hashlib
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT, to_oracle
+from oracle import oracle
+
+import spada_sim_amd as S
+from spada_sim_amd import _ffi
+
+MTX = ["general_unsorted_dups", "symmetric", "skew", "pattern_sym", "integer_rect", "pattern_general"]
+
+
+def test_library_exports_every_symbol_of_the_header():
+    """Every function include/spada_ffi.h declares is exported, and nothing is missing from the binding."""
+    hdr = open(os.path.join(ROOT, "include", "spada_ffi.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(spada_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"spada_options", "spada_stats", "spada_config"}
+    assert len(declared) >= 25
+    L = ctypes.CDLL(_ffi.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(L, name), f"{name} declared in spada_ffi.h but not exported"
+    assert declared == set(_ffi.SIGNATURES), declared ^ set(_ffi.SIGNATURES)
+    assert _ffi.lib().spada_abi_version() == 1
+
+
+def test_struct_layouts_match_the_header():
+    assert ctypes.sizeof(_ffi.CsrView) == 48
+    assert ctypes.sizeof(_ffi.Options) == 16
+    assert ctypes.sizeof(_ffi.Stats) == 7 * 8 + 7 * 8 + 2 * 12 * 8 + 2 * 8
+
+
+def test_cari_loader_pins(matrices_dir):
+    """Outputs of the reference's embedded Python loader on cari.mtx (py2rust.rs:64-79)."""
+    g = np.load(os.path.join(GOLDEN, "cari_loader.npz"))
+    m = S.load_mm_mat(matrices_dir, "cari")
+    assert m.shape == tuple(int(x) for x in g["shape"]) == (400, 1200)
+    assert m.nnz() == int(g["nnz"]) == 152800
+    assert np.array_equal(m.indptr, g["indptr"])
+    assert hashlib.sha256(m.indices.tobytes()).hexdigest() == str(g["indices_sha256"])
+    assert hashlib.sha256(m.data.tobytes()).hexdigest() == str(g["data_sha256"])   # bit-exact value parsing
+    assert np.array_equal(m.indices[:16], g["indices_head"]) and np.array_equal(m.data[:16], g["data_head"])
+    m.validate()
+
+
+@pytest.mark.parametrize("name", MTX)
+def test_mtx_variants_match_reference_loader(name):
+    g = np.load(os.path.join(GOLDEN, "mtx_loader.npz"))
+    m = S.load_mm_mat(os.path.join(GOLDEN, "mtx"), name)
+    assert m.shape == tuple(int(x) for x in g[name + "_shape"])
+    assert np.array_equal(m.indptr, g[name + "_indptr"])
+    assert np.array_equal(m.indices, g[name + "_indices"])
+    assert np.array_equal(m.data, g[name + "_data"])
+
+
+def test_mtx_errors(tmp_path):
+    with pytest.raises(S.SpadaError) as e:
+        S.load_mm_mat(str(tmp_path), "missing")
+    assert e.value.code == 5
+    (tmp_path / "dense.mtx").write_text("%%MatrixMarket matrix array real general\n2 2\n1\n2\n3\n4\n")
+    with pytest.raises(S.SpadaError) as e:
+        S.load_mm_mat(str(tmp_path), "dense")
+    assert e.value.code == 8
+    (tmp_path / "short.mtx").write_text("%%MatrixMarket matrix coordinate real general\n2 2 3\n1 1 1.0\n")
+    with pytest.raises(S.SpadaError) as e:
+        S.load_mm_mat(str(tmp_path), "short")
+    assert e.value.code == 6
+    (tmp_path / "oob.mtx").write_text("%%MatrixMarket matrix coordinate real general\n2 2 1\n3 1 1.0\n")
+    with pytest.raises(S.SpadaError):
+        S.load_mm_mat(str(tmp_path), "oob")
+
+
+def test_mtx_write_read_round_trip(tmp_path):
+    m = S.generate(S.GEN_UNIFORM, 200, 5, 3)
+    S.write_mm_mat(tmp_path / "rt.mtx", m)
+    r = S.load_mm_mat(str(tmp_path), "rt")
+    assert r.shape == m.shape and np.array_equal(r.indptr, m.indptr) and np.array_equal(r.indices, m.indices)
+    assert np.array_equal(r.data, m.data)   # %.17g round-trips f64
+
+
+def test_from_mat_rule_and_transpose(matrices_dir):
+    m = S.load_mm_mat(matrices_dir, "cari")
+    g = S.GEMM.from_mat("cari", m)
+    assert g.a is m and g.b.shape == (1200, 400)          # non-square => A * A^T (gemm.rs:45-47)
+    ref = oracle.transpose(to_oracle(m))
+    assert np.array_equal(g.b.indptr, ref.indptr) and np.array_equal(g.b.indices, ref.indices)
+    assert np.array_equal(g.b.data, ref.data)
+    sq = S.generate(S.GEN_UNIFORM, 64, 4, 1)
+    assert S.GEMM.from_mat("sq", sq).b is sq              # square => A * A (gemm.rs:43-44)
+    a, b = S.CsrMatStorage.init_with_gemm(g)
+    assert a.mat_shape == [1200, 400] and b.mat_shape == [400, 1200]   # [cols, rows], storage.rs:225
+    assert a.row_num() == 400 and a.read_row(3).len() == 382
+
+
+def test_validate_rejects_malformed_csr():
+    bad = S.CsMat((2, 2), np.array([0, 2, 2], np.uint64), np.array([1, 0], np.uint64), np.array([1.0, 2.0]))
+    with pytest.raises(S.SpadaError):
+        bad.validate()
+    bad = S.CsMat((2, 2), np.array([0, 1, 2], np.uint64), np.array([0, 5], np.uint64), np.array([1.0, 2.0]))
+    with pytest.raises(S.SpadaError):
+        bad.validate()
+
+
+def test_partition_rows_balances_products():
+    m = S.generate(S.GEN_RMAT, 12, 8, 5)
+    total = S.count_products(m, m)
+    assert total == oracle.count_products(to_oracle(m), to_oracle(m))
+    for nparts in (1, 2, 3, 8):
+        b = S.partition_rows(m, m, nparts)
+        assert b[0] == 0 and b[-1] == m.shape[0] and all(x <= y for x, y in zip(b, b[1:]))
+        parts = [S.count_products(m, m, r0, r1) for r0, r1 in zip(b[:-1], b[1:])]
+        assert sum(parts) == total
+        if nparts > 1:
+            heaviest_row = max(S.count_products(m, m, r, r + 1) for r in range(0, m.shape[0], 97))
+            assert max(parts) <= total / nparts + max(heaviest_row, total // 50) + m.shape[0]
+
+
+def test_generators_are_deterministic_and_canonical():
+    for kind, p0, p1 in [(S.GEN_RMAT, 10, 8), (S.GEN_WEBBASE_LIKE, 5000, 15000), (S.GEN_COP20K_LIKE, 3000, 0),
+                         (S.GEN_CAGE12_LIKE, 3000, 0), (S.GEN_MC2DEPI_LIKE, 779 * 4, 0), (S.GEN_UNIFORM, 500, 7)]:
+        a = S.generate(kind, p0, p1, 99)
+        b = S.generate(kind, p0, p1, 99)
+        a.validate()
+        assert np.array_equal(a.indptr, b.indptr) and np.array_equal(a.indices, b.indices) and np.array_equal(a.data, b.data)
+        assert a.data.min() >= 0.1          # uniform(0.1, 1.0), duplicates summed
+        c = S.generate(kind, p0, p1, 100)
+        if kind != S.GEN_MC2DEPI_LIKE:      # the stencil's pattern does not depend on the seed
+            assert not np.array_equal(a.indices, c.indices) or not np.array_equal(a.indptr, c.indptr)
+
+
+def test_parse_config(tmp_path):
+    cfg = S.parse_config(os.path.join(ROOT, "config", "config_1mb_row1.json"))
+    assert cfg["ss_filepath"] == "./matrices" and cfg["pe_num"] == 2 and cfg["at_num"] == 16 and cfg["lane_num"] == 8
+    assert cfg["cache_size"] == 1572864 and cfg["word_byte"] == 8 and cfg["block_shape"] == [1, 10000000]
+    assert cfg["mem_latency"] == 30 and cfg["channel"] == 16 and cfg["bandwidth_per_channel"] == 8.0 and cfg["freq"] == 1.0
+    base = json.load(open(os.path.join(ROOT, "config", "config_1mb_row1.json")))
+    for k in ("accumulator", "gpus", "repeat"):
+        base.pop(k)
+    p = tmp_path / "min.json"
+    p.write_text(json.dumps(base))
+    assert S.parse_config(p)["accumulator"] == 0      # optional engine keys default
+    for missing in ("lane_num", "block_shape", "ss_filepath"):
+        d = dict(base)
+        d.pop(missing)
+        p.write_text(json.dumps(d))
+        with pytest.raises(S.SpadaError) as e:       # serde: "missing field `x`"
+            S.parse_config(p)
+        assert e.value.code == 6 and missing in str(e.value)
+    p.write_text("{ not json")
+    with pytest.raises(S.SpadaError):
+        S.parse_config(p)
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    """Without a gfx950 device the engine refuses to exist; nothing computes on the CPU."""
+    if S.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(S.SpadaError) as e:
+        S.Engine()
+    assert e.value.code == 2
+    L = _ffi.lib()
+    nnz = ctypes.c_uint64(0)
+    m = S.generate(S.GEN_UNIFORM, 10, 2, 1)
+    rc = L.spada_spgemm_symbolic(None, ctypes.byref(m.view()), ctypes.byref(m.view()), ctypes.byref(nnz))
+    assert rc == 7    # SPADA_ERR_STATE
+
+
+def test_product_path_does_not_touch_the_oracle():
+    """The package and the native sources never import / link the oracle."""
+    for d, _, files in os.walk(os.path.join(ROOT, "spada_sim_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hpp", ".hip", "Makefile")):
+                text = open(os.path.join(d, f), errors="replace").read()
+                assert "oracle" not in text.replace("oracle_rowwise", ""), f"{f} mentions the oracle"

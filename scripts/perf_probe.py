@@ -31,5 +31,5 @@ for name in names:
     print(f"   {st['c_nnz'] / dev / 1e6:.2f} G nnzC/s   read {st['bytes_read'] / dev / 1e6:.1f} GB/s "
           f"({st['bytes_read'] / dev / 1e6 / 8000 * 100:.2f}% of 8 TB/s)")
     print(f"   sym bins {st['sym_bin_rows'][:9]}")
-    print(f"   num bins {st['num_bin_rows'][:11]}  spill {st['spill_rows']}")
+    print(f"   num bins {st['num_bin_rows'][:12]}  spill {st['spill_rows']}")
     eng.free(d)

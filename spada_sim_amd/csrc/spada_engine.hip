@@ -83,6 +83,10 @@ struct spada_ctx {
     hipStream_t stream = nullptr;
     int accumulator = SPADA_ACC_LDS_HASH;
     hipEvent_t ev[EV_COUNT] = {};
+    // independent bins run concurrently: one side stream per bin, forked from / joined to `stream`
+    hipStream_t side[SPADA_N_BINS] = {};
+    hipEvent_t ev_fork = nullptr, ev_join[SPADA_N_BINS] = {};
+    hipStream_t cur = nullptr;        // stream the launch helpers use
     // state carried from symbolic to numeric
     bool have_symbolic = false;
     const spada_dev_csr *A = nullptr, *B = nullptr;
@@ -95,6 +99,8 @@ struct spada_ctx {
     DevBuf row_nprod, row_nnzc, row_bin, sym_rows, num_rows, counters, cptr, tile_sums, bitmaps, slabs;
     DevBuf own_idx, own_val, own_ptr, wide_idx;
     uint64_t spill_slabs = 0, spill_cols = 0;
+    bool bm_fits = false;             // LDS column bitmap fits for the current B
+    uint32_t bm_vcap = 0;             // value-row capacity of k_num_bitmap<true> (0 = variant unused)
     Counters *h_counters = nullptr;   // pinned
     uint64_t *h_u64 = nullptr;        // pinned
     // matrices uploaded by the host-pointer API
@@ -123,7 +129,7 @@ int launch_sym(spada_ctx *c, uint32_t off, uint32_t n)
     constexpr int BLOCK = G <= 64 ? 256 : G;
     constexpr int RPB = BLOCK / G;
     const uint32_t grid = (n + RPB - 1) / RPB;
-    hipLaunchKernelGGL((k_sym_hash<G, LOG_T>), dim3(grid), dim3(BLOCK), (sym_lds<G, LOG_T>()), c->stream, c->A->view(),
+    hipLaunchKernelGGL((k_sym_hash<G, LOG_T>), dim3(grid), dim3(BLOCK), (sym_lds<G, LOG_T>()), c->cur, c->A->view(),
                        c->B->view(), c->r0, c->sym_rows.as<uint32_t>() + off, n, c->row_nnzc.as<uint32_t>());
     HIP_TRY(hipGetLastError());
     return SPADA_OK;
@@ -136,7 +142,7 @@ int launch_num(spada_ctx *c, uint32_t off, uint32_t n, uint32_t *c_idx, double *
     constexpr int BLOCK = G <= 64 ? 256 : G;
     constexpr int RPB = BLOCK / G;
     const uint32_t grid = (n + RPB - 1) / RPB;
-    hipLaunchKernelGGL((k_num_hash<G, LOG_T>), dim3(grid), dim3(BLOCK), (num_lds<G, LOG_T>()), c->stream, c->A->view(),
+    hipLaunchKernelGGL((k_num_hash<G, LOG_T>), dim3(grid), dim3(BLOCK), (num_lds<G, LOG_T>()), c->cur, c->A->view(),
                        c->B->view(), c->r0, c->num_rows.as<uint32_t>() + off, n, c->cptr.as<uint64_t>(), c_idx, c_val);
     HIP_TRY(hipGetLastError());
     return SPADA_OK;
@@ -160,6 +166,31 @@ int ensure_spill(spada_ctx *c, uint32_t rows_in_bin, bool need_slabs)
     if (rc) return rc;
     if (need_slabs) rc = c->slabs.ensure(c->spill_slabs * words * 4, false, c->stream, &c->ws_bytes);
     return rc;
+}
+
+// fork: side stream `k` starts after everything queued on the main stream so far
+int fork_to(spada_ctx *c, int k)
+{
+    HIP_TRY(hipStreamWaitEvent(c->side[k], c->ev_fork, 0));
+    c->cur = c->side[k];
+    return SPADA_OK;
+}
+// join: the main stream continues after side stream `k`
+int join_from(spada_ctx *c, int k)
+{
+    HIP_TRY(hipEventRecord(c->ev_join[k], c->side[k]));
+    HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join[k], 0));
+    c->cur = c->stream;
+    return SPADA_OK;
+}
+
+constexpr size_t LDS_MAX = 160 * 1024;
+
+// persistent grid for the LDS bitmap kernels: as many workgroups as the LDS footprint admits per CU
+uint32_t bm_grid(uint32_t rows, size_t lds)
+{
+    const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(4, LDS_MAX / lds));
+    return std::min<uint32_t>(rows, 256u * per_cu);
 }
 
 float ev_ms(spada_ctx *c, int a, int b)
@@ -216,29 +247,60 @@ int run_numeric(spada_ctx *c, uint64_t *d_ptr, uint32_t *d_idx, double *d_val)
     off[0] = 0;
     for (int b = 0; b < SPADA_N_BINS; ++b) off[b + 1] = off[b] + cnt[b];
     int rc;
-    if (cnt[1]) {
-        const uint32_t grid = (cnt[1] + 15) / 16;
-        hipLaunchKernelGGL((k_num_copy<16>), dim3(grid), dim3(256), 0, c->stream, c->A->view(), c->B->view(), c->r0,
-                           c->num_rows.as<uint32_t>() + off[1], cnt[1], c->cptr.as<uint64_t>(), d_idx, d_val);
-        HIP_TRY(hipGetLastError());
-    }
-    if ((rc = launch_num<8, 6>(c, off[2], cnt[2], d_idx, d_val))) return rc;
-    if ((rc = launch_num<16, 7>(c, off[3], cnt[3], d_idx, d_val))) return rc;
-    if ((rc = launch_num<32, 8>(c, off[4], cnt[4], d_idx, d_val))) return rc;
-    if ((rc = launch_num<32, 9>(c, off[5], cnt[5], d_idx, d_val))) return rc;
-    if ((rc = launch_num<64, 10>(c, off[6], cnt[6], d_idx, d_val))) return rc;
-    if ((rc = launch_num<128, 11>(c, off[7], cnt[7], d_idx, d_val))) return rc;
-    if ((rc = launch_num<256, 12>(c, off[8], cnt[8], d_idx, d_val))) return rc;
-    if ((rc = launch_num<1024, 13>(c, off[9], cnt[9], d_idx, d_val))) return rc;
+    HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
+    // heaviest bins first; every bin on its own stream
     if (cnt[NUM_SPILL_BIN]) {
         const uint32_t nsp = cnt[NUM_SPILL_BIN];
-        if ((rc = ensure_spill(c, nsp, true))) return rc;
-        const uint64_t words = ((c->B->cols + 31) / 32 + 3) & ~3ull;
-        const uint32_t grid = (uint32_t)std::min<uint64_t>(nsp, c->spill_slabs);
-        hipLaunchKernelGGL(k_num_spill, dim3(grid), dim3(SPILL_BLOCK), 0, c->stream, c->A->view(), c->B->view(), c->r0,
-                           c->num_rows.as<uint32_t>() + off[NUM_SPILL_BIN], nsp, c->bitmaps.as<uint32_t>(),
-                           c->slabs.as<uint32_t>(), words, c->cptr.as<uint64_t>(), d_idx, d_val);
+        if (c->bm_fits) {
+            if ((rc = fork_to(c, NUM_SPILL_BIN))) return rc;
+            const size_t lds = bm_lds_bytes(c->B->cols, 0);
+            hipLaunchKernelGGL(k_num_bitmap<false>, dim3(bm_grid(nsp, lds)), dim3(BM_BLOCK), lds, c->cur, c->A->view(),
+                               c->B->view(), c->r0, c->num_rows.as<uint32_t>() + off[NUM_SPILL_BIN], nsp, c->B->cols, 0u,
+                               c->cptr.as<uint64_t>(), d_idx, d_val);
+        } else {
+            if ((rc = ensure_spill(c, nsp, true))) return rc;
+            if ((rc = fork_to(c, NUM_SPILL_BIN))) return rc;
+            const uint64_t words = ((c->B->cols + 31) / 32 + 3) & ~3ull;
+            const uint32_t grid = (uint32_t)std::min<uint64_t>(nsp, c->spill_slabs);
+            hipLaunchKernelGGL(k_num_spill, dim3(grid), dim3(SPILL_BLOCK), 0, c->cur, c->A->view(), c->B->view(), c->r0,
+                               c->num_rows.as<uint32_t>() + off[NUM_SPILL_BIN], nsp, c->bitmaps.as<uint32_t>(),
+                               c->slabs.as<uint32_t>(), words, c->cptr.as<uint64_t>(), d_idx, d_val);
+        }
         HIP_TRY(hipGetLastError());
+        if ((rc = join_from(c, NUM_SPILL_BIN))) return rc;
+    }
+    if (cnt[NUM_BMV_BIN]) {
+        const uint32_t nb = cnt[NUM_BMV_BIN];
+        if ((rc = fork_to(c, NUM_BMV_BIN))) return rc;
+        const size_t lds = bm_lds_bytes(c->B->cols, c->bm_vcap);
+        hipLaunchKernelGGL(k_num_bitmap<true>, dim3(bm_grid(nb, lds)), dim3(BM_BLOCK), lds, c->cur, c->A->view(),
+                           c->B->view(), c->r0, c->num_rows.as<uint32_t>() + off[NUM_BMV_BIN], nb, c->B->cols, c->bm_vcap,
+                           c->cptr.as<uint64_t>(), d_idx, d_val);
+        HIP_TRY(hipGetLastError());
+        if ((rc = join_from(c, NUM_BMV_BIN))) return rc;
+    }
+#define NUM_BIN(BIN, G, LT)                                                            \
+    if (cnt[BIN]) {                                                                    \
+        if ((rc = fork_to(c, BIN))) return rc;                                         \
+        if ((rc = launch_num<G, LT>(c, off[BIN], cnt[BIN], d_idx, d_val))) return rc;  \
+        if ((rc = join_from(c, BIN))) return rc;                                       \
+    }
+    NUM_BIN(9, 1024, 13)
+    NUM_BIN(8, 256, 12)
+    NUM_BIN(7, 128, 11)
+    NUM_BIN(6, 64, 10)
+    NUM_BIN(5, 32, 9)
+    NUM_BIN(4, 32, 8)
+    NUM_BIN(3, 16, 7)
+    NUM_BIN(2, 8, 6)
+#undef NUM_BIN
+    if (cnt[1]) {
+        if ((rc = fork_to(c, 1))) return rc;
+        const uint32_t grid = (cnt[1] + 15) / 16;
+        hipLaunchKernelGGL((k_num_copy<16>), dim3(grid), dim3(256), 0, c->cur, c->A->view(), c->B->view(), c->r0,
+                           c->num_rows.as<uint32_t>() + off[1], cnt[1], c->cptr.as<uint64_t>(), d_idx, d_val);
+        HIP_TRY(hipGetLastError());
+        if ((rc = join_from(c, 1))) return rc;
     }
     HIP_TRY(hipEventRecord(c->ev[EV_NUM_END], c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -293,6 +355,10 @@ int spada_create(const spada_options *opts, spada_ctx **out)
     c->accumulator = o.accumulator;
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     for (auto &e : c->ev) HIP_TRY(hipEventCreate(&e));
+    for (auto &st : c->side) HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    for (auto &e : c->ev_join) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    c->cur = c->stream;
     HIP_TRY(hipHostMalloc((void **)&c->h_counters, sizeof(Counters), hipHostMallocDefault));
     HIP_TRY(hipHostMalloc((void **)&c->h_u64, 64, hipHostMallocDefault));
     int rc;
@@ -310,6 +376,9 @@ int spada_create(const spada_options *opts, spada_ctx **out)
     if ((rc = allow_lds(k_num_hash<128, 11>, num_lds<128, 11>()))) return rc;
     if ((rc = allow_lds(k_num_hash<256, 12>, num_lds<256, 12>()))) return rc;
     if ((rc = allow_lds(k_num_hash<1024, 13>, num_lds<1024, 13>()))) return rc;
+    if ((rc = allow_lds(k_sym_bitmap, LDS_MAX))) return rc;
+    if ((rc = allow_lds(k_num_bitmap<true>, LDS_MAX))) return rc;
+    if ((rc = allow_lds(k_num_bitmap<false>, LDS_MAX))) return rc;
     *out = c.release();
     return SPADA_OK;
 }
@@ -328,6 +397,11 @@ void spada_destroy(spada_ctx *c)
     if (c->h_u64) (void)hipHostFree(c->h_u64);
     for (auto &e : c->ev)
         if (e) (void)hipEventDestroy(e);
+    for (auto &e : c->ev_join)
+        if (e) (void)hipEventDestroy(e);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    for (auto &st : c->side)
+        if (st) (void)hipStreamDestroy(st);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -370,6 +444,12 @@ int spada_dev_spgemm_symbolic(spada_ctx *c, const spada_dev_csr *a, const spada_
     c->nrows = (uint32_t)(row_end - row_begin);
     c->nnz_c = 0;
     std::memset(&c->stats, 0, sizeof c->stats);
+    {
+        const size_t base = bm_lds_bytes(b->cols, 0);
+        c->bm_fits = base <= LDS_MAX;
+        c->bm_vcap = 0;
+        if (c->bm_fits && LDS_MAX - base >= 8192 * 8) c->bm_vcap = (uint32_t)std::min<size_t>(16384, (LDS_MAX - base) / 8);
+    }
     const uint32_t n = c->nrows;
     hipStream_t s = c->stream;
     int rc;
@@ -411,21 +491,40 @@ int spada_dev_spgemm_symbolic(spada_ctx *c, const spada_dev_csr *a, const spada_
         uint32_t off[SPADA_N_BINS + 1];
         off[0] = 0;
         for (int k = 0; k < SPADA_N_BINS; ++k) off[k + 1] = off[k] + cnt[k];
-        if ((rc = launch_sym<8, 6>(c, off[2], cnt[2]))) return rc;
-        if ((rc = launch_sym<16, 8>(c, off[3], cnt[3]))) return rc;
-        if ((rc = launch_sym<64, 10>(c, off[4], cnt[4]))) return rc;
-        if ((rc = launch_sym<256, 12>(c, off[5], cnt[5]))) return rc;
-        if ((rc = launch_sym<512, 14>(c, off[6], cnt[6]))) return rc;
-        if ((rc = launch_sym<1024, 15>(c, off[7], cnt[7]))) return rc;
-        if (cnt[8]) {
-            if ((rc = ensure_spill(c, cnt[8], false))) return rc;
-            const uint64_t words = ((b->cols + 31) / 32 + 3) & ~3ull;
-            const uint32_t grid = (uint32_t)std::min<uint64_t>(cnt[8], c->spill_slabs);
-            hipLaunchKernelGGL(k_sym_spill, dim3(grid), dim3(SPILL_BLOCK), 0, s, a->view(), b->view(), c->r0,
-                               c->sym_rows.as<uint32_t>() + off[8], cnt[8], c->bitmaps.as<uint32_t>(), words,
-                               c->row_nnzc.as<uint32_t>());
+        HIP_TRY(hipEventRecord(c->ev_fork, s));
+        if (cnt[SYM_SPILL_BIN]) {
+            const uint32_t nsp = cnt[SYM_SPILL_BIN];
+            if (c->bm_fits) {
+                if ((rc = fork_to(c, SYM_SPILL_BIN))) return rc;
+                const size_t lds = bm_lds_bytes(b->cols, 0);
+                hipLaunchKernelGGL(k_sym_bitmap, dim3(bm_grid(nsp, lds)), dim3(BM_BLOCK), lds, c->cur, a->view(), b->view(),
+                                   c->r0, c->sym_rows.as<uint32_t>() + off[SYM_SPILL_BIN], nsp, b->cols,
+                                   c->row_nnzc.as<uint32_t>());
+            } else {
+                if ((rc = ensure_spill(c, nsp, false))) return rc;
+                if ((rc = fork_to(c, SYM_SPILL_BIN))) return rc;
+                const uint64_t words = ((b->cols + 31) / 32 + 3) & ~3ull;
+                const uint32_t grid = (uint32_t)std::min<uint64_t>(nsp, c->spill_slabs);
+                hipLaunchKernelGGL(k_sym_spill, dim3(grid), dim3(SPILL_BLOCK), 0, c->cur, a->view(), b->view(), c->r0,
+                                   c->sym_rows.as<uint32_t>() + off[SYM_SPILL_BIN], nsp, c->bitmaps.as<uint32_t>(), words,
+                                   c->row_nnzc.as<uint32_t>());
+            }
             HIP_TRY(hipGetLastError());
+            if ((rc = join_from(c, SYM_SPILL_BIN))) return rc;
         }
+#define SYM_BIN(BIN, G, LT)                                                   \
+    if (cnt[BIN]) {                                                           \
+        if ((rc = fork_to(c, BIN))) return rc;                                \
+        if ((rc = launch_sym<G, LT>(c, off[BIN], cnt[BIN]))) return rc;       \
+        if ((rc = join_from(c, BIN))) return rc;                              \
+    }
+        SYM_BIN(7, 1024, 15)
+        SYM_BIN(6, 512, 14)
+        SYM_BIN(5, 256, 12)
+        SYM_BIN(4, 64, 10)
+        SYM_BIN(3, 16, 8)
+        SYM_BIN(2, 8, 6)
+#undef SYM_BIN
     }
     HIP_TRY(hipEventRecord(c->ev[EV_SYM], s));
 
@@ -438,7 +537,7 @@ int spada_dev_spgemm_symbolic(spada_ctx *c, const spada_dev_csr *a, const spada_
     HIP_TRY(hipGetLastError());
     if (n) {
         hipLaunchKernelGGL(k_num_classify, dim3(g256), dim3(256), 0, s, a->ptr, c->r0, n, c->row_nprod.as<uint32_t>(),
-                           c->row_nnzc.as<uint32_t>(), c->row_bin.as<uint8_t>(), dc->num_counts);
+                           c->row_nnzc.as<uint32_t>(), c->row_bin.as<uint8_t>(), dc->num_counts, c->bm_vcap);
         hipLaunchKernelGGL(k_bin_scatter, dim3(g256), dim3(256), 0, s, c->row_bin.as<uint8_t>(), n, dc->num_counts,
                            dc->num_cursor, c->num_rows.as<uint32_t>());
         HIP_TRY(hipGetLastError());
@@ -469,7 +568,7 @@ int spada_dev_spgemm_symbolic(spada_ctx *c, const spada_dev_csr *a, const spada_
         st.sym_bin_rows[k] = c->h_sym_counts[k];
         st.num_bin_rows[k] = c->h_num_counts[k];
     }
-    st.spill_rows = c->h_sym_counts[SYM_SPILL_BIN] + c->h_num_counts[NUM_SPILL_BIN];
+    st.spill_rows = c->h_sym_counts[SYM_SPILL_BIN] + c->h_num_counts[NUM_SPILL_BIN] + c->h_num_counts[NUM_BMV_BIN];
     st.workspace_bytes = c->ws_bytes;
     return SPADA_OK;
 }

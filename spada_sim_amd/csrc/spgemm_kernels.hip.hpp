@@ -43,8 +43,11 @@ struct DevCsrView {
 //   0: n == 0                        1: L == 1 (scaled copy kernel)
 //   2: n <= 32   G=8   T=64          3: n <= 64   G=16  T=128         4: n <= 128  G=32  T=256
 //   5: n <= 256  G=32  T=512         6: n <= 512  G=64  T=1024        7: n <= 1024 G=128 T=2048
-//   8: n <= 2048 G=256 T=4096        9: n <= 6144 G=1024 T=8192      10: spill (bitmap-ranked C row in HBM)
-constexpr int NUM_SPILL_BIN = 10;
+//   8: n <= 2048 G=256 T=4096        9: n <= 6144 G=1024 T=8192
+//  10: n <= vcap: LDS bitmap-rank with the value row in LDS (only when the column bitmap leaves room)
+//  11: everything larger: LDS bitmap-rank with values accumulated in the C row, or the HBM spill path
+constexpr int NUM_BMV_BIN = 10;
+constexpr int NUM_SPILL_BIN = 11;
 constexpr int SYM_SPILL_BIN = 8;
 __host__ __device__ inline int sym_bin_of(uint64_t P, uint32_t L)
 {
@@ -58,12 +61,12 @@ __host__ __device__ inline int sym_bin_of(uint64_t P, uint32_t L)
     if (P <= 24576) return 7;
     return 8;
 }
-__host__ __device__ inline int num_bin_of(uint32_t n, uint64_t P, uint32_t L)
+__host__ __device__ inline int num_bin_of(uint32_t n, uint64_t P, uint32_t L, uint32_t vcap)
 {
     if (n == 0) return 0;
     if (L == 1) return 1;
     const int bn = n <= 32 ? 2 : n <= 64 ? 3 : n <= 128 ? 4 : n <= 256 ? 5 : n <= 512 ? 6 : n <= 1024 ? 7 : n <= 2048 ? 8
-                 : n <= 6144 ? 9 : 10;
+                 : n <= 6144 ? 9 : n <= vcap ? NUM_BMV_BIN : NUM_SPILL_BIN;
     const int bp = P <= 512 ? 2 : P <= 1024 ? 3 : P <= 2048 ? 4 : P <= 4096 ? 6 : P <= 8192 ? 7 : P <= 16384 ? 8 : 9;
     return bn > bp ? bn : bp;
 }
@@ -286,7 +289,7 @@ __global__ __launch_bounds__(256) void k_bin_scatter(const uint8_t *__restrict__
 __global__ __launch_bounds__(256) void k_num_classify(const uint64_t *__restrict__ aptr, uint64_t r0, uint32_t nrows,
                                                       const uint32_t *__restrict__ row_nprod,
                                                       const uint32_t *__restrict__ row_nnzc, uint8_t *__restrict__ row_bin,
-                                                      uint32_t *__restrict__ bin_counts)
+                                                      uint32_t *__restrict__ bin_counts, uint32_t vcap)
 {
     __shared__ uint32_t s_hist[SPADA_N_BINS];
     if (threadIdx.x < SPADA_N_BINS) s_hist[threadIdx.x] = 0;
@@ -294,7 +297,7 @@ __global__ __launch_bounds__(256) void k_num_classify(const uint64_t *__restrict
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < nrows) {
         const uint32_t L = (uint32_t)(aptr[r0 + i + 1] - aptr[r0 + i]);
-        const int bin = num_bin_of(row_nnzc[i], row_nprod[i], L);
+        const int bin = num_bin_of(row_nnzc[i], row_nprod[i], L, vcap);
         row_bin[i] = (uint8_t)bin;
         atomicAdd(&s_hist[bin], 1u);
     }
@@ -780,6 +783,139 @@ __global__ __launch_bounds__(SPILL_BLOCK) void k_num_spill(DevCsrView A, DevCsrV
         if (lo != 0xFFFFFFFFu)
             for (uint32_t w = lo + threadIdx.x; w <= hi; w += SPILL_BLOCK) bm[w] = 0;
         stores_to_l2();
+        __syncthreads();
+    }
+}
+
+// ---- 8. large rows, LDS bitmap-rank path (matrices with <= ~1.1 M columns) ----------------------------------
+// Same idea as the HBM spill path, but the row's column bitmap lives in LDS (cols/8 bytes: 128 KiB at 1 M columns,
+// which fits the 160 KiB LDS of a CDNA4 CU): products set bits with ds_or, the popcount prefix gives each column
+// its final position, values are accumulated at that position -- in an LDS f64 row when nnz(C_i) fits
+// (LDS_VALS), else directly in the C row with device-scope atomics (compact, L2 resident).  No hash, no sort.
+// LDS: 128 B hdr | walk scratch | coarse u32[W/8] | bitmap u32[W] | vals f64[vcap] (LDS_VALS only)
+constexpr int BM_BLOCK = 512;
+
+__host__ __device__ inline uint32_t bm_groups_per_thread(uint64_t cols)
+{
+    const uint64_t groups = (cols + 255) / 256;               // 8-word (256-column) groups
+    return (uint32_t)((groups + BM_BLOCK - 1) / BM_BLOCK);
+}
+__host__ __device__ inline size_t bm_lds_bytes(uint64_t cols, uint32_t vcap)
+{
+    const size_t W = (size_t)bm_groups_per_thread(cols) * BM_BLOCK * 8;
+    return 128 + ((walk_scratch_bytes<BM_BLOCK, true>() + 15) & ~(size_t)15) + (W / 8) * 4 + W * 4 + (size_t)vcap * 8;
+}
+
+__device__ inline uint32_t bm_block_scan(uint32_t v, uint32_t *wtot, uint32_t *total)
+{
+    return group_scan_excl<BM_BLOCK>(v, threadIdx.x, wtot, total);
+}
+
+__global__ __launch_bounds__(BM_BLOCK) void k_sym_bitmap(DevCsrView A, DevCsrView B, uint64_t r0,
+                                                         const uint32_t *__restrict__ bin_rows, uint32_t n_bin_rows,
+                                                         uint64_t cols, uint32_t *__restrict__ row_nnzc)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t *hdr = (uint32_t *)smem;
+    unsigned char *scratch = smem + 128;
+    const uint32_t gpt = bm_groups_per_thread(cols);
+    const uint32_t W = gpt * BM_BLOCK * 8;
+    uint32_t *bm = (uint32_t *)(scratch + ((walk_scratch_bytes<BM_BLOCK, true>() + 15) & ~(size_t)15) + (W / 8) * 4);
+    uint4 *bm4 = (uint4 *)bm;
+    for (uint32_t i = threadIdx.x; i < W / 4; i += BM_BLOCK) bm4[i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    for (uint32_t slot = blockIdx.x; slot < n_bin_rows; slot += gridDim.x) {
+        const uint32_t row = bin_rows[slot];
+        const uint64_t a0 = A.ptr[r0 + row], a1 = A.ptr[r0 + row + 1];
+        walk_products<BM_BLOCK, false>(A, B, a0, a1, threadIdx.x, scratch, hdr,
+                                       [&](uint32_t c, double) { atomicOr(&bm[c >> 5], 1u << (c & 31)); });
+        __syncthreads();
+        uint32_t cnt = 0;
+        for (uint32_t i = threadIdx.x; i < W / 4; i += BM_BLOCK) {
+            const uint4 w = bm4[i];
+            cnt += __popc(w.x) + __popc(w.y) + __popc(w.z) + __popc(w.w);
+            bm4[i] = make_uint4(0, 0, 0, 0);
+        }
+        cnt = group_sum<BM_BLOCK>(cnt, hdr);
+        if (threadIdx.x == 0) row_nnzc[row] = cnt;
+        __syncthreads();
+    }
+}
+
+template <bool LDS_VALS>
+__global__ __launch_bounds__(BM_BLOCK) void k_num_bitmap(DevCsrView A, DevCsrView B, uint64_t r0,
+                                                         const uint32_t *__restrict__ bin_rows, uint32_t n_bin_rows,
+                                                         uint64_t cols, uint32_t vcap, const uint64_t *__restrict__ cptr,
+                                                         uint32_t *__restrict__ c_idx, double *__restrict__ c_val)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t *hdr = (uint32_t *)smem;
+    unsigned char *scratch = smem + 128;
+    const uint32_t gpt = bm_groups_per_thread(cols);
+    const uint32_t W = gpt * BM_BLOCK * 8;
+    uint32_t *coarse = (uint32_t *)(scratch + ((walk_scratch_bytes<BM_BLOCK, true>() + 15) & ~(size_t)15));
+    uint32_t *bm = coarse + W / 8;
+    uint4 *bm4 = (uint4 *)bm;
+    double *vals = (double *)(bm + W);
+    for (uint32_t i = threadIdx.x; i < W / 4; i += BM_BLOCK) bm4[i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    for (uint32_t slot = blockIdx.x; slot < n_bin_rows; slot += gridDim.x) {
+        const uint32_t row = bin_rows[slot];
+        const uint64_t a0 = A.ptr[r0 + row], a1 = A.ptr[r0 + row + 1];
+        const uint64_t c0 = cptr[row];
+        const uint32_t n = (uint32_t)(cptr[row + 1] - c0);
+        // pass A: pattern
+        walk_products<BM_BLOCK, false>(A, B, a0, a1, threadIdx.x, scratch, hdr,
+                                       [&](uint32_t c, double) { atomicOr(&bm[c >> 5], 1u << (c & 31)); });
+        __syncthreads();
+        // pass B: every thread owns gpt consecutive 8-word groups; prefix popcounts; column indices out
+        uint32_t mine = 0;
+        const uint32_t g0 = threadIdx.x * gpt;
+        for (uint32_t g = g0; g < g0 + gpt; ++g) {
+            const uint4 lo4 = bm4[2 * g], hi4 = bm4[2 * g + 1];
+            mine += __popc(lo4.x) + __popc(lo4.y) + __popc(lo4.z) + __popc(lo4.w) + __popc(hi4.x) + __popc(hi4.y) +
+                    __popc(hi4.z) + __popc(hi4.w);
+        }
+        uint32_t total;
+        uint32_t pos = bm_block_scan(mine, hdr + 2, &total);
+        for (uint32_t g = g0; g < g0 + gpt; ++g) {
+            coarse[g] = pos;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                uint32_t bits = bm[g * 8 + j];
+                while (bits) {
+                    const int b = __ffs((int)bits) - 1;
+                    bits &= bits - 1;
+                    c_idx[c0 + pos] = ((g * 8 + j) << 5) + (uint32_t)b;
+                    ++pos;
+                }
+            }
+        }
+        if constexpr (LDS_VALS) {
+            for (uint32_t i = threadIdx.x; i < n; i += BM_BLOCK) vals[i] = 0.0;
+        } else {
+            for (uint32_t i = threadIdx.x; i < n; i += BM_BLOCK) c_val[c0 + i] = 0.0;
+            stores_to_l2();
+        }
+        __syncthreads();
+        // pass C: every product lands at its final position
+        walk_products<BM_BLOCK, true>(A, B, a0, a1, threadIdx.x, scratch, hdr, [&](uint32_t c, double v) {
+            const uint32_t w = c >> 5, g = w >> 3, j = w & 7;
+            const uint4 lo4 = bm4[2 * g], hi4 = bm4[2 * g + 1];
+            const uint32_t ww[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+            uint32_t p = coarse[g];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const uint32_t m = (uint32_t)t < j ? 0xFFFFFFFFu : ((uint32_t)t == j ? ((1u << (c & 31)) - 1u) : 0u);
+                p += __popc(ww[t] & m);
+            }
+            if constexpr (LDS_VALS) atomicAdd(&vals[p], v);
+            else atomicAdd(&c_val[c0 + p], v);
+        });
+        __syncthreads();
+        if constexpr (LDS_VALS)
+            for (uint32_t i = threadIdx.x; i < n; i += BM_BLOCK) c_val[c0 + i] = vals[i];
+        for (uint32_t i = threadIdx.x; i < W / 4; i += BM_BLOCK) bm4[i] = make_uint4(0, 0, 0, 0);
         __syncthreads();
     }
 }

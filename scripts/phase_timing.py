@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Per-phase shader-clock cycles of k_num_hash<G,*> on sampled workgroups (development aid, GPU box).
+usage: SPADA_DBG_G=<G> phase_timing.py <workload>"""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+os.environ.setdefault("SPADA_SERIAL_BINS", "1")
+import spada_sim_amd as S
+from spada_sim_amd import _ffi
+from perf_probe import W
+name = sys.argv[1] if len(sys.argv) > 1 else "webbase"
+kind, p0, p1, seed = W[name]
+m = S.generate(kind, p0, p1, seed)
+eng = S.Engine()
+d = eng.upload(m)
+for it in range(3):
+    eng.symbolic(d, d, 0, m.shape[0]); eng.numeric_owned()
+L = _ffi.lib()
+buf = np.zeros(64 * 16, np.uint64)
+L.spada_debug_read.restype = ctypes.c_int
+L.spada_debug_read.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64]
+rc = L.spada_debug_read(eng._ctx, buf.ctypes.data_as(ctypes.c_void_p), 64 * 16)
+t = buf.reshape(64, 16)[:, :8].astype(np.int64)
+ok = t[:, 7] > t[:, 0]
+t = t[ok]
+names = ["init", "walk", "keys+minmax", "bucket count", "scan", "scatter", "rank+write"]
+dt = np.diff(t, axis=1)
+print(f"G={os.environ.get('SPADA_DBG_G')} sampled {len(t)} workgroups; cycles (mean / median / max)")
+for i, n in enumerate(names):
+    print(f"  {n:14s} {dt[:, i].mean():9.0f} {np.median(dt[:, i]):9.0f} {dt[:, i].max():9.0f}")
+print(f"  {'total':14s} {(t[:,7]-t[:,0]).mean():9.0f}")

@@ -7,12 +7,13 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <vector>
 
 #include "spada_internal.hpp"
-#include "spgemm_kernels.hip.hpp"
+#include "spgemm_flat.hip.hpp"
 
 using namespace spada;
 
@@ -29,7 +30,7 @@ struct spada_dev_csr {
     uint64_t *ptr = nullptr;
     uint32_t *idx = nullptr;
     double *val = nullptr;
-    DevCsrView view() const { return DevCsrView{ptr, idx, val}; }
+    DevCsrView view() const { return DevCsrView{ptr, idx, val, nullptr, nullptr}; }
 };
 
 namespace {
@@ -72,6 +73,7 @@ struct Counters {
     uint32_t num_counts[SPADA_N_BINS];
     uint32_t num_cursor[SPADA_N_BINS];
     unsigned long long totals[2];   // nprod, a_nnz of the row range
+    uint32_t nb_sym, nb_num;        // number of flat batches (symbolic / numeric)
 };
 
 enum { EV_SYM_BEGIN, EV_STATS, EV_BINNED, EV_SYM, EV_SCAN, EV_NUM_BEGIN, EV_NUM_END, EV_COUNT };
@@ -87,6 +89,9 @@ struct spada_ctx {
     hipStream_t side[SPADA_N_BINS] = {};
     hipEvent_t ev_fork = nullptr, ev_join[SPADA_N_BINS] = {};
     hipStream_t cur = nullptr;        // stream the launch helpers use
+    int dbg_g = 0;                    // SPADA_DBG_G=<G>: phase timestamps of k_num_hash<G,*> into `dbg`
+    DevBuf dbg;
+    bool serial_bins = false;         // SPADA_SERIAL_BINS=1: one stream, for per-kernel profiling
     // state carried from symbolic to numeric
     bool have_symbolic = false;
     const spada_dev_csr *A = nullptr, *B = nullptr;
@@ -98,6 +103,13 @@ struct spada_ctx {
     size_t ws_bytes = 0;
     DevBuf row_nprod, row_nnzc, row_bin, sym_rows, num_rows, counters, cptr, tile_sums, bitmaps, slabs;
     DevBuf own_idx, own_val, own_ptr, wide_idx;
+    DevBuf eb0, elen, row_kmin, row_kmax, batch_sym, batch_num, tile_w;
+    uint32_t colbits = 0, rmax_eff = 0, num_flat_max = 0;
+    bool flat_on = false;
+    DevCsrView a_view() const
+    {
+        return DevCsrView{A->ptr, A->idx, A->val, eb0.as<uint64_t>(), elen.as<uint32_t>()};
+    }
     uint64_t spill_slabs = 0, spill_cols = 0;
     bool bm_fits = false;             // LDS column bitmap fits for the current B
     uint32_t bm_vcap = 0;             // value-row capacity of k_num_bitmap<true> (0 = variant unused)
@@ -129,7 +141,7 @@ int launch_sym(spada_ctx *c, uint32_t off, uint32_t n)
     constexpr int BLOCK = G <= 64 ? 256 : G;
     constexpr int RPB = BLOCK / G;
     const uint32_t grid = (n + RPB - 1) / RPB;
-    hipLaunchKernelGGL((k_sym_hash<G, LOG_T>), dim3(grid), dim3(BLOCK), (sym_lds<G, LOG_T>()), c->cur, c->A->view(),
+    hipLaunchKernelGGL((k_sym_hash<G, LOG_T>), dim3(grid), dim3(BLOCK), (sym_lds<G, LOG_T>()), c->cur, c->a_view(),
                        c->B->view(), c->r0, c->sym_rows.as<uint32_t>() + off, n, c->row_nnzc.as<uint32_t>());
     HIP_TRY(hipGetLastError());
     return SPADA_OK;
@@ -142,8 +154,10 @@ int launch_num(spada_ctx *c, uint32_t off, uint32_t n, uint32_t *c_idx, double *
     constexpr int BLOCK = G <= 64 ? 256 : G;
     constexpr int RPB = BLOCK / G;
     const uint32_t grid = (n + RPB - 1) / RPB;
-    hipLaunchKernelGGL((k_num_hash<G, LOG_T>), dim3(grid), dim3(BLOCK), (num_lds<G, LOG_T>()), c->cur, c->A->view(),
-                       c->B->view(), c->r0, c->num_rows.as<uint32_t>() + off, n, c->cptr.as<uint64_t>(), c_idx, c_val);
+    hipLaunchKernelGGL((k_num_hash<G, LOG_T>), dim3(grid), dim3(BLOCK), (num_lds<G, LOG_T>()), c->cur, c->a_view(),
+                       c->B->view(), c->r0, c->num_rows.as<uint32_t>() + off, n, c->cptr.as<uint64_t>(), c_idx, c_val,
+                       std::getenv("SPADA_ABLATE") ? atoi(std::getenv("SPADA_ABLATE")) : 0,
+                       (G == c->dbg_g) ? c->dbg.as<unsigned long long>() : nullptr);
     HIP_TRY(hipGetLastError());
     return SPADA_OK;
 }
@@ -171,6 +185,7 @@ int ensure_spill(spada_ctx *c, uint32_t rows_in_bin, bool need_slabs)
 // fork: side stream `k` starts after everything queued on the main stream so far
 int fork_to(spada_ctx *c, int k)
 {
+    if (c->serial_bins) return SPADA_OK;
     HIP_TRY(hipStreamWaitEvent(c->side[k], c->ev_fork, 0));
     c->cur = c->side[k];
     return SPADA_OK;
@@ -178,6 +193,7 @@ int fork_to(spada_ctx *c, int k)
 // join: the main stream continues after side stream `k`
 int join_from(spada_ctx *c, int k)
 {
+    if (c->serial_bins) return SPADA_OK;
     HIP_TRY(hipEventRecord(c->ev_join[k], c->side[k]));
     HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join[k], 0));
     c->cur = c->stream;
@@ -238,6 +254,19 @@ void dev_free(spada_dev_csr *m)
     delete m;
 }
 
+// flat-batch kernel configurations: <BLOCK, LOG_T, NOUT, RMAX>; cap = 2 * flat_max, NOUT >= cap + flat_max
+constexpr int NF_BLOCK = 256, NF_LOG_T = 12, NF_NOUT = 3072, NF_RMAX = 256;
+constexpr uint32_t NUM_FLAT_MAX = 1024, NUM_FLAT_CAP = 2048;
+constexpr int SF_BLOCK = 256, SF_RMAX = 256;
+static_assert(NF_NOUT >= NUM_FLAT_CAP + NUM_FLAT_MAX, "a batch weighs less than cap + flat_max");
+static_assert((1u << SYM_FLAT_LOG_T) * 3 >= (SYM_FLAT_CAP + SYM_FLAT_MAX) * 4, "symbolic table load <= 0.75");
+
+uint32_t flat_grid(uint64_t nb_upper, size_t lds)
+{
+    const uint64_t per_cu = std::max<size_t>(1, std::min<size_t>(8, LDS_MAX / lds));
+    return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(nb_upper, 256ull * per_cu * 4));
+}
+
 int run_numeric(spada_ctx *c, uint64_t *d_ptr, uint32_t *d_idx, double *d_val)
 {
     HIP_TRY(hipEventRecord(c->ev[EV_NUM_BEGIN], c->stream));
@@ -245,39 +274,40 @@ int run_numeric(spada_ctx *c, uint64_t *d_ptr, uint32_t *d_idx, double *d_val)
     const uint32_t *cnt = c->h_num_counts;
     uint32_t off[SPADA_N_BINS + 1];
     off[0] = 0;
-    for (int b = 0; b < SPADA_N_BINS; ++b) off[b + 1] = off[b] + cnt[b];
+    for (int b = 0; b < SPADA_N_BINS; ++b) off[b + 1] = off[b] + (b == BIN_EMPTY || b == BIN_FLAT ? 0u : cnt[b]);
     int rc;
+    Counters *dc = c->counters.as<Counters>();
     HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
     // heaviest bins first; every bin on its own stream
-    if (cnt[NUM_SPILL_BIN]) {
-        const uint32_t nsp = cnt[NUM_SPILL_BIN];
+    if (cnt[NUM2_BIN_SPILL]) {
+        const uint32_t nsp = cnt[NUM2_BIN_SPILL];
         if (c->bm_fits) {
-            if ((rc = fork_to(c, NUM_SPILL_BIN))) return rc;
+            if ((rc = fork_to(c, NUM2_BIN_SPILL))) return rc;
             const size_t lds = bm_lds_bytes(c->B->cols, 0);
-            hipLaunchKernelGGL(k_num_bitmap<false>, dim3(bm_grid(nsp, lds)), dim3(BM_BLOCK), lds, c->cur, c->A->view(),
-                               c->B->view(), c->r0, c->num_rows.as<uint32_t>() + off[NUM_SPILL_BIN], nsp, c->B->cols, 0u,
+            hipLaunchKernelGGL(k_num_bitmap<false>, dim3(bm_grid(nsp, lds)), dim3(BM_BLOCK), lds, c->cur, c->a_view(),
+                               c->B->view(), c->r0, c->num_rows.as<uint32_t>() + off[NUM2_BIN_SPILL], nsp, c->B->cols, 0u,
                                c->cptr.as<uint64_t>(), d_idx, d_val);
         } else {
             if ((rc = ensure_spill(c, nsp, true))) return rc;
-            if ((rc = fork_to(c, NUM_SPILL_BIN))) return rc;
+            if ((rc = fork_to(c, NUM2_BIN_SPILL))) return rc;
             const uint64_t words = ((c->B->cols + 31) / 32 + 3) & ~3ull;
             const uint32_t grid = (uint32_t)std::min<uint64_t>(nsp, c->spill_slabs);
-            hipLaunchKernelGGL(k_num_spill, dim3(grid), dim3(SPILL_BLOCK), 0, c->cur, c->A->view(), c->B->view(), c->r0,
-                               c->num_rows.as<uint32_t>() + off[NUM_SPILL_BIN], nsp, c->bitmaps.as<uint32_t>(),
+            hipLaunchKernelGGL(k_num_spill, dim3(grid), dim3(SPILL_BLOCK), 0, c->cur, c->a_view(), c->B->view(), c->r0,
+                               c->num_rows.as<uint32_t>() + off[NUM2_BIN_SPILL], nsp, c->bitmaps.as<uint32_t>(),
                                c->slabs.as<uint32_t>(), words, c->cptr.as<uint64_t>(), d_idx, d_val);
         }
         HIP_TRY(hipGetLastError());
-        if ((rc = join_from(c, NUM_SPILL_BIN))) return rc;
+        if ((rc = join_from(c, NUM2_BIN_SPILL))) return rc;
     }
-    if (cnt[NUM_BMV_BIN]) {
-        const uint32_t nb = cnt[NUM_BMV_BIN];
-        if ((rc = fork_to(c, NUM_BMV_BIN))) return rc;
+    if (cnt[NUM2_BIN_BMV]) {
+        const uint32_t nb = cnt[NUM2_BIN_BMV];
+        if ((rc = fork_to(c, NUM2_BIN_BMV))) return rc;
         const size_t lds = bm_lds_bytes(c->B->cols, c->bm_vcap);
-        hipLaunchKernelGGL(k_num_bitmap<true>, dim3(bm_grid(nb, lds)), dim3(BM_BLOCK), lds, c->cur, c->A->view(),
-                           c->B->view(), c->r0, c->num_rows.as<uint32_t>() + off[NUM_BMV_BIN], nb, c->B->cols, c->bm_vcap,
+        hipLaunchKernelGGL(k_num_bitmap<true>, dim3(bm_grid(nb, lds)), dim3(BM_BLOCK), lds, c->cur, c->a_view(),
+                           c->B->view(), c->r0, c->num_rows.as<uint32_t>() + off[NUM2_BIN_BMV], nb, c->B->cols, c->bm_vcap,
                            c->cptr.as<uint64_t>(), d_idx, d_val);
         HIP_TRY(hipGetLastError());
-        if ((rc = join_from(c, NUM_BMV_BIN))) return rc;
+        if ((rc = join_from(c, NUM2_BIN_BMV))) return rc;
     }
 #define NUM_BIN(BIN, G, LT)                                                            \
     if (cnt[BIN]) {                                                                    \
@@ -285,22 +315,27 @@ int run_numeric(spada_ctx *c, uint64_t *d_ptr, uint32_t *d_idx, double *d_val)
         if ((rc = launch_num<G, LT>(c, off[BIN], cnt[BIN], d_idx, d_val))) return rc;  \
         if ((rc = join_from(c, BIN))) return rc;                                       \
     }
-    NUM_BIN(9, 1024, 13)
-    NUM_BIN(8, 256, 12)
-    NUM_BIN(7, 128, 11)
-    NUM_BIN(6, 64, 10)
-    NUM_BIN(5, 32, 9)
-    NUM_BIN(4, 32, 8)
-    NUM_BIN(3, 16, 7)
-    NUM_BIN(2, 8, 6)
+    NUM_BIN(NUM2_BIN_6K, 1024, 13)
+    NUM_BIN(NUM2_BIN_2K, 256, 12)
 #undef NUM_BIN
-    if (cnt[1]) {
-        if ((rc = fork_to(c, 1))) return rc;
-        const uint32_t grid = (cnt[1] + 15) / 16;
-        hipLaunchKernelGGL((k_num_copy<16>), dim3(grid), dim3(256), 0, c->cur, c->A->view(), c->B->view(), c->r0,
-                           c->num_rows.as<uint32_t>() + off[1], cnt[1], c->cptr.as<uint64_t>(), d_idx, d_val);
+    if (cnt[BIN_FLAT]) {
+        if ((rc = fork_to(c, BIN_FLAT))) return rc;
+        constexpr size_t lds = num_flat_lds<NF_BLOCK, NF_LOG_T, NF_NOUT, NF_RMAX>();
+        hipLaunchKernelGGL((k_num_flat<NF_BLOCK, NF_LOG_T, NF_NOUT, NF_RMAX>), dim3(flat_grid(c->h_counters->nb_num, lds)),
+                           dim3(NF_BLOCK), lds, c->cur, c->A->ptr, c->A->val, c->B->idx, c->B->val, c->eb0.as<uint64_t>(),
+                           c->elen.as<uint32_t>(), c->r0, c->nrows, c->row_bin.as<uint8_t>(), c->row_kmin.as<uint32_t>(),
+                           c->row_kmax.as<uint32_t>(), c->cptr.as<uint64_t>(), c->batch_num.as<uint32_t>(), &dc->nb_num,
+                           c->colbits, d_idx, d_val);
         HIP_TRY(hipGetLastError());
-        if ((rc = join_from(c, 1))) return rc;
+        if ((rc = join_from(c, BIN_FLAT))) return rc;
+    }
+    if (cnt[BIN_COPY]) {
+        if ((rc = fork_to(c, BIN_COPY))) return rc;
+        const uint32_t grid = (cnt[BIN_COPY] + 15) / 16;
+        hipLaunchKernelGGL((k_num_copy<16>), dim3(grid), dim3(256), 0, c->cur, c->a_view(), c->B->view(), c->r0,
+                           c->num_rows.as<uint32_t>() + off[BIN_COPY], cnt[BIN_COPY], c->cptr.as<uint64_t>(), d_idx, d_val);
+        HIP_TRY(hipGetLastError());
+        if ((rc = join_from(c, BIN_COPY))) return rc;
     }
     HIP_TRY(hipEventRecord(c->ev[EV_NUM_END], c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -359,23 +394,22 @@ int spada_create(const spada_options *opts, spada_ctx **out)
     HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     for (auto &e : c->ev_join) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     c->cur = c->stream;
+    if (const char *e = std::getenv("SPADA_SERIAL_BINS")) c->serial_bins = e[0] == '1';
+    if (const char *e = std::getenv("SPADA_DBG_G")) {
+        c->dbg_g = atoi(e);
+        int rc0 = c->dbg.ensure(64 * 16 * 8, true, c->stream, &c->ws_bytes);
+        if (rc0) return rc0;
+    }
     HIP_TRY(hipHostMalloc((void **)&c->h_counters, sizeof(Counters), hipHostMallocDefault));
     HIP_TRY(hipHostMalloc((void **)&c->h_u64, 64, hipHostMallocDefault));
     int rc;
-    if ((rc = allow_lds(k_sym_hash<8, 6>, sym_lds<8, 6>()))) return rc;
-    if ((rc = allow_lds(k_sym_hash<16, 8>, sym_lds<16, 8>()))) return rc;
-    if ((rc = allow_lds(k_sym_hash<64, 10>, sym_lds<64, 10>()))) return rc;
-    if ((rc = allow_lds(k_sym_hash<256, 12>, sym_lds<256, 12>()))) return rc;
     if ((rc = allow_lds(k_sym_hash<512, 14>, sym_lds<512, 14>()))) return rc;
     if ((rc = allow_lds(k_sym_hash<1024, 15>, sym_lds<1024, 15>()))) return rc;
-    if ((rc = allow_lds(k_num_hash<8, 6>, num_lds<8, 6>()))) return rc;
-    if ((rc = allow_lds(k_num_hash<16, 7>, num_lds<16, 7>()))) return rc;
-    if ((rc = allow_lds(k_num_hash<32, 8>, num_lds<32, 8>()))) return rc;
-    if ((rc = allow_lds(k_num_hash<32, 9>, num_lds<32, 9>()))) return rc;
-    if ((rc = allow_lds(k_num_hash<64, 10>, num_lds<64, 10>()))) return rc;
-    if ((rc = allow_lds(k_num_hash<128, 11>, num_lds<128, 11>()))) return rc;
     if ((rc = allow_lds(k_num_hash<256, 12>, num_lds<256, 12>()))) return rc;
     if ((rc = allow_lds(k_num_hash<1024, 13>, num_lds<1024, 13>()))) return rc;
+    if ((rc = allow_lds(k_sym_flat<SF_BLOCK, SYM_FLAT_LOG_T, SF_RMAX>, sym_flat_lds<SF_BLOCK, SYM_FLAT_LOG_T, SF_RMAX>()))) return rc;
+    if ((rc = allow_lds(k_num_flat<NF_BLOCK, NF_LOG_T, NF_NOUT, NF_RMAX>, num_flat_lds<NF_BLOCK, NF_LOG_T, NF_NOUT, NF_RMAX>())))
+        return rc;
     if ((rc = allow_lds(k_sym_bitmap, LDS_MAX))) return rc;
     if ((rc = allow_lds(k_num_bitmap<true>, LDS_MAX))) return rc;
     if ((rc = allow_lds(k_num_bitmap<false>, LDS_MAX))) return rc;
@@ -391,7 +425,8 @@ void spada_destroy(spada_ctx *c)
     dev_free(c->hA);
     if (c->hB != c->hA) dev_free(c->hB);
     for (DevBuf *b : {&c->row_nprod, &c->row_nnzc, &c->row_bin, &c->sym_rows, &c->num_rows, &c->counters, &c->cptr,
-                      &c->tile_sums, &c->bitmaps, &c->slabs, &c->own_idx, &c->own_val, &c->own_ptr, &c->wide_idx})
+                      &c->tile_sums, &c->bitmaps, &c->slabs, &c->own_idx, &c->own_val, &c->own_ptr, &c->wide_idx,
+                      &c->eb0, &c->elen, &c->row_kmin, &c->row_kmax, &c->batch_sym, &c->batch_num, &c->tile_w, &c->dbg})
         b->release();
     if (c->h_counters) (void)hipHostFree(c->h_counters);
     if (c->h_u64) (void)hipHostFree(c->h_u64);
@@ -457,28 +492,59 @@ int spada_dev_spgemm_symbolic(spada_ctx *c, const spada_dev_csr *a, const spada_
     if ((rc = c->row_nprod.ensure(n1 * 4, false, s, &c->ws_bytes))) return rc;
     if ((rc = c->row_nnzc.ensure(n1 * 4, false, s, &c->ws_bytes))) return rc;
     if ((rc = c->row_bin.ensure(n1, false, s, &c->ws_bytes))) return rc;
+    if ((rc = c->row_kmin.ensure(n1 * 4, false, s, &c->ws_bytes))) return rc;
+    if ((rc = c->row_kmax.ensure(n1 * 4, false, s, &c->ws_bytes))) return rc;
     if ((rc = c->sym_rows.ensure(n1 * 4, false, s, &c->ws_bytes))) return rc;
     if ((rc = c->num_rows.ensure(n1 * 4, false, s, &c->ws_bytes))) return rc;
     if ((rc = c->cptr.ensure(n1 * 8, false, s, &c->ws_bytes))) return rc;
     if ((rc = c->counters.ensure(sizeof(Counters), false, s, &c->ws_bytes))) return rc;
-    const uint32_t ntiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+    if ((rc = c->eb0.ensure(std::max<uint64_t>(a->nnz, 1) * 8, false, s, &c->ws_bytes))) return rc;
+    if ((rc = c->elen.ensure(std::max<uint64_t>(a->nnz, 1) * 4, false, s, &c->ws_bytes))) return rc;
+    if ((rc = c->batch_sym.ensure((n1 / 2 + 4) * 4, false, s, &c->ws_bytes))) return rc;
+    if ((rc = c->batch_num.ensure((n1 / 2 + 4) * 4, false, s, &c->ws_bytes))) return rc;
+    const uint32_t ntiles = std::max<uint32_t>((n + SCAN_TILE - 1) / SCAN_TILE, 1);
     if ((rc = c->tile_sums.ensure(((size_t)ntiles + 2) * 8, false, s, &c->ws_bytes))) return rc;
+    if ((rc = c->tile_w.ensure(((size_t)ntiles + 2) * 8, false, s, &c->ws_bytes))) return rc;
     Counters *dc = c->counters.as<Counters>();
+
+    // composite hash keys of the flat batches: (local row << colbits) | column
+    {
+        uint32_t cb = 0;
+        while (cb < 32 && (1ull << cb) < b->cols) ++cb;
+        c->colbits = cb;
+        const uint64_t lim = cb >= 32 ? 1 : std::min<uint64_t>((1ull << (32 - cb)) - 1, 256);
+        c->rmax_eff = (uint32_t)lim;
+        c->flat_on = lim >= 4;
+        c->num_flat_max = c->flat_on ? NUM_FLAT_MAX : 0;
+    }
+    const uint32_t rmax = std::max<uint32_t>(c->rmax_eff, 4);
+    const CutParams cut_sym{SYM_FLAT_CAP, (SYM_FLAT_CAP + rmax - 1) / rmax, 0, 0};
+    const CutParams cut_num{NUM_FLAT_CAP, (NUM_FLAT_CAP + rmax - 1) / rmax, c->num_flat_max, c->bm_vcap};
 
     HIP_TRY(hipEventRecord(c->ev[EV_SYM_BEGIN], s));
     HIP_TRY(hipMemsetAsync(dc, 0, sizeof(Counters), s));
     const uint32_t g256 = (n + 255) / 256;
     if (n) {
-        hipLaunchKernelGGL(k_row_stats, dim3(g256), dim3(256), 0, s, a->ptr, a->idx, b->ptr, c->r0, n,
-                           c->row_nprod.as<uint32_t>(), c->row_nnzc.as<uint32_t>(), c->row_bin.as<uint8_t>(),
-                           dc->sym_counts, dc->totals);
+        hipLaunchKernelGGL(k_row_stats2, dim3(g256), dim3(256), 0, s, a->ptr, a->idx, b->ptr, b->idx, c->r0, n,
+                           c->eb0.as<uint64_t>(), c->elen.as<uint32_t>(), c->row_nprod.as<uint32_t>(),
+                           c->row_nnzc.as<uint32_t>(), c->row_bin.as<uint8_t>(), c->row_kmin.as<uint32_t>(),
+                           c->row_kmax.as<uint32_t>(), dc->sym_counts, dc->totals, c->flat_on ? 1 : 0);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(c->ev[EV_STATS], s));
     HIP_TRY(hipMemcpyAsync(c->h_counters, dc, sizeof(Counters), hipMemcpyDeviceToHost, s));
     if (n) {
-        hipLaunchKernelGGL(k_bin_scatter, dim3(g256), dim3(256), 0, s, c->row_bin.as<uint8_t>(), n, dc->sym_counts,
+        hipLaunchKernelGGL(k_bin_scatter2, dim3(g256), dim3(256), 0, s, c->row_bin.as<uint8_t>(), n, dc->sym_counts,
                            dc->sym_cursor, c->sym_rows.as<uint32_t>());
+        hipLaunchKernelGGL(k_cut_tile_sums<0>, dim3(ntiles), dim3(SCAN_BLOCK), 0, s, a->ptr, c->r0, n,
+                           c->row_nprod.as<uint32_t>(), c->row_nnzc.as<uint32_t>(), c->row_bin.as<uint8_t>(), cut_sym,
+                           c->tile_sums.as<uint64_t>(), c->tile_w.as<uint64_t>());
+        hipLaunchKernelGGL(k_cut_scan_tiles, dim3(1), dim3(SCAN_BLOCK), 0, s, c->tile_sums.as<uint64_t>(),
+                           c->tile_w.as<uint64_t>(), ntiles, cut_sym.cap, 0, &dc->nb_sym);
+        hipLaunchKernelGGL(k_cut_apply<0>, dim3(ntiles), dim3(SCAN_BLOCK), 0, s, a->ptr, c->r0, n,
+                           c->row_nprod.as<uint32_t>(), c->row_nnzc.as<uint32_t>(), c->row_bin.as<uint8_t>(), cut_sym,
+                           c->tile_sums.as<uint64_t>(), c->tile_w.as<uint64_t>(), ntiles, (uint64_t *)nullptr,
+                           (uint8_t *)nullptr, (uint32_t *)nullptr, c->batch_sym.as<uint32_t>());
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(c->ev[EV_BINNED], s));
@@ -490,27 +556,27 @@ int spada_dev_spgemm_symbolic(spada_ctx *c, const spada_dev_csr *a, const spada_
         const uint32_t *cnt = c->h_sym_counts;
         uint32_t off[SPADA_N_BINS + 1];
         off[0] = 0;
-        for (int k = 0; k < SPADA_N_BINS; ++k) off[k + 1] = off[k] + cnt[k];
+        for (int k = 0; k < SPADA_N_BINS; ++k) off[k + 1] = off[k] + (k == BIN_EMPTY || k == BIN_FLAT ? 0u : cnt[k]);
         HIP_TRY(hipEventRecord(c->ev_fork, s));
-        if (cnt[SYM_SPILL_BIN]) {
-            const uint32_t nsp = cnt[SYM_SPILL_BIN];
+        if (cnt[SYM2_BIN_SPILL]) {
+            const uint32_t nsp = cnt[SYM2_BIN_SPILL];
             if (c->bm_fits) {
-                if ((rc = fork_to(c, SYM_SPILL_BIN))) return rc;
+                if ((rc = fork_to(c, SYM2_BIN_SPILL))) return rc;
                 const size_t lds = bm_lds_bytes(b->cols, 0);
-                hipLaunchKernelGGL(k_sym_bitmap, dim3(bm_grid(nsp, lds)), dim3(BM_BLOCK), lds, c->cur, a->view(), b->view(),
-                                   c->r0, c->sym_rows.as<uint32_t>() + off[SYM_SPILL_BIN], nsp, b->cols,
+                hipLaunchKernelGGL(k_sym_bitmap, dim3(bm_grid(nsp, lds)), dim3(BM_BLOCK), lds, c->cur, c->a_view(), b->view(),
+                                   c->r0, c->sym_rows.as<uint32_t>() + off[SYM2_BIN_SPILL], nsp, b->cols,
                                    c->row_nnzc.as<uint32_t>());
             } else {
                 if ((rc = ensure_spill(c, nsp, false))) return rc;
-                if ((rc = fork_to(c, SYM_SPILL_BIN))) return rc;
+                if ((rc = fork_to(c, SYM2_BIN_SPILL))) return rc;
                 const uint64_t words = ((b->cols + 31) / 32 + 3) & ~3ull;
                 const uint32_t grid = (uint32_t)std::min<uint64_t>(nsp, c->spill_slabs);
-                hipLaunchKernelGGL(k_sym_spill, dim3(grid), dim3(SPILL_BLOCK), 0, c->cur, a->view(), b->view(), c->r0,
-                                   c->sym_rows.as<uint32_t>() + off[SYM_SPILL_BIN], nsp, c->bitmaps.as<uint32_t>(), words,
+                hipLaunchKernelGGL(k_sym_spill, dim3(grid), dim3(SPILL_BLOCK), 0, c->cur, c->a_view(), b->view(), c->r0,
+                                   c->sym_rows.as<uint32_t>() + off[SYM2_BIN_SPILL], nsp, c->bitmaps.as<uint32_t>(), words,
                                    c->row_nnzc.as<uint32_t>());
             }
             HIP_TRY(hipGetLastError());
-            if ((rc = join_from(c, SYM_SPILL_BIN))) return rc;
+            if ((rc = join_from(c, SYM2_BIN_SPILL))) return rc;
         }
 #define SYM_BIN(BIN, G, LT)                                                   \
     if (cnt[BIN]) {                                                           \
@@ -518,27 +584,36 @@ int spada_dev_spgemm_symbolic(spada_ctx *c, const spada_dev_csr *a, const spada_
         if ((rc = launch_sym<G, LT>(c, off[BIN], cnt[BIN]))) return rc;       \
         if ((rc = join_from(c, BIN))) return rc;                              \
     }
-        SYM_BIN(7, 1024, 15)
-        SYM_BIN(6, 512, 14)
-        SYM_BIN(5, 256, 12)
-        SYM_BIN(4, 64, 10)
-        SYM_BIN(3, 16, 8)
-        SYM_BIN(2, 8, 6)
+        SYM_BIN(SYM2_BIN_24K, 1024, 15)
+        SYM_BIN(SYM2_BIN_8K, 512, 14)
 #undef SYM_BIN
+        if (cnt[BIN_FLAT]) {
+            if ((rc = fork_to(c, BIN_FLAT))) return rc;
+            constexpr size_t lds = sym_flat_lds<SF_BLOCK, SYM_FLAT_LOG_T, SF_RMAX>();
+            const uint64_t nb_upper = (nprod + (uint64_t)n * cut_sym.minw) / cut_sym.cap + 1;
+            hipLaunchKernelGGL((k_sym_flat<SF_BLOCK, SYM_FLAT_LOG_T, SF_RMAX>), dim3(flat_grid(nb_upper, lds)), dim3(SF_BLOCK),
+                               lds, c->cur, a->ptr, b->idx, c->eb0.as<uint64_t>(), c->elen.as<uint32_t>(), c->r0, n,
+                               c->row_bin.as<uint8_t>(), c->batch_sym.as<uint32_t>(), &dc->nb_sym, c->colbits,
+                               c->row_nnzc.as<uint32_t>());
+            HIP_TRY(hipGetLastError());
+            if ((rc = join_from(c, BIN_FLAT))) return rc;
+        }
     }
     HIP_TRY(hipEventRecord(c->ev[EV_SYM], s));
 
-    // exclusive scan nnzc -> cptr, then classify + bin for the numeric phase
-    hipLaunchKernelGGL(k_scan_tile_sums, dim3(std::max(ntiles, 1u)), dim3(SCAN_BLOCK), 0, s, c->row_nnzc.as<uint32_t>(), n,
-                       c->tile_sums.as<uint64_t>());
-    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(SCAN_BLOCK), 0, s, c->tile_sums.as<uint64_t>(), std::max(ntiles, 1u));
-    hipLaunchKernelGGL(k_scan_apply, dim3(std::max(ntiles, 1u)), dim3(SCAN_BLOCK), 0, s, c->row_nnzc.as<uint32_t>(), n,
-                       c->tile_sums.as<uint64_t>(), std::max(ntiles, 1u), c->cptr.as<uint64_t>());
+    // nnz(C_i) -> cptr, numeric classification, numeric batch cut, per-row bin lists
+    hipLaunchKernelGGL(k_cut_tile_sums<1>, dim3(ntiles), dim3(SCAN_BLOCK), 0, s, a->ptr, c->r0, n, c->row_nprod.as<uint32_t>(),
+                       c->row_nnzc.as<uint32_t>(), c->row_bin.as<uint8_t>(), cut_num, c->tile_sums.as<uint64_t>(),
+                       c->tile_w.as<uint64_t>());
+    hipLaunchKernelGGL(k_cut_scan_tiles, dim3(1), dim3(SCAN_BLOCK), 0, s, c->tile_sums.as<uint64_t>(), c->tile_w.as<uint64_t>(),
+                       ntiles, cut_num.cap, 1, &dc->nb_num);
+    hipLaunchKernelGGL(k_cut_apply<1>, dim3(ntiles), dim3(SCAN_BLOCK), 0, s, a->ptr, c->r0, n, c->row_nprod.as<uint32_t>(),
+                       c->row_nnzc.as<uint32_t>(), c->row_bin.as<uint8_t>(), cut_num, c->tile_sums.as<uint64_t>(),
+                       c->tile_w.as<uint64_t>(), ntiles, c->cptr.as<uint64_t>(), c->row_bin.as<uint8_t>(), dc->num_counts,
+                       c->batch_num.as<uint32_t>());
     HIP_TRY(hipGetLastError());
     if (n) {
-        hipLaunchKernelGGL(k_num_classify, dim3(g256), dim3(256), 0, s, a->ptr, c->r0, n, c->row_nprod.as<uint32_t>(),
-                           c->row_nnzc.as<uint32_t>(), c->row_bin.as<uint8_t>(), dc->num_counts, c->bm_vcap);
-        hipLaunchKernelGGL(k_bin_scatter, dim3(g256), dim3(256), 0, s, c->row_bin.as<uint8_t>(), n, dc->num_counts,
+        hipLaunchKernelGGL(k_bin_scatter2, dim3(g256), dim3(256), 0, s, c->row_bin.as<uint8_t>(), n, dc->num_counts,
                            dc->num_cursor, c->num_rows.as<uint32_t>());
         HIP_TRY(hipGetLastError());
     }
@@ -568,7 +643,7 @@ int spada_dev_spgemm_symbolic(spada_ctx *c, const spada_dev_csr *a, const spada_
         st.sym_bin_rows[k] = c->h_sym_counts[k];
         st.num_bin_rows[k] = c->h_num_counts[k];
     }
-    st.spill_rows = c->h_sym_counts[SYM_SPILL_BIN] + c->h_num_counts[NUM_SPILL_BIN] + c->h_num_counts[NUM_BMV_BIN];
+    st.spill_rows = c->h_sym_counts[SYM2_BIN_SPILL] + c->h_num_counts[NUM2_BIN_SPILL] + c->h_num_counts[NUM2_BIN_BMV];
     st.workspace_bytes = c->ws_bytes;
     return SPADA_OK;
 }
@@ -648,6 +723,21 @@ int spada_spgemm_numeric(spada_ctx *c, uint64_t *c_indptr, uint64_t *c_indices, 
     int rc = spada_dev_spgemm_numeric_owned(c, &dp, &di, &dv);
     if (rc) return rc;
     return spada_dev_download_c(c, dp, di, dv, c->nrows, c->nnz_c, c_indptr, c_indices, c_data);
+}
+
+int spada_debug_buf(spada_ctx *c, int which, void *out, uint64_t bytes)
+{
+    if (!c) return fail(SPADA_ERR_STATE, "no ctx");
+    DevBuf *b[] = {&c->num_rows, &c->sym_rows, &c->row_bin, &c->elen, &c->row_nnzc, &c->batch_num, &c->batch_sym, &c->cptr, &c->row_kmin, &c->row_kmax};
+    HIP_TRY(hipMemcpy(out, b[which]->p, bytes, hipMemcpyDeviceToHost));
+    return SPADA_OK;
+}
+
+int spada_debug_read(spada_ctx *c, unsigned long long *out, uint64_t n)
+{
+    if (!c || !c->dbg.p) return fail(SPADA_ERR_STATE, "no debug buffer");
+    HIP_TRY(hipMemcpy(out, c->dbg.p, std::min<uint64_t>(n, 64 * 16) * 8, hipMemcpyDeviceToHost));
+    return SPADA_OK;
 }
 
 int spada_get_stats(const spada_ctx *c, spada_stats *out)

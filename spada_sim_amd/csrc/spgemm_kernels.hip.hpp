@@ -30,6 +30,9 @@ struct DevCsrView {
     const uint64_t *ptr;
     const uint32_t *idx;
     const double *val;
+    // A only: per-entry descriptor of the selected B row (begin, length), written by k_row_stats2
+    const uint64_t *eb0;
+    const uint32_t *elen;
 };
 
 // ---- bin definitions (host and device agree through these) -------------------------------------------
@@ -444,10 +447,9 @@ __device__ inline void walk_products(const DevCsrView &A, const DevCsrView &B, u
         uint32_t len = 0;
         double av = 0.0;
         if (a < a1) {
-            const uint32_t k = A.idx[a];
             if constexpr (NUMERIC) av = A.val[a];
-            b0 = B.ptr[k];
-            len = (uint32_t)(B.ptr[k + 1] - b0);
+            b0 = A.eb0[a];
+            len = A.elen[a];
         }
         const uint32_t maxlen = group_max<G>(len, hdr);
         uint32_t total;
@@ -550,8 +552,11 @@ template <int G, int LOG_T>
 __global__ __launch_bounds__((G <= 64 ? 256 : G)) void k_num_hash(DevCsrView A, DevCsrView B, uint64_t r0,
                                                                    const uint32_t *__restrict__ bin_rows, uint32_t n_bin_rows,
                                                                    const uint64_t *__restrict__ cptr,
-                                                                   uint32_t *__restrict__ c_idx, double *__restrict__ c_val)
+                                                                   uint32_t *__restrict__ c_idx, double *__restrict__ c_val,
+                                                                   int ablate, unsigned long long *dbg)
 {
+#define STAMP(i) do { if (dbg && threadIdx.x == 0 && blockIdx.x % 16 == 0 && blockIdx.x / 16 < 64) dbg[(blockIdx.x / 16) * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+    STAMP(0);
     constexpr int T = 1 << LOG_T;
     constexpr int NB = T / 2;
     constexpr int BLOCK = G <= 64 ? 256 : G;
@@ -572,11 +577,14 @@ __global__ __launch_bounds__((G <= 64 ? 256 : G)) void k_num_hash(DevCsrView A, 
     }
     for (int s = gl; s < NB; s += G) cnt[s] = 0;
     group_sync<G>();
+    STAMP(1);
 
     uint32_t row = 0;
+    if (ablate >= 3) return;
     if (active) {
         row = bin_rows[slot];
         const uint64_t a0 = A.ptr[r0 + row], a1 = A.ptr[r0 + row + 1];
+        if (ablate < 2)
         walk_products<G, true>(A, B, a0, a1, gl, mine + 16 * T, hdr, [&](uint32_t c, double v) {
             uint32_t h = hash_slot<LOG_T>(c);
             for (;;) {
@@ -588,6 +596,8 @@ __global__ __launch_bounds__((G <= 64 ? 256 : G)) void k_num_hash(DevCsrView A, 
         });
     }
     group_sync<G>();
+    STAMP(2);
+    if (ablate >= 1) return;
 
     // ---- ordered emission: monotone buckets over [kmin, kmax], scan, in-bucket rank ---------------------
     // each lane keeps its T/G table keys in registers for the three passes over the table
@@ -604,6 +614,7 @@ __global__ __launch_bounds__((G <= 64 ? 256 : G)) void k_num_hash(DevCsrView A, 
     }
     kmin = group_min<G>(kmin, hdr);
     kmax = group_max<G>(kmax, hdr + 1);
+    STAMP(3);
     // an inactive group has an empty table (kmin > kmax)
     const float scale = (kmax >= kmin) ? (float)NB / ((float)(kmax - kmin) + 1.0f) : 0.0f;
     auto bucket = [&](uint32_t k) -> uint32_t {
@@ -614,7 +625,9 @@ __global__ __launch_bounds__((G <= 64 ? 256 : G)) void k_num_hash(DevCsrView A, 
     for (int i = 0; i < SPL; ++i)
         if (myk[i] != EMPTY_KEY) atomicAdd(&cnt[bucket(myk[i])], 1u);
     group_sync<G>();
+    STAMP(4);
     group_exclusive_scan<G, NB>(cnt, gl, hdr + 2);
+    STAMP(5);
 #pragma unroll
     for (int i = 0; i < SPL; ++i)
         if (myk[i] != EMPTY_KEY) {
@@ -622,6 +635,7 @@ __global__ __launch_bounds__((G <= 64 ? 256 : G)) void k_num_hash(DevCsrView A, 
             list[p] = (uint16_t)(gl + i * G);
         }
     group_sync<G>();
+    STAMP(6);
     if (active) {
         const uint64_t c0 = cptr[row];
         const uint32_t n = (uint32_t)(cptr[row + 1] - c0);
@@ -636,6 +650,8 @@ __global__ __launch_bounds__((G <= 64 ? 256 : G)) void k_num_hash(DevCsrView A, 
             c_val[c0 + r] = vals[s];
         }
     }
+    STAMP(7);
+#undef STAMP
 }
 
 // ---- 6. numeric, rows with a single A nonzero: C row = a * B row (already ascending) ------------------------
@@ -650,9 +666,8 @@ __global__ __launch_bounds__(256) void k_num_copy(DevCsrView A, DevCsrView B, ui
     if (slot >= n_bin_rows) return;
     const uint32_t row = bin_rows[slot];
     const uint64_t a = A.ptr[r0 + row];
-    const uint32_t k = A.idx[a];
     const double av = A.val[a];
-    const uint64_t b0 = B.ptr[k], b1 = B.ptr[k + 1], c0 = cptr[row];
+    const uint64_t b0 = A.eb0[a], b1 = b0 + A.elen[a], c0 = cptr[row];
     for (uint64_t q = b0 + gl; q < b1; q += G) {
         c_idx[c0 + (q - b0)] = B.idx[q];
         c_val[c0 + (q - b0)] = av * B.val[q];

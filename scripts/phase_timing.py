@@ -20,12 +20,20 @@ buf = np.zeros(64 * 16, np.uint64)
 L.spada_debug_read.restype = ctypes.c_int
 L.spada_debug_read.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64]
 rc = L.spada_debug_read(eng._ctx, buf.ctypes.data_as(ctypes.c_void_p), 64 * 16)
-t = buf.reshape(64, 16)[:, :8].astype(np.int64)
-ok = t[:, 7] > t[:, 0]
+flat = os.environ.get("SPADA_DBG_G") == "1"
+NS = 7 if flat else 8
+t = buf.reshape(64, 16)[:, :NS].astype(np.int64)
+ok = t[:, NS - 1] > t[:, 0]
 t = t[ok]
-names = ["init", "walk", "keys+minmax", "bucket count", "scan", "scatter", "rank+write"]
+names = ["rows+init", "walk", "zero bcnt", "bucket count", "scan", "scatter", "rank+write"] if not flat else ["rows+init", "walk", "bucket count", "scan", "scatter", "rank+write"]
+if not flat: names = ["init", "walk", "keys+minmax", "bucket count", "scan", "scatter", "rank+write"]
 dt = np.diff(t, axis=1)
 print(f"G={os.environ.get('SPADA_DBG_G')} sampled {len(t)} workgroups; cycles (mean / median / max)")
 for i, n in enumerate(names):
     print(f"  {n:14s} {dt[:, i].mean():9.0f} {np.median(dt[:, i]):9.0f} {dt[:, i].max():9.0f}")
-print(f"  {'total':14s} {(t[:,7]-t[:,0]).mean():9.0f}")
+print(f"  {'total':14s} {(t[:,NS-1]-t[:,0]).mean():9.0f}")
+
+if flat:
+    w = buf.reshape(64, 16)[:, 8:14].astype(np.int64)[ok]
+    for i, n in enumerate(["entry search+issue", "entry wait+scan", "lds write+barrier", "search+gather issue", "hash", "final barrier"]):
+        print(f"    walk/{n:22s} {w[:, i].mean():9.0f}")

@@ -89,6 +89,7 @@ struct spada_ctx {
     hipStream_t side[SPADA_N_BINS] = {};
     hipEvent_t ev_fork = nullptr, ev_join[SPADA_N_BINS] = {};
     hipStream_t cur = nullptr;        // stream the launch helpers use
+    int flat_cfg = 1;                 // SPADA_FLAT_CFG: 0 = 256 threads x 4 entries, 1 = 512 x 2, 2 = 1024 x 1
     int dbg_g = 0;                    // SPADA_DBG_G=<G>: phase timestamps of k_num_hash<G,*> into `dbg`
     DevBuf dbg;
     bool serial_bins = false;         // SPADA_SERIAL_BINS=1: one stream, for per-kernel profiling
@@ -255,9 +256,9 @@ void dev_free(spada_dev_csr *m)
 }
 
 // flat-batch kernel configurations: <BLOCK, LOG_T, NOUT, RMAX>; cap = 2 * flat_max, NOUT >= cap + flat_max
-constexpr int NF_BLOCK = 256, NF_LOG_T = 12, NF_NOUT = 3072, NF_RMAX = 256;
+constexpr int NF_BLOCK = 256, NF_EPT = 4, NF_LOG_T = 12, NF_NOUT = 3072, NF_RMAX = 256;
 constexpr uint32_t NUM_FLAT_MAX = 1024, NUM_FLAT_CAP = 2048;
-constexpr int SF_BLOCK = 256, SF_RMAX = 256;
+constexpr int SF_BLOCK = 256, SF_EPT = 4, SF_RMAX = 256;
 static_assert(NF_NOUT >= NUM_FLAT_CAP + NUM_FLAT_MAX, "a batch weighs less than cap + flat_max");
 static_assert((1u << SYM_FLAT_LOG_T) * 3 >= (SYM_FLAT_CAP + SYM_FLAT_MAX) * 4, "symbolic table load <= 0.75");
 
@@ -269,6 +270,7 @@ uint32_t flat_grid(uint64_t nb_upper, size_t lds)
 
 int run_numeric(spada_ctx *c, uint64_t *d_ptr, uint32_t *d_idx, double *d_val)
 {
+    if (c->dbg.p) HIP_TRY(hipMemsetAsync(c->dbg.p, 0, 64 * 16 * 8, c->stream));
     HIP_TRY(hipEventRecord(c->ev[EV_NUM_BEGIN], c->stream));
     HIP_TRY(hipMemcpyAsync(d_ptr, c->cptr.p, ((size_t)c->nrows + 1) * 8, hipMemcpyDeviceToDevice, c->stream));
     const uint32_t *cnt = c->h_num_counts;
@@ -320,12 +322,19 @@ int run_numeric(spada_ctx *c, uint64_t *d_ptr, uint32_t *d_idx, double *d_val)
 #undef NUM_BIN
     if (cnt[BIN_FLAT]) {
         if ((rc = fork_to(c, BIN_FLAT))) return rc;
-        constexpr size_t lds = num_flat_lds<NF_BLOCK, NF_LOG_T, NF_NOUT, NF_RMAX>();
-        hipLaunchKernelGGL((k_num_flat<NF_BLOCK, NF_LOG_T, NF_NOUT, NF_RMAX>), dim3(flat_grid(c->h_counters->nb_num, lds)),
-                           dim3(NF_BLOCK), lds, c->cur, c->A->ptr, c->A->val, c->B->idx, c->B->val, c->eb0.as<uint64_t>(),
-                           c->elen.as<uint32_t>(), c->r0, c->nrows, c->row_bin.as<uint8_t>(), c->row_kmin.as<uint32_t>(),
-                           c->row_kmax.as<uint32_t>(), c->cptr.as<uint64_t>(), c->batch_num.as<uint32_t>(), &dc->nb_num,
-                           c->colbits, d_idx, d_val);
+#define LAUNCH_NUM_FLAT(BL, EP)                                                                                              \
+    {                                                                                                                        \
+        constexpr size_t lds = num_flat_lds<BL, EP, NF_LOG_T, NF_NOUT, NF_RMAX>();                                           \
+        hipLaunchKernelGGL((k_num_flat<BL, EP, NF_LOG_T, NF_NOUT, NF_RMAX>), dim3(flat_grid(c->h_counters->nb_num, lds)),     \
+                           dim3(BL), lds, c->cur, c->A->ptr, c->A->val, c->B->idx, c->B->val, c->eb0.as<uint64_t>(),          \
+                           c->elen.as<uint32_t>(), c->r0, c->nrows, c->row_bin.as<uint8_t>(), c->row_kmin.as<uint32_t>(),     \
+                           c->row_kmax.as<uint32_t>(), c->cptr.as<uint64_t>(), c->batch_num.as<uint32_t>(), &dc->nb_num,      \
+                           c->colbits, d_idx, d_val, c->dbg_g == 1 ? c->dbg.as<unsigned long long>() : nullptr);             \
+    }
+        if (c->flat_cfg == 0) LAUNCH_NUM_FLAT(256, 4)
+        else if (c->flat_cfg == 1) LAUNCH_NUM_FLAT(512, 2)
+        else LAUNCH_NUM_FLAT(1024, 1)
+#undef LAUNCH_NUM_FLAT
         HIP_TRY(hipGetLastError());
         if ((rc = join_from(c, BIN_FLAT))) return rc;
     }
@@ -407,9 +416,14 @@ int spada_create(const spada_options *opts, spada_ctx **out)
     if ((rc = allow_lds(k_sym_hash<1024, 15>, sym_lds<1024, 15>()))) return rc;
     if ((rc = allow_lds(k_num_hash<256, 12>, num_lds<256, 12>()))) return rc;
     if ((rc = allow_lds(k_num_hash<1024, 13>, num_lds<1024, 13>()))) return rc;
-    if ((rc = allow_lds(k_sym_flat<SF_BLOCK, SYM_FLAT_LOG_T, SF_RMAX>, sym_flat_lds<SF_BLOCK, SYM_FLAT_LOG_T, SF_RMAX>()))) return rc;
-    if ((rc = allow_lds(k_num_flat<NF_BLOCK, NF_LOG_T, NF_NOUT, NF_RMAX>, num_flat_lds<NF_BLOCK, NF_LOG_T, NF_NOUT, NF_RMAX>())))
-        return rc;
+#define ALLOW_FLAT(BL, EP)                                                                                                   \
+    if ((rc = allow_lds(k_sym_flat<BL, EP, SYM_FLAT_LOG_T, SF_RMAX>, sym_flat_lds<BL, EP, SYM_FLAT_LOG_T, SF_RMAX>()))) return rc; \
+    if ((rc = allow_lds(k_num_flat<BL, EP, NF_LOG_T, NF_NOUT, NF_RMAX>, num_flat_lds<BL, EP, NF_LOG_T, NF_NOUT, NF_RMAX>()))) return rc;
+    ALLOW_FLAT(256, 4)
+    ALLOW_FLAT(512, 2)
+    ALLOW_FLAT(1024, 1)
+#undef ALLOW_FLAT
+    if (const char *e = std::getenv("SPADA_FLAT_CFG")) c->flat_cfg = atoi(e);
     if ((rc = allow_lds(k_sym_bitmap, LDS_MAX))) return rc;
     if ((rc = allow_lds(k_num_bitmap<true>, LDS_MAX))) return rc;
     if ((rc = allow_lds(k_num_bitmap<false>, LDS_MAX))) return rc;
@@ -523,9 +537,9 @@ int spada_dev_spgemm_symbolic(spada_ctx *c, const spada_dev_csr *a, const spada_
 
     HIP_TRY(hipEventRecord(c->ev[EV_SYM_BEGIN], s));
     HIP_TRY(hipMemsetAsync(dc, 0, sizeof(Counters), s));
-    const uint32_t g256 = (n + 255) / 256;
+    const uint32_t g256 = (n + 255) / 256, gsc = (n + 256 * SC_ITEMS - 1) / (256 * SC_ITEMS);
     if (n) {
-        hipLaunchKernelGGL(k_row_stats2, dim3(g256), dim3(256), 0, s, a->ptr, a->idx, b->ptr, b->idx, c->r0, n,
+        hipLaunchKernelGGL(k_row_stats2, dim3(std::min<uint32_t>(g256, 1024)), dim3(256), 0, s, a->ptr, a->idx, b->ptr, b->idx, c->r0, n,
                            c->eb0.as<uint64_t>(), c->elen.as<uint32_t>(), c->row_nprod.as<uint32_t>(),
                            c->row_nnzc.as<uint32_t>(), c->row_bin.as<uint8_t>(), c->row_kmin.as<uint32_t>(),
                            c->row_kmax.as<uint32_t>(), dc->sym_counts, dc->totals, c->flat_on ? 1 : 0);
@@ -534,7 +548,7 @@ int spada_dev_spgemm_symbolic(spada_ctx *c, const spada_dev_csr *a, const spada_
     HIP_TRY(hipEventRecord(c->ev[EV_STATS], s));
     HIP_TRY(hipMemcpyAsync(c->h_counters, dc, sizeof(Counters), hipMemcpyDeviceToHost, s));
     if (n) {
-        hipLaunchKernelGGL(k_bin_scatter2, dim3(g256), dim3(256), 0, s, c->row_bin.as<uint8_t>(), n, dc->sym_counts,
+        hipLaunchKernelGGL(k_bin_scatter2, dim3(gsc), dim3(256), 0, s, c->row_bin.as<uint8_t>(), n, dc->sym_counts,
                            dc->sym_cursor, c->sym_rows.as<uint32_t>());
         hipLaunchKernelGGL(k_cut_tile_sums<0>, dim3(ntiles), dim3(SCAN_BLOCK), 0, s, a->ptr, c->r0, n,
                            c->row_nprod.as<uint32_t>(), c->row_nnzc.as<uint32_t>(), c->row_bin.as<uint8_t>(), cut_sym,
@@ -589,12 +603,19 @@ int spada_dev_spgemm_symbolic(spada_ctx *c, const spada_dev_csr *a, const spada_
 #undef SYM_BIN
         if (cnt[BIN_FLAT]) {
             if ((rc = fork_to(c, BIN_FLAT))) return rc;
-            constexpr size_t lds = sym_flat_lds<SF_BLOCK, SYM_FLAT_LOG_T, SF_RMAX>();
             const uint64_t nb_upper = (nprod + (uint64_t)n * cut_sym.minw) / cut_sym.cap + 1;
-            hipLaunchKernelGGL((k_sym_flat<SF_BLOCK, SYM_FLAT_LOG_T, SF_RMAX>), dim3(flat_grid(nb_upper, lds)), dim3(SF_BLOCK),
-                               lds, c->cur, a->ptr, b->idx, c->eb0.as<uint64_t>(), c->elen.as<uint32_t>(), c->r0, n,
-                               c->row_bin.as<uint8_t>(), c->batch_sym.as<uint32_t>(), &dc->nb_sym, c->colbits,
-                               c->row_nnzc.as<uint32_t>());
+#define LAUNCH_SYM_FLAT(BL, EP)                                                                                              \
+    {                                                                                                                        \
+        constexpr size_t lds = sym_flat_lds<BL, EP, SYM_FLAT_LOG_T, SF_RMAX>();                                              \
+        hipLaunchKernelGGL((k_sym_flat<BL, EP, SYM_FLAT_LOG_T, SF_RMAX>), dim3(flat_grid(nb_upper, lds)), dim3(BL), lds,      \
+                           c->cur, a->ptr, b->idx, c->eb0.as<uint64_t>(), c->elen.as<uint32_t>(), c->r0, n,                   \
+                           c->row_bin.as<uint8_t>(), c->batch_sym.as<uint32_t>(), &dc->nb_sym, c->colbits,                    \
+                           c->row_nnzc.as<uint32_t>());                                                                      \
+    }
+            if (c->flat_cfg == 0) LAUNCH_SYM_FLAT(256, 4)
+            else if (c->flat_cfg == 1) LAUNCH_SYM_FLAT(512, 2)
+            else LAUNCH_SYM_FLAT(1024, 1)
+#undef LAUNCH_SYM_FLAT
             HIP_TRY(hipGetLastError());
             if ((rc = join_from(c, BIN_FLAT))) return rc;
         }
@@ -613,7 +634,7 @@ int spada_dev_spgemm_symbolic(spada_ctx *c, const spada_dev_csr *a, const spada_
                        c->batch_num.as<uint32_t>());
     HIP_TRY(hipGetLastError());
     if (n) {
-        hipLaunchKernelGGL(k_bin_scatter2, dim3(g256), dim3(256), 0, s, c->row_bin.as<uint8_t>(), n, dc->num_counts,
+        hipLaunchKernelGGL(k_bin_scatter2, dim3(gsc), dim3(256), 0, s, c->row_bin.as<uint8_t>(), n, dc->num_counts,
                            dc->num_cursor, c->num_rows.as<uint32_t>());
         HIP_TRY(hipGetLastError());
     }

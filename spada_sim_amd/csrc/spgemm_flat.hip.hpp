@@ -72,16 +72,7 @@ __global__ __launch_bounds__(256) void k_row_stats2(const uint64_t *__restrict__
     if (threadIdx.x < SPADA_N_BINS) s_hist[threadIdx.x] = 0;
     if (threadIdx.x < 2) s_tot[threadIdx.x] = 0;
     __syncthreads();
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
-    uint64_t a0 = 0, a1 = 0, P = 0;
-    uint32_t kmin = 0xFFFFFFFFu, kmax = 0;
-    if (i < nrows) {
-        a0 = aptr[r0 + i];
-        a1 = aptr[r0 + i + 1];
-    }
-    const uint32_t L = (uint32_t)(a1 - a0);
-    const bool is_long = L > 16;
     auto visit = [&](uint64_t q, uint64_t &part, uint32_t &mn, uint32_t &mx) {
         const uint32_t k = aidx[q];
         const uint64_t b0 = bptr[k], b1 = bptr[k + 1];
@@ -93,40 +84,56 @@ __global__ __launch_bounds__(256) void k_row_stats2(const uint64_t *__restrict__
             mx = max(mx, bidx[b1 - 1]);
         }
     };
-    if (!is_long)
-        for (uint64_t q = a0; q < a1; ++q) visit(q, P, kmin, kmax);
-    unsigned long long mask = __ballot(is_long);
-    while (mask) {
-        const int src = __ffsll((long long)mask) - 1;
-        mask &= mask - 1;
-        const uint64_t sa0 = __shfl(a0, src), sa1 = __shfl(a1, src);
-        uint64_t part = 0;
-        uint32_t mn = 0xFFFFFFFFu, mx = 0;
-        for (uint64_t q = sa0 + lane; q < sa1; q += 64) visit(q, part, mn, mx);
-        part = wave_sum_u64(part);
+    uint64_t tot_p = 0, tot_l = 0;
+    // grid-stride over row tiles: the per-bin histogram costs one global atomic per workgroup, not per tile
+    // (a hot global word sustains ~90 atomics per microsecond)
+    for (uint32_t tile = blockIdx.x * blockDim.x; tile < nrows; tile += gridDim.x * blockDim.x) {
+        const uint32_t i = tile + threadIdx.x;
+        uint64_t a0 = 0, a1 = 0, P = 0;
+        uint32_t kmin = 0xFFFFFFFFu, kmax = 0;
+        if (i < nrows) {
+            a0 = aptr[r0 + i];
+            a1 = aptr[r0 + i + 1];
+        }
+        const uint32_t L = (uint32_t)(a1 - a0);
+        const bool is_long = L > 16;
+        if (!is_long)
+            for (uint64_t q = a0; q < a1; ++q) visit(q, P, kmin, kmax);
+        unsigned long long mask = __ballot(is_long);
+        while (mask) {
+            const int src = __ffsll((long long)mask) - 1;
+            mask &= mask - 1;
+            const uint64_t sa0 = __shfl(a0, src), sa1 = __shfl(a1, src);
+            uint64_t part = 0;
+            uint32_t mn = 0xFFFFFFFFu, mx = 0;
+            for (uint64_t q = sa0 + lane; q < sa1; q += 64) visit(q, part, mn, mx);
+            part = wave_sum_u64(part);
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            mn = min(mn, (uint32_t)__shfl_xor(mn, o));
-            mx = max(mx, (uint32_t)__shfl_xor(mx, o));
+            for (int o = 32; o > 0; o >>= 1) {
+                mn = min(mn, (uint32_t)__shfl_xor(mn, o));
+                mx = max(mx, (uint32_t)__shfl_xor(mx, o));
+            }
+            if (lane == src) {
+                P = part;
+                kmin = mn;
+                kmax = mx;
+            }
         }
-        if (lane == src) {
-            P = part;
-            kmin = mn;
-            kmax = mx;
+        if (i < nrows) {
+            int bin = sym2_bin_of(P, L);
+            if (bin == BIN_FLAT && !flat_on) bin = SYM2_BIN_8K;
+            row_nprod[i] = P > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)P;
+            row_bin[i] = (uint8_t)bin;
+            row_kmin[i] = kmin;
+            row_kmax[i] = kmax;
+            if (bin == BIN_EMPTY) row_nnzc[i] = 0;
+            if (bin == BIN_COPY) row_nnzc[i] = (uint32_t)P;   // one A nonzero: C row is a scaled copy of one B row
+            atomicAdd(&s_hist[bin], 1u);
         }
+        tot_p += P;
+        tot_l += L;
     }
-    if (i < nrows) {
-        int bin = sym2_bin_of(P, L);
-        if (bin == BIN_FLAT && !flat_on) bin = SYM2_BIN_8K;
-        row_nprod[i] = P > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)P;
-        row_bin[i] = (uint8_t)bin;
-        row_kmin[i] = kmin;
-        row_kmax[i] = kmax;
-        if (bin == BIN_EMPTY) row_nnzc[i] = 0;
-        if (bin == BIN_COPY) row_nnzc[i] = (uint32_t)P;   // one A nonzero: C row is a scaled copy of one B row
-        atomicAdd(&s_hist[bin], 1u);
-    }
-    uint64_t wp = wave_sum_u64(P), wl = wave_sum_u64((uint64_t)L);
+    const uint64_t wp = wave_sum_u64(tot_p), wl = wave_sum_u64(tot_l);
     if (lane == 0) {
         atomicAdd(&s_tot[0], (unsigned long long)wp);
         atomicAdd(&s_tot[1], (unsigned long long)wl);
@@ -277,7 +284,9 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_cut_apply(const uint64_t *__rest
     }
 }
 
-// scatter the rows of the per-row bins (everything except empty / flat) into their lists
+// scatter the rows of the per-row bins (everything except empty / flat) into their lists; SC_ITEMS rows per
+// thread so that the per-bin cursors see one global atomic per 4096 rows
+constexpr int SC_ITEMS = 16;
 __global__ __launch_bounds__(256) void k_bin_scatter2(const uint8_t *__restrict__ row_bin, uint32_t nrows,
                                                       const uint32_t *__restrict__ bin_counts,
                                                       uint32_t *__restrict__ bin_cursor, uint32_t *__restrict__ bin_rows)
@@ -285,13 +294,21 @@ __global__ __launch_bounds__(256) void k_bin_scatter2(const uint8_t *__restrict_
     __shared__ uint32_t s_cnt[SPADA_N_BINS], s_base[SPADA_N_BINS];
     if (threadIdx.x < SPADA_N_BINS) s_cnt[threadIdx.x] = 0;
     __syncthreads();
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    int bin = -1;
-    uint32_t local = 0;
-    if (i < nrows) {
-        bin = row_bin[i];
-        if (bin == BIN_EMPTY || bin == BIN_FLAT) bin = -1;
-        else local = atomicAdd(&s_cnt[bin], 1u);
+    const uint32_t base = blockIdx.x * (256 * SC_ITEMS) + threadIdx.x;
+    int bin[SC_ITEMS];
+    uint32_t local[SC_ITEMS];
+#pragma unroll
+    for (int j = 0; j < SC_ITEMS; ++j) {
+        const uint32_t i = base + j * 256;
+        bin[j] = -1;
+        local[j] = 0;
+        if (i < nrows) {
+            const int b = row_bin[i];
+            if (b != BIN_EMPTY && b != BIN_FLAT) {
+                bin[j] = b;
+                local[j] = atomicAdd(&s_cnt[b], 1u);
+            }
+        }
     }
     __syncthreads();
     if (threadIdx.x < SPADA_N_BINS) {
@@ -302,7 +319,9 @@ __global__ __launch_bounds__(256) void k_bin_scatter2(const uint8_t *__restrict_
         s_base[threadIdx.x] = off + (c ? atomicAdd(&bin_cursor[threadIdx.x], c) : 0u);
     }
     __syncthreads();
-    if (bin >= 0) bin_rows[s_base[bin] + local] = i;
+#pragma unroll
+    for (int j = 0; j < SC_ITEMS; ++j)
+        if (bin[j] >= 0) bin_rows[s_base[bin[j]] + local[j]] = base + j * 256;
 }
 
 // ---- 3. flat batches: shared pieces ---------------------------------------------------------------------------
@@ -336,18 +355,227 @@ __device__ inline uint32_t row_of_entry(const uint32_t *s_re, uint32_t R, uint32
     return lo;
 }
 
-// ---- 4. symbolic, flat batches ---------------------------------------------------------------------------------
-// LDS: 128 B hdr | keys u32[T] | s_re u32[RMAX + 1] | s_cnt u32[RMAX] | s_a0 u64[RMAX] | w_b0 u64[BLOCK] |
-//      w_off u32[BLOCK + 1] | w_lr u32[BLOCK]
-template <int BLOCK, int LOG_T, int RMAX>
-__host__ __device__ constexpr size_t sym_flat_lds()
+// ---- 4. the flat product walk ------------------------------------------------------------------------------------
+// The A entries of the batch's flat rows are taken ECH = BLOCK * EPT at a time (each thread EPT consecutive
+// entries: descriptor (begin, length) of the selected B row, the A value, the local row).  Entries that select an
+// empty B row are dropped; one packed exclusive scan numbers the surviving entries and the products of the chunk
+// densely.  Products are handled in windows of PWIN: every entry sets the bit of its first product in a window
+// bitmap ("head bits"), one wave turns the word popcounts into prefix counts, and the owner entry of product p
+// is   prefix[word(p)] + popcount(bits(word(p)) up to p) - 1   -- two broadcast LDS reads instead of a binary
+// search.  Each wave takes 64 CONSECUTIVE products at a time (adjacent lanes read adjacent B entries, and the
+// lanes of a wave hit the same or neighbouring entry records), U such segments per thread and round, so that U
+// independent gathers and U independent first-probe LDS atomics are in flight.
+// LDS scratch: entry records {pack = (begin - offset) mod 2^48 | local row << 48, a value} | bm u64[PWIN / 64] |
+// bpre u32[PWIN / 64]
+constexpr int FLAT_PWIN = 8192;
+constexpr unsigned long long M48 = 0xFFFFFFFFFFFFull;
+
+struct __attribute__((aligned(16))) EntryRecNum {
+    uint64_t pack;
+    double av;
+};
+
+template <int BLOCK, int EPT, bool NUMERIC>
+__host__ __device__ constexpr size_t flat_walk_bytes()
 {
-    return 128 + ((size_t)4 << LOG_T) + (size_t)(RMAX + 1) * 4 + (size_t)RMAX * 4 + (size_t)RMAX * 8 + (size_t)BLOCK * 8 +
-           (size_t)(BLOCK + 1) * 4 + (size_t)BLOCK * 4 + 32;
+    return (size_t)BLOCK * EPT * (NUMERIC ? 16 : 8) + (size_t)(FLAT_PWIN / 64) * 12 + 16;
 }
 
-template <int BLOCK, int LOG_T, int RMAX>
-__global__ __launch_bounds__(BLOCK) void k_sym_flat(const uint64_t *__restrict__ aptr, const uint32_t *__restrict__ bidx,
+template <int BLOCK, int EPT, int RMAX, bool NUMERIC, int U, class F>
+__device__ inline void flat_walk(const uint32_t *s_re, const uint64_t *s_a0, uint32_t R, uint32_t E,
+                                 const uint64_t *__restrict__ eb0, const uint32_t *__restrict__ elen,
+                                 const double *__restrict__ aval, const uint32_t *__restrict__ bidx,
+                                 const double *__restrict__ bval, unsigned char *scratch, uint32_t *hdr, F &&f,
+                                 unsigned long long *wdbg = nullptr)
+{
+#define WSTAMP(i) do { if (wdbg && threadIdx.x == 0) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); wdbg[i] += t_ - tprev; tprev = t_; } } while (0)
+    unsigned long long tprev = wdbg ? __builtin_amdgcn_s_memtime() : 0;
+    constexpr int ECH = BLOCK * EPT;
+    constexpr int NW = BLOCK / 64;
+    constexpr int PWORDS = FLAT_PWIN / 64;
+    static_assert(PWORDS % 64 == 0 || PWORDS == 64 || PWORDS == 128, "prefix pass: whole words per lane");
+    constexpr int WPL = PWORDS / 64;   // bitmap words per lane of the prefix wave
+    EntryRecNum *w_ent = (EntryRecNum *)scratch;
+    uint64_t *w_pack = (uint64_t *)scratch;
+    unsigned long long *bm = (unsigned long long *)(scratch + (size_t)ECH * (NUMERIC ? 16 : 8));
+    uint32_t *bpre = (uint32_t *)(bm + PWORDS);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned long long le_mask = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);
+    for (uint32_t chunk = 0; chunk < E; chunk += ECH) {
+        uint64_t b0[EPT];
+        uint32_t len[EPT], lr[EPT], off[EPT];
+        double av[EPT];
+        {
+            uint32_t ee[EPT];
+#pragma unroll
+            for (int i = 0; i < EPT; ++i) {
+                ee[i] = chunk + tid * EPT + i;
+                lr[i] = 0;
+            }
+#pragma unroll
+            for (int step = RMAX / 2; step >= 1; step >>= 1) {   // EPT row searches in lock step
+                uint32_t o[EPT];
+#pragma unroll
+                for (int i = 0; i < EPT; ++i) o[i] = lr[i] + step < R ? s_re[lr[i] + step] : 0xFFFFFFFFu;
+#pragma unroll
+                for (int i = 0; i < EPT; ++i) lr[i] += o[i] <= ee[i] ? step : 0;
+            }
+#pragma unroll
+            for (int i = 0; i < EPT; ++i) {
+                b0[i] = 0;
+                len[i] = 0;
+                av[i] = 0.0;
+                if (ee[i] < E) {
+                    const uint64_t a = s_a0[lr[i]] + (ee[i] - s_re[lr[i]]);
+                    b0[i] = eb0[a];
+                    len[i] = elen[a];
+                    if constexpr (NUMERIC) av[i] = aval[a];
+                }
+            }
+        }
+        WSTAMP(0);
+        // packed scan: (entries with products) << 32 | products
+        unsigned long long mine = 0;
+#pragma unroll
+        for (int i = 0; i < EPT; ++i) mine += len[i] ? ((1ull << 32) | len[i]) : 0ull;
+        unsigned long long tot64;
+        unsigned long long ex64 = group_scan_excl_u64<BLOCK>(mine, tid, (unsigned long long *)(hdr + 4), &tot64);
+        const uint32_t total = (uint32_t)tot64;
+        WSTAMP(1);
+        {
+            uint32_t ci = (uint32_t)(ex64 >> 32), po = (uint32_t)ex64;
+#pragma unroll
+            for (int i = 0; i < EPT; ++i) {
+                off[i] = po;
+                if (len[i]) {
+                    const uint64_t pack = ((b0[i] - po) & M48) | ((uint64_t)lr[i] << 48);
+                    if constexpr (NUMERIC) w_ent[ci] = EntryRecNum{pack, av[i]};
+                    else w_pack[ci] = pack;
+                    ++ci;
+                    po += len[i];
+                }
+            }
+        }
+        for (uint32_t lo = 0; lo < total; lo += FLAT_PWIN) {
+            const uint32_t hi = min(lo + (uint32_t)FLAT_PWIN, total);
+            if (tid < PWORDS) bm[tid] = 0ull;
+            if (tid == 0) hdr[0] = 0;
+            __syncthreads();
+            uint32_t before = 0;
+#pragma unroll
+            for (int i = 0; i < EPT; ++i)
+                if (len[i]) {
+                    if (off[i] >= lo && off[i] < hi) {
+                        const uint32_t d = off[i] - lo;
+                        atomicOr((uint32_t *)bm + (d >> 5), 1u << (d & 31));
+                    }
+                    before += off[i] < lo ? 1u : 0u;
+                }
+            if (lo) {   // entries whose first product lies before this window (uniform branch)
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o);
+                if (lane == 0 && before) atomicAdd(&hdr[0], before);
+            }
+            __syncthreads();
+            if (wave == 0) {
+                uint32_t c[WPL], sum = 0;
+#pragma unroll
+                for (int k = 0; k < WPL; ++k) {
+                    c[k] = (uint32_t)__popcll(bm[lane * WPL + k]);
+                    sum += c[k];
+                }
+                uint32_t inc = sum;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const uint32_t t = __shfl_up(inc, o);
+                    if (lane >= o) inc += t;
+                }
+                uint32_t run = hdr[0] + inc - sum;
+#pragma unroll
+                for (int k = 0; k < WPL; ++k) {
+                    bpre[lane * WPL + k] = run;
+                    run += c[k];
+                }
+            }
+            __syncthreads();
+            WSTAMP(2);
+            for (uint32_t base = lo; base < hi; base += U * BLOCK) {   // uniform trip count over the workgroup
+                uint32_t col[U], plr[U];
+                double v[U];
+                uint32_t pp[U], j[U];
+                bool act[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const uint32_t p = base + (u * NW + wave) * 64 + lane;
+                    act[u] = p < hi;
+                    pp[u] = act[u] ? p : hi - 1;
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const uint32_t w = (pp[u] - lo) >> 6;
+                    const unsigned long long bits = bm[w];
+                    const unsigned long long m = ((pp[u] - lo) & 63) == 63 ? ~0ull : ((2ull << ((pp[u] - lo) & 63)) - 1ull);
+                    j[u] = bpre[w] + (uint32_t)__popcll(bits & m) - 1u;
+                }
+                uint64_t q[U];
+                double a_[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    uint64_t pack;
+                    a_[u] = 0.0;
+                    if constexpr (NUMERIC) {
+                        const EntryRecNum er = w_ent[j[u]];
+                        pack = er.pack;
+                        a_[u] = er.av;
+                    } else {
+                        pack = w_pack[j[u]];
+                    }
+                    q[u] = ((pack & M48) + pp[u]) & M48;
+                    plr[u] = act[u] ? (uint32_t)(pack >> 48) : LR_NONE;
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) col[u] = bidx[q[u]];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    v[u] = 0.0;
+                    if constexpr (NUMERIC) v[u] = a_[u] * bval[q[u]];   // simulator.rs:100-101
+                }
+                WSTAMP(3);
+                f(col, plr, v);
+                WSTAMP(4);
+            }
+            __syncthreads();
+        }
+        WSTAMP(5);
+    }
+    (void)le_mask;
+#undef WSTAMP
+}
+
+__device__ inline uint32_t compose_key(uint32_t lr, uint32_t col, uint32_t colbits)
+{
+    return colbits >= 32 ? col : ((lr << colbits) | col);
+}
+
+// per-row parameters of the ordered emission, one 16-byte LDS read per lookup
+struct __attribute__((aligned(16))) RowEmit {
+    uint32_t boff;    // first bucket (= first output slot inside the batch) of the row
+    uint32_t n;       // nnz(C row)
+    uint32_t kmin;    // smallest column that can occur
+    float scale;      // n / (kmax - kmin + 1)
+};
+
+// ---- 5. symbolic, flat batches ---------------------------------------------------------------------------------
+// LDS: 256 B hdr | keys u32[T] | s_re u32[RMAX + 1] | s_cnt u32[RMAX] | s_a0 u64[RMAX] | walk scratch
+template <int BLOCK, int EPT, int LOG_T, int RMAX>
+__host__ __device__ constexpr size_t sym_flat_lds()
+{
+    return 256 + ((size_t)4 << LOG_T) + (size_t)(RMAX + 1) * 4 + (size_t)RMAX * 4 + 8 + (size_t)RMAX * 8 +
+           flat_walk_bytes<BLOCK, EPT, false>() + 16;
+}
+
+template <int BLOCK, int EPT, int LOG_T, int RMAX>
+__global__ __launch_bounds__(BLOCK, BLOCK / 128) void k_sym_flat(const uint64_t *__restrict__ aptr, const uint32_t *__restrict__ bidx,
                                                     const uint64_t *__restrict__ eb0, const uint32_t *__restrict__ elen,
                                                     uint64_t r0, uint32_t nrows, const uint8_t *__restrict__ row_bin,
                                                     const uint32_t *__restrict__ batch_first, const uint32_t *__restrict__ nb_ptr,
@@ -355,162 +583,201 @@ __global__ __launch_bounds__(BLOCK) void k_sym_flat(const uint64_t *__restrict__
 {
     static_assert(RMAX <= BLOCK, "one thread per row of a batch");
     constexpr int T = 1 << LOG_T;
-    constexpr int U = 4;
+    constexpr int U = 8;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *hdr = (uint32_t *)smem;
-    uint32_t *keys = (uint32_t *)(smem + 128);
+    uint32_t *keys = (uint32_t *)(smem + 256);
     uint32_t *s_re = keys + T;
     uint32_t *s_cnt = s_re + RMAX + 1;
     uint64_t *s_a0 = (uint64_t *)(((uintptr_t)(s_cnt + RMAX) + 7) & ~(uintptr_t)7);
-    uint64_t *w_b0 = s_a0 + RMAX;
-    uint32_t *w_off = (uint32_t *)(w_b0 + BLOCK);
-    uint32_t *w_lr = w_off + BLOCK + 1;
+    unsigned char *scratch = (unsigned char *)(s_a0 + RMAX);
     const int tid = threadIdx.x, lane = tid & 63;
-    const uint32_t nb = *nb_ptr;
-    for (uint32_t b = blockIdx.x; b < nb; b += gridDim.x) {
-        const uint32_t rb = batch_first[b];
-        const uint32_t re = b + 1 < nb ? batch_first[b + 1] : nrows;
+    const uint32_t nb = *nb_ptr, G = gridDim.x;
+    // two-level prefetch: while batch b is processed, the rows of batch b + G and the bounds of batch b + 2G load
+    struct Rows {
+        uint64_t a0, a1;
+        uint32_t bin;
+    };
+    auto load_desc = [&](uint32_t bb, uint32_t &rb_, uint32_t &re_) {
+        rb_ = re_ = 0;
+        if (bb < nb) {
+            rb_ = batch_first[bb];
+            re_ = bb + 1 < nb ? batch_first[bb + 1] : nrows;
+        }
+    };
+    auto load_rows = [&](uint32_t rb_, uint32_t re_, Rows &rw) {
+        rw = Rows{0, 0, BIN_EMPTY};
+        if ((uint32_t)tid < re_ - rb_) {
+            rw.a0 = aptr[r0 + rb_ + tid];
+            rw.a1 = aptr[r0 + rb_ + tid + 1];
+            rw.bin = row_bin[rb_ + tid];
+        }
+    };
+    uint32_t rb, re, nrb, nre;
+    Rows cur, nxt;
+    load_desc(blockIdx.x, rb, re);
+    load_rows(rb, re, cur);
+    load_desc(blockIdx.x + G, nrb, nre);
+    uint32_t n2rb = 0, n2re = 0;
+    for (uint32_t b = blockIdx.x; b < nb; b += G) {
+        if (b != blockIdx.x) {   // rotate: next -> current, next-next -> next
+            cur = nxt;
+            rb = nrb;
+            re = nre;
+            nrb = n2rb;
+            nre = n2re;
+        }
+        load_rows(nrb, nre, nxt);
+        load_desc(b + 2 * G, n2rb, n2re);
         const uint32_t R = re - rb;   // <= RMAX by construction of the cut
         if (R == 0) continue;
-        // rows of the batch: entry prefix of the flat ones
         uint32_t L = 0;
+        const bool flat = (uint32_t)tid < R && cur.bin == BIN_FLAT;
         if ((uint32_t)tid < R) {
-            const uint64_t a0 = aptr[r0 + rb + tid], a1 = aptr[r0 + rb + tid + 1];
-            s_a0[tid] = a0;
+            s_a0[tid] = cur.a0;
             s_cnt[tid] = 0;
-            if (row_bin[rb + tid] == BIN_FLAT) L = (uint32_t)(a1 - a0);
+            if (flat) L = (uint32_t)(cur.a1 - cur.a0);
         }
         uint32_t E;
         const uint32_t ex = group_scan_excl<BLOCK>(L, tid, hdr + 2, &E);
         if ((uint32_t)tid < R) s_re[tid] = ex;
         if (tid == 0) s_re[R] = E;
-        for (int s = tid; s < T; s += BLOCK) keys[s] = EMPTY_KEY;
+        uint4 *k4 = (uint4 *)keys;
+        for (int s = tid; s < T / 4; s += BLOCK) k4[s] = make_uint4(EMPTY_KEY, EMPTY_KEY, EMPTY_KEY, EMPTY_KEY);
         __syncthreads();
-        for (uint32_t chunk = 0; chunk < E; chunk += BLOCK) {
-            const uint32_t e = chunk + tid;
-            uint64_t b0 = 0;
-            uint32_t len = 0, lr = 0;
-            if (e < E) {
-                lr = row_of_entry<RMAX>(s_re, R, e);
-                const uint64_t a = s_a0[lr] + (e - s_re[lr]);
-                b0 = eb0[a];
-                len = elen[a];
-            }
-            uint32_t total;
-            const uint32_t off = group_scan_excl<BLOCK>(len, tid, hdr + 2, &total);
-            w_b0[tid] = b0;
-            w_off[tid] = off;
-            w_lr[tid] = lr;
-            if (tid == BLOCK - 1) w_off[BLOCK] = total;
-            __syncthreads();
-            for (uint32_t base = 0; base < total; base += U * BLOCK) {
-                uint32_t key[U], plr[U];
+        flat_walk<BLOCK, EPT, RMAX, false, U>(
+            s_re, s_a0, R, E, eb0, elen, nullptr, bidx, nullptr, scratch, hdr, [&](uint32_t(&col)[U], uint32_t(&plr)[U], double(&)[U]) {
+                uint32_t key[U], h[U], old[U];
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    const uint32_t p = base + u * BLOCK + tid;
-                    key[u] = EMPTY_KEY;
-                    plr[u] = LR_NONE;
-                    if (p < total) {
-                        int j = 0;
-#pragma unroll
-                        for (int step = BLOCK / 2; step >= 1; step >>= 1)
-                            if (w_off[j + step] <= p) j += step;
-                        const uint32_t c = bidx[w_b0[j] + (p - w_off[j])];
-                        plr[u] = w_lr[j];
-                        key[u] = (plr[u] << colbits) | c;
-                    }
+                    key[u] = compose_key(plr[u], col[u], colbits);
+                    h[u] = hash_slot<LOG_T>(key[u]);
+                    old[u] = key[u];
+                    if (plr[u] != LR_NONE) old[u] = atomicCAS(&keys[h[u]], EMPTY_KEY, key[u]);
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    bool isnew = false;
-                    if (key[u] != EMPTY_KEY) {
-                        uint32_t h = hash_slot<LOG_T>(key[u]);
+                    bool isnew = old[u] == EMPTY_KEY;
+                    if (!isnew && old[u] != key[u]) {
+                        uint32_t hh = h[u];
                         for (;;) {
-                            const uint32_t old = atomicCAS(&keys[h], EMPTY_KEY, key[u]);
-                            if (old == EMPTY_KEY) { isnew = true; break; }
-                            if (old == key[u]) break;
-                            h = (h + 1) & (T - 1);
+                            hh = (hh + 1) & (T - 1);
+                            const uint32_t o = atomicCAS(&keys[hh], EMPTY_KEY, key[u]);
+                            if (o == EMPTY_KEY) { isnew = true; break; }
+                            if (o == key[u]) break;
                         }
                     }
                     segmented_count_add(plr[u], isnew, s_cnt, lane);
                 }
-            }
-            __syncthreads();
-        }
-        if ((uint32_t)tid < R && row_bin[rb + tid] == BIN_FLAT) row_nnzc[rb + tid] = s_cnt[tid];
+            });
+        if (flat) row_nnzc[rb + tid] = s_cnt[tid];
         __syncthreads();
     }
 }
 
-// ---- 5. numeric, flat batches -----------------------------------------------------------------------------------
-// LDS: 128 B hdr | table: keys u32[T], vals f64[T]  (re-used after accumulation as lk u32[NOUT], lv f64[NOUT])
-//      | bcnt u32[NOUT]  (the walk scratch w_b0 / w_av / w_off / w_lr aliases it: disjoint phases)
-//      | rows: s_re u32[RMAX+1], s_boff u32[RMAX+1], s_kmin u32[RMAX], s_scale f32[RMAX], s_a0 u64[RMAX], s_out u64[RMAX]
-template <int BLOCK, int LOG_T, int NOUT, int RMAX>
+// ---- 6. numeric, flat batches -----------------------------------------------------------------------------------
+// LDS: 256 B hdr | table: keys u32[T], vals f64[T]  (re-used after accumulation as lk u32[NOUT], lv f64[NOUT])
+//      | region 2: bcnt u32[NOUT], aliased by the walk scratch (disjoint phases)
+//      | rows: s_re u32[RMAX+1], s_row RowEmit[RMAX + 1], s_a0 u64[RMAX], s_out u64[RMAX]
+template <int BLOCK, int EPT, int NOUT>
+__host__ __device__ constexpr size_t num_flat_region2()
+{
+    return (flat_walk_bytes<BLOCK, EPT, true>() > (size_t)NOUT * 4 ? flat_walk_bytes<BLOCK, EPT, true>() : (size_t)NOUT * 4) + 16;
+}
+template <int BLOCK, int EPT, int LOG_T, int NOUT, int RMAX>
 __host__ __device__ constexpr size_t num_flat_lds()
 {
-    constexpr size_t walk = (size_t)BLOCK * 8 * 2 + (size_t)(BLOCK + 1) * 4 + (size_t)BLOCK * 4 + 16;
-    constexpr size_t bc = (size_t)NOUT * 4;
-    return 128 + ((size_t)12 << LOG_T) + (bc > walk ? bc : walk) + (size_t)(RMAX + 1) * 8 + (size_t)RMAX * 8 + (size_t)RMAX * 16 + 32;
+    return 256 + ((size_t)12 << LOG_T) + num_flat_region2<BLOCK, EPT, NOUT>() + (size_t)(RMAX + 1) * 4 + 16 +
+           (size_t)(RMAX + 1) * 16 + (size_t)RMAX * 16 + 32;
 }
 
-template <int BLOCK, int LOG_T, int NOUT, int RMAX>
-__global__ __launch_bounds__(BLOCK) void k_num_flat(const uint64_t *__restrict__ aptr, const double *__restrict__ aval,
+template <int BLOCK, int EPT, int LOG_T, int NOUT, int RMAX>
+__global__ __launch_bounds__(BLOCK, BLOCK / 128) void k_num_flat(const uint64_t *__restrict__ aptr, const double *__restrict__ aval,
                                                     const uint32_t *__restrict__ bidx, const double *__restrict__ bval,
                                                     const uint64_t *__restrict__ eb0, const uint32_t *__restrict__ elen,
                                                     uint64_t r0, uint32_t nrows, const uint8_t *__restrict__ row_bin,
                                                     const uint32_t *__restrict__ row_kmin, const uint32_t *__restrict__ row_kmax,
                                                     const uint64_t *__restrict__ cptr, const uint32_t *__restrict__ batch_first,
                                                     const uint32_t *__restrict__ nb_ptr, uint32_t colbits,
-                                                    uint32_t *__restrict__ c_idx, double *__restrict__ c_val)
+                                                    uint32_t *__restrict__ c_idx, double *__restrict__ c_val,
+                                                    unsigned long long *dbg)
 {
+#define STAMP(i) do { if (dbg && threadIdx.x == 0 && b % 64 == 0 && b / 64 < 64) dbg[(b / 64) * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
     static_assert(RMAX <= BLOCK, "one thread per row of a batch");
     static_assert(NOUT % BLOCK == 0, "flat scan length");
     static_assert((size_t)NOUT * 12 <= ((size_t)12 << LOG_T), "compacted (key, value) lists re-use the table");
     constexpr int T = 1 << LOG_T;
     constexpr int SPT = T / BLOCK;   // table slots per thread
-    constexpr int U = 4;
+    constexpr int U = 8;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *hdr = (uint32_t *)smem;
-    uint32_t *keys = (uint32_t *)(smem + 128);
+    uint32_t *keys = (uint32_t *)(smem + 256);
     double *vals = (double *)(keys + T);
-    uint32_t *lk = keys;                       // after accumulation: keys in bucket order
-    double *lv = (double *)(smem + 128 + (((size_t)NOUT * 4 + 7) & ~(size_t)7));   // and their values
-    unsigned char *region2 = smem + 128 + ((size_t)12 << LOG_T);
+    uint32_t *lk = keys;                                                              // keys in bucket order
+    double *lv = (double *)(smem + 256 + (((size_t)NOUT * 4 + 7) & ~(size_t)7));      // and their values
+    unsigned char *region2 = smem + 256 + ((size_t)12 << LOG_T);
     uint32_t *bcnt = (uint32_t *)region2;
-    uint64_t *w_b0 = (uint64_t *)region2;
-    double *w_av = (double *)(w_b0 + BLOCK);
-    uint32_t *w_off = (uint32_t *)(w_av + BLOCK);
-    uint32_t *w_lr = w_off + BLOCK + 1;
-    constexpr size_t walk = (size_t)BLOCK * 8 * 2 + (size_t)(BLOCK + 1) * 4 + (size_t)BLOCK * 4 + 16;
-    constexpr size_t r2 = ((size_t)NOUT * 4 > walk ? (size_t)NOUT * 4 : walk);
-    uint32_t *s_re = (uint32_t *)(region2 + ((r2 + 7) & ~(size_t)7));
-    uint32_t *s_boff = s_re + RMAX + 1;
-    uint32_t *s_kmin = s_boff + RMAX + 1;
-    float *s_scale = (float *)(s_kmin + RMAX);
-    uint64_t *s_a0 = (uint64_t *)(((uintptr_t)(s_scale + RMAX) + 7) & ~(uintptr_t)7);
+    unsigned char *rows = region2 + ((num_flat_region2<BLOCK, EPT, NOUT>() + 15) & ~(size_t)15);
+    RowEmit *s_row = (RowEmit *)rows;
+    uint64_t *s_a0 = (uint64_t *)(s_row + RMAX + 1);
     uint64_t *s_out = s_a0 + RMAX;
+    uint32_t *s_re = (uint32_t *)(s_out + RMAX);
     const int tid = threadIdx.x;
-    const uint32_t nb = *nb_ptr;
+    const uint32_t nb = *nb_ptr, G = gridDim.x;
     const uint32_t colmask = colbits >= 32 ? 0xFFFFFFFFu : ((1u << colbits) - 1u);
+    // two-level prefetch: while batch b is processed, the rows of batch b + G and the bounds of batch b + 2G load
+    struct Rows {
+        uint64_t a0, a1, c0, c1;
+        uint32_t kmin, kmax, bin;
+    };
+    auto load_desc = [&](uint32_t bb, uint32_t &rb_, uint32_t &re_) {
+        rb_ = re_ = 0;
+        if (bb < nb) {
+            rb_ = batch_first[bb];
+            re_ = bb + 1 < nb ? batch_first[bb + 1] : nrows;
+        }
+    };
+    auto load_rows = [&](uint32_t rb_, uint32_t re_, Rows &rw) {
+        rw = Rows{0, 0, 0, 0, 0, 0, BIN_EMPTY};
+        if ((uint32_t)tid < re_ - rb_) {
+            rw.a0 = aptr[r0 + rb_ + tid];
+            rw.a1 = aptr[r0 + rb_ + tid + 1];
+            rw.c0 = cptr[rb_ + tid];
+            rw.c1 = cptr[rb_ + tid + 1];
+            rw.kmin = row_kmin[rb_ + tid];
+            rw.kmax = row_kmax[rb_ + tid];
+            rw.bin = row_bin[rb_ + tid];
+        }
+    };
+    uint32_t rb, re, nrb, nre;
+    Rows cur, nxt;
+    load_desc(blockIdx.x, rb, re);
+    load_rows(rb, re, cur);
+    load_desc(blockIdx.x + G, nrb, nre);
 
-    for (uint32_t b = blockIdx.x; b < nb; b += gridDim.x) {
-        const uint32_t rb = batch_first[b];
-        const uint32_t re = b + 1 < nb ? batch_first[b + 1] : nrows;
+    uint32_t n2rb = 0, n2re = 0;
+    for (uint32_t b = blockIdx.x; b < nb; b += G) {
+        if (b != blockIdx.x) {   // rotate: next -> current, next-next -> next
+            cur = nxt;
+            rb = nrb;
+            re = nre;
+            nrb = n2rb;
+            nre = n2re;
+        }
+        load_rows(nrb, nre, nxt);
+        load_desc(b + 2 * G, n2rb, n2re);
         const uint32_t R = re - rb;
         if (R == 0) continue;
-        uint32_t L = 0, n = 0;
+        STAMP(0);
+        uint32_t L = 0, n = 0, kmin = 0, kmax = 0;
         if ((uint32_t)tid < R) {
-            const uint64_t a0 = aptr[r0 + rb + tid], a1 = aptr[r0 + rb + tid + 1];
-            const uint64_t c0 = cptr[rb + tid], c1 = cptr[rb + tid + 1];
-            s_a0[tid] = a0;
-            s_out[tid] = c0;
-            if (row_bin[rb + tid] == BIN_FLAT) {
-                L = (uint32_t)(a1 - a0);
-                n = (uint32_t)(c1 - c0);
-                const uint32_t kmin = row_kmin[rb + tid], kmax = row_kmax[rb + tid];
-                s_kmin[tid] = kmin;
-                s_scale[tid] = (float)n / ((float)(kmax - kmin) + 1.0f);
+            s_a0[tid] = cur.a0;
+            s_out[tid] = cur.c0;
+            if (cur.bin == BIN_FLAT) {
+                L = (uint32_t)(cur.a1 - cur.a0);
+                n = (uint32_t)(cur.c1 - cur.c0);
+                kmin = cur.kmin;
+                kmax = cur.kmax;
             }
         }
         uint32_t E, NO;
@@ -519,74 +786,46 @@ __global__ __launch_bounds__(BLOCK) void k_num_flat(const uint64_t *__restrict__
         const uint32_t exn = group_scan_excl<BLOCK>(n, tid, hdr + 2, &NO);
         if ((uint32_t)tid < R) {
             s_re[tid] = exl;
-            s_boff[tid] = exn;
+            s_row[tid] = RowEmit{exn, n, kmin, (float)n / ((float)(kmax - kmin) + 1.0f)};
         }
-        if (tid == 0) {
-            s_re[R] = E;
-            s_boff[R] = NO;
-        }
-        for (int s = tid; s < T; s += BLOCK) {
-            keys[s] = EMPTY_KEY;
-            vals[s] = 0.0;
+        if (tid == 0) s_re[R] = E;
+        {
+            uint4 *k4 = (uint4 *)keys;
+            for (int s = tid; s < T / 4; s += BLOCK) k4[s] = make_uint4(EMPTY_KEY, EMPTY_KEY, EMPTY_KEY, EMPTY_KEY);
+            double2 *v2 = (double2 *)vals;
+            for (int s = tid; s < T / 2; s += BLOCK) v2[s] = make_double2(0.0, 0.0);
         }
         __syncthreads();
+        STAMP(1);
 
         // ---- expand - scale - accumulate --------------------------------------------------------------------
-        for (uint32_t chunk = 0; chunk < E; chunk += BLOCK) {
-            const uint32_t e = chunk + tid;
-            uint64_t b0 = 0;
-            uint32_t len = 0, lr = 0;
-            double av = 0.0;
-            if (e < E) {
-                lr = row_of_entry<RMAX>(s_re, R, e);
-                const uint64_t a = s_a0[lr] + (e - s_re[lr]);
-                b0 = eb0[a];
-                len = elen[a];
-                av = aval[a];
-            }
-            uint32_t total;
-            const uint32_t off = group_scan_excl<BLOCK>(len, tid, hdr + 2, &total);
-            w_b0[tid] = b0;
-            w_av[tid] = av;
-            w_off[tid] = off;
-            w_lr[tid] = lr << colbits;
-            if (tid == BLOCK - 1) w_off[BLOCK] = total;
-            __syncthreads();
-            for (uint32_t p0 = tid; p0 < total; p0 += U * BLOCK) {
-                uint32_t key[U];
-                double v[U];
+        flat_walk<BLOCK, EPT, RMAX, true, U>(
+            s_re, s_a0, R, E, eb0, elen, aval, bidx, bval, region2, hdr, [&](uint32_t(&col)[U], uint32_t(&plr)[U], double(&v)[U]) {
+                uint32_t key[U], h[U], old[U];
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    const uint32_t p = p0 + u * BLOCK;
-                    key[u] = EMPTY_KEY;
-                    v[u] = 0.0;
-                    if (p < total) {
-                        int j = 0;
-#pragma unroll
-                        for (int step = BLOCK / 2; step >= 1; step >>= 1)
-                            if (w_off[j + step] <= p) j += step;
-                        const uint64_t q = w_b0[j] + (p - w_off[j]);
-                        key[u] = w_lr[j] | bidx[q];
-                        v[u] = w_av[j] * bval[q];   // simulator.rs:100-101
-                    }
+                    key[u] = compose_key(plr[u], col[u], colbits);
+                    h[u] = hash_slot<LOG_T>(key[u]);
+                    old[u] = key[u];
+                    if (plr[u] != LR_NONE) old[u] = atomicCAS(&keys[h[u]], EMPTY_KEY, key[u]);
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u)
-                    if (key[u] != EMPTY_KEY) {
-                        uint32_t h = hash_slot<LOG_T>(key[u]);
+                    if (old[u] != EMPTY_KEY && old[u] != key[u]) {
                         for (;;) {
-                            const uint32_t old = atomicCAS(&keys[h], EMPTY_KEY, key[u]);
-                            if (old == EMPTY_KEY || old == key[u]) break;
-                            h = (h + 1) & (T - 1);
+                            h[u] = (h[u] + 1) & (T - 1);
+                            const uint32_t o = atomicCAS(&keys[h[u]], EMPTY_KEY, key[u]);
+                            if (o == EMPTY_KEY || o == key[u]) break;
                         }
-                        atomicAdd(&vals[h], v[u]);   // simulator.rs:213-218 (order differs)
                     }
-            }
-            __syncthreads();
-        }
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    if (plr[u] != LR_NONE) atomicAdd(&vals[h[u]], v[u]);   // simulator.rs:213-218 (order differs)
+            }, (dbg && b % 64 == 0 && b / 64 < 64) ? dbg + (b / 64) * 16 + 8 : nullptr);
+        STAMP(2);
 
         // ---- ordered emission -------------------------------------------------------------------------------
-        // every occupied slot -> bucket = s_boff[lr] + floor((col - kmin) * n / span): monotone inside a row and
+        // every occupied slot -> bucket = boff[lr] + floor((col - kmin) * n / span): monotone inside a row and
         // rows are laid out in order, so the bucket order IS the order of the batch's slice of C up to
         // permutations inside one bucket
         for (int s = tid; s < NOUT; s += BLOCK) bcnt[s] = 0;
@@ -594,16 +833,16 @@ __global__ __launch_bounds__(BLOCK) void k_num_flat(const uint64_t *__restrict__
         uint32_t myk[SPT];
         uint16_t myb[SPT];
 #pragma unroll
+        for (int i = 0; i < SPT; ++i) myk[i] = keys[tid + i * BLOCK];
+#pragma unroll
         for (int i = 0; i < SPT; ++i) {
-            const uint32_t k = keys[tid + i * BLOCK];
-            myk[i] = k;
             myb[i] = 0;
-            if (k != EMPTY_KEY) {
-                const uint32_t lr = colbits >= 32 ? 0u : (k >> colbits), col = k & colmask;
-                const uint32_t nr = s_boff[lr + 1] - s_boff[lr];
-                uint32_t bk = (uint32_t)((float)(col - s_kmin[lr]) * s_scale[lr]);
-                bk = bk < nr ? bk : nr - 1;
-                myb[i] = (uint16_t)(s_boff[lr] + bk);
+            if (myk[i] != EMPTY_KEY) {
+                const uint32_t lr = colbits >= 32 ? 0u : (myk[i] >> colbits), col = myk[i] & colmask;
+                const RowEmit rw = s_row[lr];
+                uint32_t bk = (uint32_t)((float)(col - rw.kmin) * rw.scale);
+                bk = bk < rw.n ? bk : rw.n - 1;
+                myb[i] = (uint16_t)(rw.boff + bk);
                 atomicAdd(&bcnt[myb[i]], 1u);
             }
         }
@@ -611,7 +850,9 @@ __global__ __launch_bounds__(BLOCK) void k_num_flat(const uint64_t *__restrict__
 #pragma unroll
         for (int i = 0; i < SPT; ++i) myv[i] = vals[tid + i * BLOCK];
         __syncthreads();
+        STAMP(3);
         group_exclusive_scan<BLOCK, NOUT>(bcnt, tid, hdr + 2);   // ends with a barrier: table fully read by now
+        STAMP(4);
 #pragma unroll
         for (int i = 0; i < SPT; ++i)
             if (myk[i] != EMPTY_KEY) {
@@ -620,21 +861,49 @@ __global__ __launch_bounds__(BLOCK) void k_num_flat(const uint64_t *__restrict__
                 lv[p] = myv[i];
             }
         __syncthreads();
-        for (uint32_t p = tid; p < NO; p += BLOCK) {
-            const uint32_t k = lk[p];
-            const uint32_t lr = colbits >= 32 ? 0u : (k >> colbits), col = k & colmask;
-            const uint32_t nr = s_boff[lr + 1] - s_boff[lr];
-            uint32_t bk = (uint32_t)((float)(col - s_kmin[lr]) * s_scale[lr]);
-            bk = s_boff[lr] + (bk < nr ? bk : nr - 1);
-            const uint32_t lo = bk ? bcnt[bk - 1] : 0u, hi = bcnt[bk];
-            uint32_t r = lo;
-            for (uint32_t j = lo; j < hi; ++j) r += (lk[j] < k) ? 1u : 0u;
-            const uint64_t pos = s_out[lr] + (r - s_boff[lr]);
-            c_idx[pos] = col;
-            c_val[pos] = lv[p];
+        STAMP(5);
+        constexpr int W = 2;   // outputs ranked per thread and iteration (independent LDS chains)
+        for (uint32_t p0 = tid; p0 < NO; p0 += W * BLOCK) {
+            uint32_t k[W], lo[W], hi[W], r[W], base[W];
+            uint64_t outp[W];
+#pragma unroll
+            for (int w = 0; w < W; ++w) {
+                const uint32_t p = p0 + w * BLOCK;
+                k[w] = p < NO ? lk[p] : EMPTY_KEY;
+            }
+#pragma unroll
+            for (int w = 0; w < W; ++w) {
+                lo[w] = hi[w] = 0;
+                base[w] = 0;
+                outp[w] = 0;
+                if (k[w] != EMPTY_KEY) {
+                    const uint32_t lr = colbits >= 32 ? 0u : (k[w] >> colbits), col = k[w] & colmask;
+                    const RowEmit rw = s_row[lr];
+                    uint32_t bk = (uint32_t)((float)(col - rw.kmin) * rw.scale);
+                    bk = rw.boff + (bk < rw.n ? bk : rw.n - 1);
+                    lo[w] = bk ? bcnt[bk - 1] : 0u;
+                    hi[w] = bcnt[bk];
+                    base[w] = rw.boff;
+                    outp[w] = s_out[lr];
+                }
+            }
+#pragma unroll
+            for (int w = 0; w < W; ++w) {
+                r[w] = lo[w];
+                for (uint32_t j = lo[w]; j < hi[w]; ++j) r[w] += (lk[j] < k[w]) ? 1u : 0u;
+            }
+#pragma unroll
+            for (int w = 0; w < W; ++w)
+                if (k[w] != EMPTY_KEY) {
+                    const uint64_t pos = outp[w] + (r[w] - base[w]);
+                    c_idx[pos] = k[w] & colmask;
+                    c_val[pos] = lv[p0 + w * BLOCK];
+                }
         }
         __syncthreads();
+        STAMP(6);
     }
+#undef STAMP
 }
 
 }  // namespace spada

@@ -433,6 +433,33 @@ __device__ inline uint32_t group_scan_excl(uint32_t v, int gl, uint32_t *wtot, u
     }
 }
 
+// exclusive scan of one u64 per thread across a workgroup of G threads (G a multiple of 64); *total = sum
+template <int G>
+__device__ inline unsigned long long group_scan_excl_u64(unsigned long long v, int gl, unsigned long long *wtot,
+                                                         unsigned long long *total)
+{
+    static_assert(G % 64 == 0 && G >= 64, "whole waves");
+    const int wl = gl & 63, w = gl >> 6;
+    unsigned long long inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned long long t = __shfl_up(inc, o);
+        if (wl >= o) inc += t;
+    }
+    __syncthreads();
+    if (wl == 63) wtot[w] = inc;
+    __syncthreads();
+    unsigned long long add = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < G / 64; ++k) {
+        const unsigned long long t = wtot[k];
+        if (k < w) add += t;
+        tot += t;
+    }
+    *total = tot;
+    return inc - v + add;
+}
+
 template <int G, bool NUMERIC, class F>
 __device__ inline void walk_products(const DevCsrView &A, const DevCsrView &B, uint64_t a0, uint64_t a1, int gl,
                                      unsigned char *scratch, uint32_t *hdr, F &&f)

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define SPADA_ABI_VERSION 1
+#define SPADA_ABI_VERSION 2
 
 enum spada_status {
     SPADA_OK = 0,
@@ -94,6 +94,14 @@ typedef struct spada_stats {
     uint64_t num_bin_rows[SPADA_N_BINS];   /* rows per numeric bin */
     uint64_t spill_rows;      /* rows that took the global-memory (spill) path */
     uint64_t workspace_bytes; /* device scratch owned by the context */
+    /* per numeric bin: products, nnz(C) and A entries of its rows (algorithmic bytes of one kernel =
+     * 12 * prod + 28 * entries + 8 * rows read, 12 * nnz written) */
+    uint64_t num_bin_prod[SPADA_N_BINS];
+    uint64_t num_bin_nnz[SPADA_N_BINS];
+    uint64_t num_bin_entries[SPADA_N_BINS];
+    uint64_t sym_bin_prod[SPADA_N_BINS];
+    double ms_sym_flat;       /* duration of the flat-batch symbolic kernel (hipEvents on its stream) */
+    double ms_num_flat;       /* duration of the flat-batch numeric kernel */
 } spada_stats;
 
 typedef struct spada_ctx spada_ctx;          /* engine context: one GPU, one stream, scratch */

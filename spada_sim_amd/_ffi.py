@@ -42,7 +42,10 @@ class Stats(ctypes.Structure):
                 ("ms_row_stats", ctypes.c_double), ("ms_binning", ctypes.c_double),
                 ("ms_symbolic", ctypes.c_double), ("ms_scan", ctypes.c_double), ("ms_numeric", ctypes.c_double),
                 ("sym_bin_rows", u64 * SPADA_N_BINS), ("num_bin_rows", u64 * SPADA_N_BINS),
-                ("spill_rows", u64), ("workspace_bytes", u64)]
+                ("spill_rows", u64), ("workspace_bytes", u64),
+                ("num_bin_prod", u64 * SPADA_N_BINS), ("num_bin_nnz", u64 * SPADA_N_BINS),
+                ("num_bin_entries", u64 * SPADA_N_BINS), ("sym_bin_prod", u64 * SPADA_N_BINS),
+                ("ms_sym_flat", ctypes.c_double), ("ms_num_flat", ctypes.c_double)]
 
     def as_dict(self):
         d = {}

@@ -74,9 +74,11 @@ struct Counters {
     uint32_t num_cursor[SPADA_N_BINS];
     unsigned long long totals[2];   // nprod, a_nnz of the row range
     uint32_t nb_sym, nb_num;        // number of flat batches (symbolic / numeric)
+    unsigned long long num_sums[3 * SPADA_N_BINS];   // per numeric bin: products | nnz(C) | A entries
+    unsigned long long sym_prod[SPADA_N_BINS];
 };
 
-enum { EV_SYM_BEGIN, EV_STATS, EV_BINNED, EV_SYM, EV_SCAN, EV_NUM_BEGIN, EV_NUM_END, EV_COUNT };
+enum { EV_SYM_BEGIN, EV_STATS, EV_BINNED, EV_SYM, EV_SCAN, EV_NUM_BEGIN, EV_NUM_END, EV_SFLAT_0, EV_SFLAT_1, EV_NFLAT_0, EV_NFLAT_1, EV_COUNT };
 
 }  // namespace
 
@@ -100,6 +102,7 @@ struct spada_ctx {
     uint32_t nrows = 0;
     uint64_t nnz_c = 0;
     uint32_t h_sym_counts[SPADA_N_BINS] = {}, h_num_counts[SPADA_N_BINS] = {};
+    unsigned long long h_sym_prod[SPADA_N_BINS] = {};
     // workspace
     size_t ws_bytes = 0;
     DevBuf row_nprod, row_nnzc, row_bin, sym_rows, num_rows, counters, cptr, tile_sums, bitmaps, slabs;
@@ -331,10 +334,12 @@ int run_numeric(spada_ctx *c, uint64_t *d_ptr, uint32_t *d_idx, double *d_val)
                            c->row_kmax.as<uint32_t>(), c->cptr.as<uint64_t>(), c->batch_num.as<uint32_t>(), &dc->nb_num,      \
                            c->colbits, d_idx, d_val, c->dbg_g == 1 ? c->dbg.as<unsigned long long>() : nullptr);             \
     }
+        HIP_TRY(hipEventRecord(c->ev[EV_NFLAT_0], c->cur));
         if (c->flat_cfg == 0) LAUNCH_NUM_FLAT(256, 4)
         else if (c->flat_cfg == 1) LAUNCH_NUM_FLAT(512, 2)
         else LAUNCH_NUM_FLAT(1024, 1)
 #undef LAUNCH_NUM_FLAT
+        HIP_TRY(hipEventRecord(c->ev[EV_NFLAT_1], c->cur));
         HIP_TRY(hipGetLastError());
         if ((rc = join_from(c, BIN_FLAT))) return rc;
     }
@@ -349,6 +354,7 @@ int run_numeric(spada_ctx *c, uint64_t *d_ptr, uint32_t *d_idx, double *d_val)
     HIP_TRY(hipEventRecord(c->ev[EV_NUM_END], c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->stats.ms_numeric = c->stats.ms_numeric_call = ev_ms(c, EV_NUM_BEGIN, EV_NUM_END);
+    c->stats.ms_num_flat = cnt[BIN_FLAT] ? ev_ms(c, EV_NFLAT_0, EV_NFLAT_1) : 0.0;
     c->stats.workspace_bytes = c->ws_bytes;
     return SPADA_OK;
 }
@@ -542,7 +548,7 @@ int spada_dev_spgemm_symbolic(spada_ctx *c, const spada_dev_csr *a, const spada_
         hipLaunchKernelGGL(k_row_stats2, dim3(std::min<uint32_t>(g256, 1024)), dim3(256), 0, s, a->ptr, a->idx, b->ptr, b->idx, c->r0, n,
                            c->eb0.as<uint64_t>(), c->elen.as<uint32_t>(), c->row_nprod.as<uint32_t>(),
                            c->row_nnzc.as<uint32_t>(), c->row_bin.as<uint8_t>(), c->row_kmin.as<uint32_t>(),
-                           c->row_kmax.as<uint32_t>(), dc->sym_counts, dc->totals, c->flat_on ? 1 : 0);
+                           c->row_kmax.as<uint32_t>(), dc->sym_counts, dc->totals, dc->sym_prod, c->flat_on ? 1 : 0);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(c->ev[EV_STATS], s));
@@ -558,12 +564,14 @@ int spada_dev_spgemm_symbolic(spada_ctx *c, const spada_dev_csr *a, const spada_
         hipLaunchKernelGGL(k_cut_apply<0>, dim3(ntiles), dim3(SCAN_BLOCK), 0, s, a->ptr, c->r0, n,
                            c->row_nprod.as<uint32_t>(), c->row_nnzc.as<uint32_t>(), c->row_bin.as<uint8_t>(), cut_sym,
                            c->tile_sums.as<uint64_t>(), c->tile_w.as<uint64_t>(), ntiles, (uint64_t *)nullptr,
-                           (uint8_t *)nullptr, (uint32_t *)nullptr, c->batch_sym.as<uint32_t>());
+                           (uint8_t *)nullptr, (uint32_t *)nullptr, (unsigned long long *)nullptr,
+                           c->batch_sym.as<uint32_t>());
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(c->ev[EV_BINNED], s));
     HIP_TRY(hipStreamSynchronize(s));
     std::memcpy(c->h_sym_counts, c->h_counters->sym_counts, sizeof c->h_sym_counts);
+    std::memcpy(c->h_sym_prod, c->h_counters->sym_prod, sizeof c->h_sym_prod);
     const uint64_t nprod = c->h_counters->totals[0], a_nnz = c->h_counters->totals[1];
 
     {
@@ -612,10 +620,12 @@ int spada_dev_spgemm_symbolic(spada_ctx *c, const spada_dev_csr *a, const spada_
                            c->row_bin.as<uint8_t>(), c->batch_sym.as<uint32_t>(), &dc->nb_sym, c->colbits,                    \
                            c->row_nnzc.as<uint32_t>());                                                                      \
     }
+            HIP_TRY(hipEventRecord(c->ev[EV_SFLAT_0], c->cur));
             if (c->flat_cfg == 0) LAUNCH_SYM_FLAT(256, 4)
             else if (c->flat_cfg == 1) LAUNCH_SYM_FLAT(512, 2)
             else LAUNCH_SYM_FLAT(1024, 1)
 #undef LAUNCH_SYM_FLAT
+            HIP_TRY(hipEventRecord(c->ev[EV_SFLAT_1], c->cur));
             HIP_TRY(hipGetLastError());
             if ((rc = join_from(c, BIN_FLAT))) return rc;
         }
@@ -631,7 +641,7 @@ int spada_dev_spgemm_symbolic(spada_ctx *c, const spada_dev_csr *a, const spada_
     hipLaunchKernelGGL(k_cut_apply<1>, dim3(ntiles), dim3(SCAN_BLOCK), 0, s, a->ptr, c->r0, n, c->row_nprod.as<uint32_t>(),
                        c->row_nnzc.as<uint32_t>(), c->row_bin.as<uint8_t>(), cut_num, c->tile_sums.as<uint64_t>(),
                        c->tile_w.as<uint64_t>(), ntiles, c->cptr.as<uint64_t>(), c->row_bin.as<uint8_t>(), dc->num_counts,
-                       c->batch_num.as<uint32_t>());
+                       dc->num_sums, c->batch_num.as<uint32_t>());
     HIP_TRY(hipGetLastError());
     if (n) {
         hipLaunchKernelGGL(k_bin_scatter2, dim3(gsc), dim3(256), 0, s, c->row_bin.as<uint8_t>(), n, dc->num_counts,
@@ -664,6 +674,13 @@ int spada_dev_spgemm_symbolic(spada_ctx *c, const spada_dev_csr *a, const spada_
         st.sym_bin_rows[k] = c->h_sym_counts[k];
         st.num_bin_rows[k] = c->h_num_counts[k];
     }
+    for (int k = 0; k < SPADA_N_BINS; ++k) {
+        st.num_bin_prod[k] = c->h_counters->num_sums[k];
+        st.num_bin_nnz[k] = c->h_counters->num_sums[SPADA_N_BINS + k];
+        st.num_bin_entries[k] = c->h_counters->num_sums[2 * SPADA_N_BINS + k];
+        st.sym_bin_prod[k] = c->h_sym_prod[k];
+    }
+    st.ms_sym_flat = c->h_sym_counts[BIN_FLAT] ? ev_ms(c, EV_SFLAT_0, EV_SFLAT_1) : 0.0;
     st.spill_rows = c->h_sym_counts[SYM2_BIN_SPILL] + c->h_num_counts[NUM2_BIN_SPILL] + c->h_num_counts[NUM2_BIN_BMV];
     st.workspace_bytes = c->ws_bytes;
     return SPADA_OK;

@@ -65,10 +65,11 @@ __global__ __launch_bounds__(256) void k_row_stats2(const uint64_t *__restrict__
                                                     uint32_t *__restrict__ row_kmin, uint32_t *__restrict__ row_kmax,
                                                     uint32_t *__restrict__ bin_counts,
                                                     unsigned long long *__restrict__ totals /* [0]=nprod [1]=a_nnz */,
-                                                    int flat_on)
+                                                    unsigned long long *__restrict__ bin_prod, int flat_on)
 {
     __shared__ uint32_t s_hist[SPADA_N_BINS];
-    __shared__ unsigned long long s_tot[2];
+    __shared__ unsigned long long s_tot[2], s_bp[SPADA_N_BINS];
+    if (threadIdx.x < SPADA_N_BINS) s_bp[threadIdx.x] = 0;
     if (threadIdx.x < SPADA_N_BINS) s_hist[threadIdx.x] = 0;
     if (threadIdx.x < 2) s_tot[threadIdx.x] = 0;
     __syncthreads();
@@ -129,6 +130,7 @@ __global__ __launch_bounds__(256) void k_row_stats2(const uint64_t *__restrict__
             if (bin == BIN_EMPTY) row_nnzc[i] = 0;
             if (bin == BIN_COPY) row_nnzc[i] = (uint32_t)P;   // one A nonzero: C row is a scaled copy of one B row
             atomicAdd(&s_hist[bin], 1u);
+            if (bin > BIN_COPY) atomicAdd(&s_bp[bin], (unsigned long long)P);
         }
         tot_p += P;
         tot_l += L;
@@ -141,6 +143,7 @@ __global__ __launch_bounds__(256) void k_row_stats2(const uint64_t *__restrict__
     __syncthreads();
     if (threadIdx.x < SPADA_N_BINS && s_hist[threadIdx.x]) atomicAdd(&bin_counts[threadIdx.x], s_hist[threadIdx.x]);
     if (threadIdx.x < 2 && s_tot[threadIdx.x]) atomicAdd(&totals[threadIdx.x], s_tot[threadIdx.x]);
+    if (threadIdx.x < SPADA_N_BINS && s_bp[threadIdx.x]) atomicAdd(&bin_prod[threadIdx.x], s_bp[threadIdx.x]);
 }
 
 // ---- 2. scans: nnz(C_i) -> cptr, numeric classification, and batch cutting ------------------------------------
@@ -237,11 +240,14 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_cut_apply(const uint64_t *__rest
                                                           uint64_t *__restrict__ cptr /* n + 1, MODE 1 */,
                                                           uint8_t *__restrict__ row_bin_out /* MODE 1 */,
                                                           uint32_t *__restrict__ bin_counts /* MODE 1 */,
+                                                          unsigned long long *__restrict__ bin_sums /* MODE 1: prod | nnz | entries */,
                                                           uint32_t *__restrict__ batch_first)
 {
     __shared__ uint64_t s_w[SCAN_BLOCK / 64];
     __shared__ uint32_t s_hist[SPADA_N_BINS];
+    __shared__ unsigned long long s_sum[3 * SPADA_N_BINS];
     if (threadIdx.x < SPADA_N_BINS) s_hist[threadIdx.x] = 0;
+    if (threadIdx.x < 3 * SPADA_N_BINS) s_sum[threadIdx.x] = 0;
     const uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
     uint32_t nnz[SCAN_ITEMS], w[SCAN_ITEMS];
     int bin[SCAN_ITEMS];
@@ -269,6 +275,11 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_cut_apply(const uint64_t *__rest
                 cptr[i] = exn;
                 row_bin_out[i] = (uint8_t)bin[j];
                 atomicAdd(&s_hist[bin[j]], 1u);
+                if (bin[j] != BIN_EMPTY) {
+                    atomicAdd(&s_sum[bin[j]], (unsigned long long)row_nprod[i]);
+                    atomicAdd(&s_sum[SPADA_N_BINS + bin[j]], (unsigned long long)nnz[j]);
+                    atomicAdd(&s_sum[2 * SPADA_N_BINS + bin[j]], (unsigned long long)(aptr[r0 + i + 1] - aptr[r0 + i]));
+                }
             }
         }
         exw += w[j];
@@ -281,6 +292,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_cut_apply(const uint64_t *__rest
     if constexpr (MODE == 1) {
         __syncthreads();
         if (threadIdx.x < SPADA_N_BINS && s_hist[threadIdx.x]) atomicAdd(&bin_counts[threadIdx.x], s_hist[threadIdx.x]);
+        if (threadIdx.x < 3 * SPADA_N_BINS && s_sum[threadIdx.x]) atomicAdd(&bin_sums[threadIdx.x], s_sum[threadIdx.x]);
     }
 }
 

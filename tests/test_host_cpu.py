@@ -29,13 +29,25 @@ def test_library_exports_every_symbol_of_the_header():
     for name in sorted(declared):
         assert hasattr(L, name), f"{name} declared in spada_ffi.h but not exported"
     assert declared == set(_ffi.SIGNATURES), declared ^ set(_ffi.SIGNATURES)
-    assert _ffi.lib().spada_abi_version() == 1
+    assert _ffi.lib().spada_abi_version() == 2
 
 
 def test_struct_layouts_match_the_header():
     assert ctypes.sizeof(_ffi.CsrView) == 48
     assert ctypes.sizeof(_ffi.Options) == 16
-    assert ctypes.sizeof(_ffi.Stats) == 7 * 8 + 7 * 8 + 2 * 12 * 8 + 2 * 8
+    assert ctypes.sizeof(_ffi.Stats) == 7 * 8 + 7 * 8 + 2 * 12 * 8 + 2 * 8 + 4 * 12 * 8 + 2 * 8
+    # and against the C compiler's view of include/spada_ffi.h
+    import subprocess, tempfile
+    with tempfile.TemporaryDirectory() as d:
+        src = os.path.join(d, "sz.c")
+        with open(src, "w") as f:
+            f.write('#include <stdio.h>\n#include "spada_ffi.h"\nint main(void){printf("%zu %zu %zu %zu\\n", '
+                    'sizeof(spada_csr_view), sizeof(spada_options), sizeof(spada_stats), sizeof(spada_config));return 0;}\n')
+        exe = os.path.join(d, "sz")
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), src, "-o", exe])
+        sizes = [int(x) for x in subprocess.check_output([exe]).split()]
+    assert sizes == [ctypes.sizeof(_ffi.CsrView), ctypes.sizeof(_ffi.Options), ctypes.sizeof(_ffi.Stats),
+                     ctypes.sizeof(_ffi.Config)]
 
 
 def test_cari_loader_pins(matrices_dir):

@@ -103,6 +103,7 @@ struct spada_ctx {
     uint64_t nnz_c = 0;
     uint32_t h_sym_counts[SPADA_N_BINS] = {}, h_num_counts[SPADA_N_BINS] = {};
     unsigned long long h_sym_prod[SPADA_N_BINS] = {};
+    uint32_t h_nb_sym = 1;
     // workspace
     size_t ws_bytes = 0;
     DevBuf row_nprod, row_nnzc, row_bin, sym_rows, num_rows, counters, cptr, tile_sums, bitmaps, slabs;
@@ -323,7 +324,19 @@ int run_numeric(spada_ctx *c, uint64_t *d_ptr, uint32_t *d_idx, double *d_val)
     NUM_BIN(NUM2_BIN_6K, 1024, 13)
     NUM_BIN(NUM2_BIN_2K, 256, 12)
 #undef NUM_BIN
-    if (cnt[BIN_FLAT]) {
+    if (cnt[BIN_FLAT] && c->accumulator == SPADA_ACC_SORT_MERGE) {
+        // sort-merge accumulator: the rows of the symbolic (product-weighted) batches
+        if ((rc = fork_to(c, BIN_FLAT))) return rc;
+        constexpr size_t lds = num_sm_lds<1024, 1, SF_RMAX>();
+        HIP_TRY(hipEventRecord(c->ev[EV_NFLAT_0], c->cur));
+        hipLaunchKernelGGL((k_num_sortmerge<1024, 1, SF_RMAX>), dim3(flat_grid(c->h_nb_sym, lds)), dim3(1024), lds, c->cur,
+                           c->A->ptr, c->A->val, c->B->idx, c->B->val, c->eb0.as<uint64_t>(), c->elen.as<uint32_t>(), c->r0,
+                           c->nrows, c->row_bin.as<uint8_t>(), c->cptr.as<uint64_t>(), c->batch_sym.as<uint32_t>(),
+                           &dc->nb_sym, c->colbits, d_idx, d_val);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(c->ev[EV_NFLAT_1], c->cur));
+        if ((rc = join_from(c, BIN_FLAT))) return rc;
+    } else if (cnt[BIN_FLAT]) {
         if ((rc = fork_to(c, BIN_FLAT))) return rc;
 #define LAUNCH_NUM_FLAT(BL, EP)                                                                                              \
     {                                                                                                                        \
@@ -429,6 +442,7 @@ int spada_create(const spada_options *opts, spada_ctx **out)
     ALLOW_FLAT(512, 2)
     ALLOW_FLAT(1024, 1)
 #undef ALLOW_FLAT
+    if ((rc = allow_lds(k_num_sortmerge<1024, 1, SF_RMAX>, num_sm_lds<1024, 1, SF_RMAX>()))) return rc;
     if (const char *e = std::getenv("SPADA_FLAT_CFG")) c->flat_cfg = atoi(e);
     if ((rc = allow_lds(k_sym_bitmap, LDS_MAX))) return rc;
     if ((rc = allow_lds(k_num_bitmap<true>, LDS_MAX))) return rc;
@@ -538,8 +552,10 @@ int spada_dev_spgemm_symbolic(spada_ctx *c, const spada_dev_csr *a, const spada_
         c->num_flat_max = c->flat_on ? NUM_FLAT_MAX : 0;
     }
     const uint32_t rmax = std::max<uint32_t>(c->rmax_eff, 4);
-    const CutParams cut_sym{SYM_FLAT_CAP, (SYM_FLAT_CAP + rmax - 1) / rmax, 0, 0};
-    const CutParams cut_num{NUM_FLAT_CAP, (NUM_FLAT_CAP + rmax - 1) / rmax, c->num_flat_max, c->bm_vcap};
+    const CutParams cut_sym{SYM_FLAT_CAP, (SYM_FLAT_CAP + rmax - 1) / rmax, 0, 0, 0};
+    const bool sort_merge = c->accumulator == SPADA_ACC_SORT_MERGE && c->flat_on;
+    const CutParams cut_num{NUM_FLAT_CAP, (NUM_FLAT_CAP + rmax - 1) / rmax, c->num_flat_max, c->bm_vcap,
+                            sort_merge ? SYM_FLAT_MAX : 0u};
 
     HIP_TRY(hipEventRecord(c->ev[EV_SYM_BEGIN], s));
     HIP_TRY(hipMemsetAsync(dc, 0, sizeof(Counters), s));
@@ -654,6 +670,7 @@ int spada_dev_spgemm_symbolic(spada_ctx *c, const spada_dev_csr *a, const spada_
     HIP_TRY(hipStreamSynchronize(s));
     std::memcpy(c->h_num_counts, c->h_counters->num_counts, sizeof c->h_num_counts);
     c->nnz_c = c->h_u64[0];
+    c->h_nb_sym = std::max<uint32_t>(c->h_counters->nb_sym, 1);
     *nnz_c = c->nnz_c;
     c->have_symbolic = true;
 

@@ -100,6 +100,9 @@ def main():
     ap.add_argument("--workload", default="webbase-1M")
     ap.add_argument("--accumulator", default="lds_hash", choices=["lds_hash", "sort_merge"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--chunk-products", type=float, default=0,
+                    help="stream C in A-row chunks of about this many products (0 = automatic: chunk when the product "
+                         "count of a rank exceeds 3e9, i.e. when C would not fit next to the inputs)")
     args = ap.parse_args()
 
     import torch
@@ -129,7 +132,47 @@ def main():
     da = eng.upload(a)                    # A and B = A resident in HBM before the timed region
     dev = torch.device("cuda", local_rank)
 
+    # chunked mode (R-MAT scale 22): the rank's row block is cut into product-balanced row chunks whose C is produced,
+    # checksummed and dropped one after the other; nothing is gathered (C of the whole job would not fit one GPU)
+    my_products = S.count_products(a, a, r0, r1)
+    chunk_products = args.chunk_products or (2.0 ** 31 if my_products > 3e9 else 0)
+    chunk_bounds = None
+    if chunk_products:
+        nchunks = max(1, int(np.ceil(my_products / chunk_products)))
+        fine = S.partition_rows(a, a, world * nchunks)
+        chunk_bounds = [b for b in fine if r0 <= b <= r1]
+        if chunk_bounds[0] != r0:
+            chunk_bounds.insert(0, r0)
+        if chunk_bounds[-1] != r1:
+            chunk_bounds.append(r1)
+    checksum = torch.zeros(1, dtype=torch.float64, device=dev)
+
     def step():
+        if chunk_bounds is not None:
+            bufs = {}
+            agg = {"c_nnz": 0, "nprod": 0, "bytes_read": 0, "bytes_write": 0}
+            tms = {}
+
+            def alloc(nrows, nnz):
+                bufs["p"] = torch.empty(nrows + 1, dtype=torch.int64, device=dev)
+                bufs["i"] = torch.empty(max(nnz, 1), dtype=torch.int32, device=dev)
+                bufs["v"] = torch.empty(max(nnz, 1), dtype=torch.float64, device=dev)
+                return bufs["p"].data_ptr(), bufs["i"].data_ptr(), bufs["v"].data_ptr()
+
+            def consume(b0, b1, nnz, st):
+                checksum.add_(bufs["v"][:nnz].sum())
+                for k in agg:
+                    agg[k] += st[k]
+                for k, v in st.items():
+                    if k.startswith("ms_"):
+                        tms[k] = tms.get(k, 0.0) + v
+                for k in ("num_bin_rows", "num_bin_prod", "num_bin_entries", "num_bin_nnz"):
+                    agg[k] = [x + y for x, y in zip(agg.get(k, [0] * len(st[k])), st[k])]
+
+            nnz = eng.spgemm_row_chunks(da, da, chunk_bounds, alloc, consume)
+            st = dict(agg)
+            st.update(tms)
+            return st, nnz, None
         nnz = eng.symbolic(da, da, r0, r1)
         c_ptr = torch.empty(r1 - r0 + 1, dtype=torch.int64, device=dev)
         c_idx = torch.empty(max(nnz, 1), dtype=torch.int32, device=dev)
@@ -197,11 +240,15 @@ def main():
             "data": data_desc,
             "config": {"workload": f"{args.workload} A*A", "rows": rows, "nnz_a": a.nnz(), "products": nprod_total,
                        "nnz_c": nnz_total, "accumulator": args.accumulator,
-                       "parallelism": f"row-block x{world}, B replicated" + (", allgatherv of C" if world > 1 else "")},
+                       "parallelism": f"row-block x{world}, B replicated" +
+                                      (f", C streamed in {len(chunk_bounds) - 1} row chunks per rank and not gathered"
+                                       if chunk_bounds is not None else (", allgatherv of C" if world > 1 else ""))},
             "roofline": {
                 "bound": "hbm",
-                "kernel": "k_num_flat (flat-batch numeric: expand-scale-accumulate-order of every C row with nnz <= 1024), "
-                          "average duration over the timed steps by HIP events on its stream, rank 0",
+                "kernel": ("k_num_sortmerge (sort-merge accumulator over the rows with <= 2048 products)"
+                           if args.accumulator == "sort_merge" else
+                           "k_num_flat (flat-batch numeric: expand-scale-accumulate-order of every C row with nnz <= 1024)") +
+                          ", average duration per step by HIP events on its stream, rank 0",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",

@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libspada_spgemm.so")
+LIB_PATH = os.environ.get("SPADA_LIB_PATH") or os.path.join(_HERE, "lib", "libspada_spgemm.so")   # env: development A/B builds
 
 SPADA_N_BINS = 12
 

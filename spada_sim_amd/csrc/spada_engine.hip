@@ -358,9 +358,10 @@ int run_numeric(spada_ctx *c, uint64_t *d_ptr, uint32_t *d_idx, double *d_val)
     }
     if (cnt[BIN_COPY]) {
         if ((rc = fork_to(c, BIN_COPY))) return rc;
-        const uint32_t grid = (cnt[BIN_COPY] + 15) / 16;
-        hipLaunchKernelGGL((k_num_copy<16>), dim3(grid), dim3(256), 0, c->cur, c->a_view(), c->B->view(), c->r0,
-                           c->num_rows.as<uint32_t>() + off[BIN_COPY], cnt[BIN_COPY], c->cptr.as<uint64_t>(), d_idx, d_val);
+        const uint32_t grid = std::min<uint32_t>((c->nrows + 255) / 256, 256u * 8 * 4);
+        hipLaunchKernelGGL(k_num_copy2, dim3(grid), dim3(256), 0, c->cur, c->A->ptr, c->A->val, c->B->idx, c->B->val,
+                           c->eb0.as<uint64_t>(), c->elen.as<uint32_t>(), c->r0, c->nrows, c->row_bin.as<uint8_t>(),
+                           c->cptr.as<uint64_t>(), d_idx, d_val);
         HIP_TRY(hipGetLastError());
         if ((rc = join_from(c, BIN_COPY))) return rc;
     }

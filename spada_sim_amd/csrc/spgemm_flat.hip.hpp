@@ -382,6 +382,12 @@ __device__ inline uint32_t row_of_entry(const uint32_t *s_re, uint32_t R, uint32
 // LDS scratch: entry records {pack = (begin - offset) mod 2^48 | local row << 48, a value} | bm u64[PWIN / 64] |
 // bpre u32[PWIN / 64]
 constexpr int FLAT_PWIN = 8192;
+#ifndef SPADA_FLAT_U
+#define SPADA_FLAT_U 4
+#endif
+#ifndef SPADA_FLAT_PREFETCH
+#define SPADA_FLAT_PREFETCH 0
+#endif
 constexpr unsigned long long M48 = 0xFFFFFFFFFFFFull;
 
 struct __attribute__((aligned(16))) EntryRecNum {
@@ -601,7 +607,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void k_sym_flat(const uint64_t 
 {
     static_assert(RMAX <= BLOCK, "one thread per row of a batch");
     constexpr int T = 1 << LOG_T;
-    constexpr int U = 8;
+    constexpr int U = SPADA_FLAT_U;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *hdr = (uint32_t *)smem;
     uint32_t *keys = (uint32_t *)(smem + 256);
@@ -645,8 +651,13 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void k_sym_flat(const uint64_t 
             nrb = n2rb;
             nre = n2re;
         }
-        load_rows(nrb, nre, nxt);
-        load_desc(b + 2 * G, n2rb, n2re);
+        if (SPADA_FLAT_PREFETCH) {
+            load_rows(nrb, nre, nxt);
+            load_desc(b + 2 * G, n2rb, n2re);
+        } else {   // A/B switch: load this batch's rows on demand
+            load_desc(b, rb, re);
+            load_rows(rb, re, cur);
+        }
         const uint32_t R = re - rb;   // <= RMAX by construction of the cut
         if (R == 0) continue;
         uint32_t L = 0;
@@ -726,7 +737,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void k_num_flat(const uint64_t 
     static_assert((size_t)NOUT * 12 <= ((size_t)12 << LOG_T), "compacted (key, value) lists re-use the table");
     constexpr int T = 1 << LOG_T;
     constexpr int SPT = T / BLOCK;   // table slots per thread
-    constexpr int U = 8;
+    constexpr int U = SPADA_FLAT_U;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *hdr = (uint32_t *)smem;
     uint32_t *keys = (uint32_t *)(smem + 256);
@@ -782,8 +793,13 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void k_num_flat(const uint64_t 
             nrb = n2rb;
             nre = n2re;
         }
-        load_rows(nrb, nre, nxt);
-        load_desc(b + 2 * G, n2rb, n2re);
+        if (SPADA_FLAT_PREFETCH) {
+            load_rows(nrb, nre, nxt);
+            load_desc(b + 2 * G, n2rb, n2re);
+        } else {   // A/B switch: load this batch's rows on demand
+            load_desc(b, rb, re);
+            load_rows(rb, re, cur);
+        }
         const uint32_t R = re - rb;
         if (R == 0) continue;
         STAMP(0);
@@ -922,6 +938,65 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void k_num_flat(const uint64_t 
         STAMP(6);
     }
 #undef STAMP
+}
+
+// ---- 6b. numeric, rows with a single A nonzero: C row = a * B row (already ascending) ---------------------------------
+// Matrix order, one lane per row: the row pointers, bins and C offsets of 64 consecutive rows are three coalesced
+// loads, the (descriptor, value) of the single A entry one gather.  Short B rows are copied by their own lane
+// (independent iterations, 4 in flight); rows longer than COPY_SHORT are handed to the whole wave one after the
+// other, 64 entries per step.
+constexpr uint32_t COPY_SHORT = 24;
+__global__ __launch_bounds__(256) void k_num_copy2(const uint64_t *__restrict__ aptr, const double *__restrict__ aval,
+                                                   const uint32_t *__restrict__ bidx, const double *__restrict__ bval,
+                                                   const uint64_t *__restrict__ eb0, const uint32_t *__restrict__ elen,
+                                                   uint64_t r0, uint32_t nrows, const uint8_t *__restrict__ row_bin,
+                                                   const uint64_t *__restrict__ cptr, uint32_t *__restrict__ c_idx,
+                                                   double *__restrict__ c_val)
+{
+    const int lane = threadIdx.x & 63;
+    for (uint32_t tile = blockIdx.x * blockDim.x; tile < nrows; tile += gridDim.x * blockDim.x) {
+        const uint32_t i = tile + threadIdx.x;
+        uint64_t b0 = 0, c0 = 0;
+        uint32_t len = 0;
+        double av = 0.0;
+        if (i < nrows && row_bin[i] == BIN_COPY) {
+            const uint64_t a = aptr[r0 + i];
+            c0 = cptr[i];
+            b0 = eb0[a];
+            len = elen[a];
+            av = aval[a];
+        }
+        if (len <= COPY_SHORT) {
+            for (uint32_t t = 0; t < len; t += 4) {
+                uint32_t k[4];
+                double v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t tt = t + u < len ? t + u : len - 1;
+                    k[u] = bidx[b0 + tt];
+                    v[u] = bval[b0 + tt];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (t + u < len) {
+                        c_idx[c0 + t + u] = k[u];
+                        c_val[c0 + t + u] = av * v[u];
+                    }
+            }
+        }
+        unsigned long long mask = __ballot(len > COPY_SHORT);
+        while (mask) {
+            const int src = __ffsll((long long)mask) - 1;
+            mask &= mask - 1;
+            const uint64_t sb0 = __shfl(b0, src), sc0 = __shfl(c0, src);
+            const uint32_t slen = __shfl(len, src);
+            const double sav = __shfl(av, src);
+            for (uint32_t t = lane; t < slen; t += 64) {
+                c_idx[sc0 + t] = bidx[sb0 + t];
+                c_val[sc0 + t] = sav * bval[sb0 + t];
+            }
+        }
+    }
 }
 
 // ---- 7. numeric, flat batches, SORT-MERGE accumulator (SPADA_ACC_SORT_MERGE) ---------------------------------------

@@ -488,22 +488,34 @@ __device__ inline void walk_products(const DevCsrView &A, const DevCsrView &B, u
         group_sync<G>();
         if (maxlen < (0xFFFFFFFFu / G)) {
             for (uint32_t p0 = gl; p0 < total; p0 += U * G) {
-                uint32_t c[U];
+                uint32_t c[U], pp[U];
                 double v[U];
+                int j[U];
+                // the U owner searches advance in lock step (U independent LDS reads per round), then the U gathers
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const uint32_t p = p0 + u * G;
-                    c[u] = EMPTY_KEY;
-                    v[u] = 0.0;
-                    if (p < total) {
-                        int j = 0;
+                    pp[u] = p < total ? p : total - 1;
+                    j[u] = 0;
+                }
 #pragma unroll
-                        for (int step = G / 2; step >= 1; step >>= 1)
-                            if (s_off[j + step] <= p) j += step;
-                        const uint64_t q = s_b0[j] + (p - s_off[j]);
-                        c[u] = B.idx[q];
-                        if constexpr (NUMERIC) v[u] = s_av[j] * B.val[q];   // simulator.rs:100-101
-                    }
+                for (int step = G / 2; step >= 1; step >>= 1) {
+                    uint32_t o[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) o[u] = s_off[j[u] + step];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) j[u] += o[u] <= pp[u] ? step : 0;
+                }
+                uint64_t q[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) q[u] = s_b0[j[u]] + (pp[u] - s_off[j[u]]);
+#pragma unroll
+                for (int u = 0; u < U; ++u) c[u] = B.idx[q[u]];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    v[u] = 0.0;
+                    if constexpr (NUMERIC) v[u] = s_av[j[u]] * B.val[q[u]];   // simulator.rs:100-101
+                    if (p0 + u * G >= total) c[u] = EMPTY_KEY;
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u)

@@ -254,6 +254,23 @@ class Engine:
                                            c_data.ctypes.data_as(_ffi.f64p)))
         return CsMat((rows, cols), c_indptr, c_indices, c_data)
 
+    def spgemm_row_chunks(self, da, db, bounds, alloc, consume):
+        """C = A * B one A-row chunk at a time (bounds[i] .. bounds[i + 1]), for products too large to hold at once
+        (R-MAT scale 22: nnz(C) x 12 B exceeds one GPU's HBM).  `alloc(rows, nnz)` returns three device pointers
+        (u64[rows + 1], u32[nnz], f64[nnz]); `consume(row_begin, row_end, nnz, stats)` sees the finished chunk before
+        the next one overwrites nothing of it -- the caller owns the buffers.  Returns the total nnz(C)."""
+        total = 0
+        for i in range(len(bounds) - 1):
+            b0, b1 = int(bounds[i]), int(bounds[i + 1])
+            if b1 <= b0:
+                continue
+            nnz = self.symbolic(da, db, b0, b1)
+            p, ix, v = alloc(b1 - b0, nnz)
+            self.numeric(p, ix, v)
+            consume(b0, b1, nnz, self.stats())
+            total += nnz
+        return total
+
     def stats(self):
         st = _ffi.Stats()
         check(self._L.spada_get_stats(self._ctx, ctypes.byref(st)))

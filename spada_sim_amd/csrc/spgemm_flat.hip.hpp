@@ -385,6 +385,9 @@ constexpr int FLAT_PWIN = 8192;
 #ifndef SPADA_FLAT_U
 #define SPADA_FLAT_U 4
 #endif
+#ifndef SPADA_FLAT_DENSE_RANK
+#define SPADA_FLAT_DENSE_RANK 0   /* measured slower on every surrogate (two more barriers); kept for tightly clustered inputs */
+#endif
 #ifndef SPADA_FLAT_PREFETCH
 #define SPADA_FLAT_PREFETCH 0
 #endif
@@ -896,44 +899,85 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void k_num_flat(const uint64_t 
             }
         __syncthreads();
         STAMP(5);
-        constexpr int W = 2;   // outputs ranked per thread and iteration (independent LDS chains)
-        for (uint32_t p0 = tid; p0 < NO; p0 += W * BLOCK) {
-            uint32_t k[W], lo[W], hi[W], r[W], base[W];
-            uint64_t outp[W];
+        // Rank inside a bucket.  Buckets with fewer than 4 entries count smaller keys (<= 9 reads).  A larger bucket is
+        // usually a cluster of neighbouring columns (site-local links, mesh neighbours): if its keys span at most
+        // 32 * (m - 2) columns, the m words aux[lo .. hi) that belong to the bucket hold {min, max, bitmap of
+        // (key - min)} and the rank is a prefix popcount -- O(span / 32) per entry instead of O(m).
+        constexpr int OPT = NOUT / BLOCK;   // outputs per thread
+        uint32_t *aux = (uint32_t *)(smem + 256 + (size_t)NOUT * 12);
+        static_assert(((size_t)12 << LOG_T) >= (size_t)NOUT * 16, "aux words live behind the (key, value) lists");
+        uint32_t ok_[OPT], olo[OPT], ohi[OPT], obase[OPT];
+        uint64_t oout[OPT];
+        bool any_heavy = false;
 #pragma unroll
-            for (int w = 0; w < W; ++w) {
-                const uint32_t p = p0 + w * BLOCK;
-                k[w] = p < NO ? lk[p] : EMPTY_KEY;
-            }
-#pragma unroll
-            for (int w = 0; w < W; ++w) {
-                lo[w] = hi[w] = 0;
-                base[w] = 0;
-                outp[w] = 0;
-                if (k[w] != EMPTY_KEY) {
-                    const uint32_t lr = colbits >= 32 ? 0u : (k[w] >> colbits), col = k[w] & colmask;
-                    const RowEmit rw = s_row[lr];
-                    uint32_t bk = (uint32_t)((float)(col - rw.kmin) * rw.scale);
-                    bk = rw.boff + (bk < rw.n ? bk : rw.n - 1);
-                    lo[w] = bk ? bcnt[bk - 1] : 0u;
-                    hi[w] = bcnt[bk];
-                    base[w] = rw.boff;
-                    outp[w] = s_out[lr];
-                }
-            }
-#pragma unroll
-            for (int w = 0; w < W; ++w) {
-                r[w] = lo[w];
-                for (uint32_t j = lo[w]; j < hi[w]; ++j) r[w] += (lk[j] < k[w]) ? 1u : 0u;
-            }
-#pragma unroll
-            for (int w = 0; w < W; ++w)
-                if (k[w] != EMPTY_KEY) {
-                    const uint64_t pos = outp[w] + (r[w] - base[w]);
-                    c_idx[pos] = k[w] & colmask;
-                    c_val[pos] = lv[p0 + w * BLOCK];
-                }
+        for (int w = 0; w < OPT; ++w) {
+            const uint32_t p = tid + w * BLOCK;
+            ok_[w] = p < NO ? lk[p] : EMPTY_KEY;
+            olo[w] = ohi[w] = obase[w] = 0;
+            oout[w] = 0;
         }
+#pragma unroll
+        for (int w = 0; w < OPT; ++w)
+            if (ok_[w] != EMPTY_KEY) {
+                const uint32_t lr = colbits >= 32 ? 0u : (ok_[w] >> colbits), col = ok_[w] & colmask;
+                const RowEmit rw = s_row[lr];
+                uint32_t bk = (uint32_t)((float)(col - rw.kmin) * rw.scale);
+                bk = rw.boff + (bk < rw.n ? bk : rw.n - 1);
+                olo[w] = bk ? bcnt[bk - 1] : 0u;
+                ohi[w] = bcnt[bk];
+                obase[w] = rw.boff;
+                oout[w] = s_out[lr];
+                if (SPADA_FLAT_DENSE_RANK && ohi[w] - olo[w] >= 4) {
+                    any_heavy = true;
+                    const uint32_t p = tid + w * BLOCK;
+                    aux[p] = p == olo[w] ? 0xFFFFFFFFu : 0u;   // [lo] = min, [lo + 1] = max, the rest = bitmap words
+                }
+            }
+        const bool heavy_block = SPADA_FLAT_DENSE_RANK ? __syncthreads_or(any_heavy) : false;
+        uint32_t omn[OPT], ospan[OPT];
+        if (heavy_block) {
+#pragma unroll
+            for (int w = 0; w < OPT; ++w)
+                if (ohi[w] - olo[w] >= 4) {
+                    atomicMin(&aux[olo[w]], ok_[w]);
+                    atomicMax(&aux[olo[w] + 1], ok_[w]);
+                }
+            __syncthreads();
+#pragma unroll
+            for (int w = 0; w < OPT; ++w) {
+                omn[w] = 0;
+                ospan[w] = 0xFFFFFFFFu;
+                const uint32_t m = ohi[w] - olo[w];
+                if (m >= 4) {
+                    omn[w] = aux[olo[w]];
+                    const uint32_t span = aux[olo[w] + 1] - omn[w];
+                    if (span < 32u * (m - 2)) ospan[w] = span;
+                }
+            }
+#pragma unroll
+            for (int w = 0; w < OPT; ++w)
+                if (ospan[w] != 0xFFFFFFFFu) {
+                    const uint32_t d = ok_[w] - omn[w];
+                    atomicOr(&aux[olo[w] + 2 + (d >> 5)], 1u << (d & 31));
+                }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int w = 0; w < OPT; ++w)
+            if (ok_[w] != EMPTY_KEY) {
+                uint32_t r = olo[w];
+                if (heavy_block && ohi[w] - olo[w] >= 4 && ospan[w] != 0xFFFFFFFFu) {
+                    const uint32_t d = ok_[w] - omn[w];
+                    const uint32_t *bmw = aux + olo[w] + 2;
+                    for (uint32_t q = 0; q < (d >> 5); ++q) r += __popc(bmw[q]);
+                    r += __popc(bmw[d >> 5] & ((1u << (d & 31)) - 1u));
+                } else {
+                    for (uint32_t j = olo[w]; j < ohi[w]; ++j) r += (lk[j] < ok_[w]) ? 1u : 0u;
+                }
+                const uint64_t pos = oout[w] + (r - obase[w]);
+                c_idx[pos] = ok_[w] & colmask;
+                c_val[pos] = lv[tid + w * BLOCK];
+            }
         __syncthreads();
         STAMP(6);
     }

@@ -191,3 +191,96 @@ def test_sort_merge_generated_workloads(engine_sm, name, kind, p0, p1, seed):
         # every row went through the copy or the sort-merge kernel, which add in ascending k like the CPU
         # restatement (simulator.rs:209-220 adds left to right): values are bit-identical, not just within 1e-9
         assert np.array_equal(c.data, ref.data)
+
+
+# ---- flat-batch pipeline: edge cases of the batch cut, the composite keys and the bucket order ---------------------
+def _random_csr(rng, rows, cols, row_lens, col_sampler):
+    import spada_sim_amd as S
+    indptr = np.zeros(rows + 1, np.uint64)
+    idx, val = [], []
+    for r in range(rows):
+        c = np.unique(col_sampler(r, int(row_lens[r])))
+        c = c[(c >= 0) & (c < cols)]
+        idx.append(c.astype(np.uint64))
+        val.append(rng.uniform(0.1, 1.0, len(c)))
+        indptr[r + 1] = indptr[r] + len(c)
+    return S.CsMat((rows, cols), indptr, np.concatenate(idx) if idx else np.zeros(0, np.uint64),
+                   np.concatenate(val) if val else np.zeros(0))
+
+
+def test_clustered_columns_with_far_outliers(engine):
+    """Rows whose columns are tight clusters plus a few far outliers: the value-proportional buckets of the ordered
+    emission degenerate (most entries in one bucket) -- the result must still be exact."""
+    rng = np.random.default_rng(7)
+    n = 3000
+
+    def cols(r, k):
+        base = (r * 37) % (n - 200)
+        local = base + rng.integers(0, 40, size=k)             # dense cluster next to `base`
+        far = rng.integers(0, n, size=max(1, k // 8))           # a few far links
+        return np.concatenate([local, far])
+
+    m = _random_csr(rng, n, n, rng.integers(2, 40, size=n), cols)
+    ao = to_oracle(m)
+    assert assert_parity(engine.spgemm(m, m), oracle.spgemm_spa(ao, ao), ao, ao, RTOL) == 0
+
+
+@pytest.mark.parametrize("cols_log2", [24, 27, 30, 31])
+def test_wide_column_spaces(engine, cols_log2):
+    """cols up to 2^31: the (local row, column) composite key leaves 8, 5, 2 and 1 bits for the local row, i.e. at most
+    255 / 31 / 3 rows per batch and finally the per-row kernels only (flat batches off)."""
+    import spada_sim_amd as S
+    rng = np.random.default_rng(cols_log2)
+    rows, inner, cols = 400, 300, 1 << cols_log2
+    a = _random_csr(rng, rows, inner, rng.integers(0, 12, size=rows), lambda r, k: rng.integers(0, inner, size=k))
+    b = _random_csr(rng, inner, cols, rng.integers(0, 30, size=inner),
+                    lambda r, k: rng.integers(0, cols, size=k, dtype=np.int64))
+    c = engine.spgemm(a, b)
+    ref = oracle.spgemm_sortmerge(to_oracle(a), to_oracle(b))
+    assert_parity(c, ref, to_oracle(a), to_oracle(b), RTOL)
+
+
+def test_row_chunks_stream_the_same_product(engine):
+    """Chunked execution (what bench.py uses for R-MAT scale 22) concatenates to the one-shot product."""
+    import spada_sim_amd as S
+    import torch
+    m = S.generate(S.GEN_RMAT, 12, 8, 5)
+    ao = to_oracle(m)
+    ref = oracle.spgemm_spa(ao, ao)
+    bounds = S.partition_rows(m, m, 7)
+    d = engine.upload(m)
+    dev = torch.device("cuda", 0)
+    got = {"idx": [], "val": [], "len": []}
+    bufs = {}
+
+    def alloc(nrows, nnz):
+        bufs["p"] = torch.empty(nrows + 1, dtype=torch.int64, device=dev)
+        bufs["i"] = torch.empty(max(nnz, 1), dtype=torch.int32, device=dev)
+        bufs["v"] = torch.empty(max(nnz, 1), dtype=torch.float64, device=dev)
+        return bufs["p"].data_ptr(), bufs["i"].data_ptr(), bufs["v"].data_ptr()
+
+    def consume(b0, b1, nnz, st):
+        got["idx"].append(bufs["i"][:nnz].cpu().numpy().astype(np.uint64))
+        got["val"].append(bufs["v"][:nnz].cpu().numpy())
+        got["len"].append(np.diff(bufs["p"].cpu().numpy()))
+
+    total = engine.spgemm_row_chunks(d, d, bounds, alloc, consume)
+    engine.free(d)
+    assert total == ref.nnz
+    assert np.array_equal(np.concatenate(got["idx"]), ref.indices)
+    assert np.array_equal(np.concatenate([[0], np.cumsum(np.concatenate(got["len"]))]).astype(np.uint64), ref.indptr)
+    assert np.all(np.abs(np.concatenate(got["val"]) - ref.data) <= RTOL * np.abs(ref.data))
+
+
+def test_stats_account_for_every_product(engine):
+    import spada_sim_amd as S
+    m = S.generate(S.GEN_RMAT, 13, 12, 9)
+    c = engine.spgemm(m, m)
+    st = engine.stats()
+    ao = to_oracle(m)
+    assert st["nprod"] == oracle.count_products(ao, ao)
+    assert sum(st["num_bin_rows"]) == m.shape[0] and sum(st["sym_bin_rows"]) == m.shape[0]
+    assert sum(st["num_bin_nnz"]) == c.nnz() == st["c_nnz"]
+    assert sum(st["num_bin_entries"]) + 0 <= m.nnz()          # rows with an empty C row are not counted
+    assert sum(st["num_bin_prod"]) == st["nprod"]
+    assert st["bytes_read"] == (m.shape[0] + 1) * 8 + m.nnz() * 28 + st["nprod"] * 12

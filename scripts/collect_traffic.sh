@@ -13,7 +13,7 @@ CMD="python3 $REPO/bench.py --steps 10 --warmup 2 --no-cpu-baseline --workload $
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o p -- $CMD > $OUT/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -o p -- $CMD > $OUT/write.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o p -- $CMD > $OUT/stats.log 2>&1
-cp $OUT/stats/p_kernel_stats.csv $REPO/profiles/r01_${WL}_kernel_stats.csv
+cp $OUT/stats/p_kernel_stats.csv $REPO/profiles/r01_${WL}_kernel_stats.csv   # profiles/ on the box is not merged back: gpurun_out/ is
 python3 - <<PY
 import csv, json, collections
 def per_kernel(path, counter):
@@ -35,6 +35,7 @@ for n in sorted(set(f) | set(w)):
     out[n] = {"fetch_bytes_per_launch": fb, "fetch_bytes_per_launch_x2": 2 * fb, "write_bytes_per_launch": wb,
               "hbm_bytes_per_launch": fb + wb, "launches": f.get(n, (0, 0))[1]}
 json.dump(out, open("$REPO/profiles/r01_traffic_$WL.json", "w"), indent=1)
+json.dump(out, open("$OUT/r01_traffic_$WL.json", "w"), indent=1)
 for n in ("k_num_flat", "k_sym_flat", "k_num_hash", "k_num_bitmap", "k_num_copy", "k_row_stats2"):
     if n in out: print(n, out[n])
 PY

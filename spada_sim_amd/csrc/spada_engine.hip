@@ -338,24 +338,42 @@ int run_numeric(spada_ctx *c, uint64_t *d_ptr, uint32_t *d_idx, double *d_val)
         if ((rc = join_from(c, BIN_FLAT))) return rc;
     } else if (cnt[BIN_FLAT]) {
         if ((rc = fork_to(c, BIN_FLAT))) return rc;
-#define LAUNCH_NUM_FLAT(BL, EP)                                                                                              \
+#define LAUNCH_NUM_FLAT(BL, EP, LS)                                                                                             \
     {                                                                                                                        \
         constexpr size_t lds = num_flat_lds<BL, EP, NF_LOG_T, NF_NOUT, NF_RMAX>();                                           \
-        hipLaunchKernelGGL((k_num_flat<BL, EP, NF_LOG_T, NF_NOUT, NF_RMAX>), dim3(flat_grid(c->h_counters->nb_num, lds)),     \
+        hipLaunchKernelGGL((k_num_flat<BL, EP, NF_LOG_T, NF_NOUT, NF_RMAX, LS>), dim3(flat_grid(nf_batches, lds)),                \
                            dim3(BL), lds, c->cur, c->A->ptr, c->A->val, c->B->idx, c->B->val, c->eb0.as<uint64_t>(),          \
                            c->elen.as<uint32_t>(), c->r0, c->nrows, c->row_bin.as<uint8_t>(), c->row_kmin.as<uint32_t>(),     \
-                           c->row_kmax.as<uint32_t>(), c->cptr.as<uint64_t>(), c->batch_num.as<uint32_t>(), &dc->nb_num,      \
-                           c->colbits, d_idx, d_val, c->dbg_g == 1 ? c->dbg.as<unsigned long long>() : nullptr);             \
+                           c->row_kmax.as<uint32_t>(), c->cptr.as<uint64_t>(), c->batch_num.as<uint32_t>(), nf_nb,            \
+                           c->colbits, d_idx, d_val, nf_dbg, nf_list, nf_bin);                                               \
     }
         HIP_TRY(hipEventRecord(c->ev[EV_NFLAT_0], c->cur));
-        if (c->flat_cfg == 0) LAUNCH_NUM_FLAT(256, 4)
-        else if (c->flat_cfg == 1) LAUNCH_NUM_FLAT(512, 2)
-        else LAUNCH_NUM_FLAT(1024, 1)
-#undef LAUNCH_NUM_FLAT
+        {
+            const uint64_t nf_batches = c->h_counters->nb_num;
+            const uint32_t *nf_nb = &dc->nb_num, *nf_list = nullptr;
+            const uint32_t nf_bin = BIN_FLAT;
+            unsigned long long *nf_dbg = c->dbg_g == 1 ? c->dbg.as<unsigned long long>() : nullptr;
+            if (c->flat_cfg == 0) LAUNCH_NUM_FLAT(256, 4, false)
+            else if (c->flat_cfg == 1) LAUNCH_NUM_FLAT(512, 2, false)
+            else LAUNCH_NUM_FLAT(1024, 1, false)
+        }
         HIP_TRY(hipEventRecord(c->ev[EV_NFLAT_1], c->cur));
         HIP_TRY(hipGetLastError());
         if ((rc = join_from(c, BIN_FLAT))) return rc;
     }
+    if (cnt[NUM2_BIN_MID]) {   // one row per batch from the bin's row list
+        if ((rc = fork_to(c, NUM2_BIN_MID))) return rc;
+        const uint64_t nf_batches = cnt[NUM2_BIN_MID];
+        const uint32_t *nf_nb = &dc->num_counts[NUM2_BIN_MID], *nf_list = c->num_rows.as<uint32_t>() + off[NUM2_BIN_MID];
+        const uint32_t nf_bin = NUM2_BIN_MID;
+        unsigned long long *nf_dbg = nullptr;
+        if (c->flat_cfg == 0) LAUNCH_NUM_FLAT(256, 4, true)
+        else if (c->flat_cfg == 1) LAUNCH_NUM_FLAT(512, 2, true)
+        else LAUNCH_NUM_FLAT(1024, 1, true)
+        HIP_TRY(hipGetLastError());
+        if ((rc = join_from(c, NUM2_BIN_MID))) return rc;
+    }
+#undef LAUNCH_NUM_FLAT
     if (cnt[BIN_COPY]) {
         if ((rc = fork_to(c, BIN_COPY))) return rc;
         const uint32_t grid = std::min<uint32_t>((c->nrows + 255) / 256, 256u * 8 * 4);
@@ -437,8 +455,10 @@ int spada_create(const spada_options *opts, spada_ctx **out)
     if ((rc = allow_lds(k_num_hash<256, 12>, num_lds<256, 12>()))) return rc;
     if ((rc = allow_lds(k_num_hash<1024, 13>, num_lds<1024, 13>()))) return rc;
 #define ALLOW_FLAT(BL, EP)                                                                                                   \
-    if ((rc = allow_lds(k_sym_flat<BL, EP, SYM_FLAT_LOG_T, SF_RMAX>, sym_flat_lds<BL, EP, SYM_FLAT_LOG_T, SF_RMAX>()))) return rc; \
-    if ((rc = allow_lds(k_num_flat<BL, EP, NF_LOG_T, NF_NOUT, NF_RMAX>, num_flat_lds<BL, EP, NF_LOG_T, NF_NOUT, NF_RMAX>()))) return rc;
+    if ((rc = allow_lds(k_sym_flat<BL, EP, SYM_FLAT_LOG_T, SF_RMAX, false>, sym_flat_lds<BL, EP, SYM_FLAT_LOG_T, SF_RMAX>()))) return rc; \
+    if ((rc = allow_lds(k_sym_flat<BL, EP, SYM_FLAT_LOG_T, SF_RMAX, true>, sym_flat_lds<BL, EP, SYM_FLAT_LOG_T, SF_RMAX>()))) return rc; \
+    if ((rc = allow_lds(k_num_flat<BL, EP, NF_LOG_T, NF_NOUT, NF_RMAX, false>, num_flat_lds<BL, EP, NF_LOG_T, NF_NOUT, NF_RMAX>()))) return rc; \
+    if ((rc = allow_lds(k_num_flat<BL, EP, NF_LOG_T, NF_NOUT, NF_RMAX, true>, num_flat_lds<BL, EP, NF_LOG_T, NF_NOUT, NF_RMAX>()))) return rc;
     ALLOW_FLAT(256, 4)
     ALLOW_FLAT(512, 2)
     ALLOW_FLAT(1024, 1)
@@ -629,23 +649,39 @@ int spada_dev_spgemm_symbolic(spada_ctx *c, const spada_dev_csr *a, const spada_
         if (cnt[BIN_FLAT]) {
             if ((rc = fork_to(c, BIN_FLAT))) return rc;
             const uint64_t nb_upper = (nprod + (uint64_t)n * cut_sym.minw) / cut_sym.cap + 1;
-#define LAUNCH_SYM_FLAT(BL, EP)                                                                                              \
+#define LAUNCH_SYM_FLAT(BL, EP, LS)                                                                                             \
     {                                                                                                                        \
         constexpr size_t lds = sym_flat_lds<BL, EP, SYM_FLAT_LOG_T, SF_RMAX>();                                              \
-        hipLaunchKernelGGL((k_sym_flat<BL, EP, SYM_FLAT_LOG_T, SF_RMAX>), dim3(flat_grid(nb_upper, lds)), dim3(BL), lds,      \
+        hipLaunchKernelGGL((k_sym_flat<BL, EP, SYM_FLAT_LOG_T, SF_RMAX, LS>), dim3(flat_grid(sf_batches, lds)), dim3(BL), lds,    \
                            c->cur, a->ptr, b->idx, c->eb0.as<uint64_t>(), c->elen.as<uint32_t>(), c->r0, n,                   \
-                           c->row_bin.as<uint8_t>(), c->batch_sym.as<uint32_t>(), &dc->nb_sym, c->colbits,                    \
-                           c->row_nnzc.as<uint32_t>());                                                                      \
+                           c->row_bin.as<uint8_t>(), c->batch_sym.as<uint32_t>(), sf_nb, c->colbits,                         \
+                           c->row_nnzc.as<uint32_t>(), sf_list, sf_bin);                                                     \
     }
             HIP_TRY(hipEventRecord(c->ev[EV_SFLAT_0], c->cur));
-            if (c->flat_cfg == 0) LAUNCH_SYM_FLAT(256, 4)
-            else if (c->flat_cfg == 1) LAUNCH_SYM_FLAT(512, 2)
-            else LAUNCH_SYM_FLAT(1024, 1)
-#undef LAUNCH_SYM_FLAT
+            {
+                const uint64_t sf_batches = nb_upper;
+                const uint32_t *sf_nb = &dc->nb_sym, *sf_list = nullptr;
+                const uint32_t sf_bin = BIN_FLAT;
+                if (c->flat_cfg == 0) LAUNCH_SYM_FLAT(256, 4, false)
+                else if (c->flat_cfg == 1) LAUNCH_SYM_FLAT(512, 2, false)
+                else LAUNCH_SYM_FLAT(1024, 1, false)
+            }
             HIP_TRY(hipEventRecord(c->ev[EV_SFLAT_1], c->cur));
             HIP_TRY(hipGetLastError());
             if ((rc = join_from(c, BIN_FLAT))) return rc;
         }
+        if (cnt[SYM2_BIN_MID]) {   // one row per batch from the bin's row list
+            if ((rc = fork_to(c, SYM2_BIN_MID))) return rc;
+            const uint64_t sf_batches = cnt[SYM2_BIN_MID];
+            const uint32_t *sf_nb = &dc->sym_counts[SYM2_BIN_MID], *sf_list = c->sym_rows.as<uint32_t>() + off[SYM2_BIN_MID];
+            const uint32_t sf_bin = SYM2_BIN_MID;
+            if (c->flat_cfg == 0) LAUNCH_SYM_FLAT(256, 4, true)
+            else if (c->flat_cfg == 1) LAUNCH_SYM_FLAT(512, 2, true)
+            else LAUNCH_SYM_FLAT(1024, 1, true)
+            HIP_TRY(hipGetLastError());
+            if ((rc = join_from(c, SYM2_BIN_MID))) return rc;
+        }
+#undef LAUNCH_SYM_FLAT
     }
     HIP_TRY(hipEventRecord(c->ev[EV_SYM], s));
 

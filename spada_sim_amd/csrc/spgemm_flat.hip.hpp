@@ -21,8 +21,12 @@ namespace spada {
 // numeric : 0 empty | 1 copy | 2 flat (n <= num_flat_max) | 3 n <= 2048 and P <= 16384 (k_num_hash<256,12>)
 //           4 n <= 6144 (k_num_hash<1024,13>) | 5 LDS bitmap with LDS values (n <= vcap) | 6 bitmap / spill
 constexpr int BIN_EMPTY = 0, BIN_COPY = 1, BIN_FLAT = 2;
-constexpr int SYM2_BIN_8K = 3, SYM2_BIN_24K = 4, SYM2_BIN_SPILL = 5;
-constexpr int NUM2_BIN_2K = 3, NUM2_BIN_6K = 4, NUM2_BIN_BMV = 5, NUM2_BIN_SPILL = 6;
+constexpr int SYM2_BIN_8K = 3, SYM2_BIN_24K = 4, SYM2_BIN_SPILL = 5, SYM2_BIN_MID = 6;
+constexpr int NUM2_BIN_2K = 3, NUM2_BIN_6K = 4, NUM2_BIN_BMV = 5, NUM2_BIN_SPILL = 6, NUM2_BIN_MID = 7;
+// "mid" rows: too large for a shared batch, small enough for the flat kernels' table -- one row per batch, taken
+// from the bin's row list (list mode of k_sym_flat / k_num_flat)
+constexpr uint32_t SYM_MID_MAX = 6144;   // products: 0.75 of the 8192-key symbolic table
+constexpr uint32_t NUM_MID_MAX = 3072;   // outputs:  0.75 of the 4096-slot numeric table, = its bucket array
 
 constexpr uint32_t SYM_FLAT_CAP = 4096, SYM_FLAT_MAX = 2048;   // products per batch / per flat row
 constexpr int SYM_FLAT_LOG_T = 13;                             // 8192 keys: load <= 0.75, typically 0.5
@@ -32,6 +36,7 @@ __host__ __device__ inline int sym2_bin_of(uint64_t P, uint32_t L)
     if (P == 0) return BIN_EMPTY;
     if (L == 1) return BIN_COPY;
     if (P <= SYM_FLAT_MAX) return BIN_FLAT;
+    if (P <= SYM_MID_MAX) return SYM2_BIN_MID;
     if (P <= 8192) return SYM2_BIN_8K;
     if (P <= 24576) return SYM2_BIN_24K;
     return SYM2_BIN_SPILL;
@@ -43,6 +48,7 @@ __host__ __device__ inline int num2_bin_of(uint32_t n, uint64_t P, uint32_t L, u
     if (n == 0) return BIN_EMPTY;
     if (L == 1) return BIN_COPY;
     if (sm_pmax ? P <= sm_pmax : (n <= flat_max && P <= (1u << 22))) return BIN_FLAT;
+    if (flat_max && n <= NUM_MID_MAX && P <= (1u << 22)) return NUM2_BIN_MID;
     if (n <= 2048 && P <= 16384) return NUM2_BIN_2K;
     if (n <= 6144) return NUM2_BIN_6K;
     if (n <= vcap) return NUM2_BIN_BMV;
@@ -124,7 +130,7 @@ __global__ __launch_bounds__(256) void k_row_stats2(const uint64_t *__restrict__
         }
         if (i < nrows) {
             int bin = sym2_bin_of(P, L);
-            if (bin == BIN_FLAT && !flat_on) bin = SYM2_BIN_8K;
+            if ((bin == BIN_FLAT || bin == SYM2_BIN_MID) && !flat_on) bin = SYM2_BIN_8K;
             row_nprod[i] = P > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)P;
             row_bin[i] = (uint8_t)bin;
             row_kmin[i] = kmin;
@@ -601,13 +607,15 @@ __host__ __device__ constexpr size_t sym_flat_lds()
            flat_walk_bytes<BLOCK, EPT, false>() + 16;
 }
 
-template <int BLOCK, int EPT, int LOG_T, int RMAX>
+template <int BLOCK, int EPT, int LOG_T, int RMAX, bool LIST>
 __global__ __launch_bounds__(BLOCK, BLOCK / 128) void k_sym_flat(const uint64_t *__restrict__ aptr, const uint32_t *__restrict__ bidx,
                                                     const uint64_t *__restrict__ eb0, const uint32_t *__restrict__ elen,
                                                     uint64_t r0, uint32_t nrows, const uint8_t *__restrict__ row_bin,
                                                     const uint32_t *__restrict__ batch_first, const uint32_t *__restrict__ nb_ptr,
-                                                    uint32_t colbits, uint32_t *__restrict__ row_nnzc)
+                                                    uint32_t colbits, uint32_t *__restrict__ row_nnzc,
+                                                    const uint32_t *__restrict__ list, uint32_t want_bin)
 {
+    // LIST = false: batches of consecutive rows (batch_first); LIST = true: one row of `list` per batch
     static_assert(RMAX <= BLOCK, "one thread per row of a batch");
     constexpr int T = 1 << LOG_T;
     constexpr int U = SPADA_FLAT_U;
@@ -628,8 +636,13 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void k_sym_flat(const uint64_t 
     auto load_desc = [&](uint32_t bb, uint32_t &rb_, uint32_t &re_) {
         rb_ = re_ = 0;
         if (bb < nb) {
-            rb_ = batch_first[bb];
-            re_ = bb + 1 < nb ? batch_first[bb + 1] : nrows;
+            if constexpr (LIST) {
+                rb_ = list[bb];
+                re_ = rb_ + 1;
+            } else {
+                rb_ = batch_first[bb];
+                re_ = bb + 1 < nb ? batch_first[bb + 1] : nrows;
+            }
         }
     };
     auto load_rows = [&](uint32_t rb_, uint32_t re_, Rows &rw) {
@@ -664,7 +677,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void k_sym_flat(const uint64_t 
         const uint32_t R = re - rb;   // <= RMAX by construction of the cut
         if (R == 0) continue;
         uint32_t L = 0;
-        const bool flat = (uint32_t)tid < R && cur.bin == BIN_FLAT;
+        const bool flat = (uint32_t)tid < R && cur.bin == want_bin;
         if ((uint32_t)tid < R) {
             s_a0[tid] = cur.a0;
             s_cnt[tid] = 0;
@@ -723,7 +736,7 @@ __host__ __device__ constexpr size_t num_flat_lds()
            (size_t)(RMAX + 1) * 16 + (size_t)RMAX * 16 + 32;
 }
 
-template <int BLOCK, int EPT, int LOG_T, int NOUT, int RMAX>
+template <int BLOCK, int EPT, int LOG_T, int NOUT, int RMAX, bool LIST>
 __global__ __launch_bounds__(BLOCK, BLOCK / 128) void k_num_flat(const uint64_t *__restrict__ aptr, const double *__restrict__ aval,
                                                     const uint32_t *__restrict__ bidx, const double *__restrict__ bval,
                                                     const uint64_t *__restrict__ eb0, const uint32_t *__restrict__ elen,
@@ -732,7 +745,8 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void k_num_flat(const uint64_t 
                                                     const uint64_t *__restrict__ cptr, const uint32_t *__restrict__ batch_first,
                                                     const uint32_t *__restrict__ nb_ptr, uint32_t colbits,
                                                     uint32_t *__restrict__ c_idx, double *__restrict__ c_val,
-                                                    unsigned long long *dbg)
+                                                    unsigned long long *dbg, const uint32_t *__restrict__ list,
+                                                    uint32_t want_bin)
 {
 #define STAMP(i) do { if (dbg && threadIdx.x == 0 && b % 64 == 0 && b / 64 < 64) dbg[(b / 64) * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
     static_assert(RMAX <= BLOCK, "one thread per row of a batch");
@@ -765,8 +779,13 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void k_num_flat(const uint64_t 
     auto load_desc = [&](uint32_t bb, uint32_t &rb_, uint32_t &re_) {
         rb_ = re_ = 0;
         if (bb < nb) {
-            rb_ = batch_first[bb];
-            re_ = bb + 1 < nb ? batch_first[bb + 1] : nrows;
+            if constexpr (LIST) {
+                rb_ = list[bb];
+                re_ = rb_ + 1;
+            } else {
+                rb_ = batch_first[bb];
+                re_ = bb + 1 < nb ? batch_first[bb + 1] : nrows;
+            }
         }
     };
     auto load_rows = [&](uint32_t rb_, uint32_t re_, Rows &rw) {
@@ -810,7 +829,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void k_num_flat(const uint64_t 
         if ((uint32_t)tid < R) {
             s_a0[tid] = cur.a0;
             s_out[tid] = cur.c0;
-            if (cur.bin == BIN_FLAT) {
+            if (cur.bin == want_bin) {
                 L = (uint32_t)(cur.a1 - cur.a0);
                 n = (uint32_t)(cur.c1 - cur.c0);
                 kmin = cur.kmin;

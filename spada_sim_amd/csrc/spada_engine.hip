@@ -74,6 +74,7 @@ struct Counters {
     uint32_t num_cursor[SPADA_N_BINS];
     unsigned long long totals[2];   // nprod, a_nnz of the row range
     uint32_t nb_sym, nb_num;        // number of flat batches (symbolic / numeric)
+    uint32_t queue[4];              // dynamic dequeue cursors of the huge-row kernels
     unsigned long long num_sums[3 * SPADA_N_BINS];   // per numeric bin: products | nnz(C) | A entries
     unsigned long long sym_prod[SPADA_N_BINS];
 };
@@ -91,6 +92,7 @@ struct spada_ctx {
     hipStream_t side[SPADA_N_BINS] = {};
     hipEvent_t ev_fork = nullptr, ev_join[SPADA_N_BINS] = {};
     hipStream_t cur = nullptr;        // stream the launch helpers use
+    bool sort_huge = false;           // SPADA_SORT_HUGE=1
     int flat_cfg = 1;                 // SPADA_FLAT_CFG: 0 = 256 threads x 4 entries, 1 = 512 x 2, 2 = 1024 x 1
     int dbg_g = 0;                    // SPADA_DBG_G=<G>: phase timestamps of k_num_hash<G,*> into `dbg`
     DevBuf dbg;
@@ -292,7 +294,7 @@ int run_numeric(spada_ctx *c, uint64_t *d_ptr, uint32_t *d_idx, double *d_val)
             const size_t lds = bm_lds_bytes(c->B->cols, 0);
             hipLaunchKernelGGL(k_num_bitmap<false>, dim3(bm_grid(nsp, lds)), dim3(BM_BLOCK), lds, c->cur, c->a_view(),
                                c->B->view(), c->r0, c->num_rows.as<uint32_t>() + off[NUM2_BIN_SPILL], nsp, c->B->cols, 0u,
-                               c->cptr.as<uint64_t>(), d_idx, d_val);
+                               c->cptr.as<uint64_t>(), d_idx, d_val, &dc->queue[0]);
         } else {
             if ((rc = ensure_spill(c, nsp, true))) return rc;
             if ((rc = fork_to(c, NUM2_BIN_SPILL))) return rc;
@@ -311,7 +313,7 @@ int run_numeric(spada_ctx *c, uint64_t *d_ptr, uint32_t *d_idx, double *d_val)
         const size_t lds = bm_lds_bytes(c->B->cols, c->bm_vcap);
         hipLaunchKernelGGL(k_num_bitmap<true>, dim3(bm_grid(nb, lds)), dim3(BM_BLOCK), lds, c->cur, c->a_view(),
                            c->B->view(), c->r0, c->num_rows.as<uint32_t>() + off[NUM2_BIN_BMV], nb, c->B->cols, c->bm_vcap,
-                           c->cptr.as<uint64_t>(), d_idx, d_val);
+                           c->cptr.as<uint64_t>(), d_idx, d_val, &dc->queue[1]);
         HIP_TRY(hipGetLastError());
         if ((rc = join_from(c, NUM2_BIN_BMV))) return rc;
     }
@@ -465,6 +467,7 @@ int spada_create(const spada_options *opts, spada_ctx **out)
 #undef ALLOW_FLAT
     if ((rc = allow_lds(k_num_sortmerge<1024, 1, SF_RMAX>, num_sm_lds<1024, 1, SF_RMAX>()))) return rc;
     if (const char *e = std::getenv("SPADA_FLAT_CFG")) c->flat_cfg = atoi(e);
+    if (const char *e = std::getenv("SPADA_SORT_HUGE")) c->sort_huge = e[0] == '1';
     if ((rc = allow_lds(k_sym_bitmap, LDS_MAX))) return rc;
     if ((rc = allow_lds(k_num_bitmap<true>, LDS_MAX))) return rc;
     if ((rc = allow_lds(k_num_bitmap<false>, LDS_MAX))) return rc;
@@ -699,6 +702,12 @@ int spada_dev_spgemm_symbolic(spada_ctx *c, const spada_dev_csr *a, const spada_
     if (n) {
         hipLaunchKernelGGL(k_bin_scatter2, dim3(gsc), dim3(256), 0, s, c->row_bin.as<uint8_t>(), n, dc->num_counts,
                            dc->num_cursor, c->num_rows.as<uint32_t>());
+        // largest-first order of the huge rows (k_sort_rows_desc) measured -85 us on the serialised bitmap kernel but
+        // nothing on the concurrent pipeline (other bins fill the idle CUs) while costing 16 us here: opt-in
+        if (c->sort_huge)
+            for (int hb : {NUM2_BIN_SPILL, NUM2_BIN_BMV})
+                hipLaunchKernelGGL(k_sort_rows_desc, dim3(1), dim3(1024), 0, s, c->num_rows.as<uint32_t>(), dc->num_counts,
+                                   hb, c->row_nprod.as<uint32_t>());
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipMemcpyAsync(c->h_counters, dc, sizeof(Counters), hipMemcpyDeviceToHost, s));

@@ -344,6 +344,41 @@ __global__ __launch_bounds__(256) void k_bin_scatter2(const uint8_t *__restrict_
         if (bin[j] >= 0) bin_rows[s_base[bin[j]] + local[j]] = base + j * 256;
 }
 
+// Largest-first order for the few huge rows: they run one row per persistent workgroup, so a static round robin leaves
+// the CUs that drew the 40 k-product rows running long after the others (LPT scheduling: sort by products,
+// descending, then dequeue dynamically).  One workgroup; lists longer than SORT_ROWS_MAX are left alone (with
+// thousands of rows per CU the imbalance averages out).
+constexpr int SORT_ROWS_MAX = 4096;
+__global__ __launch_bounds__(1024) void k_sort_rows_desc(uint32_t *__restrict__ bin_rows, const uint32_t *__restrict__ bin_counts,
+                                                         int bin, const uint32_t *__restrict__ row_nprod)
+{
+    __shared__ unsigned long long sk[SORT_ROWS_MAX];
+    uint32_t off = 0;
+    for (int u = 0; u < bin; ++u)
+        if (u != BIN_EMPTY && u != BIN_FLAT) off += bin_counts[u];
+    const uint32_t n = bin_counts[bin];
+    if (n < 2 || n > (uint32_t)SORT_ROWS_MAX) return;
+    uint32_t *list = bin_rows + off;
+    uint32_t N = 2;
+    while (N < n) N <<= 1;   // network size: next power of two
+    for (uint32_t i = threadIdx.x; i < N; i += blockDim.x)
+        sk[i] = i < n ? (((unsigned long long)(0xFFFFFFFFu - row_nprod[list[i]]) << 32) | list[i]) : ~0ull;
+    __syncthreads();
+    for (uint32_t k = 2; k <= N; k <<= 1)
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t t = threadIdx.x; t < N / 2; t += blockDim.x) {
+                const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), x = i | j;
+                const unsigned long long a = sk[i], c = sk[x];
+                if ((a > c) == ((i & k) == 0)) {
+                    sk[i] = c;
+                    sk[x] = a;
+                }
+            }
+            __syncthreads();
+        }
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) list[i] = (uint32_t)sk[i];
+}
+
 // ---- 3. flat batches: shared pieces ---------------------------------------------------------------------------
 constexpr uint32_t LR_NONE = 0xFFFFFFFFu;
 

@@ -900,7 +900,8 @@ template <bool LDS_VALS>
 __global__ __launch_bounds__(BM_BLOCK) void k_num_bitmap(DevCsrView A, DevCsrView B, uint64_t r0,
                                                          const uint32_t *__restrict__ bin_rows, uint32_t n_bin_rows,
                                                          uint64_t cols, uint32_t vcap, const uint64_t *__restrict__ cptr,
-                                                         uint32_t *__restrict__ c_idx, double *__restrict__ c_val)
+                                                         uint32_t *__restrict__ c_idx, double *__restrict__ c_val,
+                                                         uint32_t *__restrict__ queue /* zeroed: next row of the list */)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *hdr = (uint32_t *)smem;
@@ -913,7 +914,13 @@ __global__ __launch_bounds__(BM_BLOCK) void k_num_bitmap(DevCsrView A, DevCsrVie
     double *vals = (double *)(bm + W);
     for (uint32_t i = threadIdx.x; i < W / 4; i += BM_BLOCK) bm4[i] = make_uint4(0, 0, 0, 0);
     __syncthreads();
-    for (uint32_t slot = blockIdx.x; slot < n_bin_rows; slot += gridDim.x) {
+    for (;;) {
+        // the list is sorted by products, largest first: dequeue dynamically (one device-scope atomic per row)
+        if (threadIdx.x == 0) hdr[31] = atomicAdd(queue, 1u);
+        __syncthreads();
+        const uint32_t slot = hdr[31];
+        __syncthreads();
+        if (slot >= n_bin_rows) break;
         const uint32_t row = bin_rows[slot];
         const uint64_t a0 = A.ptr[r0 + row], a1 = A.ptr[r0 + row + 1];
         const uint64_t c0 = cptr[row];

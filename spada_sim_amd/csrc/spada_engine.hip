@@ -110,6 +110,7 @@ struct spada_ctx {
     size_t ws_bytes = 0;
     DevBuf row_nprod, row_nnzc, row_bin, sym_rows, num_rows, counters, cptr, tile_sums, bitmaps, slabs;
     DevBuf own_idx, own_val, own_ptr, wide_idx;
+    DevBuf efl;   // per A entry: first / last column of the selected B row
     DevBuf eb0, elen, row_kmin, row_kmax, batch_sym, batch_num, tile_w;
     uint32_t colbits = 0, rmax_eff = 0, num_flat_max = 0;
     bool flat_on = false;
@@ -484,7 +485,7 @@ void spada_destroy(spada_ctx *c)
     if (c->hB != c->hA) dev_free(c->hB);
     for (DevBuf *b : {&c->row_nprod, &c->row_nnzc, &c->row_bin, &c->sym_rows, &c->num_rows, &c->counters, &c->cptr,
                       &c->tile_sums, &c->bitmaps, &c->slabs, &c->own_idx, &c->own_val, &c->own_ptr, &c->wide_idx,
-                      &c->eb0, &c->elen, &c->row_kmin, &c->row_kmax, &c->batch_sym, &c->batch_num, &c->tile_w, &c->dbg})
+                      &c->eb0, &c->elen, &c->efl, &c->row_kmin, &c->row_kmax, &c->batch_sym, &c->batch_num, &c->tile_w, &c->dbg})
         b->release();
     if (c->h_counters) (void)hipHostFree(c->h_counters);
     if (c->h_u64) (void)hipHostFree(c->h_u64);
@@ -558,6 +559,7 @@ int spada_dev_spgemm_symbolic(spada_ctx *c, const spada_dev_csr *a, const spada_
     if ((rc = c->counters.ensure(sizeof(Counters), false, s, &c->ws_bytes))) return rc;
     if ((rc = c->eb0.ensure(std::max<uint64_t>(a->nnz, 1) * 8, false, s, &c->ws_bytes))) return rc;
     if ((rc = c->elen.ensure(std::max<uint64_t>(a->nnz, 1) * 4, false, s, &c->ws_bytes))) return rc;
+    if ((rc = c->efl.ensure(std::max<uint64_t>(a->nnz, 1) * 8, false, s, &c->ws_bytes))) return rc;
     if ((rc = c->batch_sym.ensure((n1 / 2 + 4) * 4, false, s, &c->ws_bytes))) return rc;
     if ((rc = c->batch_num.ensure((n1 / 2 + 4) * 4, false, s, &c->ws_bytes))) return rc;
     const uint32_t ntiles = std::max<uint32_t>((n + SCAN_TILE - 1) / SCAN_TILE, 1);
@@ -585,10 +587,13 @@ int spada_dev_spgemm_symbolic(spada_ctx *c, const spada_dev_csr *a, const spada_
     HIP_TRY(hipMemsetAsync(dc, 0, sizeof(Counters), s));
     const uint32_t g256 = (n + 255) / 256, gsc = (n + 256 * SC_ITEMS - 1) / (256 * SC_ITEMS);
     if (n) {
-        hipLaunchKernelGGL(k_row_stats2, dim3(std::min<uint32_t>(g256, 1024)), dim3(256), 0, s, a->ptr, a->idx, b->ptr, b->idx, c->r0, n,
-                           c->eb0.as<uint64_t>(), c->elen.as<uint32_t>(), c->row_nprod.as<uint32_t>(),
-                           c->row_nnzc.as<uint32_t>(), c->row_bin.as<uint8_t>(), c->row_kmin.as<uint32_t>(),
-                           c->row_kmax.as<uint32_t>(), dc->sym_counts, dc->totals, dc->sym_prod, c->flat_on ? 1 : 0);
+        const uint32_t gent = (uint32_t)std::min<uint64_t>((a->nnz + 255) / 256 + 1, 256u * 8 * 8);
+        hipLaunchKernelGGL(k_entry_desc, dim3(gent), dim3(256), 0, s, a->ptr, a->idx, b->ptr, b->idx, c->r0, n,
+                           c->eb0.as<uint64_t>(), c->elen.as<uint32_t>(), c->efl.as<uint2>());
+        hipLaunchKernelGGL(k_row_stats2, dim3(std::min<uint32_t>(g256, 2048)), dim3(256), 0, s, a->ptr, c->elen.as<uint32_t>(),
+                           c->efl.as<uint2>(), c->r0, n, c->row_nprod.as<uint32_t>(), c->row_nnzc.as<uint32_t>(),
+                           c->row_bin.as<uint8_t>(), c->row_kmin.as<uint32_t>(), c->row_kmax.as<uint32_t>(), dc->sym_counts,
+                           dc->totals, dc->sym_prod, c->flat_on ? 1 : 0);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(c->ev[EV_STATS], s));

@@ -61,17 +61,34 @@ struct EntryDesc {
     const uint32_t *len;   // its length
 };
 
-// ---- 1. row statistics + entry descriptors -------------------------------------------------------------------
-// One lane per A row (rows longer than 16 nonzeros: the whole wave).  Per entry: B row begin / length (the
-// irregular 16-byte gather of the path, done exactly once) and the row's first / last column, which bound the
-// columns of C_i and later steer the order-preserving buckets of the numeric phase.
-__global__ __launch_bounds__(256) void k_row_stats2(const uint64_t *__restrict__ aptr, const uint32_t *__restrict__ aidx,
+// ---- 1. entry descriptors + row statistics -------------------------------------------------------------------------
+// k_entry_desc: one lane per A entry (coalesced A.indices; the irregular 16-byte B.indptr gather of the path, done
+// exactly once, and the first / last column of the selected B row) -- pure throughput, no per-row chains.
+// k_row_stats2: one lane per A row (rows longer than 16 nonzeros: the whole wave) over the now contiguous
+// descriptors: products P_i, first / last possible column of C_i (they steer the order-preserving buckets of the
+// numeric phase), symbolic bin, histogram.
+__global__ __launch_bounds__(256) void k_entry_desc(const uint64_t *__restrict__ aptr, const uint32_t *__restrict__ aidx,
                                                     const uint64_t *__restrict__ bptr, const uint32_t *__restrict__ bidx,
                                                     uint64_t r0, uint32_t nrows, uint64_t *__restrict__ eb0,
-                                                    uint32_t *__restrict__ elen, uint32_t *__restrict__ row_nprod,
-                                                    uint32_t *__restrict__ row_nnzc, uint8_t *__restrict__ row_bin,
-                                                    uint32_t *__restrict__ row_kmin, uint32_t *__restrict__ row_kmax,
-                                                    uint32_t *__restrict__ bin_counts,
+                                                    uint32_t *__restrict__ elen, uint2 *__restrict__ efl)
+{
+    const uint64_t a_begin = aptr[r0], a_end = aptr[r0 + nrows];
+    for (uint64_t q = a_begin + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < a_end; q += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t k = aidx[q];
+        const uint64_t b0 = bptr[k], b1 = bptr[k + 1];
+        eb0[q] = b0;
+        elen[q] = (uint32_t)(b1 - b0);
+        uint2 fl = make_uint2(0xFFFFFFFFu, 0u);
+        if (b1 > b0) fl = make_uint2(bidx[b0], bidx[b1 - 1]);
+        efl[q] = fl;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_row_stats2(const uint64_t *__restrict__ aptr, const uint32_t *__restrict__ elen,
+                                                    const uint2 *__restrict__ efl, uint64_t r0, uint32_t nrows,
+                                                    uint32_t *__restrict__ row_nprod, uint32_t *__restrict__ row_nnzc,
+                                                    uint8_t *__restrict__ row_bin, uint32_t *__restrict__ row_kmin,
+                                                    uint32_t *__restrict__ row_kmax, uint32_t *__restrict__ bin_counts,
                                                     unsigned long long *__restrict__ totals /* [0]=nprod [1]=a_nnz */,
                                                     unsigned long long *__restrict__ bin_prod, int flat_on)
 {
@@ -83,15 +100,10 @@ __global__ __launch_bounds__(256) void k_row_stats2(const uint64_t *__restrict__
     __syncthreads();
     const int lane = threadIdx.x & 63;
     auto visit = [&](uint64_t q, uint64_t &part, uint32_t &mn, uint32_t &mx) {
-        const uint32_t k = aidx[q];
-        const uint64_t b0 = bptr[k], b1 = bptr[k + 1];
-        eb0[q] = b0;
-        elen[q] = (uint32_t)(b1 - b0);
-        part += b1 - b0;
-        if (b1 > b0) {
-            mn = min(mn, bidx[b0]);
-            mx = max(mx, bidx[b1 - 1]);
-        }
+        const uint2 fl = efl[q];
+        part += elen[q];
+        mn = min(mn, fl.x);
+        mx = max(mx, fl.y);
     };
     uint64_t tot_p = 0, tot_l = 0;
     // grid-stride over row tiles: the per-bin histogram costs one global atomic per workgroup, not per tile
@@ -107,7 +119,23 @@ __global__ __launch_bounds__(256) void k_row_stats2(const uint64_t *__restrict__
         const uint32_t L = (uint32_t)(a1 - a0);
         const bool is_long = L > 16;
         if (!is_long)
-            for (uint64_t q = a0; q < a1; ++q) visit(q, P, kmin, kmax);
+            for (uint64_t q = a0; q < a1; q += 4) {   // four independent loads per round
+                uint32_t l4[4];
+                uint2 f4[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint64_t qq = q + u < a1 ? q + u : a1 - 1;
+                    l4[u] = elen[qq];
+                    f4[u] = efl[qq];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (q + u < a1) {
+                        P += l4[u];
+                        kmin = min(kmin, f4[u].x);
+                        kmax = max(kmax, f4[u].y);
+                    }
+            }
         unsigned long long mask = __ballot(is_long);
         while (mask) {
             const int src = __ffsll((long long)mask) - 1;

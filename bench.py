@@ -146,6 +146,7 @@ def main():
         if chunk_bounds[-1] != r1:
             chunk_bounds.append(r1)
     checksum = torch.zeros(1, dtype=torch.float64, device=dev)
+    gather_s = [0.0]   # seconds spent in the allgatherv of C (N > 1), timed steps only
 
     def step():
         if chunk_bounds is not None:
@@ -177,10 +178,14 @@ def main():
         c_ptr = torch.empty(r1 - r0 + 1, dtype=torch.int64, device=dev)
         c_idx = torch.empty(max(nnz, 1), dtype=torch.int32, device=dev)
         c_val = torch.empty(max(nnz, 1), dtype=torch.float64, device=dev)
-        eng.numeric(c_ptr.data_ptr(), c_idx.data_ptr(), c_val.data_ptr())
+        eng.numeric(c_ptr.data_ptr(), c_idx.data_ptr(), c_val.data_ptr())     # returns after its stream has drained
         st = eng.stats()
         if world > 1:
-            return st, nnz, parallel.allgatherv_c(c_ptr, c_idx[:nnz], c_val[:nnz])
+            tg = time.perf_counter()
+            full = parallel.allgatherv_c(c_ptr, c_idx[:nnz], c_val[:nnz])
+            torch.cuda.synchronize()
+            gather_s[0] += time.perf_counter() - tg
+            return st, nnz, full
         return st, nnz, (c_ptr, c_idx, c_val)
 
     def sync():
@@ -192,6 +197,7 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
+    gather_s[0] = 0.0
     t0 = time.perf_counter()
     acc = {}
     for _ in range(args.steps):
@@ -238,6 +244,11 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": data_desc,
+            "multi_gpu": None if world == 1 else {
+                "allgatherv_ms_per_step_rank0": gather_s[0] / K * 1e3,
+                "compute_ms_per_step_rank0": ms_step - gather_s[0] / K * 1e3,
+                "note": "value includes the allgatherv that replicates C on every rank (north_star); every GPU must take in "
+                        "(N-1)/N of 12 B x nnz(C) over xGMI, which bounds strong scaling once that exceeds the compute time"},
             "config": {"workload": f"{args.workload} A*A", "rows": rows, "nnz_a": a.nnz(), "products": nprod_total,
                        "nnz_c": nnz_total, "accumulator": args.accumulator,
                        "parallelism": f"row-block x{world}, B replicated" +

@@ -20,13 +20,15 @@ buf = np.zeros(64 * 16, np.uint64)
 L.spada_debug_read.restype = ctypes.c_int
 L.spada_debug_read.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64]
 rc = L.spada_debug_read(eng._ctx, buf.ctypes.data_as(ctypes.c_void_p), 64 * 16)
-flat = os.environ.get("SPADA_DBG_G") == "1"
-NS = 7 if flat else 8
+flat = os.environ.get("SPADA_DBG_G") in ("1", "2")
+symk = os.environ.get("SPADA_DBG_G") == "2"
+NS = 4 if symk else (7 if flat else 8)
 t = buf.reshape(64, 16)[:, :NS].astype(np.int64)
 ok = t[:, NS - 1] > t[:, 0]
 t = t[ok]
 names = ["rows+init", "walk", "zero bcnt", "bucket count", "scan", "scatter", "rank+write"] if not flat else ["rows+init", "walk", "bucket count", "scan", "scatter", "rank+write"]
 if not flat: names = ["init", "walk", "keys+minmax", "bucket count", "scan", "scatter", "rank+write"]
+if symk: names = ["rows+init", "walk", "write counts"]
 dt = np.diff(t, axis=1)
 print(f"G={os.environ.get('SPADA_DBG_G')} sampled {len(t)} workgroups; cycles (mean / median / max)")
 for i, n in enumerate(names):

@@ -277,7 +277,7 @@ uint32_t flat_grid(uint64_t nb_upper, size_t lds)
 
 int run_numeric(spada_ctx *c, uint64_t *d_ptr, uint32_t *d_idx, double *d_val)
 {
-    if (c->dbg.p) HIP_TRY(hipMemsetAsync(c->dbg.p, 0, 64 * 16 * 8, c->stream));
+    if (c->dbg.p && c->dbg_g != 2) HIP_TRY(hipMemsetAsync(c->dbg.p, 0, 64 * 16 * 8, c->stream));
     HIP_TRY(hipEventRecord(c->ev[EV_NUM_BEGIN], c->stream));
     HIP_TRY(hipMemcpyAsync(d_ptr, c->cptr.p, ((size_t)c->nrows + 1) * 8, hipMemcpyDeviceToDevice, c->stream));
     const uint32_t *cnt = c->h_num_counts;
@@ -583,6 +583,7 @@ int spada_dev_spgemm_symbolic(spada_ctx *c, const spada_dev_csr *a, const spada_
     const CutParams cut_num{NUM_FLAT_CAP, (NUM_FLAT_CAP + rmax - 1) / rmax, c->num_flat_max, c->bm_vcap,
                             sort_merge ? SYM_FLAT_MAX : 0u};
 
+    if (c->dbg.p && c->dbg_g == 2) HIP_TRY(hipMemsetAsync(c->dbg.p, 0, 64 * 16 * 8, s));
     HIP_TRY(hipEventRecord(c->ev[EV_SYM_BEGIN], s));
     HIP_TRY(hipMemsetAsync(dc, 0, sizeof(Counters), s));
     const uint32_t g256 = (n + 255) / 256, gsc = (n + 256 * SC_ITEMS - 1) / (256 * SC_ITEMS);
@@ -663,13 +664,14 @@ int spada_dev_spgemm_symbolic(spada_ctx *c, const spada_dev_csr *a, const spada_
         hipLaunchKernelGGL((k_sym_flat<BL, EP, SYM_FLAT_LOG_T, SF_RMAX, LS>), dim3(flat_grid(sf_batches, lds)), dim3(BL), lds,    \
                            c->cur, a->ptr, b->idx, c->eb0.as<uint64_t>(), c->elen.as<uint32_t>(), c->r0, n,                   \
                            c->row_bin.as<uint8_t>(), c->batch_sym.as<uint32_t>(), sf_nb, c->colbits,                         \
-                           c->row_nnzc.as<uint32_t>(), sf_list, sf_bin);                                                     \
+                           c->row_nnzc.as<uint32_t>(), sf_list, sf_bin, sf_dbg);                                             \
     }
             HIP_TRY(hipEventRecord(c->ev[EV_SFLAT_0], c->cur));
             {
                 const uint64_t sf_batches = nb_upper;
                 const uint32_t *sf_nb = &dc->nb_sym, *sf_list = nullptr;
                 const uint32_t sf_bin = BIN_FLAT;
+                unsigned long long *sf_dbg = c->dbg_g == 2 ? c->dbg.as<unsigned long long>() : nullptr;
                 if (c->flat_cfg == 0) LAUNCH_SYM_FLAT(256, 4, false)
                 else if (c->flat_cfg == 1) LAUNCH_SYM_FLAT(512, 2, false)
                 else LAUNCH_SYM_FLAT(1024, 1, false)
@@ -683,6 +685,7 @@ int spada_dev_spgemm_symbolic(spada_ctx *c, const spada_dev_csr *a, const spada_
             const uint64_t sf_batches = cnt[SYM2_BIN_MID];
             const uint32_t *sf_nb = &dc->sym_counts[SYM2_BIN_MID], *sf_list = c->sym_rows.as<uint32_t>() + off[SYM2_BIN_MID];
             const uint32_t sf_bin = SYM2_BIN_MID;
+            unsigned long long *sf_dbg = nullptr;
             if (c->flat_cfg == 0) LAUNCH_SYM_FLAT(256, 4, true)
             else if (c->flat_cfg == 1) LAUNCH_SYM_FLAT(512, 2, true)
             else LAUNCH_SYM_FLAT(1024, 1, true)

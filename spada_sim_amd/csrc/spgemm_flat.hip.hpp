@@ -676,8 +676,10 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void k_sym_flat(const uint64_t 
                                                     uint64_t r0, uint32_t nrows, const uint8_t *__restrict__ row_bin,
                                                     const uint32_t *__restrict__ batch_first, const uint32_t *__restrict__ nb_ptr,
                                                     uint32_t colbits, uint32_t *__restrict__ row_nnzc,
-                                                    const uint32_t *__restrict__ list, uint32_t want_bin)
+                                                    const uint32_t *__restrict__ list, uint32_t want_bin,
+                                                    unsigned long long *dbg = nullptr)
 {
+#define SSTAMP(i) do { if (dbg && threadIdx.x == 0 && b % 64 == 0 && b / 64 < 64) dbg[(b / 64) * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
     // LIST = false: batches of consecutive rows (batch_first); LIST = true: one row of `list` per batch
     static_assert(RMAX <= BLOCK, "one thread per row of a batch");
     constexpr int T = 1 << LOG_T;
@@ -739,6 +741,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void k_sym_flat(const uint64_t 
         }
         const uint32_t R = re - rb;   // <= RMAX by construction of the cut
         if (R == 0) continue;
+        SSTAMP(0);
         uint32_t L = 0;
         const bool flat = (uint32_t)tid < R && cur.bin == want_bin;
         if ((uint32_t)tid < R) {
@@ -753,6 +756,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void k_sym_flat(const uint64_t 
         uint4 *k4 = (uint4 *)keys;
         for (int s = tid; s < T / 4; s += BLOCK) k4[s] = make_uint4(EMPTY_KEY, EMPTY_KEY, EMPTY_KEY, EMPTY_KEY);
         __syncthreads();
+        SSTAMP(1);
         flat_walk<BLOCK, EPT, RMAX, false, U>(
             s_re, s_a0, R, E, eb0, elen, nullptr, bidx, nullptr, scratch, hdr, [&](uint32_t(&col)[U], uint32_t(&plr)[U], double(&)[U], uint32_t(&)[U]) {
                 uint32_t key[U], h[U], old[U];
@@ -777,10 +781,13 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void k_sym_flat(const uint64_t 
                     }
                     segmented_count_add(plr[u], isnew, s_cnt, lane);
                 }
-            });
+            }, (dbg && b % 64 == 0 && b / 64 < 64) ? dbg + (b / 64) * 16 + 8 : nullptr);
+        SSTAMP(2);
         if (flat) row_nnzc[rb + tid] = s_cnt[tid];
         __syncthreads();
+        SSTAMP(3);
     }
+#undef SSTAMP
 }
 
 // ---- 6. numeric, flat batches -----------------------------------------------------------------------------------
@@ -1132,7 +1139,7 @@ __global__ __launch_bounds__(256) void k_num_copy2(const uint64_t *__restrict__ 
 // than SM_NP products per batch): every product is written to LDS as  key = (local row, column, product number)
 // packed in 64 bits  +  value; a bitonic network sorts the keys; the first product of every run adds its run in
 // ascending product number -- i.e. in ascending k, the order of the CPU restatement, so the values are
-// bit-identical to the oracle's.  Kept for the accumulator comparison of BASELINE.json configs[2]; the LDS-hash
+// bit-identical to a sequential CPU sort-merge.  Kept for the accumulator comparison of BASELINE.json configs[2]; the LDS-hash
 // kernels are the fast path.
 // LDS: 256 B hdr | sk u64[SM_NP] | sv f64[SM_NP] | heads u64[SM_NP / 64] | hpre u32[SM_NP / 64] | walk scratch |
 //      rows: s_re, s_boff u32[RMAX + 1], s_a0, s_out u64[RMAX]

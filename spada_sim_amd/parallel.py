@@ -23,7 +23,17 @@ def _allgather_uneven(local, counts, group=None):
         views.append(full[off:off + n])
         off += n
     if dist.get_backend(group) == "nccl":
-        dist.all_gather(views, local.contiguous(), group=group)
+        try:
+            dist.all_gather(views, local.contiguous(), group=group)
+        except (RuntimeError, ValueError):
+            # backend without uneven all_gather: one equal-size RCCL all-gather of padded segments, then compaction
+            cap = max(max(counts), 1)
+            send = torch.zeros(cap, dtype=local.dtype, device=local.device)
+            send[:local.numel()].copy_(local)
+            recv = torch.empty(world * cap, dtype=local.dtype, device=local.device)
+            dist.all_gather_into_tensor(recv, send, group=group)
+            for r, n in enumerate(counts):
+                views[r].copy_(recv[r * cap:r * cap + n])
     else:
         views[rank].copy_(local)
         works = [dist.broadcast(views[r], src=dist.get_global_rank(group, r) if group is not None else r,

@@ -263,9 +263,16 @@ void dev_free(spada_dev_csr *m)
 }
 
 // flat-batch kernel configurations: <BLOCK, LOG_T, NOUT, RMAX>; cap = 2 * flat_max, NOUT >= cap + flat_max
-constexpr int NF_BLOCK = 256, NF_EPT = 4, NF_LOG_T = 12, NF_NOUT = 3072, NF_RMAX = 256;
+#ifndef SPADA_NF_LARGE   // default: four 256-thread workgroups per CU, 2048-slot tables (A/B: -7 % numeric time on the regular surrogates vs two 512-thread workgroups with 4096-slot tables = SPADA_NF_LARGE)
+constexpr int NF_LOG_T = 11, NF_NOUT = 1536, NF_RMAX = 128;
+constexpr uint32_t NUM_FLAT_MAX = 512, NUM_FLAT_CAP = 1024;
+#define NF_CFG_LIST(X) X(256, 2)
+#else
+constexpr int NF_LOG_T = 12, NF_NOUT = 3072, NF_RMAX = 256;
 constexpr uint32_t NUM_FLAT_MAX = 1024, NUM_FLAT_CAP = 2048;
-constexpr int SF_BLOCK = 256, SF_EPT = 4, SF_RMAX = 256;
+#define NF_CFG_LIST(X) X(256, 4) X(512, 2) X(1024, 1)
+#endif
+constexpr int SF_RMAX = 256;
 static_assert(NF_NOUT >= NUM_FLAT_CAP + NUM_FLAT_MAX, "a batch weighs less than cap + flat_max");
 static_assert((1u << SYM_FLAT_LOG_T) * 3 >= (SYM_FLAT_CAP + SYM_FLAT_MAX) * 4, "symbolic table load <= 0.75");
 
@@ -350,15 +357,21 @@ int run_numeric(spada_ctx *c, uint64_t *d_ptr, uint32_t *d_idx, double *d_val)
                            c->row_kmax.as<uint32_t>(), c->cptr.as<uint64_t>(), c->batch_num.as<uint32_t>(), nf_nb,            \
                            c->colbits, d_idx, d_val, nf_dbg, nf_list, nf_bin);                                               \
     }
+#ifndef SPADA_NF_LARGE
+#define NUM_FLAT_DISPATCH(LS) LAUNCH_NUM_FLAT(256, 2, LS)
+#else
+#define NUM_FLAT_DISPATCH(LS)                          \
+    if (c->flat_cfg == 0) LAUNCH_NUM_FLAT(256, 4, LS)  \
+    else if (c->flat_cfg == 1) LAUNCH_NUM_FLAT(512, 2, LS) \
+    else LAUNCH_NUM_FLAT(1024, 1, LS)
+#endif
         HIP_TRY(hipEventRecord(c->ev[EV_NFLAT_0], c->cur));
         {
             const uint64_t nf_batches = c->h_counters->nb_num;
             const uint32_t *nf_nb = &dc->nb_num, *nf_list = nullptr;
             const uint32_t nf_bin = BIN_FLAT;
             unsigned long long *nf_dbg = c->dbg_g == 1 ? c->dbg.as<unsigned long long>() : nullptr;
-            if (c->flat_cfg == 0) LAUNCH_NUM_FLAT(256, 4, false)
-            else if (c->flat_cfg == 1) LAUNCH_NUM_FLAT(512, 2, false)
-            else LAUNCH_NUM_FLAT(1024, 1, false)
+            NUM_FLAT_DISPATCH(false)
         }
         HIP_TRY(hipEventRecord(c->ev[EV_NFLAT_1], c->cur));
         HIP_TRY(hipGetLastError());
@@ -370,9 +383,7 @@ int run_numeric(spada_ctx *c, uint64_t *d_ptr, uint32_t *d_idx, double *d_val)
         const uint32_t *nf_nb = &dc->num_counts[NUM2_BIN_MID], *nf_list = c->num_rows.as<uint32_t>() + off[NUM2_BIN_MID];
         const uint32_t nf_bin = NUM2_BIN_MID;
         unsigned long long *nf_dbg = nullptr;
-        if (c->flat_cfg == 0) LAUNCH_NUM_FLAT(256, 4, true)
-        else if (c->flat_cfg == 1) LAUNCH_NUM_FLAT(512, 2, true)
-        else LAUNCH_NUM_FLAT(1024, 1, true)
+        NUM_FLAT_DISPATCH(true)
         HIP_TRY(hipGetLastError());
         if ((rc = join_from(c, NUM2_BIN_MID))) return rc;
     }
@@ -459,13 +470,17 @@ int spada_create(const spada_options *opts, spada_ctx **out)
     if ((rc = allow_lds(k_num_hash<1024, 13>, num_lds<1024, 13>()))) return rc;
 #define ALLOW_FLAT(BL, EP)                                                                                                   \
     if ((rc = allow_lds(k_sym_flat<BL, EP, SYM_FLAT_LOG_T, SF_RMAX, false>, sym_flat_lds<BL, EP, SYM_FLAT_LOG_T, SF_RMAX>()))) return rc; \
-    if ((rc = allow_lds(k_sym_flat<BL, EP, SYM_FLAT_LOG_T, SF_RMAX, true>, sym_flat_lds<BL, EP, SYM_FLAT_LOG_T, SF_RMAX>()))) return rc; \
-    if ((rc = allow_lds(k_num_flat<BL, EP, NF_LOG_T, NF_NOUT, NF_RMAX, false>, num_flat_lds<BL, EP, NF_LOG_T, NF_NOUT, NF_RMAX>()))) return rc; \
-    if ((rc = allow_lds(k_num_flat<BL, EP, NF_LOG_T, NF_NOUT, NF_RMAX, true>, num_flat_lds<BL, EP, NF_LOG_T, NF_NOUT, NF_RMAX>()))) return rc;
+    if ((rc = allow_lds(k_sym_flat<BL, EP, SYM_FLAT_LOG_T, SF_RMAX, true>, sym_flat_lds<BL, EP, SYM_FLAT_LOG_T, SF_RMAX>()))) return rc;
+
     ALLOW_FLAT(256, 4)
     ALLOW_FLAT(512, 2)
     ALLOW_FLAT(1024, 1)
 #undef ALLOW_FLAT
+#define ALLOW_NFLAT(BL, EP)                                                                                                  \
+    if ((rc = allow_lds(k_num_flat<BL, EP, NF_LOG_T, NF_NOUT, NF_RMAX, false>, num_flat_lds<BL, EP, NF_LOG_T, NF_NOUT, NF_RMAX>()))) return rc; \
+    if ((rc = allow_lds(k_num_flat<BL, EP, NF_LOG_T, NF_NOUT, NF_RMAX, true>, num_flat_lds<BL, EP, NF_LOG_T, NF_NOUT, NF_RMAX>()))) return rc;
+    NF_CFG_LIST(ALLOW_NFLAT)
+#undef ALLOW_NFLAT
     if ((rc = allow_lds(k_num_sortmerge<1024, 1, SF_RMAX>, num_sm_lds<1024, 1, SF_RMAX>()))) return rc;
     if (const char *e = std::getenv("SPADA_FLAT_CFG")) c->flat_cfg = atoi(e);
     if (const char *e = std::getenv("SPADA_SORT_HUGE")) c->sort_huge = e[0] == '1';
@@ -580,7 +595,8 @@ int spada_dev_spgemm_symbolic(spada_ctx *c, const spada_dev_csr *a, const spada_
     const uint32_t rmax = std::max<uint32_t>(c->rmax_eff, 4);
     const CutParams cut_sym{SYM_FLAT_CAP, (SYM_FLAT_CAP + rmax - 1) / rmax, 0, 0, 0};
     const bool sort_merge = c->accumulator == SPADA_ACC_SORT_MERGE && c->flat_on;
-    const CutParams cut_num{NUM_FLAT_CAP, (NUM_FLAT_CAP + rmax - 1) / rmax, c->num_flat_max, c->bm_vcap,
+    const uint32_t rmax_n = std::min<uint32_t>(rmax, NF_RMAX);
+    const CutParams cut_num{NUM_FLAT_CAP, (NUM_FLAT_CAP + rmax_n - 1) / rmax_n, c->num_flat_max, c->bm_vcap,
                             sort_merge ? SYM_FLAT_MAX : 0u};
 
     if (c->dbg.p && c->dbg_g == 2) HIP_TRY(hipMemsetAsync(c->dbg.p, 0, 64 * 16 * 8, s));

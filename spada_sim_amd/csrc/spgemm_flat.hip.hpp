@@ -26,7 +26,11 @@ constexpr int NUM2_BIN_2K = 3, NUM2_BIN_6K = 4, NUM2_BIN_BMV = 5, NUM2_BIN_SPILL
 // "mid" rows: too large for a shared batch, small enough for the flat kernels' table -- one row per batch, taken
 // from the bin's row list (list mode of k_sym_flat / k_num_flat)
 constexpr uint32_t SYM_MID_MAX = 6144;   // products: 0.75 of the 8192-key symbolic table
+#ifndef SPADA_NF_LARGE
+constexpr uint32_t NUM_MID_MAX = 1536;
+#else
 constexpr uint32_t NUM_MID_MAX = 3072;   // outputs:  0.75 of the 4096-slot numeric table, = its bucket array
+#endif
 
 constexpr uint32_t SYM_FLAT_CAP = 4096, SYM_FLAT_MAX = 2048;   // products per batch / per flat row
 constexpr int SYM_FLAT_LOG_T = 13;                             // 8192 keys: load <= 0.75, typically 0.5

@@ -272,7 +272,13 @@ constexpr int NF_LOG_T = 12, NF_NOUT = 3072, NF_RMAX = 256;
 constexpr uint32_t NUM_FLAT_MAX = 1024, NUM_FLAT_CAP = 2048;
 #define NF_CFG_LIST(X) X(256, 4) X(512, 2) X(1024, 1)
 #endif
+#ifndef SPADA_SF_LARGE   /* default: 256-thread workgroups, 4096-key tables (A/B: -17..21 % symbolic time) */
+constexpr int SF_RMAX = 128;
+#define SF_CFG_LIST(X) X(256, 2)
+#else
 constexpr int SF_RMAX = 256;
+#define SF_CFG_LIST(X) X(256, 4) X(512, 2) X(1024, 1)
+#endif
 static_assert(NF_NOUT >= NUM_FLAT_CAP + NUM_FLAT_MAX, "a batch weighs less than cap + flat_max");
 static_assert((1u << SYM_FLAT_LOG_T) * 3 >= (SYM_FLAT_CAP + SYM_FLAT_MAX) * 4, "symbolic table load <= 0.75");
 
@@ -472,9 +478,7 @@ int spada_create(const spada_options *opts, spada_ctx **out)
     if ((rc = allow_lds(k_sym_flat<BL, EP, SYM_FLAT_LOG_T, SF_RMAX, false>, sym_flat_lds<BL, EP, SYM_FLAT_LOG_T, SF_RMAX>()))) return rc; \
     if ((rc = allow_lds(k_sym_flat<BL, EP, SYM_FLAT_LOG_T, SF_RMAX, true>, sym_flat_lds<BL, EP, SYM_FLAT_LOG_T, SF_RMAX>()))) return rc;
 
-    ALLOW_FLAT(256, 4)
-    ALLOW_FLAT(512, 2)
-    ALLOW_FLAT(1024, 1)
+    SF_CFG_LIST(ALLOW_FLAT)
 #undef ALLOW_FLAT
 #define ALLOW_NFLAT(BL, EP)                                                                                                  \
     if ((rc = allow_lds(k_num_flat<BL, EP, NF_LOG_T, NF_NOUT, NF_RMAX, false>, num_flat_lds<BL, EP, NF_LOG_T, NF_NOUT, NF_RMAX>()))) return rc; \
@@ -593,7 +597,8 @@ int spada_dev_spgemm_symbolic(spada_ctx *c, const spada_dev_csr *a, const spada_
         c->num_flat_max = c->flat_on ? NUM_FLAT_MAX : 0;
     }
     const uint32_t rmax = std::max<uint32_t>(c->rmax_eff, 4);
-    const CutParams cut_sym{SYM_FLAT_CAP, (SYM_FLAT_CAP + rmax - 1) / rmax, 0, 0, 0};
+    const uint32_t rmax_s = std::min<uint32_t>(rmax, SF_RMAX);
+    const CutParams cut_sym{SYM_FLAT_CAP, (SYM_FLAT_CAP + rmax_s - 1) / rmax_s, 0, 0, 0};
     const bool sort_merge = c->accumulator == SPADA_ACC_SORT_MERGE && c->flat_on;
     const uint32_t rmax_n = std::min<uint32_t>(rmax, NF_RMAX);
     const CutParams cut_num{NUM_FLAT_CAP, (NUM_FLAT_CAP + rmax_n - 1) / rmax_n, c->num_flat_max, c->bm_vcap,
@@ -682,15 +687,21 @@ int spada_dev_spgemm_symbolic(spada_ctx *c, const spada_dev_csr *a, const spada_
                            c->row_bin.as<uint8_t>(), c->batch_sym.as<uint32_t>(), sf_nb, c->colbits,                         \
                            c->row_nnzc.as<uint32_t>(), sf_list, sf_bin, sf_dbg);                                             \
     }
+#ifndef SPADA_SF_LARGE   /* default: 256-thread workgroups, 4096-key tables (A/B: -17..21 % symbolic time) */
+#define SYM_FLAT_DISPATCH(LS) LAUNCH_SYM_FLAT(256, 2, LS)
+#else
+#define SYM_FLAT_DISPATCH(LS)                          \
+    if (c->flat_cfg == 0) LAUNCH_SYM_FLAT(256, 4, LS)  \
+    else if (c->flat_cfg == 1) LAUNCH_SYM_FLAT(512, 2, LS) \
+    else LAUNCH_SYM_FLAT(1024, 1, LS)
+#endif
             HIP_TRY(hipEventRecord(c->ev[EV_SFLAT_0], c->cur));
             {
                 const uint64_t sf_batches = nb_upper;
                 const uint32_t *sf_nb = &dc->nb_sym, *sf_list = nullptr;
                 const uint32_t sf_bin = BIN_FLAT;
                 unsigned long long *sf_dbg = c->dbg_g == 2 ? c->dbg.as<unsigned long long>() : nullptr;
-                if (c->flat_cfg == 0) LAUNCH_SYM_FLAT(256, 4, false)
-                else if (c->flat_cfg == 1) LAUNCH_SYM_FLAT(512, 2, false)
-                else LAUNCH_SYM_FLAT(1024, 1, false)
+                SYM_FLAT_DISPATCH(false)
             }
             HIP_TRY(hipEventRecord(c->ev[EV_SFLAT_1], c->cur));
             HIP_TRY(hipGetLastError());
@@ -702,9 +713,7 @@ int spada_dev_spgemm_symbolic(spada_ctx *c, const spada_dev_csr *a, const spada_
             const uint32_t *sf_nb = &dc->sym_counts[SYM2_BIN_MID], *sf_list = c->sym_rows.as<uint32_t>() + off[SYM2_BIN_MID];
             const uint32_t sf_bin = SYM2_BIN_MID;
             unsigned long long *sf_dbg = nullptr;
-            if (c->flat_cfg == 0) LAUNCH_SYM_FLAT(256, 4, true)
-            else if (c->flat_cfg == 1) LAUNCH_SYM_FLAT(512, 2, true)
-            else LAUNCH_SYM_FLAT(1024, 1, true)
+            SYM_FLAT_DISPATCH(true)
             HIP_TRY(hipGetLastError());
             if ((rc = join_from(c, SYM2_BIN_MID))) return rc;
         }

@@ -25,15 +25,24 @@ constexpr int SYM2_BIN_8K = 3, SYM2_BIN_24K = 4, SYM2_BIN_SPILL = 5, SYM2_BIN_MI
 constexpr int NUM2_BIN_2K = 3, NUM2_BIN_6K = 4, NUM2_BIN_BMV = 5, NUM2_BIN_SPILL = 6, NUM2_BIN_MID = 7;
 // "mid" rows: too large for a shared batch, small enough for the flat kernels' table -- one row per batch, taken
 // from the bin's row list (list mode of k_sym_flat / k_num_flat)
+#ifndef SPADA_SF_LARGE   /* default: 256-thread workgroups, 4096-key tables (A/B: -17..21 % symbolic time) */
+constexpr uint32_t SYM_MID_MAX = 3072;
+#else
 constexpr uint32_t SYM_MID_MAX = 6144;   // products: 0.75 of the 8192-key symbolic table
+#endif
 #ifndef SPADA_NF_LARGE
 constexpr uint32_t NUM_MID_MAX = 1536;
 #else
 constexpr uint32_t NUM_MID_MAX = 3072;   // outputs:  0.75 of the 4096-slot numeric table, = its bucket array
 #endif
 
+#ifndef SPADA_SF_LARGE   /* default: 256-thread workgroups, 4096-key tables (A/B: -17..21 % symbolic time) */
+constexpr uint32_t SYM_FLAT_CAP = 2048, SYM_FLAT_MAX = 1024;
+constexpr int SYM_FLAT_LOG_T = 12;
+#else
 constexpr uint32_t SYM_FLAT_CAP = 4096, SYM_FLAT_MAX = 2048;   // products per batch / per flat row
 constexpr int SYM_FLAT_LOG_T = 13;                             // 8192 keys: load <= 0.75, typically 0.5
+#endif
 
 __host__ __device__ inline int sym2_bin_of(uint64_t P, uint32_t L)
 {
@@ -1147,7 +1156,11 @@ __global__ __launch_bounds__(256) void k_num_copy2(const uint64_t *__restrict__ 
 // kernels are the fast path.
 // LDS: 256 B hdr | sk u64[SM_NP] | sv f64[SM_NP] | heads u64[SM_NP / 64] | hpre u32[SM_NP / 64] | walk scratch |
 //      rows: s_re, s_boff u32[RMAX + 1], s_a0, s_out u64[RMAX]
+#ifndef SPADA_SF_LARGE   /* default: 256-thread workgroups, 4096-key tables (A/B: -17..21 % symbolic time) */
+constexpr int SM_NP = 4096;
+#else
 constexpr int SM_NP = 8192;
+#endif
 static_assert(SM_NP >= SYM_FLAT_CAP + SYM_FLAT_MAX, "a symbolic batch holds fewer than cap + max products");
 
 template <int BLOCK, int EPT, int RMAX>

@@ -81,6 +81,16 @@ def cpu_baseline(a, budget_s=12.0):
                       f"oracle SPA variant, OpenMP {nt} threads"}
 
 
+def pick_traffic(traffic, tmpl_suffix):
+    """hbm_bytes_per_launch of the k_num_flat instantiation whose template list ends with `tmpl_suffix`."""
+    if not traffic:
+        return None
+    for name, v in traffic.items():
+        if name.startswith("k_num_flat<") and name.endswith(tmpl_suffix):
+            return v["hbm_bytes_per_launch"]
+    return None
+
+
 def load_traffic(workload):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/r01_traffic_<workload>.json,
     written by scripts/collect_traffic.sh on the GPU box); None when that file is absent."""
@@ -203,7 +213,7 @@ def main():
     for _ in range(args.steps):
         st, nnz_local, _ = step()
         for k in ("ms_symbolic_call", "ms_numeric_call", "ms_row_stats", "ms_binning", "ms_symbolic", "ms_scan",
-                  "ms_numeric", "ms_sym_flat", "ms_num_flat"):
+                  "ms_numeric", "ms_sym_flat", "ms_num_flat", "ms_num_mid"):
             acc[k] = acc.get(k, 0.0) + st[k]
     sync()
     elapsed = time.perf_counter() - t0
@@ -222,14 +232,21 @@ def main():
         ms_step = elapsed / K * 1e3
         dev_ms = (acc["ms_symbolic_call"] + acc["ms_numeric_call"]) / K      # rank 0, HIP events on the engine stream
         pipe_gbs = st["bytes_read"] / (dev_ms * 1e-3) / 1e9
-        # dominant kernel: the flat-batch numeric kernel (k_num_flat), timed by HIP events on the stream it runs on
-        FLAT = 2
-        flat_rows, flat_prod = st["num_bin_rows"][FLAT], st["num_bin_prod"][FLAT]
-        flat_ent, flat_nnz = st["num_bin_entries"][FLAT], st["num_bin_nnz"][FLAT]
-        k_read = 12 * flat_prod + 28 * flat_ent + 8 * flat_rows       # SURVEY 8(d) per-unit figures x units of one launch
-        k_write = 12 * flat_nnz + 8 * flat_rows
-        k_ms = acc["ms_num_flat"] / K
-        achieved = k_read / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        # dominant kernel: the flat-batch numeric kernel k_num_flat, timed by HIP events on the stream it runs on.  It is
+        # launched twice per step: shared batches of consecutive rows (bin 2) and list mode, one mid row per batch (bin 7);
+        # the launch with the larger algorithmic byte count is reported as `roofline`, the other under `roofline.other`.
+        def launch(bin_id, ms_key, label, tmpl):
+            r_, p_, e_, n_ = (st[k][bin_id] for k in ("num_bin_rows", "num_bin_prod", "num_bin_entries", "num_bin_nnz"))
+            rd, wr, ms = 12 * p_ + 28 * e_ + 8 * r_, 12 * n_ + 8 * r_, acc[ms_key] / K
+            return {"label": label, "tmpl": tmpl, "ms": ms, "read": rd, "write": wr, "gbs": rd / (ms * 1e-3) / 1e9 if ms > 0 else 0.0,
+                    "units": {"rows": r_, "products": p_, "a_entries": e_, "nnz_c": n_}}
+        cands = [launch(2, "ms_num_flat", "shared batches of consecutive rows (nnz(C_i) <= 512)", "false>"),
+                 launch(7, "ms_num_mid", "list mode, one row per batch (512 < nnz(C_i) <= 1536)", "true>")]
+        if args.accumulator == "sort_merge":
+            cands = cands[:1]
+        cands.sort(key=lambda d: -d["read"])
+        dom = cands[0]
+        achieved, k_ms, k_read, k_write = dom["gbs"], dom["ms"], dom["read"], dom["write"]
         traffic, traffic_src = load_traffic(args.workload)
         out = {
             "metric": "nnz(C)/sec on A*A SpGEMM",
@@ -256,18 +273,20 @@ def main():
                                        if chunk_bounds is not None else (", allgatherv of C" if world > 1 else ""))},
             "roofline": {
                 "bound": "hbm",
-                "kernel": ("k_num_sortmerge (sort-merge accumulator over the rows with <= 2048 products)"
+                "kernel": ("k_num_sortmerge (sort-merge accumulator over the rows with <= 1024 products)"
                            if args.accumulator == "sort_merge" else
-                           "k_num_flat (flat-batch numeric: expand-scale-accumulate-order of every C row with nnz <= 1024)") +
-                          ", average duration per step by HIP events on its stream, rank 0",
+                           "k_num_flat (flat-batch numeric: expand - scale - accumulate - order), " + dom["label"]) +
+                          "; average duration per step by HIP events on its stream, rank 0",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic["k_num_flat"]["hbm_bytes_per_launch"] if traffic else None,
+                "traffic": pick_traffic(traffic, dom["tmpl"]) if args.accumulator != "sort_merge" else None,
                 "traffic_source": os.path.relpath(traffic_src, ROOT) if traffic else None,
                 "kernel_ms": k_ms,
-                "kernel_units": {"rows": flat_rows, "products": flat_prod, "a_entries": flat_ent, "nnz_c": flat_nnz},
+                "kernel_units": dom["units"],
+                "other": [{"kernel": "k_num_flat, " + o["label"], "kernel_ms": o["ms"], "achieved": o["gbs"],
+                           "frac": o["gbs"] / HBM_PEAK_GBS, "kernel_units": o["units"]} for o in cands[1:]],
                 "kernel_algorithmic_bytes_read": k_read,
                 "kernel_algorithmic_bytes_write": k_write,
                 "pipeline": {"achieved": pipe_gbs, "frac": pipe_gbs / HBM_PEAK_GBS, "device_ms_per_step": dev_ms,

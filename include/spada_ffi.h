@@ -101,7 +101,8 @@ typedef struct spada_stats {
     uint64_t num_bin_entries[SPADA_N_BINS];
     uint64_t sym_bin_prod[SPADA_N_BINS];
     double ms_sym_flat;       /* duration of the flat-batch symbolic kernel (hipEvents on its stream) */
-    double ms_num_flat;       /* duration of the flat-batch numeric kernel */
+    double ms_num_flat;       /* duration of the flat-batch numeric kernel (shared batches of consecutive rows) */
+    double ms_num_mid;        /* duration of its list-mode launch (one "mid" row per batch) */
 } spada_stats;
 
 typedef struct spada_ctx spada_ctx;          /* engine context: one GPU, one stream, scratch */

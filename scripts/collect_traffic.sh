@@ -20,7 +20,7 @@ def per_kernel(path, counter):
     agg = collections.defaultdict(float); calls = collections.Counter()
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] != counter: continue
-        n = r["Kernel_Name"].replace("spada::", "").split("(")[0].replace("void ", "").split("<")[0]
+        n = r["Kernel_Name"].replace("spada::", "").split("(")[0].replace("void ", "").strip()   # full template name
         agg[n] += float(r["Counter_Value"]); calls[n] += 1
     return {n: (agg[n] / calls[n], calls[n]) for n in agg}
 f = per_kernel("$OUT/fetch/p_counter_collection.csv", "FETCH_SIZE")
@@ -36,6 +36,6 @@ for n in sorted(set(f) | set(w)):
               "hbm_bytes_per_launch": fb + wb, "launches": f.get(n, (0, 0))[1]}
 json.dump(out, open("$REPO/profiles/r01_traffic_$WL.json", "w"), indent=1)
 json.dump(out, open("$OUT/r01_traffic_$WL.json", "w"), indent=1)
-for n in ("k_num_flat", "k_sym_flat", "k_num_hash", "k_num_bitmap", "k_num_copy", "k_row_stats2"):
-    if n in out: print(n, out[n])
+for n in out:
+    if n.startswith("k_num") or n.startswith("k_sym_flat"): print(n, out[n])
 PY

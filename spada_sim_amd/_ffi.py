@@ -45,7 +45,7 @@ class Stats(ctypes.Structure):
                 ("spill_rows", u64), ("workspace_bytes", u64),
                 ("num_bin_prod", u64 * SPADA_N_BINS), ("num_bin_nnz", u64 * SPADA_N_BINS),
                 ("num_bin_entries", u64 * SPADA_N_BINS), ("sym_bin_prod", u64 * SPADA_N_BINS),
-                ("ms_sym_flat", ctypes.c_double), ("ms_num_flat", ctypes.c_double)]
+                ("ms_sym_flat", ctypes.c_double), ("ms_num_flat", ctypes.c_double), ("ms_num_mid", ctypes.c_double)]
 
     def as_dict(self):
         d = {}

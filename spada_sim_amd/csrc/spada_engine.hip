@@ -79,7 +79,7 @@ struct Counters {
     unsigned long long sym_prod[SPADA_N_BINS];
 };
 
-enum { EV_SYM_BEGIN, EV_STATS, EV_BINNED, EV_SYM, EV_SCAN, EV_NUM_BEGIN, EV_NUM_END, EV_SFLAT_0, EV_SFLAT_1, EV_NFLAT_0, EV_NFLAT_1, EV_COUNT };
+enum { EV_SYM_BEGIN, EV_STATS, EV_BINNED, EV_SYM, EV_SCAN, EV_NUM_BEGIN, EV_NUM_END, EV_SFLAT_0, EV_SFLAT_1, EV_NFLAT_0, EV_NFLAT_1, EV_NMID_0, EV_NMID_1, EV_COUNT };
 
 }  // namespace
 
@@ -408,8 +408,10 @@ int run_numeric(spada_ctx *c, uint64_t *d_ptr, uint32_t *d_idx, double *d_val)
         const uint32_t *nf_nb = &dc->num_counts[NUM2_BIN_MID], *nf_list = c->num_rows.as<uint32_t>() + off[NUM2_BIN_MID];
         const uint32_t nf_bin = NUM2_BIN_MID;
         unsigned long long *nf_dbg = nullptr;
+        HIP_TRY(hipEventRecord(c->ev[EV_NMID_0], c->cur));
         NUM_FLAT_DISPATCH(true)
         HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(c->ev[EV_NMID_1], c->cur));
         if ((rc = join_from(c, NUM2_BIN_MID))) return rc;
     }
 #undef LAUNCH_NUM_FLAT
@@ -426,6 +428,7 @@ int run_numeric(spada_ctx *c, uint64_t *d_ptr, uint32_t *d_idx, double *d_val)
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->stats.ms_numeric = c->stats.ms_numeric_call = ev_ms(c, EV_NUM_BEGIN, EV_NUM_END);
     c->stats.ms_num_flat = cnt[BIN_FLAT] ? ev_ms(c, EV_NFLAT_0, EV_NFLAT_1) : 0.0;
+    c->stats.ms_num_mid = cnt[NUM2_BIN_MID] ? ev_ms(c, EV_NMID_0, EV_NMID_1) : 0.0;
     c->stats.workspace_bytes = c->ws_bytes;
     return SPADA_OK;
 }

@@ -479,7 +479,17 @@ int spada_create(const spada_options *opts, spada_ctx **out)
     c->accumulator = o.accumulator;
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     for (auto &e : c->ev) HIP_TRY(hipEventCreate(&e));
-    for (auto &st : c->side) HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    {
+        // the one-workgroup-per-CU kernels (large / huge rows) need a whole CU's LDS: give their streams priority, otherwise
+        // the many small workgroups of the flat kernels keep every CU partly occupied and starve them until the end
+        int prio_lo = 0, prio_hi = 0;
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+        const bool use_prio = !(std::getenv("SPADA_NO_PRIO") && std::getenv("SPADA_NO_PRIO")[0] == '1');
+        for (int k = 0; k < SPADA_N_BINS; ++k) {
+            const bool big = k == NUM2_BIN_6K || k == NUM2_BIN_2K || k == NUM2_BIN_BMV || k == NUM2_BIN_SPILL;
+            HIP_TRY(hipStreamCreateWithPriority(&c->side[k], hipStreamNonBlocking, big && use_prio ? prio_hi : 0));   // 0 = default priority
+        }
+    }
     HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     for (auto &e : c->ev_join) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     c->cur = c->stream;

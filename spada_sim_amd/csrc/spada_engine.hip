@@ -92,6 +92,8 @@ struct spada_ctx {
     hipStream_t side[SPADA_N_BINS] = {};
     hipEvent_t ev_fork = nullptr, ev_join[SPADA_N_BINS] = {};
     hipStream_t cur = nullptr;        // stream the launch helpers use
+    bool merge_on = false;            // SPADA_MERGE=1: multiway-merge class (k_num_merge) for rows with <= 8 long B rows; measured
+                                      // neutral on the webbase surrogate (1.77 ms either way), so off by default
     bool flat_big = false;            // SPADA_FLAT_BIG=1: flat kernel (list mode) instead of k_num_hash for rows above the mid class
     bool sort_huge = false;           // SPADA_SORT_HUGE=1
     int flat_cfg = 1;                 // SPADA_FLAT_CFG: 0 = 256 threads x 4 entries, 1 = 512 x 2, 2 = 1024 x 1
@@ -415,6 +417,20 @@ int run_numeric(spada_ctx *c, uint64_t *d_ptr, uint32_t *d_idx, double *d_val)
         if ((rc = join_from(c, NUM2_BIN_MID))) return rc;
     }
 #undef LAUNCH_NUM_FLAT
+#define LAUNCH_MERGE(BIN, PM)                                                                                               \
+    if (cnt[BIN]) {                                                                                                        \
+        if ((rc = fork_to(c, BIN))) return rc;                                                                             \
+        constexpr size_t lds = 4 * ((num_merge_wave_bytes<PM>() + 15) & ~(size_t)15);                                      \
+        const uint32_t grid = (uint32_t)std::min<uint64_t>((cnt[BIN] + 3) / 4, 256ull * (LDS_MAX / lds) * 4);               \
+        hipLaunchKernelGGL(k_num_merge<PM>, dim3(grid), dim3(256), lds, c->cur, c->A->ptr, c->A->val, c->B->idx, c->B->val,  \
+                           c->eb0.as<uint64_t>(), c->elen.as<uint32_t>(), c->r0, c->num_rows.as<uint32_t>() + off[BIN],     \
+                           cnt[BIN], c->cptr.as<uint64_t>(), d_idx, d_val);                                               \
+        HIP_TRY(hipGetLastError());                                                                                        \
+        if ((rc = join_from(c, BIN))) return rc;                                                                           \
+    }
+    LAUNCH_MERGE(NUM2_BIN_MERGE_L, 1024)
+    LAUNCH_MERGE(NUM2_BIN_MERGE_S, 512)
+#undef LAUNCH_MERGE
     if (cnt[BIN_COPY]) {
         if ((rc = fork_to(c, BIN_COPY))) return rc;
         const uint32_t grid = std::min<uint32_t>((c->nrows + 255) / 256, 256u * 8 * 4);
@@ -521,6 +537,9 @@ int spada_create(const spada_options *opts, spada_ctx **out)
     if (const char *e = std::getenv("SPADA_FLAT_CFG")) c->flat_cfg = atoi(e);
     if (const char *e = std::getenv("SPADA_SORT_HUGE")) c->sort_huge = e[0] == '1';
     if (const char *e = std::getenv("SPADA_FLAT_BIG")) c->flat_big = e[0] == '1';
+    if (const char *e = std::getenv("SPADA_MERGE")) c->merge_on = e[0] == '1';
+    if ((rc = allow_lds(k_num_merge<512>, 4 * ((num_merge_wave_bytes<512>() + 15) & ~(size_t)15)))) return rc;
+    if ((rc = allow_lds(k_num_merge<1024>, 4 * ((num_merge_wave_bytes<1024>() + 15) & ~(size_t)15)))) return rc;
     if ((rc = allow_lds(k_num_flat<1024, 1, 13, 6144, 128, true>, num_flat_lds<1024, 1, 13, 6144, 128>()))) return rc;
     if ((rc = allow_lds(k_sym_bitmap, LDS_MAX))) return rc;
     if ((rc = allow_lds(k_num_bitmap<true>, LDS_MAX))) return rc;
@@ -632,11 +651,11 @@ int spada_dev_spgemm_symbolic(spada_ctx *c, const spada_dev_csr *a, const spada_
     }
     const uint32_t rmax = std::max<uint32_t>(c->rmax_eff, 4);
     const uint32_t rmax_s = std::min<uint32_t>(rmax, SF_RMAX);
-    const CutParams cut_sym{SYM_FLAT_CAP, (SYM_FLAT_CAP + rmax_s - 1) / rmax_s, 0, 0, 0};
+    const CutParams cut_sym{SYM_FLAT_CAP, (SYM_FLAT_CAP + rmax_s - 1) / rmax_s, 0, 0, 0, 0};
     const bool sort_merge = c->accumulator == SPADA_ACC_SORT_MERGE && c->flat_on;
     const uint32_t rmax_n = std::min<uint32_t>(rmax, NF_RMAX);
     const CutParams cut_num{NUM_FLAT_CAP, (NUM_FLAT_CAP + rmax_n - 1) / rmax_n, c->num_flat_max, c->bm_vcap,
-                            sort_merge ? SYM_FLAT_MAX : 0u};
+                            sort_merge ? SYM_FLAT_MAX : 0u, c->merge_on && c->colbits <= 21 ? 1024u : 0u};
 
     if (c->dbg.p && c->dbg_g == 2) HIP_TRY(hipMemsetAsync(c->dbg.p, 0, 64 * 16 * 8, s));
     HIP_TRY(hipEventRecord(c->ev[EV_SYM_BEGIN], s));

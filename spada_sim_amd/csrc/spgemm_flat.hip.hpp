@@ -23,6 +23,8 @@ namespace spada {
 constexpr int BIN_EMPTY = 0, BIN_COPY = 1, BIN_FLAT = 2;
 constexpr int SYM2_BIN_8K = 3, SYM2_BIN_24K = 4, SYM2_BIN_SPILL = 5, SYM2_BIN_MID = 6;
 constexpr int NUM2_BIN_2K = 3, NUM2_BIN_6K = 4, NUM2_BIN_BMV = 5, NUM2_BIN_SPILL = 6, NUM2_BIN_MID = 7;
+constexpr int NUM2_BIN_MERGE_S = 8, NUM2_BIN_MERGE_L = 9;   // multiway merge, <= 512 / <= 1024 products
+constexpr uint32_t MERGE_LMAX = 8, MERGE_PMIN = 96;
 // "mid" rows: too large for a shared batch, small enough for the flat kernels' table -- one row per batch, taken
 // from the bin's row list (list mode of k_sym_flat / k_num_flat)
 #ifndef SPADA_SF_LARGE   /* default: 256-thread workgroups, 4096-key tables (A/B: -17..21 % symbolic time) */
@@ -55,11 +57,13 @@ __host__ __device__ inline int sym2_bin_of(uint64_t P, uint32_t L)
     return SYM2_BIN_SPILL;
 }
 // sm_pmax > 0 selects the sort-merge accumulator: "flat" then means P <= sm_pmax (the rows of the symbolic batches)
+// merge_pmax > 0 enables the multiway-merge class (rows with few, long B rows): L <= 32, MERGE_PMIN <= P <= merge_pmax
 __host__ __device__ inline int num2_bin_of(uint32_t n, uint64_t P, uint32_t L, uint32_t flat_max, uint32_t vcap,
-                                           uint32_t sm_pmax = 0)
+                                           uint32_t sm_pmax = 0, uint32_t merge_pmax = 0)
 {
     if (n == 0) return BIN_EMPTY;
     if (L == 1) return BIN_COPY;
+    if (merge_pmax && L <= MERGE_LMAX && P >= MERGE_PMIN && P <= merge_pmax) return P <= 512 ? NUM2_BIN_MERGE_S : NUM2_BIN_MERGE_L;
     if (sm_pmax ? P <= sm_pmax : (n <= flat_max && P <= (1u << 22))) return BIN_FLAT;
     if (flat_max && n <= NUM_MID_MAX && P <= (1u << 22)) return NUM2_BIN_MID;
     if (n <= 2048 && P <= 16384) return NUM2_BIN_2K;
@@ -202,6 +206,7 @@ __global__ __launch_bounds__(256) void k_row_stats2(const uint64_t *__restrict__
 // of the next batch when its own interval [S_i, S_i + w_i) reaches the next multiple of cap.
 struct CutParams {
     uint32_t cap, minw, flat_max /* numeric */, vcap /* numeric */, sm_pmax /* numeric, sort-merge accumulator */;
+    uint32_t merge_pmax /* numeric: multiway-merge class, 0 = off */;
 };
 
 // MODE 0: symbolic cut (weights from row_nprod / row_bin)      MODE 1: numeric (nnzc -> cptr, classify, cut)
@@ -221,7 +226,7 @@ __device__ inline void scan_row_values(uint32_t i, uint32_t n, const uint64_t *a
     } else {
         nnz = row_nnzc[i];
         const uint32_t L = (uint32_t)(aptr[r0 + i + 1] - aptr[r0 + i]);
-        bin = num2_bin_of(nnz, row_nprod[i], L, cp.flat_max, cp.vcap, cp.sm_pmax);
+        bin = num2_bin_of(nnz, row_nprod[i], L, cp.flat_max, cp.vcap, cp.sm_pmax, cp.merge_pmax);
         w = bin == BIN_FLAT ? max(nnz, cp.minw) : cp.minw;
     }
 }
@@ -1142,6 +1147,161 @@ __global__ __launch_bounds__(256) void k_num_copy2(const uint64_t *__restrict__ 
                 c_val[sc0 + t] = sav * bval[sb0 + t];
             }
         }
+    }
+}
+
+// ---- 6c. numeric, rows with few but long B rows: multiway merge, one wavefront per row ------------------------------
+// A C row whose A row has L <= 32 entries is the union of L sorted B rows: no hash table and no sort are needed, the
+// reference's own answer -- a comparator merge tree followed by an adder (adder_tree.rs:145-188, :73-83) -- is also the
+// cheapest one here.  One 64-lane wavefront per row, nothing but wave-level synchronisation: the products are
+// expanded to LDS as keys (column << PB | product number), ceil(log2 L) merge-path rounds merge neighbouring runs
+// pairwise (every lane produces a contiguous slice of the output: one diagonal search, then a sequential two-way
+// merge), runs of equal column are added in ascending product number (= ascending k: bit-identical to a sequential
+// CPU sort-merge) and stored.  ~5 LDS operations per product and round instead of ~50 for hash + ordered emission.
+// LDS per wave: kA, kB u32[PMAX] | val f64[PMAX] | ebase u64[32] | eav f64[32] | off u32[34] | heads u64[PMAX/64] |
+// hpre u32[PMAX/64]
+template <int PMAX>
+__host__ __device__ constexpr size_t num_merge_wave_bytes()
+{
+    return (size_t)PMAX * 16 + 32 * 16 + 34 * 4 + 8 + (size_t)(PMAX / 64) * 12 + 16;
+}
+
+template <int PMAX>
+__global__ __launch_bounds__(256) void k_num_merge(const uint64_t *__restrict__ aptr, const double *__restrict__ aval,
+                                                   const uint32_t *__restrict__ bidx, const double *__restrict__ bval,
+                                                   const uint64_t *__restrict__ eb0, const uint32_t *__restrict__ elen,
+                                                   uint64_t r0, const uint32_t *__restrict__ list, uint32_t n_list,
+                                                   const uint64_t *__restrict__ cptr, uint32_t *__restrict__ c_idx,
+                                                   double *__restrict__ c_val)
+{
+    constexpr int PB = PMAX == 1024 ? 10 : 9;
+    static_assert(PMAX == 1024 || PMAX == 512, "product-number bits");
+    constexpr uint32_t PMASK = (1u << PB) - 1u, MAXK = 0xFFFFFFFFu;
+    constexpr int NCH = PMAX / 64;
+    constexpr size_t WB = (num_merge_wave_bytes<PMAX>() + 15) & ~(size_t)15;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned char *base = smem + (size_t)wave * WB;
+    uint32_t *kA = (uint32_t *)base, *kB = kA + PMAX;
+    double *val = (double *)(kB + PMAX);
+    uint64_t *ebase = (uint64_t *)(val + PMAX);
+    double *eav = (double *)(ebase + 32);
+    unsigned long long *heads = (unsigned long long *)(eav + 32);
+    uint32_t *hpre = (uint32_t *)(heads + NCH);
+    uint32_t *off = hpre + NCH;   // 34 entries: off[j] = first product of entry j, off[j >= L] = P
+    auto wave_sync = [] {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    };
+    for (uint32_t slot = blockIdx.x * 4 + wave; slot < n_list; slot += gridDim.x * 4) {
+        const uint32_t row = list[slot];
+        const uint64_t a0 = aptr[r0 + row];
+        const uint32_t L = (uint32_t)(aptr[r0 + row + 1] - a0);   // 2 .. 32
+        const uint64_t c0 = cptr[row];
+        uint64_t b0 = 0;
+        uint32_t len = 0;
+        double av = 0.0;
+        if ((uint32_t)lane < L) {
+            b0 = eb0[a0 + lane];
+            len = elen[a0 + lane];
+            av = aval[a0 + lane];
+        }
+        uint32_t inc = len;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = __shfl_up(inc, o);
+            if (lane >= o) inc += t;
+        }
+        const uint32_t P = __shfl(inc, 63);   // <= PMAX by classification
+        if (lane < 34) off[lane] = (uint32_t)lane < L ? inc - len : P;
+        if (lane < 32) {
+            ebase[lane] = b0 - (inc - len);
+            eav[lane] = av;
+        }
+        wave_sync();
+        // expand + scale (simulator.rs:86-111)
+        for (uint32_t p = lane; p < P; p += 64) {
+            uint32_t j = 0;
+#pragma unroll
+            for (uint32_t step = 16; step >= 1; step >>= 1)
+                if (off[j + step] <= p) j += step;
+            const uint64_t q = ebase[j] + p;
+            kA[p] = (bidx[q] << PB) | p;
+            val[p] = eav[j] * bval[q];
+        }
+        wave_sync();
+        // merge tree (adder_tree.rs:145-188): runs of w lists -> runs of 2w lists
+        uint32_t *src = kA, *dst = kB;
+        const uint32_t VT = (P + 63) / 64;
+        for (uint32_t w = 1; w < L; w <<= 1) {
+            uint32_t o = lane * VT;
+            const uint32_t oend = min(o + VT, P);
+            while (o < oend) {
+                uint32_t j = 0;   // first list of the pair that produces output o: a multiple of 2w
+#pragma unroll
+                for (uint32_t step = 16; step >= 1; step >>= 1)
+                    if (step >= 2 * w && off[min(j + step, 32u)] <= o) j += step;
+                const uint32_t s0 = off[j], s1 = off[min(j + w, 32u)], s2 = off[min(j + 2 * w, 32u)];
+                const uint32_t nx = s1 - s0, ny = s2 - s1, k = o - s0;
+                uint32_t lo = k > ny ? k - ny : 0u, hi = k < nx ? k : nx;
+                while (lo < hi) {   // merge path: how many of the first k outputs come from the left run
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (src[s0 + mid] < src[s1 + (k - 1 - mid)]) lo = mid + 1;
+                    else hi = mid;
+                }
+                uint32_t i = lo, jy = k - lo;
+                const uint32_t lim = min(oend, s2);
+                uint32_t x = i < nx ? src[s0 + i] : MAXK, y = jy < ny ? src[s1 + jy] : MAXK;
+                while (o < lim) {   // branch-free two-way merge step: one LDS read per output
+                    const bool tx = x < y;
+                    dst[o] = tx ? x : y;
+                    i += tx ? 1u : 0u;
+                    jy += tx ? 0u : 1u;
+                    const bool in = tx ? i < nx : jy < ny;
+                    const uint32_t nxt = src[in ? (tx ? s0 + i : s1 + jy) : 0u];
+                    x = tx ? (in ? nxt : MAXK) : x;
+                    y = tx ? y : (in ? nxt : MAXK);
+                    ++o;
+                }
+            }
+            wave_sync();
+            uint32_t *t = src;
+            src = dst;
+            dst = t;
+        }
+        // adder (adder_tree.rs:73-83): runs of equal column, added left to right
+        const uint32_t nch = (P + 63) / 64;
+        for (uint32_t ch = 0; ch < nch; ++ch) {
+            const uint32_t p = ch * 64 + lane;
+            const uint32_t cur = p < P ? src[p] : MAXK, prev = (p > 0 && p < P) ? src[p - 1] : MAXK;
+            const bool head = p < P && (p == 0 || (cur >> PB) != (prev >> PB));
+            const unsigned long long m = __ballot(head);
+            if (lane == 0) heads[ch] = m;
+        }
+        wave_sync();
+        {
+            const uint32_t c = (uint32_t)lane < nch ? (uint32_t)__popcll(heads[lane]) : 0u;
+            uint32_t ic = c;
+#pragma unroll
+            for (int o = 1; o < NCH; o <<= 1) {
+                const uint32_t t = __shfl_up(ic, o);
+                if (lane >= o) ic += t;
+            }
+            if (lane < NCH) hpre[lane] = ic - c;
+        }
+        wave_sync();
+        for (uint32_t p = lane; p < P; p += 64) {
+            const unsigned long long hw = heads[p >> 6];
+            if (!((hw >> (p & 63)) & 1ull)) continue;
+            const uint32_t rank = hpre[p >> 6] + (uint32_t)__popcll(hw & ((1ull << (p & 63)) - 1ull));
+            const uint32_t key = src[p];
+            double acc = val[key & PMASK];
+            for (uint32_t q = p + 1; q < P && (src[q] >> PB) == (key >> PB); ++q) acc += val[src[q] & PMASK];
+            c_idx[c0 + rank] = key >> PB;
+            c_val[c0 + rank] = acc;
+        }
+        wave_sync();
     }
 }
 

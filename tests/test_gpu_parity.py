@@ -187,7 +187,7 @@ def test_sort_merge_generated_workloads(engine_sm, name, kind, p0, p1, seed):
     ref = oracle.spgemm_sortmerge(a, a)
     assert assert_parity(c, ref, a, a, RTOL) == 0
     st = engine_sm.stats()
-    if sum(st["num_bin_rows"][3:]) == 0:
+    if sum(st["num_bin_rows"][3:8]) == 0:   # bins 8, 9 (multiway merge) also add in ascending k
         # every row went through the copy or the sort-merge kernel, which add in ascending k like the CPU
         # restatement (simulator.rs:209-220 adds left to right): values are bit-identical, not just within 1e-9
         assert np.array_equal(c.data, ref.data)
@@ -284,3 +284,41 @@ def test_stats_account_for_every_product(engine):
     assert sum(st["num_bin_entries"]) + 0 <= m.nnz()          # rows with an empty C row are not counted
     assert sum(st["num_bin_prod"]) == st["nprod"]
     assert st["bytes_read"] == (m.shape[0] + 1) * 8 + m.nnz() * 28 + st["nprod"] * 12
+
+
+def test_multiway_merge_class(monkeypatch):
+    """SPADA_MERGE=1 routes rows with <= 8 long B rows through k_num_merge (one wavefront per row: merge-path tree +
+    adder, the reference's adder_tree.rs datapath).  It adds in ascending k, so its rows are bit-identical to the
+    sequential restatement."""
+    import spada_sim_amd as S
+    monkeypatch.setenv("SPADA_MERGE", "1")
+    eng = S.Engine()
+    try:
+        rng = np.random.default_rng(11)
+        n = 4000
+        hubs = rng.choice(n, size=60, replace=False)
+
+        def cols(r, k):
+            if r in set(hubs.tolist()):
+                return rng.integers(0, n, size=300)          # long rows: the B rows the others select
+            return rng.choice(hubs, size=k)                    # few entries, all pointing at long rows
+
+        m = _random_csr(rng, n, n, rng.integers(1, 9, size=n), cols)
+        c = eng.spgemm(m, m)
+        ao = to_oracle(m)
+        ref = oracle.spgemm_sortmerge(ao, ao)
+        assert assert_parity(c, ref, ao, ao, RTOL) == 0
+        st = eng.stats()
+        merged = st["num_bin_rows"][8] + st["num_bin_rows"][9]
+        assert merged > 1000
+        # rows of the merge and copy classes are bit-identical
+        ip = ref.indptr.astype(np.int64)
+        L = np.diff(m.indptr.astype(np.int64))
+        P = np.array([sum(int(m.indptr[k + 1] - m.indptr[k]) for k in m.indices[int(m.indptr[r]):int(m.indptr[r + 1])])
+                      for r in range(n)])
+        sel = np.nonzero((L >= 2) & (L <= 8) & (P >= 96) & (P <= 1024))[0]
+        assert len(sel) == merged
+        for r in sel[:500]:
+            assert np.array_equal(c.data[ip[r]:ip[r + 1]], ref.data[ip[r]:ip[r + 1]])
+    finally:
+        eng.close()

@@ -322,3 +322,14 @@ def test_multiway_merge_class(monkeypatch):
             assert np.array_equal(c.data[ip[r]:ip[r + 1]], ref.data[ip[r]:ip[r + 1]])
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_parity_sweep(engine, engine_sm, seed):
+    """Random shapes and row-length profiles (tests/fuzz_cases.py), both accumulators."""
+    from fuzz_cases import random_case
+    a, b, desc = random_case(seed)
+    ao, bo = to_oracle(a), to_oracle(b)
+    ref = oracle.spgemm_sortmerge(ao, bo)
+    for e in (engine, engine_sm):
+        assert_parity(e.spgemm(a, b), ref, ao, bo, RTOL)

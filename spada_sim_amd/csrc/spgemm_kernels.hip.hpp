@@ -1,20 +1,19 @@
-// gfx950 (MI355X, CDNA4) kernels of the row-wise expand-scale-merge SpGEMM  C = A * B  on CSR.
+// gfx950 (MI355X, CDNA4) kernels of the row-wise expand-scale-merge SpGEMM  C = A * B  on CSR, part 1: helpers and the
+// one-workgroup-per-row kernels for LARGE rows (LDS hash: k_sym_hash / k_num_hash) and HUGE rows (column bitmap in
+// LDS: k_*_bitmap, or in HBM: k_*_spill).  Small and mid rows -- the bulk -- take the flat-batch kernels of
+// spgemm_flat.hip.hpp, which also holds the row statistics, the scans and the bin definitions.
 //
-// They replace, as one pipeline, what spada-sim simulates cycle by cycle (citations into
-// /root/reference/src): window fetch of A scalars (scheduler.rs:482-606, storage.rs:279-323), B-fiber
-// streaming (simulator.rs:892-953), the multiplier array (simulator.rs:86-111), sorting network + merge
-// tree (simulator.rs:143-230), psum write-back / partial-fiber merging (simulator.rs:955-983,
-// scheduler.rs:381-480, adder_tree.rs:145-188) and result assembly (simulator.rs:1034-1062).
-//
-// Pipeline:  row_stats -> bin scatter -> symbolic (per bin) -> scan -> classify/bin -> numeric (per bin)
-//   * 64-wide wavefronts throughout; sub-wave groups of 8/16 lanes take small rows so that one
-//     wave keeps 8/4 rows (and their dependent load chains) in flight.
-//   * per-row accumulators live in LDS: open-addressing hash (u32 key, f64 value), ds_cmpst for the
-//     key, ds_add_f64 for the value; column compaction + ordering by a monotone bucket pass with
-//     LDS counters, a group-wide scan and an in-bucket rank, then ascending stores to C.
-//   * rows too large for LDS take the spill path: per-block bitmap / dense f64 slab in HBM with
-//     device-scope atomics, emitted in ascending column order from the bitmap.
-//   * no MFMA: this is irregular gather-accumulate, bounded by memory latency / HBM bandwidth.
+// Together they replace what spada-sim simulates cycle by cycle (citations into /root/reference/src): window
+// fetch of A scalars (scheduler.rs:482-606, storage.rs:279-323), B-fiber streaming (simulator.rs:892-953), the
+// multiplier array (simulator.rs:86-111), sorting network + merge tree (simulator.rs:143-230), psum write-back /
+// partial-fiber merging (simulator.rs:955-983, scheduler.rs:381-480, adder_tree.rs:145-188) and result assembly
+// (simulator.rs:1034-1062).
+//   * 64-wide wavefronts; per-row accumulators live in LDS: open-addressing hash (u32 key, f64 value), ds_cmpst for
+//     the key, ds_add_f64 for the value; column compaction + ordering by a monotone bucket pass with LDS counters,
+//     a group-wide scan and an in-bucket rank, then ascending stores to C.
+//   * rows too large for an LDS table: column bitmap (LDS up to ~1.1 M columns, else HBM), prefix popcounts give
+//     every column its final position, values by f64 atomics.
+//   * no MFMA: this is irregular gather-accumulate, bounded by memory latency, LDS throughput and HBM bandwidth.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -35,45 +34,7 @@ struct DevCsrView {
     const uint32_t *elen;
 };
 
-// ---- bin definitions (host and device agree through these) -------------------------------------------
-// symbolic bins, by P = products of the row and L = nnz of the A row (table must hold up to P keys)
-//   0: P == 0 (empty C row)          1: L == 1 (C row = scaled B row, nnz = P; no kernel)
-//   2: P <= 32    G=8    T=64        3: P <= 128   G=16   T=256      4: P <= 512   G=64  T=1024
-//   5: P <= 2048  G=256  T=4096      6: P <= 8192  G=512  T=16384    7: P <= 24576 G=1024 T=32768
-//   8: spill (bitmap in HBM)
-// numeric bins, by n = nnz(C row) (known exactly now), P and L: table T = 2 n_max, G lanes per row,
-// and at most 64 products per lane
-//   0: n == 0                        1: L == 1 (scaled copy kernel)
-//   2: n <= 32   G=8   T=64          3: n <= 64   G=16  T=128         4: n <= 128  G=32  T=256
-//   5: n <= 256  G=32  T=512         6: n <= 512  G=64  T=1024        7: n <= 1024 G=128 T=2048
-//   8: n <= 2048 G=256 T=4096        9: n <= 6144 G=1024 T=8192
-//  10: n <= vcap: LDS bitmap-rank with the value row in LDS (only when the column bitmap leaves room)
-//  11: everything larger: LDS bitmap-rank with values accumulated in the C row, or the HBM spill path
-constexpr int NUM_BMV_BIN = 10;
-constexpr int NUM_SPILL_BIN = 11;
-constexpr int SYM_SPILL_BIN = 8;
-__host__ __device__ inline int sym_bin_of(uint64_t P, uint32_t L)
-{
-    if (P == 0) return 0;
-    if (L == 1) return 1;
-    if (P <= 32) return 2;
-    if (P <= 128) return 3;
-    if (P <= 512) return 4;
-    if (P <= 2048) return 5;
-    if (P <= 8192) return 6;
-    if (P <= 24576) return 7;
-    return 8;
-}
-__host__ __device__ inline int num_bin_of(uint32_t n, uint64_t P, uint32_t L, uint32_t vcap)
-{
-    if (n == 0) return 0;
-    if (L == 1) return 1;
-    const int bn = n <= 32 ? 2 : n <= 64 ? 3 : n <= 128 ? 4 : n <= 256 ? 5 : n <= 512 ? 6 : n <= 1024 ? 7 : n <= 2048 ? 8
-                 : n <= 6144 ? 9 : n <= vcap ? NUM_BMV_BIN : NUM_SPILL_BIN;
-    const int bp = P <= 512 ? 2 : P <= 1024 ? 3 : P <= 2048 ? 4 : P <= 4096 ? 6 : P <= 8192 ? 7 : P <= 16384 ? 8 : 9;
-    return bn > bp ? bn : bp;
-}
-
+// bins: see spgemm_flat.hip.hpp (sym2_bin_of / num2_bin_of)
 // ---- small helpers -----------------------------------------------------------------------------------
 __device__ inline uint64_t wave_sum_u64(uint64_t v)
 {
@@ -201,114 +162,7 @@ __device__ inline uint32_t hash_slot(uint32_t col)
     return (col * 0x9E3779B1u) >> (32 - LOG_T);
 }
 
-// ---- 1. row statistics + symbolic binning --------------------------------------------------------------
-// One lane per A row; rows longer than 16 nonzeros are then walked by the whole wave.
-// Coalescing: consecutive lanes read consecutive A row pointers and (for short rows) adjacent A column
-// indices; the B row-pointer pairs are the irregular gather of the path (16 B per A nonzero).
-__global__ __launch_bounds__(256) void k_row_stats(const uint64_t *__restrict__ aptr, const uint32_t *__restrict__ aidx,
-                                                   const uint64_t *__restrict__ bptr, uint64_t r0, uint32_t nrows,
-                                                   uint32_t *__restrict__ row_nprod, uint32_t *__restrict__ row_nnzc,
-                                                   uint8_t *__restrict__ row_bin, uint32_t *__restrict__ bin_counts,
-                                                   unsigned long long *__restrict__ totals /* [0]=nprod [1]=a_nnz */)
-{
-    __shared__ uint32_t s_hist[SPADA_N_BINS];
-    __shared__ unsigned long long s_tot[2];
-    if (threadIdx.x < SPADA_N_BINS) s_hist[threadIdx.x] = 0;
-    if (threadIdx.x < 2) s_tot[threadIdx.x] = 0;
-    __syncthreads();
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int lane = threadIdx.x & 63;
-    uint64_t a0 = 0, a1 = 0, P = 0;
-    if (i < nrows) {
-        a0 = aptr[r0 + i];
-        a1 = aptr[r0 + i + 1];
-    }
-    const uint32_t L = (uint32_t)(a1 - a0);
-    const bool is_long = L > 16;
-    if (!is_long) {
-        for (uint64_t q = a0; q < a1; ++q) {
-            uint32_t k = aidx[q];
-            P += bptr[k + 1] - bptr[k];
-        }
-    }
-    unsigned long long mask = __ballot(is_long);
-    while (mask) {
-        const int src = __ffsll((long long)mask) - 1;
-        mask &= mask - 1;
-        const uint64_t sa0 = __shfl(a0, src), sa1 = __shfl(a1, src);
-        uint64_t part = 0;
-        for (uint64_t q = sa0 + lane; q < sa1; q += 64) {
-            uint32_t k = aidx[q];
-            part += bptr[k + 1] - bptr[k];
-        }
-        part = wave_sum_u64(part);
-        if (lane == src) P = part;
-    }
-    if (i < nrows) {
-        const int bin = sym_bin_of(P, L);
-        row_nprod[i] = P > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)P;
-        row_bin[i] = (uint8_t)bin;
-        if (bin == 0) row_nnzc[i] = 0;
-        if (bin == 1) row_nnzc[i] = (uint32_t)P;   // one A nonzero: C row is a scaled copy of one B row
-        atomicAdd(&s_hist[bin], 1u);
-    }
-    uint64_t wp = wave_sum_u64(P), wl = wave_sum_u64((uint64_t)L);
-    if (lane == 0) {
-        atomicAdd(&s_tot[0], (unsigned long long)wp);
-        atomicAdd(&s_tot[1], (unsigned long long)wl);
-    }
-    __syncthreads();
-    if (threadIdx.x < SPADA_N_BINS && s_hist[threadIdx.x]) atomicAdd(&bin_counts[threadIdx.x], s_hist[threadIdx.x]);
-    if (threadIdx.x < 2 && s_tot[threadIdx.x]) atomicAdd(&totals[threadIdx.x], s_tot[threadIdx.x]);
-}
-
-// Scatter row ids into per-bin lists.  bin_counts = histogram (complete), bin_cursor zeroed.
-__global__ __launch_bounds__(256) void k_bin_scatter(const uint8_t *__restrict__ row_bin, uint32_t nrows,
-                                                     const uint32_t *__restrict__ bin_counts,
-                                                     uint32_t *__restrict__ bin_cursor, uint32_t *__restrict__ bin_rows)
-{
-    __shared__ uint32_t s_cnt[SPADA_N_BINS], s_base[SPADA_N_BINS];
-    if (threadIdx.x < SPADA_N_BINS) s_cnt[threadIdx.x] = 0;
-    __syncthreads();
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    int bin = -1;
-    uint32_t local = 0;
-    if (i < nrows) {
-        bin = row_bin[i];
-        local = atomicAdd(&s_cnt[bin], 1u);
-    }
-    __syncthreads();
-    if (threadIdx.x < SPADA_N_BINS) {
-        uint32_t off = 0;
-        for (int u = 0; u < (int)threadIdx.x; ++u) off += bin_counts[u];
-        uint32_t c = s_cnt[threadIdx.x];
-        s_base[threadIdx.x] = off + (c ? atomicAdd(&bin_cursor[threadIdx.x], c) : 0u);
-    }
-    __syncthreads();
-    if (bin >= 0) bin_rows[s_base[bin] + local] = i;
-}
-
-// numeric classification: row_bin <- num_bin_of(nnzc, nprod, L) + histogram
-__global__ __launch_bounds__(256) void k_num_classify(const uint64_t *__restrict__ aptr, uint64_t r0, uint32_t nrows,
-                                                      const uint32_t *__restrict__ row_nprod,
-                                                      const uint32_t *__restrict__ row_nnzc, uint8_t *__restrict__ row_bin,
-                                                      uint32_t *__restrict__ bin_counts, uint32_t vcap)
-{
-    __shared__ uint32_t s_hist[SPADA_N_BINS];
-    if (threadIdx.x < SPADA_N_BINS) s_hist[threadIdx.x] = 0;
-    __syncthreads();
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < nrows) {
-        const uint32_t L = (uint32_t)(aptr[r0 + i + 1] - aptr[r0 + i]);
-        const int bin = num_bin_of(row_nnzc[i], row_nprod[i], L, vcap);
-        row_bin[i] = (uint8_t)bin;
-        atomicAdd(&s_hist[bin], 1u);
-    }
-    __syncthreads();
-    if (threadIdx.x < SPADA_N_BINS && s_hist[threadIdx.x]) atomicAdd(&bin_counts[threadIdx.x], s_hist[threadIdx.x]);
-}
-
-// ---- 2. exclusive scan  nnzc[u32] -> cptr[u64]  (three small kernels) -----------------------------------
+// ---- 2. block-wide scan helpers (the scan kernels themselves: k_cut_* in spgemm_flat.hip.hpp) ---------------
 constexpr int SCAN_BLOCK = 256;
 constexpr int SCAN_ITEMS = 8;
 constexpr int SCAN_TILE = SCAN_BLOCK * SCAN_ITEMS;
@@ -332,59 +186,6 @@ __device__ inline uint64_t block_exclusive_scan_u64(uint64_t v, uint64_t *s_w /*
     }
     *total = tot;
     return inc - v + add;
-}
-
-__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_tile_sums(const uint32_t *__restrict__ in, uint32_t n,
-                                                               uint64_t *__restrict__ tile_sums)
-{
-    __shared__ uint64_t s_w[SCAN_BLOCK / 64];
-    const uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
-    uint64_t s = 0;
-#pragma unroll
-    for (int j = 0; j < SCAN_ITEMS; ++j)
-        if (base + j < n) s += in[base + j];
-    uint64_t tot;
-    block_exclusive_scan_u64(s, s_w, &tot);
-    if (threadIdx.x == 0) tile_sums[blockIdx.x] = tot;
-}
-
-// single workgroup: exclusive scan of tile_sums in place, total -> tile_sums[ntiles]
-__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_tiles(uint64_t *__restrict__ tile_sums, uint32_t ntiles)
-{
-    __shared__ uint64_t s_w[SCAN_BLOCK / 64];
-    uint64_t carry = 0;
-    for (uint32_t b = 0; b < ntiles; b += SCAN_BLOCK) {
-        const uint32_t i = b + threadIdx.x;
-        uint64_t v = i < ntiles ? tile_sums[i] : 0, tot;
-        uint64_t ex = block_exclusive_scan_u64(v, s_w, &tot);
-        if (i < ntiles) tile_sums[i] = carry + ex;
-        carry += tot;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) tile_sums[ntiles] = carry;
-}
-
-__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_apply(const uint32_t *__restrict__ in, uint32_t n,
-                                                           const uint64_t *__restrict__ tile_sums, uint32_t ntiles,
-                                                           uint64_t *__restrict__ out /* n + 1 */)
-{
-    __shared__ uint64_t s_w[SCAN_BLOCK / 64];
-    const uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
-    uint32_t v[SCAN_ITEMS];
-    uint64_t s = 0;
-#pragma unroll
-    for (int j = 0; j < SCAN_ITEMS; ++j) {
-        v[j] = base + j < n ? in[base + j] : 0;
-        s += v[j];
-    }
-    uint64_t tot;
-    uint64_t ex = block_exclusive_scan_u64(s, s_w, &tot) + tile_sums[blockIdx.x];
-#pragma unroll
-    for (int j = 0; j < SCAN_ITEMS; ++j) {
-        if (base + j < n) out[base + j] = ex;
-        ex += v[j];
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = tile_sums[ntiles];
 }
 
 // ---- 3. balanced walk over the products of one A row --------------------------------------------------------
@@ -592,7 +393,7 @@ __global__ __launch_bounds__((G <= 64 ? 256 : G)) void k_num_hash(DevCsrView A, 
                                                                    const uint32_t *__restrict__ bin_rows, uint32_t n_bin_rows,
                                                                    const uint64_t *__restrict__ cptr,
                                                                    uint32_t *__restrict__ c_idx, double *__restrict__ c_val,
-                                                                   int ablate, unsigned long long *dbg)
+                                                                   unsigned long long *dbg)
 {
 #define STAMP(i) do { if (dbg && threadIdx.x == 0 && blockIdx.x % 16 == 0 && blockIdx.x / 16 < 64) dbg[(blockIdx.x / 16) * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
     STAMP(0);
@@ -619,11 +420,9 @@ __global__ __launch_bounds__((G <= 64 ? 256 : G)) void k_num_hash(DevCsrView A, 
     STAMP(1);
 
     uint32_t row = 0;
-    if (ablate >= 3) return;
     if (active) {
         row = bin_rows[slot];
         const uint64_t a0 = A.ptr[r0 + row], a1 = A.ptr[r0 + row + 1];
-        if (ablate < 2)
         walk_products<G, true>(A, B, a0, a1, gl, mine + 16 * T, hdr, [&](uint32_t c, double v) {
             uint32_t h = hash_slot<LOG_T>(c);
             for (;;) {
@@ -636,7 +435,6 @@ __global__ __launch_bounds__((G <= 64 ? 256 : G)) void k_num_hash(DevCsrView A, 
     }
     group_sync<G>();
     STAMP(2);
-    if (ablate >= 1) return;
 
     // ---- ordered emission: monotone buckets over [kmin, kmax], scan, in-bucket rank ---------------------
     // each lane keeps its T/G table keys in registers for the three passes over the table
@@ -691,26 +489,6 @@ __global__ __launch_bounds__((G <= 64 ? 256 : G)) void k_num_hash(DevCsrView A, 
     }
     STAMP(7);
 #undef STAMP
-}
-
-// ---- 6. numeric, rows with a single A nonzero: C row = a * B row (already ascending) ------------------------
-template <int G>
-__global__ __launch_bounds__(256) void k_num_copy(DevCsrView A, DevCsrView B, uint64_t r0,
-                                                  const uint32_t *__restrict__ bin_rows, uint32_t n_bin_rows,
-                                                  const uint64_t *__restrict__ cptr, uint32_t *__restrict__ c_idx,
-                                                  double *__restrict__ c_val)
-{
-    const uint32_t slot = blockIdx.x * (256 / G) + threadIdx.x / G;
-    const int gl = threadIdx.x % G;
-    if (slot >= n_bin_rows) return;
-    const uint32_t row = bin_rows[slot];
-    const uint64_t a = A.ptr[r0 + row];
-    const double av = A.val[a];
-    const uint64_t b0 = A.eb0[a], b1 = b0 + A.elen[a], c0 = cptr[row];
-    for (uint64_t q = b0 + gl; q < b1; q += G) {
-        c_idx[c0 + (q - b0)] = B.idx[q];
-        c_val[c0 + (q - b0)] = av * B.val[q];
-    }
 }
 
 // ---- 7. spill path: rows whose accumulator does not fit LDS ---------------------------------------------------

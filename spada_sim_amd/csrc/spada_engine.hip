@@ -94,6 +94,7 @@ struct spada_ctx {
     hipStream_t cur = nullptr;        // stream the launch helpers use
     bool merge_on = false;            // SPADA_MERGE=1: multiway-merge class (k_num_merge) for rows with <= 8 long B rows; measured
                                       // neutral on the webbase surrogate (1.77 ms either way), so off by default
+    size_t lds_pad = 0;               // SPADA_LDS_PAD=<bytes>: occupancy experiments (fewer flat workgroups per CU)
     bool flat_big = false;            // SPADA_FLAT_BIG=1: flat kernel (list mode) instead of k_num_hash for rows above the mid class
     bool sort_huge = false;           // SPADA_SORT_HUGE=1
     int flat_cfg = 1;                 // SPADA_FLAT_CFG: 0 = 256 threads x 4 entries, 1 = 512 x 2, 2 = 1024 x 1
@@ -376,7 +377,7 @@ int run_numeric(spada_ctx *c, uint64_t *d_ptr, uint32_t *d_idx, double *d_val)
         if ((rc = fork_to(c, BIN_FLAT))) return rc;
 #define LAUNCH_NUM_FLAT(BL, EP, LS)                                                                                             \
     {                                                                                                                        \
-        constexpr size_t lds = num_flat_lds<BL, EP, NF_LOG_T, NF_NOUT, NF_RMAX>();                                           \
+        const size_t lds = num_flat_lds<BL, EP, NF_LOG_T, NF_NOUT, NF_RMAX>() + c->lds_pad;                                  \
         hipLaunchKernelGGL((k_num_flat<BL, EP, NF_LOG_T, NF_NOUT, NF_RMAX, LS>), dim3(flat_grid(nf_batches, lds)),                \
                            dim3(BL), lds, c->cur, c->A->ptr, c->A->val, c->B->idx, c->B->val, c->eb0.as<uint64_t>(),          \
                            c->elen.as<uint32_t>(), c->r0, c->nrows, c->row_bin.as<uint8_t>(), c->row_kmin.as<uint32_t>(),     \
@@ -528,14 +529,15 @@ int spada_create(const spada_options *opts, spada_ctx **out)
     SF_CFG_LIST(ALLOW_FLAT)
 #undef ALLOW_FLAT
 #define ALLOW_NFLAT(BL, EP)                                                                                                  \
-    if ((rc = allow_lds(k_num_flat<BL, EP, NF_LOG_T, NF_NOUT, NF_RMAX, false>, num_flat_lds<BL, EP, NF_LOG_T, NF_NOUT, NF_RMAX>()))) return rc; \
-    if ((rc = allow_lds(k_num_flat<BL, EP, NF_LOG_T, NF_NOUT, NF_RMAX, true>, num_flat_lds<BL, EP, NF_LOG_T, NF_NOUT, NF_RMAX>()))) return rc;
+    if ((rc = allow_lds(k_num_flat<BL, EP, NF_LOG_T, NF_NOUT, NF_RMAX, false>, LDS_MAX))) return rc; \
+    if ((rc = allow_lds(k_num_flat<BL, EP, NF_LOG_T, NF_NOUT, NF_RMAX, true>, LDS_MAX))) return rc;
     NF_CFG_LIST(ALLOW_NFLAT)
 #undef ALLOW_NFLAT
     if ((rc = allow_lds(k_num_sortmerge<1024, 1, SF_RMAX>, num_sm_lds<1024, 1, SF_RMAX>()))) return rc;
     if (const char *e = std::getenv("SPADA_FLAT_CFG")) c->flat_cfg = atoi(e);
     if (const char *e = std::getenv("SPADA_SORT_HUGE")) c->sort_huge = e[0] == '1';
     if (const char *e = std::getenv("SPADA_FLAT_BIG")) c->flat_big = e[0] == '1';
+    if (const char *e = std::getenv("SPADA_LDS_PAD")) c->lds_pad = (size_t)atol(e);
     if (const char *e = std::getenv("SPADA_MERGE")) c->merge_on = e[0] == '1';
     if ((rc = allow_lds(k_num_merge<512>, 4 * ((num_merge_wave_bytes<512>() + 15) & ~(size_t)15)))) return rc;
     if ((rc = allow_lds(k_num_merge<1024>, 4 * ((num_merge_wave_bytes<1024>() + 15) & ~(size_t)15)))) return rc;

@@ -1012,7 +1012,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void k_num_flat(const uint64_t 
         // (key - min)} and the rank is a prefix popcount -- O(span / 32) per entry instead of O(m).
         constexpr int OPT = NOUT / BLOCK;   // outputs per thread
         uint32_t *aux = (uint32_t *)(smem + 256 + (size_t)NOUT * 12);
-        static_assert(((size_t)12 << LOG_T) >= (size_t)NOUT * 16, "aux words live behind the (key, value) lists");
+        static_assert(!SPADA_FLAT_DENSE_RANK || ((size_t)12 << LOG_T) >= (size_t)NOUT * 16, "aux words live behind the (key, value) lists");
         uint32_t ok_[OPT], olo[OPT], ohi[OPT], obase[OPT];
         uint64_t oout[OPT];
         bool any_heavy = false;

@@ -924,10 +924,12 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void k_num_flat(const uint64_t 
                 kmax = cur.kmax;
             }
         }
-        uint32_t E, NO;
-        const uint32_t exl = group_scan_excl<BLOCK>(L, tid, hdr + 2, &E);
-        __syncthreads();
-        const uint32_t exn = group_scan_excl<BLOCK>(n, tid, hdr + 2, &NO);
+        // one packed scan: entries of the flat rows in the low, their outputs in the high 32 bits
+        unsigned long long tot64;
+        const unsigned long long ex64 = group_scan_excl_u64<BLOCK>(((unsigned long long)n << 32) | L, tid,
+                                                                   (unsigned long long *)(hdr + 4), &tot64);
+        const uint32_t E = (uint32_t)tot64, NO = (uint32_t)(tot64 >> 32);
+        const uint32_t exl = (uint32_t)ex64, exn = (uint32_t)(ex64 >> 32);
         if ((uint32_t)tid < R) {
             s_re[tid] = exl;
             s_row[tid] = RowEmit{exn, n, kmin, (float)n / ((float)(kmax - kmin) + 1.0f)};

@@ -129,10 +129,18 @@ def main():
         raise SystemExit("launch N > 1 through torch.distributed.run (one rank per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
+    # SPADA_BENCH_BACKEND=gloo: validation of the N > 1 path with several ranks sharing one GPU (RCCL refuses that);
+    # the default and the measured configuration is nccl (= RCCL), one rank per GPU
+    backend = os.environ.get("SPADA_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     a, data_desc = load_workload(S, args.workload)
     rows, cols = a.shape
@@ -218,10 +226,11 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        rdev = dev if dist.get_backend() == "nccl" else torch.device("cpu")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
-        tot = torch.tensor([st["c_nnz"], st["nprod"], st["bytes_read"], st["bytes_write"]], dtype=torch.int64, device=dev)
+        tot = torch.tensor([st["c_nnz"], st["nprod"], st["bytes_read"], st["bytes_write"]], dtype=torch.int64, device=rdev)
         dist.all_reduce(tot)
         nnz_total, nprod_total = int(tot[0]), int(tot[1])
     else:

@@ -17,6 +17,9 @@ def _allgather_uneven(local, counts, group=None):
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     total = sum(counts)
+    if dist.get_backend(group) != "nccl" and local.is_cuda:
+        # gloo with device tensors (validation runs of the N > 1 path on a single GPU): stage through the host
+        return _allgather_uneven(local.cpu(), counts, group).to(local.device)
     full = torch.empty(total, dtype=local.dtype, device=local.device)
     views, off = [], 0
     for n in counts:
@@ -48,8 +51,9 @@ def allgatherv_c(c_ptr, c_idx, c_val, group=None):
     Returns (indptr[int64, total_rows + 1], indices, data) of the whole C."""
     world = dist.get_world_size(group)
     dev = c_ptr.device
-    mine = torch.tensor([c_ptr.numel() - 1, c_idx.numel()], dtype=torch.int64, device=dev)
-    allc = torch.empty(world * 2, dtype=torch.int64, device=dev)
+    cdev = dev if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    mine = torch.tensor([c_ptr.numel() - 1, c_idx.numel()], dtype=torch.int64, device=cdev)
+    allc = torch.empty(world * 2, dtype=torch.int64, device=cdev)
     dist.all_gather_into_tensor(allc, mine, group=group)
     allc = allc.view(world, 2).cpu()
     rows = [int(x) for x in allc[:, 0]]

@@ -511,7 +511,8 @@ __device__ inline void flat_walk(const uint32_t *s_re, const uint64_t *s_a0, uin
     unsigned long long *bm = (unsigned long long *)(scratch + (size_t)ECH * (NUMERIC ? 16 : 8));
     uint32_t *bpre = (uint32_t *)(bm + PWORDS);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const unsigned long long le_mask = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);
+    const uint32_t wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const unsigned long long lane_bit = 1ull << lane;
     for (uint32_t chunk = 0; chunk < E; chunk += ECH) {
         uint64_t b0[EPT];
         uint32_t len[EPT], lr[EPT], off[EPT];
@@ -615,18 +616,20 @@ __device__ inline void flat_walk(const uint32_t *s_re, const uint64_t *s_a0, uin
                 double v[U];
                 uint32_t pp[U], j[U];
                 bool act[U];
+                // lane l of a segment holds product seg + l, i.e. bit l of one bitmap word (lo, base and the segments are
+                // multiples of 64): the word and its prefix are wave-uniform reads, the rank is a v_mbcnt pair.  Lanes past
+                // the end fall back to product 0 of entry 0 (a valid address; their result is discarded).
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    const uint32_t p = base + (u * NW + wave) * 64 + lane;
+                    const uint32_t seg = base + (u * NW + wave_u) * 64;      // wave-uniform
+                    const uint32_t p = seg + lane;
                     act[u] = p < hi;
-                    pp[u] = act[u] ? p : hi - 1;
-                }
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const uint32_t w = (pp[u] - lo) >> 6;
+                    const uint32_t w = min((seg - lo) >> 6, (uint32_t)PWORDS - 1u);
                     const unsigned long long bits = bm[w];
-                    const unsigned long long m = ((pp[u] - lo) & 63) == 63 ? ~0ull : ((2ull << ((pp[u] - lo) & 63)) - 1ull);
-                    j[u] = bpre[w] + (uint32_t)__popcll(bits & m) - 1u;
+                    const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(bits >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bits, 0u));
+                    const uint32_t self = (bits & lane_bit) ? 1u : 0u;
+                    j[u] = act[u] ? bpre[w] + below + self - 1u : 0u;
+                    pp[u] = act[u] ? p : 0u;
                 }
                 uint64_t q[U];
                 double a_[U];
@@ -662,7 +665,6 @@ __device__ inline void flat_walk(const uint32_t *s_re, const uint64_t *s_a0, uin
         pbase += total;
         WSTAMP(5);
     }
-    (void)le_mask;
 #undef WSTAMP
 }
 

@@ -250,7 +250,7 @@ def main():
             return {"label": label, "tmpl": tmpl, "ms": ms, "read": rd, "write": wr, "gbs": rd / (ms * 1e-3) / 1e9 if ms > 0 else 0.0,
                     "units": {"rows": r_, "products": p_, "a_entries": e_, "nnz_c": n_}}
         cands = [launch(2, "ms_num_flat", "shared batches of consecutive rows (nnz(C_i) <= 512)", "false>"),
-                 launch(7, "ms_num_mid", "list mode, one row per batch (512 < nnz(C_i) <= 1536)", "true>")]
+                 launch(7, "ms_num_mid", "list mode, one row per batch (768 < nnz(C_i) <= 1536)", "true>")]
         if args.accumulator == "sort_merge":
             cands = cands[:1]
         cands.sort(key=lambda d: -d["read"])

@@ -352,7 +352,7 @@ int run_numeric(spada_ctx *c, uint64_t *d_ptr, uint32_t *d_idx, double *d_val)
                                    c->elen.as<uint32_t>(), c->r0, c->nrows, c->row_bin.as<uint8_t>(),
                                    c->row_kmin.as<uint32_t>(), c->row_kmax.as<uint32_t>(), c->cptr.as<uint64_t>(),
                                    c->batch_num.as<uint32_t>(), &dc->num_counts[bin], c->colbits, d_idx, d_val,
-                                   (unsigned long long *)nullptr, c->num_rows.as<uint32_t>() + off[bin], (uint32_t)bin);
+                                   (unsigned long long *)nullptr, c->num_rows.as<uint32_t>() + off[bin], (uint32_t)bin, 1u);
                 HIP_TRY(hipGetLastError());
                 if ((rc = join_from(c, bin))) return rc;
             }
@@ -382,7 +382,7 @@ int run_numeric(spada_ctx *c, uint64_t *d_ptr, uint32_t *d_idx, double *d_val)
                            dim3(BL), lds, c->cur, c->A->ptr, c->A->val, c->B->idx, c->B->val, c->eb0.as<uint64_t>(),          \
                            c->elen.as<uint32_t>(), c->r0, c->nrows, c->row_bin.as<uint8_t>(), c->row_kmin.as<uint32_t>(),     \
                            c->row_kmax.as<uint32_t>(), c->cptr.as<uint64_t>(), c->batch_num.as<uint32_t>(), nf_nb,            \
-                           c->colbits, d_idx, d_val, nf_dbg, nf_list, nf_bin);                                               \
+                           c->colbits, d_idx, d_val, nf_dbg, nf_list, nf_bin, nf_rpb);                                               \
     }
 #ifndef SPADA_NF_LARGE
 #define NUM_FLAT_DISPATCH(LS) LAUNCH_NUM_FLAT(256, 2, LS)
@@ -396,7 +396,7 @@ int run_numeric(spada_ctx *c, uint64_t *d_ptr, uint32_t *d_idx, double *d_val)
         {
             const uint64_t nf_batches = c->h_counters->nb_num;
             const uint32_t *nf_nb = &dc->nb_num, *nf_list = nullptr;
-            const uint32_t nf_bin = BIN_FLAT;
+            const uint32_t nf_bin = BIN_FLAT, nf_rpb = 1;
             unsigned long long *nf_dbg = c->dbg_g == 1 ? c->dbg.as<unsigned long long>() : nullptr;
             NUM_FLAT_DISPATCH(false)
         }
@@ -404,17 +404,20 @@ int run_numeric(spada_ctx *c, uint64_t *d_ptr, uint32_t *d_idx, double *d_val)
         HIP_TRY(hipGetLastError());
         if ((rc = join_from(c, BIN_FLAT))) return rc;
     }
-    if (cnt[NUM2_BIN_MID]) {   // one row per batch from the bin's row list
-        if ((rc = fork_to(c, NUM2_BIN_MID))) return rc;
-        const uint64_t nf_batches = cnt[NUM2_BIN_MID];
-        const uint32_t *nf_nb = &dc->num_counts[NUM2_BIN_MID], *nf_list = c->num_rows.as<uint32_t>() + off[NUM2_BIN_MID];
-        const uint32_t nf_bin = NUM2_BIN_MID;
+    for (int pass = 0; pass < 2; ++pass) {   // mid rows from their row lists: one row per batch, or two of the lower half
+        const int bin = pass == 0 ? NUM2_BIN_MID : NUM2_BIN_MID2;
+        if (!cnt[bin]) continue;
+        if ((rc = fork_to(c, bin))) return rc;
+        const uint32_t nf_rpb = pass == 0 ? 1 : 2;
+        const uint64_t nf_batches = (cnt[bin] + nf_rpb - 1) / nf_rpb;
+        const uint32_t *nf_nb = &dc->num_counts[bin], *nf_list = c->num_rows.as<uint32_t>() + off[bin];
+        const uint32_t nf_bin = (uint32_t)bin;
         unsigned long long *nf_dbg = nullptr;
-        HIP_TRY(hipEventRecord(c->ev[EV_NMID_0], c->cur));
+        if (pass == 0) HIP_TRY(hipEventRecord(c->ev[EV_NMID_0], c->cur));
         NUM_FLAT_DISPATCH(true)
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipEventRecord(c->ev[EV_NMID_1], c->cur));
-        if ((rc = join_from(c, NUM2_BIN_MID))) return rc;
+        if (pass == 0) HIP_TRY(hipEventRecord(c->ev[EV_NMID_1], c->cur));
+        if ((rc = join_from(c, bin))) return rc;
     }
 #undef LAUNCH_NUM_FLAT
 #define LAUNCH_MERGE(BIN, PM)                                                                                               \
@@ -739,7 +742,7 @@ int spada_dev_spgemm_symbolic(spada_ctx *c, const spada_dev_csr *a, const spada_
         hipLaunchKernelGGL((k_sym_flat<BL, EP, SYM_FLAT_LOG_T, SF_RMAX, LS>), dim3(flat_grid(sf_batches, lds)), dim3(BL), lds,    \
                            c->cur, a->ptr, b->idx, c->eb0.as<uint64_t>(), c->elen.as<uint32_t>(), c->r0, n,                   \
                            c->row_bin.as<uint8_t>(), c->batch_sym.as<uint32_t>(), sf_nb, c->colbits,                         \
-                           c->row_nnzc.as<uint32_t>(), sf_list, sf_bin, sf_dbg);                                             \
+                           c->row_nnzc.as<uint32_t>(), sf_list, sf_bin, sf_rpb, sf_dbg);                                             \
     }
 #ifndef SPADA_SF_LARGE   /* default: 256-thread workgroups, 4096-key tables (A/B: -17..21 % symbolic time) */
 #define SYM_FLAT_DISPATCH(LS) LAUNCH_SYM_FLAT(256, 2, LS)
@@ -753,7 +756,7 @@ int spada_dev_spgemm_symbolic(spada_ctx *c, const spada_dev_csr *a, const spada_
             {
                 const uint64_t sf_batches = nb_upper;
                 const uint32_t *sf_nb = &dc->nb_sym, *sf_list = nullptr;
-                const uint32_t sf_bin = BIN_FLAT;
+                const uint32_t sf_bin = BIN_FLAT, sf_rpb = 1;
                 unsigned long long *sf_dbg = c->dbg_g == 2 ? c->dbg.as<unsigned long long>() : nullptr;
                 SYM_FLAT_DISPATCH(false)
             }
@@ -761,15 +764,18 @@ int spada_dev_spgemm_symbolic(spada_ctx *c, const spada_dev_csr *a, const spada_
             HIP_TRY(hipGetLastError());
             if ((rc = join_from(c, BIN_FLAT))) return rc;
         }
-        if (cnt[SYM2_BIN_MID]) {   // one row per batch from the bin's row list
-            if ((rc = fork_to(c, SYM2_BIN_MID))) return rc;
-            const uint64_t sf_batches = cnt[SYM2_BIN_MID];
-            const uint32_t *sf_nb = &dc->sym_counts[SYM2_BIN_MID], *sf_list = c->sym_rows.as<uint32_t>() + off[SYM2_BIN_MID];
-            const uint32_t sf_bin = SYM2_BIN_MID;
+        for (int pass = 0; pass < 2; ++pass) {   // mid rows from their row lists: one row per batch, or two of the lower half
+            const int bin = pass == 0 ? SYM2_BIN_MID : SYM2_BIN_MID2;
+            if (!cnt[bin]) continue;
+            if ((rc = fork_to(c, bin))) return rc;
+            const uint32_t sf_rpb = pass == 0 ? 1 : 2;
+            const uint64_t sf_batches = (cnt[bin] + sf_rpb - 1) / sf_rpb;
+            const uint32_t *sf_nb = &dc->sym_counts[bin], *sf_list = c->sym_rows.as<uint32_t>() + off[bin];
+            const uint32_t sf_bin = (uint32_t)bin;
             unsigned long long *sf_dbg = nullptr;
             SYM_FLAT_DISPATCH(true)
             HIP_TRY(hipGetLastError());
-            if ((rc = join_from(c, SYM2_BIN_MID))) return rc;
+            if ((rc = join_from(c, bin))) return rc;
         }
 #undef LAUNCH_SYM_FLAT
     }

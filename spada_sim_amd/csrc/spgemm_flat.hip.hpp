@@ -21,9 +21,10 @@ namespace spada {
 // numeric : 0 empty | 1 copy | 2 flat (n <= num_flat_max) | 3 n <= 2048 and P <= 16384 (k_num_hash<256,12>)
 //           4 n <= 6144 (k_num_hash<1024,13>) | 5 LDS bitmap with LDS values (n <= vcap) | 6 bitmap / spill
 constexpr int BIN_EMPTY = 0, BIN_COPY = 1, BIN_FLAT = 2;
-constexpr int SYM2_BIN_8K = 3, SYM2_BIN_24K = 4, SYM2_BIN_SPILL = 5, SYM2_BIN_MID = 6;
+constexpr int SYM2_BIN_8K = 3, SYM2_BIN_24K = 4, SYM2_BIN_SPILL = 5, SYM2_BIN_MID = 6, SYM2_BIN_MID2 = 7;
 constexpr int NUM2_BIN_2K = 3, NUM2_BIN_6K = 4, NUM2_BIN_BMV = 5, NUM2_BIN_SPILL = 6, NUM2_BIN_MID = 7;
 constexpr int NUM2_BIN_MERGE_S = 8, NUM2_BIN_MERGE_L = 9;   // multiway merge, <= 512 / <= 1024 products
+constexpr int NUM2_BIN_MID2 = 10;   // lower half of the mid class: two rows per list-mode batch
 constexpr uint32_t MERGE_LMAX = 8, MERGE_PMIN = 96;
 // "mid" rows: too large for a shared batch, small enough for the flat kernels' table -- one row per batch, taken
 // from the bin's row list (list mode of k_sym_flat / k_num_flat)
@@ -51,6 +52,7 @@ __host__ __device__ inline int sym2_bin_of(uint64_t P, uint32_t L)
     if (P == 0) return BIN_EMPTY;
     if (L == 1) return BIN_COPY;
     if (P <= SYM_FLAT_MAX) return BIN_FLAT;
+    if (P <= SYM_MID_MAX / 2) return SYM2_BIN_MID2;   // any two of them fit one table
     if (P <= SYM_MID_MAX) return SYM2_BIN_MID;
     if (P <= 8192) return SYM2_BIN_8K;
     if (P <= 24576) return SYM2_BIN_24K;
@@ -65,6 +67,7 @@ __host__ __device__ inline int num2_bin_of(uint32_t n, uint64_t P, uint32_t L, u
     if (L == 1) return BIN_COPY;
     if (merge_pmax && L <= MERGE_LMAX && P >= MERGE_PMIN && P <= merge_pmax) return P <= 512 ? NUM2_BIN_MERGE_S : NUM2_BIN_MERGE_L;
     if (sm_pmax ? P <= sm_pmax : (n <= flat_max && P <= (1u << 22))) return BIN_FLAT;
+    if (flat_max && n <= NUM_MID_MAX / 2 && P <= (1u << 22)) return NUM2_BIN_MID2;   // any two of them fit one table
     if (flat_max && n <= NUM_MID_MAX && P <= (1u << 22)) return NUM2_BIN_MID;
     if (n <= 2048 && P <= 16384) return NUM2_BIN_2K;
     if (n <= 6144) return NUM2_BIN_6K;
@@ -175,7 +178,7 @@ __global__ __launch_bounds__(256) void k_row_stats2(const uint64_t *__restrict__
         }
         if (i < nrows) {
             int bin = sym2_bin_of(P, L);
-            if ((bin == BIN_FLAT || bin == SYM2_BIN_MID) && !flat_on) bin = SYM2_BIN_8K;
+            if ((bin == BIN_FLAT || bin == SYM2_BIN_MID || bin == SYM2_BIN_MID2) && !flat_on) bin = SYM2_BIN_8K;
             row_nprod[i] = P > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)P;
             row_bin[i] = (uint8_t)bin;
             row_kmin[i] = kmin;
@@ -696,11 +699,11 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void k_sym_flat(const uint64_t 
                                                     uint64_t r0, uint32_t nrows, const uint8_t *__restrict__ row_bin,
                                                     const uint32_t *__restrict__ batch_first, const uint32_t *__restrict__ nb_ptr,
                                                     uint32_t colbits, uint32_t *__restrict__ row_nnzc,
-                                                    const uint32_t *__restrict__ list, uint32_t want_bin,
+                                                    const uint32_t *__restrict__ list, uint32_t want_bin, uint32_t rpb,
                                                     unsigned long long *dbg = nullptr)
 {
 #define SSTAMP(i) do { if (dbg && threadIdx.x == 0 && b % 64 == 0 && b / 64 < 64) dbg[(b / 64) * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
-    // LIST = false: batches of consecutive rows (batch_first); LIST = true: one row of `list` per batch
+    // LIST = false: batches of consecutive rows (batch_first); LIST = true: `rpb` consecutive rows of `list` per batch
     static_assert(RMAX <= BLOCK, "one thread per row of a batch");
     constexpr int T = 1 << LOG_T;
     constexpr int U = SPADA_FLAT_U;
@@ -712,62 +715,29 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void k_sym_flat(const uint64_t 
     uint64_t *s_a0 = (uint64_t *)(((uintptr_t)(s_cnt + RMAX) + 7) & ~(uintptr_t)7);
     unsigned char *scratch = (unsigned char *)(s_a0 + RMAX);
     const int tid = threadIdx.x, lane = tid & 63;
-    const uint32_t nb = *nb_ptr, G = gridDim.x;
-    // two-level prefetch: while batch b is processed, the rows of batch b + G and the bounds of batch b + 2G load
-    struct Rows {
-        uint64_t a0, a1;
-        uint32_t bin;
-    };
-    auto load_desc = [&](uint32_t bb, uint32_t &rb_, uint32_t &re_) {
-        rb_ = re_ = 0;
-        if (bb < nb) {
-            if constexpr (LIST) {
-                rb_ = list[bb];
-                re_ = rb_ + 1;
-            } else {
-                rb_ = batch_first[bb];
-                re_ = bb + 1 < nb ? batch_first[bb + 1] : nrows;
-            }
-        }
-    };
-    auto load_rows = [&](uint32_t rb_, uint32_t re_, Rows &rw) {
-        rw = Rows{0, 0, BIN_EMPTY};
-        if ((uint32_t)tid < re_ - rb_) {
-            rw.a0 = aptr[r0 + rb_ + tid];
-            rw.a1 = aptr[r0 + rb_ + tid + 1];
-            rw.bin = row_bin[rb_ + tid];
-        }
-    };
-    uint32_t rb, re, nrb, nre;
-    Rows cur, nxt;
-    load_desc(blockIdx.x, rb, re);
-    load_rows(rb, re, cur);
-    load_desc(blockIdx.x + G, nrb, nre);
-    uint32_t n2rb = 0, n2re = 0;
+    const uint32_t nl = *nb_ptr, G = gridDim.x;
+    const uint32_t nb = LIST ? (nl + rpb - 1) / rpb : nl;   // LIST: nl rows in the list, rpb of them per batch
     for (uint32_t b = blockIdx.x; b < nb; b += G) {
-        if (b != blockIdx.x) {   // rotate: next -> current, next-next -> next
-            cur = nxt;
-            rb = nrb;
-            re = nre;
-            nrb = n2rb;
-            nre = n2re;
-        }
-        if (SPADA_FLAT_PREFETCH) {
-            load_rows(nrb, nre, nxt);
-            load_desc(b + 2 * G, n2rb, n2re);
-        } else {   // A/B switch: load this batch's rows on demand
-            load_desc(b, rb, re);
-            load_rows(rb, re, cur);
+        uint32_t rb, re;   // rows [rb, re) of the matrix, or positions [rb, re) of the list
+        if constexpr (LIST) {
+            rb = b * rpb;
+            re = min(rb + rpb, nl);
+        } else {
+            rb = batch_first[b];
+            re = b + 1 < nb ? batch_first[b + 1] : nrows;
         }
         const uint32_t R = re - rb;   // <= RMAX by construction of the cut
         if (R == 0) continue;
         SSTAMP(0);
-        uint32_t L = 0;
-        const bool flat = (uint32_t)tid < R && cur.bin == want_bin;
+        uint32_t L = 0, rid = 0;
+        bool flat = false;
         if ((uint32_t)tid < R) {
-            s_a0[tid] = cur.a0;
+            rid = LIST ? list[rb + tid] : rb + tid;
+            const uint64_t a0 = aptr[r0 + rid], a1 = aptr[r0 + rid + 1];
+            flat = row_bin[rid] == want_bin;
+            s_a0[tid] = a0;
             s_cnt[tid] = 0;
-            if (flat) L = (uint32_t)(cur.a1 - cur.a0);
+            if (flat) L = (uint32_t)(a1 - a0);
         }
         uint32_t E;
         const uint32_t ex = group_scan_excl<BLOCK>(L, tid, hdr + 2, &E);
@@ -803,7 +773,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void k_sym_flat(const uint64_t 
                 }
             }, (dbg && b % 64 == 0 && b / 64 < 64) ? dbg + (b / 64) * 16 + 8 : nullptr);
         SSTAMP(2);
-        if (flat) row_nnzc[rb + tid] = s_cnt[tid];
+        if (flat) row_nnzc[rid] = s_cnt[tid];
         __syncthreads();
         SSTAMP(3);
     }
@@ -836,7 +806,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void k_num_flat(const uint64_t 
                                                     const uint32_t *__restrict__ nb_ptr, uint32_t colbits,
                                                     uint32_t *__restrict__ c_idx, double *__restrict__ c_val,
                                                     unsigned long long *dbg, const uint32_t *__restrict__ list,
-                                                    uint32_t want_bin)
+                                                    uint32_t want_bin, uint32_t rpb)
 {
 #define STAMP(i) do { if (dbg && threadIdx.x == 0 && b % 64 == 0 && b / 64 < 64) dbg[(b / 64) * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
     static_assert(RMAX <= BLOCK, "one thread per row of a batch");
@@ -859,71 +829,34 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void k_num_flat(const uint64_t 
     uint64_t *s_out = s_a0 + RMAX;
     uint32_t *s_re = (uint32_t *)(s_out + RMAX);
     const int tid = threadIdx.x;
-    const uint32_t nb = *nb_ptr, G = gridDim.x;
+    const uint32_t nl = *nb_ptr, G = gridDim.x;
+    const uint32_t nb = LIST ? (nl + rpb - 1) / rpb : nl;   // LIST: nl rows in the list, rpb of them per batch
     const uint32_t colmask = colbits >= 32 ? 0xFFFFFFFFu : ((1u << colbits) - 1u);
-    // two-level prefetch: while batch b is processed, the rows of batch b + G and the bounds of batch b + 2G load
-    struct Rows {
-        uint64_t a0, a1, c0, c1;
-        uint32_t kmin, kmax, bin;
-    };
-    auto load_desc = [&](uint32_t bb, uint32_t &rb_, uint32_t &re_) {
-        rb_ = re_ = 0;
-        if (bb < nb) {
-            if constexpr (LIST) {
-                rb_ = list[bb];
-                re_ = rb_ + 1;
-            } else {
-                rb_ = batch_first[bb];
-                re_ = bb + 1 < nb ? batch_first[bb + 1] : nrows;
-            }
-        }
-    };
-    auto load_rows = [&](uint32_t rb_, uint32_t re_, Rows &rw) {
-        rw = Rows{0, 0, 0, 0, 0, 0, BIN_EMPTY};
-        if ((uint32_t)tid < re_ - rb_) {
-            rw.a0 = aptr[r0 + rb_ + tid];
-            rw.a1 = aptr[r0 + rb_ + tid + 1];
-            rw.c0 = cptr[rb_ + tid];
-            rw.c1 = cptr[rb_ + tid + 1];
-            rw.kmin = row_kmin[rb_ + tid];
-            rw.kmax = row_kmax[rb_ + tid];
-            rw.bin = row_bin[rb_ + tid];
-        }
-    };
-    uint32_t rb, re, nrb, nre;
-    Rows cur, nxt;
-    load_desc(blockIdx.x, rb, re);
-    load_rows(rb, re, cur);
-    load_desc(blockIdx.x + G, nrb, nre);
 
-    uint32_t n2rb = 0, n2re = 0;
     for (uint32_t b = blockIdx.x; b < nb; b += G) {
-        if (b != blockIdx.x) {   // rotate: next -> current, next-next -> next
-            cur = nxt;
-            rb = nrb;
-            re = nre;
-            nrb = n2rb;
-            nre = n2re;
-        }
-        if (SPADA_FLAT_PREFETCH) {
-            load_rows(nrb, nre, nxt);
-            load_desc(b + 2 * G, n2rb, n2re);
-        } else {   // A/B switch: load this batch's rows on demand
-            load_desc(b, rb, re);
-            load_rows(rb, re, cur);
+        uint32_t rb, re;   // rows [rb, re) of the matrix, or positions [rb, re) of the list
+        if constexpr (LIST) {
+            rb = b * rpb;
+            re = min(rb + rpb, nl);
+        } else {
+            rb = batch_first[b];
+            re = b + 1 < nb ? batch_first[b + 1] : nrows;
         }
         const uint32_t R = re - rb;
         if (R == 0) continue;
         STAMP(0);
         uint32_t L = 0, n = 0, kmin = 0, kmax = 0;
         if ((uint32_t)tid < R) {
-            s_a0[tid] = cur.a0;
-            s_out[tid] = cur.c0;
-            if (cur.bin == want_bin) {
-                L = (uint32_t)(cur.a1 - cur.a0);
-                n = (uint32_t)(cur.c1 - cur.c0);
-                kmin = cur.kmin;
-                kmax = cur.kmax;
+            const uint32_t rid = LIST ? list[rb + tid] : rb + tid;
+            const uint64_t a0 = aptr[r0 + rid], a1 = aptr[r0 + rid + 1];
+            const uint64_t c0 = cptr[rid], c1 = cptr[rid + 1];
+            s_a0[tid] = a0;
+            s_out[tid] = c0;
+            if (row_bin[rid] == want_bin) {
+                L = (uint32_t)(a1 - a0);
+                n = (uint32_t)(c1 - c0);
+                kmin = row_kmin[rid];
+                kmax = row_kmax[rid];
             }
         }
         // one packed scan: entries of the flat rows in the low, their outputs in the high 32 bits

@@ -249,8 +249,8 @@ def main():
             rd, wr, ms = 12 * p_ + 28 * e_ + 8 * r_, 12 * n_ + 8 * r_, acc[ms_key] / K
             return {"label": label, "tmpl": tmpl, "ms": ms, "read": rd, "write": wr, "gbs": rd / (ms * 1e-3) / 1e9 if ms > 0 else 0.0,
                     "units": {"rows": r_, "products": p_, "a_entries": e_, "nnz_c": n_}}
-        cands = [launch(2, "ms_num_flat", "shared batches of consecutive rows (nnz(C_i) <= 512)", "false>"),
-                 launch(7, "ms_num_mid", "list mode, one row per batch (768 < nnz(C_i) <= 1536)", "true>")]
+        cands = [launch(2, "ms_num_flat", "shared batches of consecutive rows (nnz(C_i) <= 512)", "false, 1>"),
+                 launch(7, "ms_num_mid", "list mode, one row per batch (768 < nnz(C_i) <= 1536)", "true, 1>")]
         if args.accumulator == "sort_merge":
             cands = cands[:1]
         cands.sort(key=lambda d: -d["read"])

@@ -347,12 +347,12 @@ int run_numeric(spada_ctx *c, uint64_t *d_ptr, uint32_t *d_idx, double *d_val)
             if (cnt[bin]) {
                 if ((rc = fork_to(c, bin))) return rc;
                 constexpr size_t lds = num_flat_lds<1024, 1, 13, 6144, 128>();
-                hipLaunchKernelGGL((k_num_flat<1024, 1, 13, 6144, 128, true>), dim3(flat_grid(cnt[bin], lds)), dim3(1024), lds,
+                hipLaunchKernelGGL((k_num_flat<1024, 1, 13, 6144, 128, true, 1>), dim3(flat_grid(cnt[bin], lds)), dim3(1024), lds,
                                    c->cur, c->A->ptr, c->A->val, c->B->idx, c->B->val, c->eb0.as<uint64_t>(),
                                    c->elen.as<uint32_t>(), c->r0, c->nrows, c->row_bin.as<uint8_t>(),
                                    c->row_kmin.as<uint32_t>(), c->row_kmax.as<uint32_t>(), c->cptr.as<uint64_t>(),
                                    c->batch_num.as<uint32_t>(), &dc->num_counts[bin], c->colbits, d_idx, d_val,
-                                   (unsigned long long *)nullptr, c->num_rows.as<uint32_t>() + off[bin], (uint32_t)bin, 1u);
+                                   (unsigned long long *)nullptr, c->num_rows.as<uint32_t>() + off[bin], (uint32_t)bin);
                 HIP_TRY(hipGetLastError());
                 if ((rc = join_from(c, bin))) return rc;
             }
@@ -375,30 +375,30 @@ int run_numeric(spada_ctx *c, uint64_t *d_ptr, uint32_t *d_idx, double *d_val)
         if ((rc = join_from(c, BIN_FLAT))) return rc;
     } else if (cnt[BIN_FLAT]) {
         if ((rc = fork_to(c, BIN_FLAT))) return rc;
-#define LAUNCH_NUM_FLAT(BL, EP, LS)                                                                                             \
+#define LAUNCH_NUM_FLAT(BL, EP, LS, RP)                                                                                             \
     {                                                                                                                        \
         const size_t lds = num_flat_lds<BL, EP, NF_LOG_T, NF_NOUT, NF_RMAX>() + c->lds_pad;                                  \
-        hipLaunchKernelGGL((k_num_flat<BL, EP, NF_LOG_T, NF_NOUT, NF_RMAX, LS>), dim3(flat_grid(nf_batches, lds)),                \
+        hipLaunchKernelGGL((k_num_flat<BL, EP, NF_LOG_T, NF_NOUT, NF_RMAX, LS, RP>), dim3(flat_grid(nf_batches, lds)),                \
                            dim3(BL), lds, c->cur, c->A->ptr, c->A->val, c->B->idx, c->B->val, c->eb0.as<uint64_t>(),          \
                            c->elen.as<uint32_t>(), c->r0, c->nrows, c->row_bin.as<uint8_t>(), c->row_kmin.as<uint32_t>(),     \
                            c->row_kmax.as<uint32_t>(), c->cptr.as<uint64_t>(), c->batch_num.as<uint32_t>(), nf_nb,            \
-                           c->colbits, d_idx, d_val, nf_dbg, nf_list, nf_bin, nf_rpb);                                               \
+                           c->colbits, d_idx, d_val, nf_dbg, nf_list, nf_bin);                                               \
     }
 #ifndef SPADA_NF_LARGE
-#define NUM_FLAT_DISPATCH(LS) LAUNCH_NUM_FLAT(256, 2, LS)
+#define NUM_FLAT_DISPATCH(LS, RP) LAUNCH_NUM_FLAT(256, 2, LS, RP)
 #else
-#define NUM_FLAT_DISPATCH(LS)                          \
-    if (c->flat_cfg == 0) LAUNCH_NUM_FLAT(256, 4, LS)  \
-    else if (c->flat_cfg == 1) LAUNCH_NUM_FLAT(512, 2, LS) \
-    else LAUNCH_NUM_FLAT(1024, 1, LS)
+#define NUM_FLAT_DISPATCH(LS, RP)                          \
+    if (c->flat_cfg == 0) LAUNCH_NUM_FLAT(256, 4, LS, RP)  \
+    else if (c->flat_cfg == 1) LAUNCH_NUM_FLAT(512, 2, LS, RP) \
+    else LAUNCH_NUM_FLAT(1024, 1, LS, RP)
 #endif
         HIP_TRY(hipEventRecord(c->ev[EV_NFLAT_0], c->cur));
         {
             const uint64_t nf_batches = c->h_counters->nb_num;
             const uint32_t *nf_nb = &dc->nb_num, *nf_list = nullptr;
-            const uint32_t nf_bin = BIN_FLAT, nf_rpb = 1;
+            const uint32_t nf_bin = BIN_FLAT;
             unsigned long long *nf_dbg = c->dbg_g == 1 ? c->dbg.as<unsigned long long>() : nullptr;
-            NUM_FLAT_DISPATCH(false)
+            NUM_FLAT_DISPATCH(false, 1)
         }
         HIP_TRY(hipEventRecord(c->ev[EV_NFLAT_1], c->cur));
         HIP_TRY(hipGetLastError());
@@ -408,13 +408,12 @@ int run_numeric(spada_ctx *c, uint64_t *d_ptr, uint32_t *d_idx, double *d_val)
         const int bin = pass == 0 ? NUM2_BIN_MID : NUM2_BIN_MID2;
         if (!cnt[bin]) continue;
         if ((rc = fork_to(c, bin))) return rc;
-        const uint32_t nf_rpb = pass == 0 ? 1 : 2;
-        const uint64_t nf_batches = (cnt[bin] + nf_rpb - 1) / nf_rpb;
+        const uint64_t nf_batches = (cnt[bin] + pass) / (pass + 1);
         const uint32_t *nf_nb = &dc->num_counts[bin], *nf_list = c->num_rows.as<uint32_t>() + off[bin];
         const uint32_t nf_bin = (uint32_t)bin;
         unsigned long long *nf_dbg = nullptr;
         if (pass == 0) HIP_TRY(hipEventRecord(c->ev[EV_NMID_0], c->cur));
-        NUM_FLAT_DISPATCH(true)
+        if (pass == 0) { NUM_FLAT_DISPATCH(true, 1) } else { NUM_FLAT_DISPATCH(true, 2) }
         HIP_TRY(hipGetLastError());
         if (pass == 0) HIP_TRY(hipEventRecord(c->ev[EV_NMID_1], c->cur));
         if ((rc = join_from(c, bin))) return rc;
@@ -526,14 +525,16 @@ int spada_create(const spada_options *opts, spada_ctx **out)
     if ((rc = allow_lds(k_num_hash<256, 12>, num_lds<256, 12>()))) return rc;
     if ((rc = allow_lds(k_num_hash<1024, 13>, num_lds<1024, 13>()))) return rc;
 #define ALLOW_FLAT(BL, EP)                                                                                                   \
-    if ((rc = allow_lds(k_sym_flat<BL, EP, SYM_FLAT_LOG_T, SF_RMAX, false>, sym_flat_lds<BL, EP, SYM_FLAT_LOG_T, SF_RMAX>()))) return rc; \
-    if ((rc = allow_lds(k_sym_flat<BL, EP, SYM_FLAT_LOG_T, SF_RMAX, true>, sym_flat_lds<BL, EP, SYM_FLAT_LOG_T, SF_RMAX>()))) return rc;
+    if ((rc = allow_lds(k_sym_flat<BL, EP, SYM_FLAT_LOG_T, SF_RMAX, false, 1>, sym_flat_lds<BL, EP, SYM_FLAT_LOG_T, SF_RMAX>()))) return rc; \
+    if ((rc = allow_lds(k_sym_flat<BL, EP, SYM_FLAT_LOG_T, SF_RMAX, true, 1>, sym_flat_lds<BL, EP, SYM_FLAT_LOG_T, SF_RMAX>()))) return rc; \
+    if ((rc = allow_lds(k_sym_flat<BL, EP, SYM_FLAT_LOG_T, SF_RMAX, true, 2>, sym_flat_lds<BL, EP, SYM_FLAT_LOG_T, SF_RMAX>()))) return rc;
 
     SF_CFG_LIST(ALLOW_FLAT)
 #undef ALLOW_FLAT
 #define ALLOW_NFLAT(BL, EP)                                                                                                  \
-    if ((rc = allow_lds(k_num_flat<BL, EP, NF_LOG_T, NF_NOUT, NF_RMAX, false>, LDS_MAX))) return rc; \
-    if ((rc = allow_lds(k_num_flat<BL, EP, NF_LOG_T, NF_NOUT, NF_RMAX, true>, LDS_MAX))) return rc;
+    if ((rc = allow_lds(k_num_flat<BL, EP, NF_LOG_T, NF_NOUT, NF_RMAX, false, 1>, LDS_MAX))) return rc; \
+    if ((rc = allow_lds(k_num_flat<BL, EP, NF_LOG_T, NF_NOUT, NF_RMAX, true, 1>, LDS_MAX))) return rc; \
+    if ((rc = allow_lds(k_num_flat<BL, EP, NF_LOG_T, NF_NOUT, NF_RMAX, true, 2>, LDS_MAX))) return rc;
     NF_CFG_LIST(ALLOW_NFLAT)
 #undef ALLOW_NFLAT
     if ((rc = allow_lds(k_num_sortmerge<1024, 1, SF_RMAX>, num_sm_lds<1024, 1, SF_RMAX>()))) return rc;
@@ -544,7 +545,7 @@ int spada_create(const spada_options *opts, spada_ctx **out)
     if (const char *e = std::getenv("SPADA_MERGE")) c->merge_on = e[0] == '1';
     if ((rc = allow_lds(k_num_merge<512>, 4 * ((num_merge_wave_bytes<512>() + 15) & ~(size_t)15)))) return rc;
     if ((rc = allow_lds(k_num_merge<1024>, 4 * ((num_merge_wave_bytes<1024>() + 15) & ~(size_t)15)))) return rc;
-    if ((rc = allow_lds(k_num_flat<1024, 1, 13, 6144, 128, true>, num_flat_lds<1024, 1, 13, 6144, 128>()))) return rc;
+    if ((rc = allow_lds(k_num_flat<1024, 1, 13, 6144, 128, true, 1>, num_flat_lds<1024, 1, 13, 6144, 128>()))) return rc;
     if ((rc = allow_lds(k_sym_bitmap, LDS_MAX))) return rc;
     if ((rc = allow_lds(k_num_bitmap<true>, LDS_MAX))) return rc;
     if ((rc = allow_lds(k_num_bitmap<false>, LDS_MAX))) return rc;
@@ -736,29 +737,29 @@ int spada_dev_spgemm_symbolic(spada_ctx *c, const spada_dev_csr *a, const spada_
         if (cnt[BIN_FLAT]) {
             if ((rc = fork_to(c, BIN_FLAT))) return rc;
             const uint64_t nb_upper = (nprod + (uint64_t)n * cut_sym.minw) / cut_sym.cap + 1;
-#define LAUNCH_SYM_FLAT(BL, EP, LS)                                                                                             \
+#define LAUNCH_SYM_FLAT(BL, EP, LS, RP)                                                                                             \
     {                                                                                                                        \
         constexpr size_t lds = sym_flat_lds<BL, EP, SYM_FLAT_LOG_T, SF_RMAX>();                                              \
-        hipLaunchKernelGGL((k_sym_flat<BL, EP, SYM_FLAT_LOG_T, SF_RMAX, LS>), dim3(flat_grid(sf_batches, lds)), dim3(BL), lds,    \
+        hipLaunchKernelGGL((k_sym_flat<BL, EP, SYM_FLAT_LOG_T, SF_RMAX, LS, RP>), dim3(flat_grid(sf_batches, lds)), dim3(BL), lds,    \
                            c->cur, a->ptr, b->idx, c->eb0.as<uint64_t>(), c->elen.as<uint32_t>(), c->r0, n,                   \
                            c->row_bin.as<uint8_t>(), c->batch_sym.as<uint32_t>(), sf_nb, c->colbits,                         \
-                           c->row_nnzc.as<uint32_t>(), sf_list, sf_bin, sf_rpb, sf_dbg);                                             \
+                           c->row_nnzc.as<uint32_t>(), sf_list, sf_bin, sf_dbg);                                             \
     }
 #ifndef SPADA_SF_LARGE   /* default: 256-thread workgroups, 4096-key tables (A/B: -17..21 % symbolic time) */
-#define SYM_FLAT_DISPATCH(LS) LAUNCH_SYM_FLAT(256, 2, LS)
+#define SYM_FLAT_DISPATCH(LS, RP) LAUNCH_SYM_FLAT(256, 2, LS, RP)
 #else
-#define SYM_FLAT_DISPATCH(LS)                          \
-    if (c->flat_cfg == 0) LAUNCH_SYM_FLAT(256, 4, LS)  \
-    else if (c->flat_cfg == 1) LAUNCH_SYM_FLAT(512, 2, LS) \
-    else LAUNCH_SYM_FLAT(1024, 1, LS)
+#define SYM_FLAT_DISPATCH(LS, RP)                          \
+    if (c->flat_cfg == 0) LAUNCH_SYM_FLAT(256, 4, LS, RP)  \
+    else if (c->flat_cfg == 1) LAUNCH_SYM_FLAT(512, 2, LS, RP) \
+    else LAUNCH_SYM_FLAT(1024, 1, LS, RP)
 #endif
             HIP_TRY(hipEventRecord(c->ev[EV_SFLAT_0], c->cur));
             {
                 const uint64_t sf_batches = nb_upper;
                 const uint32_t *sf_nb = &dc->nb_sym, *sf_list = nullptr;
-                const uint32_t sf_bin = BIN_FLAT, sf_rpb = 1;
+                const uint32_t sf_bin = BIN_FLAT;
                 unsigned long long *sf_dbg = c->dbg_g == 2 ? c->dbg.as<unsigned long long>() : nullptr;
-                SYM_FLAT_DISPATCH(false)
+                SYM_FLAT_DISPATCH(false, 1)
             }
             HIP_TRY(hipEventRecord(c->ev[EV_SFLAT_1], c->cur));
             HIP_TRY(hipGetLastError());
@@ -768,12 +769,11 @@ int spada_dev_spgemm_symbolic(spada_ctx *c, const spada_dev_csr *a, const spada_
             const int bin = pass == 0 ? SYM2_BIN_MID : SYM2_BIN_MID2;
             if (!cnt[bin]) continue;
             if ((rc = fork_to(c, bin))) return rc;
-            const uint32_t sf_rpb = pass == 0 ? 1 : 2;
-            const uint64_t sf_batches = (cnt[bin] + sf_rpb - 1) / sf_rpb;
+            const uint64_t sf_batches = (cnt[bin] + pass) / (pass + 1);
             const uint32_t *sf_nb = &dc->sym_counts[bin], *sf_list = c->sym_rows.as<uint32_t>() + off[bin];
             const uint32_t sf_bin = (uint32_t)bin;
             unsigned long long *sf_dbg = nullptr;
-            SYM_FLAT_DISPATCH(true)
+            if (pass == 0) { SYM_FLAT_DISPATCH(true, 1) } else { SYM_FLAT_DISPATCH(true, 2) }
             HIP_TRY(hipGetLastError());
             if ((rc = join_from(c, bin))) return rc;
         }

@@ -693,17 +693,17 @@ __host__ __device__ constexpr size_t sym_flat_lds()
            flat_walk_bytes<BLOCK, EPT, false>() + 16;
 }
 
-template <int BLOCK, int EPT, int LOG_T, int RMAX, bool LIST>
+template <int BLOCK, int EPT, int LOG_T, int RMAX, bool LIST, int RPB>
 __global__ __launch_bounds__(BLOCK, BLOCK / 128) void k_sym_flat(const uint64_t *__restrict__ aptr, const uint32_t *__restrict__ bidx,
                                                     const uint64_t *__restrict__ eb0, const uint32_t *__restrict__ elen,
                                                     uint64_t r0, uint32_t nrows, const uint8_t *__restrict__ row_bin,
                                                     const uint32_t *__restrict__ batch_first, const uint32_t *__restrict__ nb_ptr,
                                                     uint32_t colbits, uint32_t *__restrict__ row_nnzc,
-                                                    const uint32_t *__restrict__ list, uint32_t want_bin, uint32_t rpb,
+                                                    const uint32_t *__restrict__ list, uint32_t want_bin,
                                                     unsigned long long *dbg = nullptr)
 {
 #define SSTAMP(i) do { if (dbg && threadIdx.x == 0 && b % 64 == 0 && b / 64 < 64) dbg[(b / 64) * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
-    // LIST = false: batches of consecutive rows (batch_first); LIST = true: `rpb` consecutive rows of `list` per batch
+    // LIST = false: batches of consecutive rows (batch_first); LIST = true: RPB consecutive rows of `list` per batch
     static_assert(RMAX <= BLOCK, "one thread per row of a batch");
     constexpr int T = 1 << LOG_T;
     constexpr int U = SPADA_FLAT_U;
@@ -716,7 +716,8 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void k_sym_flat(const uint64_t 
     unsigned char *scratch = (unsigned char *)(s_a0 + RMAX);
     const int tid = threadIdx.x, lane = tid & 63;
     const uint32_t nl = *nb_ptr, G = gridDim.x;
-    const uint32_t nb = LIST ? (nl + rpb - 1) / rpb : nl;   // LIST: nl rows in the list, rpb of them per batch
+    constexpr uint32_t rpb = RPB;
+    const uint32_t nb = LIST ? (nl + rpb - 1) / rpb : nl;   // LIST: nl rows in the list, RPB of them per batch
     for (uint32_t b = blockIdx.x; b < nb; b += G) {
         uint32_t rb, re;   // rows [rb, re) of the matrix, or positions [rb, re) of the list
         if constexpr (LIST) {
@@ -796,7 +797,7 @@ __host__ __device__ constexpr size_t num_flat_lds()
            (size_t)(RMAX + 1) * 16 + (size_t)RMAX * 16 + 32;
 }
 
-template <int BLOCK, int EPT, int LOG_T, int NOUT, int RMAX, bool LIST>
+template <int BLOCK, int EPT, int LOG_T, int NOUT, int RMAX, bool LIST, int RPB>
 __global__ __launch_bounds__(BLOCK, BLOCK / 128) void k_num_flat(const uint64_t *__restrict__ aptr, const double *__restrict__ aval,
                                                     const uint32_t *__restrict__ bidx, const double *__restrict__ bval,
                                                     const uint64_t *__restrict__ eb0, const uint32_t *__restrict__ elen,
@@ -806,7 +807,7 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void k_num_flat(const uint64_t 
                                                     const uint32_t *__restrict__ nb_ptr, uint32_t colbits,
                                                     uint32_t *__restrict__ c_idx, double *__restrict__ c_val,
                                                     unsigned long long *dbg, const uint32_t *__restrict__ list,
-                                                    uint32_t want_bin, uint32_t rpb)
+                                                    uint32_t want_bin)
 {
 #define STAMP(i) do { if (dbg && threadIdx.x == 0 && b % 64 == 0 && b / 64 < 64) dbg[(b / 64) * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
     static_assert(RMAX <= BLOCK, "one thread per row of a batch");
@@ -830,7 +831,8 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void k_num_flat(const uint64_t 
     uint32_t *s_re = (uint32_t *)(s_out + RMAX);
     const int tid = threadIdx.x;
     const uint32_t nl = *nb_ptr, G = gridDim.x;
-    const uint32_t nb = LIST ? (nl + rpb - 1) / rpb : nl;   // LIST: nl rows in the list, rpb of them per batch
+    constexpr uint32_t rpb = RPB;
+    const uint32_t nb = LIST ? (nl + rpb - 1) / rpb : nl;   // LIST: nl rows in the list, RPB of them per batch
     const uint32_t colmask = colbits >= 32 ? 0xFFFFFFFFu : ((1u << colbits) - 1u);
 
     for (uint32_t b = blockIdx.x; b < nb; b += G) {

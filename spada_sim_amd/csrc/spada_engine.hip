@@ -919,14 +919,7 @@ int spada_spgemm_numeric(spada_ctx *c, uint64_t *c_indptr, uint64_t *c_indices, 
     return spada_dev_download_c(c, dp, di, dv, c->nrows, c->nnz_c, c_indptr, c_indices, c_data);
 }
 
-int spada_debug_buf(spada_ctx *c, int which, void *out, uint64_t bytes)
-{
-    if (!c) return fail(SPADA_ERR_STATE, "no ctx");
-    DevBuf *b[] = {&c->num_rows, &c->sym_rows, &c->row_bin, &c->elen, &c->row_nnzc, &c->batch_num, &c->batch_sym, &c->cptr, &c->row_kmin, &c->row_kmax};
-    HIP_TRY(hipMemcpy(out, b[which]->p, bytes, hipMemcpyDeviceToHost));
-    return SPADA_OK;
-}
-
+// development aid (scripts/phase_timing.py): s_memtime stamps written by the kernels when SPADA_DBG_G is set
 int spada_debug_read(spada_ctx *c, unsigned long long *out, uint64_t n)
 {
     if (!c || !c->dbg.p) return fail(SPADA_ERR_STATE, "no debug buffer");

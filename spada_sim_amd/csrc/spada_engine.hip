@@ -168,7 +168,8 @@ int launch_num(spada_ctx *c, uint32_t off, uint32_t n, uint32_t *c_idx, double *
     const uint32_t grid = (n + RPB - 1) / RPB;
     hipLaunchKernelGGL((k_num_hash<G, LOG_T>), dim3(grid), dim3(BLOCK), (num_lds<G, LOG_T>()), c->cur, c->a_view(),
                        c->B->view(), c->r0, c->num_rows.as<uint32_t>() + off, n, c->cptr.as<uint64_t>(), c_idx, c_val,
-                       (G == c->dbg_g) ? c->dbg.as<unsigned long long>() : nullptr);
+                       (G == c->dbg_g) ? c->dbg.as<unsigned long long>() : nullptr, c->row_kmin.as<uint32_t>(),
+                       c->row_kmax.as<uint32_t>());
     HIP_TRY(hipGetLastError());
     return SPADA_OK;
 }

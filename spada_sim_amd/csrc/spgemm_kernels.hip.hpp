@@ -393,7 +393,9 @@ __global__ __launch_bounds__((G <= 64 ? 256 : G)) void k_num_hash(DevCsrView A, 
                                                                    const uint32_t *__restrict__ bin_rows, uint32_t n_bin_rows,
                                                                    const uint64_t *__restrict__ cptr,
                                                                    uint32_t *__restrict__ c_idx, double *__restrict__ c_val,
-                                                                   unsigned long long *dbg)
+                                                                   unsigned long long *dbg,
+                                                                   const uint32_t *__restrict__ row_kmin,
+                                                                   const uint32_t *__restrict__ row_kmax)
 {
 #define STAMP(i) do { if (dbg && threadIdx.x == 0 && blockIdx.x % 16 == 0 && blockIdx.x / 16 < 64) dbg[(blockIdx.x / 16) * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
     STAMP(0);
@@ -440,17 +442,10 @@ __global__ __launch_bounds__((G <= 64 ? 256 : G)) void k_num_hash(DevCsrView A, 
     // each lane keeps its T/G table keys in registers for the three passes over the table
     constexpr int SPL = T / G;
     uint32_t myk[SPL];
-    uint32_t kmin = 0xFFFFFFFFu, kmax = 0;
 #pragma unroll
-    for (int i = 0; i < SPL; ++i) {
-        myk[i] = keys[gl + i * G];
-        if (myk[i] != EMPTY_KEY) {
-            kmin = min(kmin, myk[i]);
-            kmax = max(kmax, myk[i]);
-        }
-    }
-    kmin = group_min<G>(kmin, hdr);
-    kmax = group_max<G>(kmax, hdr + 1);
+    for (int i = 0; i < SPL; ++i) myk[i] = keys[gl + i * G];
+    // smallest / largest column of the row = first / last column of the selected B rows (k_row_stats2): no reduction
+    const uint32_t kmin = active ? row_kmin[row] : 0xFFFFFFFFu, kmax = active ? row_kmax[row] : 0u;
     STAMP(3);
     // an inactive group has an empty table (kmin > kmax)
     const float scale = (kmax >= kmin) ? (float)NB / ((float)(kmax - kmin) + 1.0f) : 0.0f;

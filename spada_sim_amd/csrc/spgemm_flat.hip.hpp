@@ -861,17 +861,32 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void k_num_flat(const uint64_t 
                 kmax = row_kmax[rid];
             }
         }
-        // one packed scan: entries of the flat rows in the low, their outputs in the high 32 bits
-        unsigned long long tot64;
-        const unsigned long long ex64 = group_scan_excl_u64<BLOCK>(((unsigned long long)n << 32) | L, tid,
-                                                                   (unsigned long long *)(hdr + 4), &tot64);
-        const uint32_t E = (uint32_t)tot64, NO = (uint32_t)(tot64 >> 32);
-        const uint32_t exl = (uint32_t)ex64, exn = (uint32_t)(ex64 >> 32);
-        if ((uint32_t)tid < R) {
-            s_re[tid] = exl;
-            s_row[tid] = RowEmit{exn, n, kmin, (float)n / ((float)(kmax - kmin) + 1.0f)};
+        uint32_t E, NO;
+        if constexpr (LIST && RPB == 1) {
+            // a single row: no scan, thread 0 publishes its two totals through the header
+            if (tid == 0) {
+                s_re[0] = 0;
+                s_re[1] = L;
+                s_row[0] = RowEmit{0u, n, kmin, (float)n / ((float)(kmax - kmin) + 1.0f)};
+                hdr[40] = L;
+                hdr[41] = n;
+            }
+        } else {
+            // one packed scan: entries of the flat rows in the low, their outputs in the high 32 bits
+            unsigned long long tot64;
+            const unsigned long long ex64 = group_scan_excl_u64<BLOCK>(((unsigned long long)n << 32) | L, tid,
+                                                                       (unsigned long long *)(hdr + 4), &tot64);
+            const uint32_t exl = (uint32_t)ex64, exn = (uint32_t)(ex64 >> 32);
+            if ((uint32_t)tid < R) {
+                s_re[tid] = exl;
+                s_row[tid] = RowEmit{exn, n, kmin, (float)n / ((float)(kmax - kmin) + 1.0f)};
+            }
+            if (tid == 0) {
+                s_re[R] = (uint32_t)tot64;
+                hdr[40] = (uint32_t)tot64;
+                hdr[41] = (uint32_t)(tot64 >> 32);
+            }
         }
-        if (tid == 0) s_re[R] = E;
         {
             uint4 *k4 = (uint4 *)keys;
             for (int s = tid; s < T / 4; s += BLOCK) k4[s] = make_uint4(EMPTY_KEY, EMPTY_KEY, EMPTY_KEY, EMPTY_KEY);
@@ -879,6 +894,8 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void k_num_flat(const uint64_t 
             for (int s = tid; s < T / 2; s += BLOCK) v2[s] = make_double2(0.0, 0.0);
         }
         __syncthreads();
+        E = hdr[40];
+        NO = hdr[41];
         STAMP(1);
 
         // ---- expand - scale - accumulate --------------------------------------------------------------------

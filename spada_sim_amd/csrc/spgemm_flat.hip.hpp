@@ -1050,9 +1050,9 @@ __global__ __launch_bounds__(BLOCK, BLOCK / 128) void k_num_flat(const uint64_t 
 // ---- 6b. numeric, rows with a single A nonzero: C row = a * B row (already ascending) ---------------------------------
 // Matrix order, one lane per row: the row pointers, bins and C offsets of 64 consecutive rows are three coalesced
 // loads, the (descriptor, value) of the single A entry one gather.  Short B rows are copied by their own lane
-// (independent iterations, 4 in flight); rows longer than COPY_SHORT are handed to the whole wave one after the
+// (independent iterations, 4 in flight); rows longer than COPY_SHORT (A/B: 8 beats 24 and 64) are handed to the whole wave one after the
 // other, 64 entries per step.
-constexpr uint32_t COPY_SHORT = 24;
+constexpr uint32_t COPY_SHORT = 8;
 __global__ __launch_bounds__(256) void k_num_copy2(const uint64_t *__restrict__ aptr, const double *__restrict__ aval,
                                                    const uint32_t *__restrict__ bidx, const double *__restrict__ bval,
                                                    const uint64_t *__restrict__ eb0, const uint32_t *__restrict__ elen,

@@ -333,3 +333,23 @@ def test_random_parity_sweep(engine, engine_sm, seed):
     ref = oracle.spgemm_sortmerge(ao, bo)
     for e in (engine, engine_sm):
         assert_parity(e.spgemm(a, b), ref, ao, bo, RTOL)
+
+
+@pytest.mark.parametrize("kind,name", [(1, "webbase-1M surrogate"), (2, "cop20k_A surrogate"), (4, "mc2depi surrogate")])
+def test_bench_workloads_at_full_size(engine, kind, name):
+    """The workloads bench.py times, at BASELINE.json's full sizes, against the oracle (structure bit-exact, values within
+    1e-9): 67 M / 29 M / 5 M nnz(C).  The oracle's OpenMP SPA variant finishes them in seconds."""
+    import spada_sim_amd as S
+    seeds = {1: 12347, 2: 12346, 4: 12349}
+    m = S.generate(kind, 0, 0, seeds[kind])
+    d = engine.upload(m)
+    nnz = engine.symbolic(d, d, 0, m.shape[0])
+    p, i, v = engine.numeric_owned()
+    c = engine.download(p, i, v, m.shape[0], nnz, m.shape[1])
+    engine.free(d)
+    ao = to_oracle(m)
+    ref = oracle.spgemm_spa(ao, ao)
+    assert nnz == ref.nnz
+    assert np.array_equal(c.indptr, ref.indptr)
+    assert np.array_equal(c.indices, ref.indices)
+    assert np.all(np.abs(c.data - ref.data) <= RTOL * np.abs(ref.data))

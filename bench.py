@@ -192,10 +192,12 @@ def main():
             st = dict(agg)
             st.update(tms)
             return st, nnz, None
+        c_ptr = torch.empty(r1 - r0 + 1, dtype=torch.int64, device=dev)       # size known before the symbolic phase
         nnz = eng.symbolic(da, da, r0, r1)
-        c_ptr = torch.empty(r1 - r0 + 1, dtype=torch.int64, device=dev)
-        c_idx = torch.empty(max(nnz, 1), dtype=torch.int32, device=dev)
-        c_val = torch.empty(max(nnz, 1), dtype=torch.float64, device=dev)
+        # C's values and column indices: one allocation (values first: 8-byte aligned), sized by the symbolic result
+        buf = torch.empty(max(nnz, 1) * 12, dtype=torch.uint8, device=dev)
+        c_val = buf[:max(nnz, 1) * 8].view(torch.float64)
+        c_idx = buf[max(nnz, 1) * 8:].view(torch.int32)
         eng.numeric(c_ptr.data_ptr(), c_idx.data_ptr(), c_val.data_ptr())     # returns after its stream has drained
         st = eng.stats()
         if world > 1:

@@ -187,28 +187,51 @@ static void gen_uniform(uint64_t n, uint64_t k, uint64_t seed, spada_host_csr &o
 // 4700), pages grouped into sites whose members link to the site's first pages (shared navigation
 // targets), the rest of the links go to hubs drawn Zipf(0.8) from the 100 000 pages with the largest
 // noisy out-degree (hubs are both popular and link-rich, which is what makes A*A expensive).
+// Web-crawl surrogate (SURVEY 8d "webbase-like"), calibrated to the literature counts of webbase-1M within 5 %
+// (nnz 3.11 M, 69.5 M products, nnz(C) 51.1 M: tests/test_host_cpu.py).  Pages are grouped into sites (consecutive
+// indices, geometric length, mean 64).  The out-degree of a page is  site richness (Zipf 2.2: few link-rich sites)
+// x position factor (the first pages of a site are its index pages) x lognormal page noise,  so link-rich pages
+// cluster.  90 % of the links are site-local, towards the site's first pages (shared navigation targets); the rest go
+// to hubs (Zipf 0.87 over the 100 000 pages with the largest noisy out-degree).  Two things give A*A the output
+// overlap real crawls have (compression 1.36): 30 % of the hub links of a page come, in order, from a list shared by
+// its whole site, and a hub link is followed by a short run of links to the pages next to the hub (same site, same
+// list), so one row selects several B rows with largely equal link sets.
 static void gen_webbase_like(uint64_t n, uint64_t nnz_target, uint64_t seed, spada_host_csr &out)
 {
     if (n == 0) n = 1000005;
     if (nnz_target == 0) nnz_target = 3105536;
     const uint64_t dmax = std::min<uint64_t>(4700, n);
-    ZipfTable degz(dmax, 2.1);
-    std::vector<uint32_t> deg(n);
-    std::vector<double> key(n);
-    uint64_t total = 0;
+    const double p_local = 0.9, p_tmpl = 0.3, p_run = 0.3;
+    std::vector<uint64_t> site_start(n), site_end(n);
+    std::vector<uint32_t> site_id(n);
+    std::vector<double> rich;
+    {
+        Rng r(seed ^ 0x3333, 0);
+        const ZipfTable richz(2000, 2.2);
+        uint64_t s0 = 0;
+        while (s0 < n) {
+            uint64_t len = r.geometric(1.0 / 64.0), s1 = std::min(n, s0 + len);
+            for (uint64_t i = s0; i < s1; ++i) { site_start[i] = s0; site_end[i] = s1; site_id[i] = (uint32_t)rich.size(); }
+            rich.push_back((double)richz.sample(r.uniform()));
+            s0 = s1;
+        }
+    }
+    std::vector<double> raw(n), key(n);
+    double total_raw = 0;
     for (uint64_t i = 0; i < n; ++i) {
         Rng r(seed ^ 0x1111, i);
-        deg[i] = (uint32_t)degz.sample(r.uniform());
-        key[i] = std::log((double)deg[i]) + 2.0 * r.normal();
-        total += deg[i];
+        raw[i] = std::exp(0.5 * r.normal()) * rich[site_id[i]] * (1.0 + 3.0 * std::exp(-(double)(i - site_start[i]) / 3.0));
+        key[i] = std::log(raw[i]) + 2.0 * r.normal();
+        total_raw += raw[i];
     }
-    // scale degrees so that the raw edge count is ~1.18 x the target (duplicates shrink it again)
-    const double scale = 1.18 * (double)nnz_target / (double)total;
-    total = 0;
+    // the raw edge count exceeds the target by the share duplicate links remove again
+    const double scale = 1.77 * (double)nnz_target / total_raw;
+    std::vector<uint32_t> deg(n);
+    uint64_t total = 0;
     for (uint64_t i = 0; i < n; ++i) {
-        double d = deg[i] * scale;
+        double d = raw[i] * scale;
         Rng r(seed ^ 0x2222, i);
-        uint32_t di = (uint32_t)d;
+        uint32_t di = (uint32_t)std::min<double>(d, (double)dmax);
         if (r.uniform() < d - di) ++di;
         deg[i] = std::max<uint32_t>(1, std::min<uint32_t>(di, (uint32_t)dmax));
         total += deg[i];
@@ -219,30 +242,31 @@ static void gen_webbase_like(uint64_t n, uint64_t nnz_target, uint64_t seed, spa
         return key[x] != key[y] ? key[x] > key[y] : x < y;
     });
     const uint64_t H = std::min<uint64_t>(100000, n);
-    ZipfTable hubz(H, 0.8);
-    // site boundaries
-    std::vector<uint64_t> site_start(n), site_end(n);
-    {
-        Rng r(seed ^ 0x3333, 0);
-        uint64_t s0 = 0;
-        while (s0 < n) {
-            uint64_t len = r.geometric(1.0 / 64.0), s1 = std::min(n, s0 + len);
-            for (uint64_t i = s0; i < s1; ++i) { site_start[i] = s0; site_end[i] = s1; }
-            s0 = s1;
-        }
-    }
+    ZipfTable hubz(H, 0.87);
     std::vector<uint64_t> ri(total), ci(total), off(n + 1, 0);
     std::vector<double> vv(total);
     for (uint64_t i = 0; i < n; ++i) off[i + 1] = off[i] + deg[i];
 #pragma omp parallel for schedule(dynamic, 1024)
     for (uint64_t i = 0; i < n; ++i) {
         Rng r(seed ^ 0x4444, i);
+        uint64_t tmpl_used = 0, run_next = 0;
+        bool in_run = false;
         for (uint64_t t = 0; t < deg[i]; ++t) {
             uint64_t e = off[i] + t, j;
-            if (r.uniform() < 0.75) {
+            if (in_run && run_next < n && r.uniform() < p_run) {
+                j = run_next++;                                   // next page of the hub's site
+            } else if (r.uniform() < p_local) {
                 j = std::min(site_start[i] + r.geometric(1.0 / 6.0) - 1, site_end[i] - 1);
+                in_run = false;
             } else {
-                j = order[hubz.sample(r.uniform()) - 1];
+                if (r.uniform() < p_tmpl) {                       // the site's shared link list, in order
+                    Rng rt(seed ^ 0x7777, ((uint64_t)site_id[i] << 20) + tmpl_used++);
+                    j = order[hubz.sample(rt.uniform()) - 1];
+                } else {
+                    j = order[hubz.sample(r.uniform()) - 1];
+                }
+                in_run = true;
+                run_next = j + 1;
             }
             ri[e] = i;
             ci[e] = j;
@@ -252,52 +276,78 @@ static void gen_webbase_like(uint64_t n, uint64_t nnz_target, uint64_t seed, spa
     coo_to_csr(n, n, ri, ci, vv, out);
 }
 
-// FEM-like symmetric surrogate (cop20k_A): diagonal + geometric band offsets, mirrored.
+// FEM-like symmetric surrogate (cop20k_A): nodes of a 3-D grid, every node has a weight (lognormal: refined and coarse
+// regions), an undirected edge to a node of the 26-neighbourhood exists with probability p1 * w_i * w_j, to a node of the
+// second ring (|d| <= 2) with p2 * w_i * w_j.  Neighbours of neighbours overlap heavily, which is what gives the real
+// matrix its compression of 4.3 in A*A.
 static void gen_cop20k_like(uint64_t n, uint64_t seed, spada_host_csr &out)
 {
     if (n == 0) n = 121192;
+    const uint64_t nx = 46, ny = 52;   // x fastest; 46 * 52 * 51 >= 121192
+    const double p1 = 0.62, p2 = 0.0225, wsig = 0.85;
+    std::vector<double> w(n);
+    for (uint64_t i = 0; i < n; ++i) {
+        // weights vary smoothly in space: one draw per 4 x 4 x 4 cell
+        const uint64_t x = i % nx, y = (i / nx) % ny, z = i / (nx * ny);
+        Rng r(seed ^ 0x6666, ((z / 4) << 40) | ((y / 4) << 20) | (x / 4));
+        w[i] = std::exp(wsig * r.normal());
+    }
     std::vector<uint64_t> ri, ci;
     std::vector<double> vv;
-    ri.reserve(n * 23);
-    ci.reserve(n * 23);
-    vv.reserve(n * 23);
+    ri.reserve(n * 24);
+    ci.reserve(n * 24);
+    vv.reserve(n * 24);
     for (uint64_t i = 0; i < n; ++i) {
-        Rng r(seed, i);
-        ri.push_back(i); ci.push_back(i); vv.push_back(r.value());
-        uint64_t k = 6 + r.below(10);   // ~10.35 lower-triangle entries on average
-        for (uint64_t t = 0; t < k; ++t) {
-            uint64_t d = r.geometric(1.0 / 48.0);
-            if (d > i) continue;
-            double v = r.value();
-            ri.push_back(i); ci.push_back(i - d); vv.push_back(v);
-            ri.push_back(i - d); ci.push_back(i); vv.push_back(v);
+        const int64_t x = (int64_t)(i % nx), y = (int64_t)((i / nx) % ny), z = (int64_t)(i / (nx * ny));
+        {
+            Rng r(seed, i);
+            ri.push_back(i); ci.push_back(i); vv.push_back(r.value());
         }
+        for (int64_t dz = -2; dz <= 2; ++dz)
+            for (int64_t dy = -2; dy <= 2; ++dy)
+                for (int64_t dx = -2; dx <= 2; ++dx) {
+                    if (!dx && !dy && !dz) continue;
+                    const int64_t xx = x + dx, yy = y + dy, zz = z + dz;
+                    if (xx < 0 || yy < 0 || zz < 0 || xx >= (int64_t)nx || yy >= (int64_t)ny) continue;
+                    const uint64_t j = (uint64_t)zz * nx * ny + (uint64_t)yy * nx + (uint64_t)xx;
+                    if (j >= n || j < i) continue;   // every undirected edge is decided once, by its lower end
+                    const bool ring1 = dx >= -1 && dx <= 1 && dy >= -1 && dy <= 1 && dz >= -1 && dz <= 1;
+                    Rng r(seed ^ 0x8888, i * 125 + (uint64_t)((dz + 2) * 25 + (dy + 2) * 5 + (dx + 2)));
+                    if (r.uniform() >= (ring1 ? p1 : p2) * w[i] * w[j]) continue;
+                    const double v = r.value();
+                    ri.push_back(i); ci.push_back(j); vv.push_back(v);
+                    ri.push_back(j); ci.push_back(i); vv.push_back(v);
+                }
     }
     coo_to_csr(n, n, ri, ci, vv, out);
 }
 
-// cage12-like: near-uniform row length (~15.6), offsets picked from a pool of 20 fixed strides
-// inside a +-n/50 locality radius.
+// cage12-like: the column offsets of a row are drawn (without replacement, each with probability q_i) from a fixed
+// two-generator lattice { x * d1 + y * d2 : |x| <= 3, |y| <= 2 } inside a +-n/50 locality radius -- sums of two
+// offsets fall on the (13 x 9)-point lattice again, so A*A has ~117 entries per row from ~260 products, like the
+// real matrix (compression 2.3).
 static void gen_cage12_like(uint64_t n, uint64_t seed, spada_host_csr &out)
 {
     if (n == 0) n = 130228;
-    const int64_t radius = std::max<int64_t>(1, (int64_t)(n / 50));
-    int64_t pool[20];
-    {
-        Rng r(seed ^ 0x5555, 0);
-        for (auto &p : pool) p = (int64_t)r.below(2 * radius + 1) - radius;
-    }
+    const int64_t d1 = std::max<int64_t>(1, (int64_t)(n / 3500)), d2 = std::max<int64_t>(2, (int64_t)(n / 160));
+    const double q = 0.226, qsig = 0.4;
     std::vector<uint64_t> ri, ci;
     std::vector<double> vv;
+    ri.reserve(n * 18);
+    ci.reserve(n * 18);
+    vv.reserve(n * 18);
     for (uint64_t i = 0; i < n; ++i) {
         Rng r(seed, i);
         ri.push_back(i); ci.push_back(i); vv.push_back(r.value());
-        uint64_t k = 14 + r.below(3);
-        for (uint64_t t = 0; t < k; ++t) {
-            int64_t j = (int64_t)i + pool[r.below(20)];
-            if (j < 0 || j >= (int64_t)n) continue;
-            ri.push_back(i); ci.push_back((uint64_t)j); vv.push_back(r.value());
-        }
+        const double qi = std::min(1.0, q * std::exp(qsig * r.normal()));
+        for (int64_t yy = -(int64_t)3; yy <= (int64_t)3; ++yy)
+            for (int64_t xx = -(int64_t)4; xx <= (int64_t)4; ++xx) {
+                if (!xx && !yy) continue;
+                const double u = r.uniform(), v = r.value();
+                const int64_t j = (int64_t)i + xx * d1 + yy * d2;
+                if (u >= qi || j < 0 || j >= (int64_t)n) continue;
+                ri.push_back(i); ci.push_back((uint64_t)j); vv.push_back(v);
+            }
     }
     coo_to_csr(n, n, ri, ci, vv, out);
 }

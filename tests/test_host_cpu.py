@@ -148,6 +148,29 @@ def test_generators_are_deterministic_and_canonical():
             assert not np.array_equal(a.indices, c.indices) or not np.array_equal(a.indptr, c.indptr)
 
 
+# literature counts of the SuiteSparse inputs (rows, nnz(A), products, nnz(C))
+LITERATURE = {
+    "webbase-1M": (S.GEN_WEBBASE_LIKE, 12347, 1000005, 3105536, 69.5e6, 51.1e6),
+    "cop20k_A": (S.GEN_COP20K_LIKE, 12346, 121192, 2624331, 79.9e6, 18.7e6),
+    "cage12": (S.GEN_CAGE12_LIKE, 12348, 130228, 2032536, 34.6e6, 15.2e6),
+    "mc2depi": (S.GEN_MC2DEPI_LIKE, 12349, 525825, 2100225, 8.4e6, 5.2e6),
+}
+
+
+@pytest.mark.parametrize("name", list(LITERATURE))
+def test_surrogates_match_the_literature_counts(name):
+    """The bench surrogates (same kind / seed as bench.py) reproduce rows exactly and nnz(A), products and nnz(C) of
+    A*A within 5 % of the literature rows of SURVEY.md section 8 -- counted by the oracle."""
+    kind, seed, rows, nnz_t, prod_t, nnzc_t = LITERATURE[name]
+    a = S.generate(kind, 0, 0, seed)
+    assert a.shape == (rows, rows)
+    ao = to_oracle(a)
+    prod = oracle.count_products(ao, ao)
+    nnzc = oracle.spgemm_spa(ao, ao, n_threads=oracle.num_threads()).nnz
+    for got, want, what in [(a.nnz(), nnz_t, "nnz(A)"), (prod, prod_t, "products"), (nnzc, nnzc_t, "nnz(C)")]:
+        assert abs(got / want - 1.0) <= 0.05, f"{name}: {what} = {got}, literature {want:.0f}"
+
+
 def test_parse_config(tmp_path):
     cfg = S.parse_config(os.path.join(ROOT, "config", "config_1mb_row1.json"))
     assert cfg["ss_filepath"] == "./matrices" and cfg["pe_num"] == 2 and cfg["at_num"] == 16 and cfg["lane_num"] == 8

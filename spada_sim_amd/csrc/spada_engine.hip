@@ -228,6 +228,15 @@ float ev_ms(spada_ctx *c, int a, int b)
     return ms;
 }
 
+void dev_free(spada_dev_csr *m)
+{
+    if (!m) return;
+    if (m->ptr) (void)hipFree(m->ptr);
+    if (m->idx) (void)hipFree(m->idx);
+    if (m->val) (void)hipFree(m->val);
+    delete m;
+}
+
 int dev_upload(spada_ctx *c, const spada_csr_view *m, spada_dev_csr **out)
 {
     if (m->cols >= 0xFFFFFFFFull)
@@ -247,23 +256,21 @@ int dev_upload(spada_ctx *c, const spada_csr_view *m, spada_dev_csr **out)
         if (d->idx) (void)hipFree(d->idx);
         return fail(SPADA_ERR_OOM, "hipMalloc failed for a %llu-nnz matrix", (unsigned long long)m->nnz);
     }
-    HIP_TRY(hipMemcpyAsync(d->ptr, m->indptr, (m->rows + 1) * 8, hipMemcpyHostToDevice, c->stream));
-    if (m->nnz) {
-        HIP_TRY(hipMemcpyAsync(d->idx, idx32.data(), m->nnz * 4, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipMemcpyAsync(d->val, m->data, m->nnz * 8, hipMemcpyHostToDevice, c->stream));
+    const auto copy_in = [&]() -> int {
+        HIP_TRY(hipMemcpyAsync(d->ptr, m->indptr, (m->rows + 1) * 8, hipMemcpyHostToDevice, c->stream));
+        if (m->nnz) {
+            HIP_TRY(hipMemcpyAsync(d->idx, idx32.data(), m->nnz * 4, hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(d->val, m->data, m->nnz * 8, hipMemcpyHostToDevice, c->stream));
+        }
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        return SPADA_OK;
+    };
+    if (int rc = copy_in()) {
+        dev_free(d.release());
+        return rc;
     }
-    HIP_TRY(hipStreamSynchronize(c->stream));
     *out = d.release();
     return SPADA_OK;
-}
-
-void dev_free(spada_dev_csr *m)
-{
-    if (!m) return;
-    if (m->ptr) (void)hipFree(m->ptr);
-    if (m->idx) (void)hipFree(m->idx);
-    if (m->val) (void)hipFree(m->val);
-    delete m;
 }
 
 // flat-batch kernel configurations: <BLOCK, LOG_T, NOUT, RMAX>; cap = 2 * flat_max, NOUT >= cap + flat_max
@@ -294,6 +301,7 @@ uint32_t flat_grid(uint64_t nb_upper, size_t lds)
 
 int run_numeric(spada_ctx *c, uint64_t *d_ptr, uint32_t *d_idx, double *d_val)
 {
+    c->cur = c->stream;   // an earlier call may have failed between a fork and its join
     if (c->dbg.p && c->dbg_g != 2) HIP_TRY(hipMemsetAsync(c->dbg.p, 0, 64 * 16 * 8, c->stream));
     HIP_TRY(hipEventRecord(c->ev[EV_NUM_BEGIN], c->stream));
     HIP_TRY(hipMemcpyAsync(d_ptr, c->cptr.p, ((size_t)c->nrows + 1) * 8, hipMemcpyDeviceToDevice, c->stream));
@@ -303,6 +311,10 @@ int run_numeric(spada_ctx *c, uint64_t *d_ptr, uint32_t *d_idx, double *d_val)
     for (int b = 0; b < SPADA_N_BINS; ++b) off[b + 1] = off[b] + (b == BIN_EMPTY || b == BIN_FLAT ? 0u : cnt[b]);
     int rc;
     Counters *dc = c->counters.as<Counters>();
+    // the dequeue cursors of the huge-row kernels: a numeric call may be repeated after one symbolic call
+    HIP_TRY(hipMemsetAsync(dc->queue, 0, sizeof dc->queue, c->stream));
+    // spill slabs are (re)allocated and zeroed on the engine stream BEFORE the fork event, so the side stream sees them
+    if (cnt[NUM2_BIN_SPILL] && !c->bm_fits && (rc = ensure_spill(c, cnt[NUM2_BIN_SPILL], true))) return rc;
     HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
     // heaviest bins first; every bin on its own stream
     if (cnt[NUM2_BIN_SPILL]) {
@@ -314,7 +326,6 @@ int run_numeric(spada_ctx *c, uint64_t *d_ptr, uint32_t *d_idx, double *d_val)
                                c->B->view(), c->r0, c->num_rows.as<uint32_t>() + off[NUM2_BIN_SPILL], nsp, c->B->cols, 0u,
                                c->cptr.as<uint64_t>(), d_idx, d_val, &dc->queue[0]);
         } else {
-            if ((rc = ensure_spill(c, nsp, true))) return rc;
             if ((rc = fork_to(c, NUM2_BIN_SPILL))) return rc;
             const uint64_t words = ((c->B->cols + 31) / 32 + 3) & ~3ull;
             const uint32_t grid = (uint32_t)std::min<uint64_t>(nsp, c->spill_slabs);
@@ -493,7 +504,8 @@ int spada_create(const spada_options *opts, spada_ctx **out)
         return fail(SPADA_ERR_NO_DEVICE, "device %d is %s; the kernels are built for gfx950 (MI355X) only", dev,
                     prop.gcnArchName);
     HIP_TRY(hipSetDevice(dev));
-    auto c = std::make_unique<spada_ctx>();
+    // a failure below releases whatever was created so far (streams, events, pinned memory) through spada_destroy
+    std::unique_ptr<spada_ctx, void (*)(spada_ctx *)> c(new spada_ctx, spada_destroy);
     c->device = dev;
     c->accumulator = o.accumulator;
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
@@ -610,6 +622,7 @@ int spada_dev_spgemm_symbolic(spada_ctx *c, const spada_dev_csr *a, const spada_
     if (row_begin > row_end || row_end > a->rows) return fail(SPADA_ERR_INVALID, "bad row range");
     HIP_TRY(hipSetDevice(c->device));
     c->have_symbolic = false;
+    c->cur = c->stream;
     c->A = a;
     c->B = b;
     c->r0 = row_begin;
@@ -638,8 +651,9 @@ int spada_dev_spgemm_symbolic(spada_ctx *c, const spada_dev_csr *a, const spada_
     if ((rc = c->eb0.ensure(std::max<uint64_t>(a->nnz, 1) * 8, false, s, &c->ws_bytes))) return rc;
     if ((rc = c->elen.ensure(std::max<uint64_t>(a->nnz, 1) * 4, false, s, &c->ws_bytes))) return rc;
     if ((rc = c->efl.ensure(std::max<uint64_t>(a->nnz, 1) * 8, false, s, &c->ws_bytes))) return rc;
-    if ((rc = c->batch_sym.ensure((n1 / 2 + 4) * 4, false, s, &c->ws_bytes))) return rc;
-    if ((rc = c->batch_num.ensure((n1 / 2 + 4) * 4, false, s, &c->ws_bytes))) return rc;
+    // batch b starts at row batch_first[b]; b <= sum of weights / cap <= rows (a row weighs at most cap)
+    if ((rc = c->batch_sym.ensure((n1 + 4) * 4, false, s, &c->ws_bytes))) return rc;
+    if ((rc = c->batch_num.ensure((n1 + 4) * 4, false, s, &c->ws_bytes))) return rc;
     const uint32_t ntiles = std::max<uint32_t>((n + SCAN_TILE - 1) / SCAN_TILE, 1);
     if ((rc = c->tile_sums.ensure(((size_t)ntiles + 2) * 8, false, s, &c->ws_bytes))) return rc;
     if ((rc = c->tile_w.ensure(((size_t)ntiles + 2) * 8, false, s, &c->ws_bytes))) return rc;
@@ -705,6 +719,7 @@ int spada_dev_spgemm_symbolic(spada_ctx *c, const spada_dev_csr *a, const spada_
         uint32_t off[SPADA_N_BINS + 1];
         off[0] = 0;
         for (int k = 0; k < SPADA_N_BINS; ++k) off[k + 1] = off[k] + (k == BIN_EMPTY || k == BIN_FLAT ? 0u : cnt[k]);
+        if (cnt[SYM2_BIN_SPILL] && !c->bm_fits && (rc = ensure_spill(c, cnt[SYM2_BIN_SPILL], false))) return rc;
         HIP_TRY(hipEventRecord(c->ev_fork, s));
         if (cnt[SYM2_BIN_SPILL]) {
             const uint32_t nsp = cnt[SYM2_BIN_SPILL];
@@ -715,7 +730,6 @@ int spada_dev_spgemm_symbolic(spada_ctx *c, const spada_dev_csr *a, const spada_
                                    c->r0, c->sym_rows.as<uint32_t>() + off[SYM2_BIN_SPILL], nsp, b->cols,
                                    c->row_nnzc.as<uint32_t>());
             } else {
-                if ((rc = ensure_spill(c, nsp, false))) return rc;
                 if ((rc = fork_to(c, SYM2_BIN_SPILL))) return rc;
                 const uint64_t words = ((b->cols + 31) / 32 + 3) & ~3ull;
                 const uint32_t grid = (uint32_t)std::min<uint64_t>(nsp, c->spill_slabs);

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define SPADA_ABI_VERSION 2
+#define SPADA_ABI_VERSION 3
 
 enum spada_status {
     SPADA_OK = 0,
@@ -48,7 +48,8 @@ enum spada_status {
     SPADA_ERR_IO = 5,           /* file could not be opened / read */
     SPADA_ERR_PARSE = 6,        /* MatrixMarket / JSON syntax, missing config key */
     SPADA_ERR_STATE = 7,        /* call sequence violated (numeric before symbolic, ...) */
-    SPADA_ERR_UNSUPPORTED = 8   /* e.g. cols >= 2^32, array-format .mtx, NN workload */
+    SPADA_ERR_UNSUPPORTED = 8,  /* e.g. cols >= 2^32, array-format .mtx, NN workload */
+    SPADA_ERR_CAPACITY = 9      /* one-pass SpGEMM: the caller's C buffers hold fewer than nnz(C) entries */
 };
 
 /* CsrMatStorage.{indptr, indices, data} (storage.rs:150-160) viewed without copying. */
@@ -103,6 +104,17 @@ typedef struct spada_stats {
     double ms_sym_flat;       /* duration of the flat-batch symbolic kernel (hipEvents on its stream) */
     double ms_num_flat;       /* duration of the flat-batch numeric kernel (shared batches of consecutive rows) */
     double ms_num_mid;        /* duration of its list-mode launch (one "mid" row per batch) */
+    /* task pipeline (the default): one persistent kernel, tasks in output order */
+    double ms_fused_call;     /* whole one-pass call (spada_dev_spgemm_fused) */
+    double ms_big_expand;     /* BIG rows: column histogram + scatter of their products into HBM scratch */
+    double ms_cut;            /* task list (three scan kernels) */
+    double ms_task;           /* the task kernel of the last call (count, numeric or one-pass) */
+    uint64_t cls_rows[8];     /* rows per class: 0 EMPTY, 1 COPY (one A entry), 2 SMALL, 3 SOLO, 4 BIG */
+    uint64_t cls_prod[8];     /* products per class */
+    uint64_t n_tasks;         /* tasks of the last run */
+    uint64_t multi_pass_tasks;/* range tasks that had to halve their column range (more distinct columns than the table takes) */
+    uint64_t scratch_products;/* products spilled to HBM scratch (= products of the BIG rows) */
+    uint64_t pipeline_runs;   /* 2 when a workspace had to grow and the pipeline was run again */
 } spada_stats;
 
 typedef struct spada_ctx spada_ctx;          /* engine context: one GPU, one stream, scratch */
@@ -125,6 +137,11 @@ void spada_destroy(spada_ctx *ctx);
  * C rows are ascending, columns ascending and unique, explicit zeros kept (simulator.rs:1034-1062). */
 int spada_spgemm_symbolic(spada_ctx *ctx, const spada_csr_view *a, const spada_csr_view *b, uint64_t *nnz_c);
 int spada_spgemm_numeric(spada_ctx *ctx, uint64_t *c_indptr, uint64_t *c_indices, double *c_data);
+/* one pass, host pointers: c_indices / c_data hold `capacity` entries (e.g. Vec::with_capacity(spada_count_products)),
+ * *nnz_c receives nnz(C).  SPADA_ERR_CAPACITY: c_indptr and *nnz_c are valid; resize to *nnz_c and call
+ * spada_spgemm_numeric. */
+int spada_spgemm_fused(spada_ctx *ctx, const spada_csr_view *a, const spada_csr_view *b, uint64_t capacity,
+                       uint64_t *c_indptr, uint64_t *c_indices, double *c_data, uint64_t *nnz_c);
 
 /* ---- device-resident SpGEMM (inputs already in HBM; what bench.py times) ---------------------
  * Row range [row_begin, row_end) of A selects the A-row block of this GPU (scheduler.rs:296-379
@@ -136,6 +153,19 @@ void spada_dev_csr_free(spada_ctx *ctx, spada_dev_csr *m);
 int spada_dev_spgemm_symbolic(spada_ctx *ctx, const spada_dev_csr *a, const spada_dev_csr *b,
                               uint64_t row_begin, uint64_t row_end, uint64_t *nnz_c);
 int spada_dev_spgemm_numeric(spada_ctx *ctx, void *d_c_indptr, void *d_c_indices, void *d_c_data);
+/* One-pass SpGEMM (additive to the two-phase contract): no symbolic phase.  The caller supplies C buffers of `capacity`
+ * entries -- any upper bound of nnz(C), e.g. spada_count_products (one product per entry at most) -- and receives
+ * C.indptr, the first *nnz_c entries of indices / data, and *nnz_c.  SPADA_ERR_CAPACITY when capacity < nnz(C): indptr and
+ * *nnz_c are complete, indices / data are not; allocate *nnz_c entries and call spada_dev_spgemm_numeric (the context then
+ * holds the state of a finished symbolic phase).  Replaces Simulator::execute + get_exec_result in one call
+ * (simulator.rs:509-890, :1034-1062). */
+int spada_dev_spgemm_fused(spada_ctx *ctx, const spada_dev_csr *a, const spada_dev_csr *b, uint64_t row_begin,
+                           uint64_t row_end, void *d_c_indptr, void *d_c_indices, void *d_c_data, uint64_t capacity,
+                           uint64_t *nnz_c);
+/* the same into device buffers owned by the context (capacity entries), valid until the next call that produces C */
+int spada_dev_spgemm_fused_owned(spada_ctx *ctx, const spada_dev_csr *a, const spada_dev_csr *b, uint64_t row_begin,
+                                 uint64_t row_end, uint64_t capacity, void **d_c_indptr, void **d_c_indices,
+                                 void **d_c_data, uint64_t *nnz_c);
 /* Convenience for callers without their own device allocator: device buffers owned by the context,
  * valid until the next symbolic call.  d_* receive device pointers. */
 int spada_dev_spgemm_numeric_owned(spada_ctx *ctx, void **d_c_indptr, void **d_c_indices, void **d_c_data);

@@ -17,7 +17,7 @@ f64p = ctypes.POINTER(ctypes.c_double)
 vp = ctypes.c_void_p
 
 STATUS_NAMES = {0: "OK", 1: "INVALID", 2: "NO_DEVICE", 3: "HIP", 4: "OOM", 5: "IO", 6: "PARSE", 7: "STATE",
-                8: "UNSUPPORTED"}
+                8: "UNSUPPORTED", 9: "CAPACITY"}
 
 
 class SpadaError(RuntimeError):
@@ -45,7 +45,10 @@ class Stats(ctypes.Structure):
                 ("spill_rows", u64), ("workspace_bytes", u64),
                 ("num_bin_prod", u64 * SPADA_N_BINS), ("num_bin_nnz", u64 * SPADA_N_BINS),
                 ("num_bin_entries", u64 * SPADA_N_BINS), ("sym_bin_prod", u64 * SPADA_N_BINS),
-                ("ms_sym_flat", ctypes.c_double), ("ms_num_flat", ctypes.c_double), ("ms_num_mid", ctypes.c_double)]
+                ("ms_sym_flat", ctypes.c_double), ("ms_num_flat", ctypes.c_double), ("ms_num_mid", ctypes.c_double),
+                ("ms_fused_call", ctypes.c_double), ("ms_big_expand", ctypes.c_double), ("ms_cut", ctypes.c_double),
+                ("ms_task", ctypes.c_double), ("cls_rows", u64 * 8), ("cls_prod", u64 * 8), ("n_tasks", u64),
+                ("multi_pass_tasks", u64), ("scratch_products", u64), ("pipeline_runs", u64)]
 
     def as_dict(self):
         d = {}
@@ -76,6 +79,10 @@ SIGNATURES = {
     "spada_dev_csr_free": (None, [vp, vp]),
     "spada_dev_spgemm_symbolic": (ctypes.c_int, [vp, vp, vp, u64, u64, u64p]),
     "spada_dev_spgemm_numeric": (ctypes.c_int, [vp, vp, vp, vp]),
+    "spada_dev_spgemm_fused": (ctypes.c_int, [vp, vp, vp, u64, u64, vp, vp, vp, u64, u64p]),
+    "spada_dev_spgemm_fused_owned": (ctypes.c_int, [vp, vp, vp, u64, u64, u64, ctypes.POINTER(vp), ctypes.POINTER(vp),
+                                                    ctypes.POINTER(vp), u64p]),
+    "spada_spgemm_fused": (ctypes.c_int, [vp, ctypes.POINTER(CsrView), ctypes.POINTER(CsrView), u64, u64p, u64p, f64p, u64p]),
     "spada_dev_spgemm_numeric_owned": (ctypes.c_int, [vp, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp)]),
     "spada_dev_download_c": (ctypes.c_int, [vp, vp, vp, vp, u64, u64, u64p, u64p, f64p]),
     "spada_get_stats": (ctypes.c_int, [vp, ctypes.POINTER(Stats)]),

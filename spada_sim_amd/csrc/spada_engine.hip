@@ -10,10 +10,12 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <string>
 #include <vector>
 
 #include "spada_internal.hpp"
 #include "spgemm_flat.hip.hpp"
+#include "spgemm_task.hip.hpp"
 
 using namespace spada;
 
@@ -30,6 +32,7 @@ struct spada_dev_csr {
     uint64_t *ptr = nullptr;
     uint32_t *idx = nullptr;
     double *val = nullptr;
+    uint32_t *rowid = nullptr;   // row of every entry: lets the row statistics run entry-parallel whatever the row lengths are
     DevCsrView view() const { return DevCsrView{ptr, idx, val, nullptr, nullptr}; }
 };
 
@@ -127,6 +130,13 @@ struct spada_ctx {
     uint32_t bm_vcap = 0;             // value-row capacity of k_num_bitmap<true> (0 = variant unused)
     Counters *h_counters = nullptr;   // pinned
     uint64_t *h_u64 = nullptr;        // pinned
+    // task pipeline (spgemm_task.hip.hpp): the default; SPADA_PIPELINE=legacy selects the round-1 per-bin kernels
+    bool use_tasks = true;
+    DevBuf t_rowP, t_rowm, t_rowtmp, t_big, t_tiles, t_tmp, t_tasks, t_status, t_rangeout, t_scrcol, t_scrval, t_ctr;
+    uint64_t t_cap_tmp = 0, t_cap_tasks = 0, t_cap_scr = 0;
+    TaskCounters *h_tctr = nullptr;   // pinned
+    hipEvent_t tev[6] = {};
+    uint32_t n_cu = 256;
     // matrices uploaded by the host-pointer API
     spada_dev_csr *hA = nullptr, *hB = nullptr;
     spada_stats stats = {};
@@ -234,6 +244,7 @@ void dev_free(spada_dev_csr *m)
     if (m->ptr) (void)hipFree(m->ptr);
     if (m->idx) (void)hipFree(m->idx);
     if (m->val) (void)hipFree(m->val);
+    if (m->rowid) (void)hipFree(m->rowid);
     delete m;
 }
 
@@ -247,13 +258,15 @@ int dev_upload(spada_ctx *c, const spada_csr_view *m, spada_dev_csr **out)
     d->rows = m->rows;
     d->cols = m->cols;
     d->nnz = m->nnz;
-    std::vector<uint32_t> idx32(m->nnz);
+    std::vector<uint32_t> idx32(m->nnz), rid32(m->nnz);
     for (uint64_t q = 0; q < m->nnz; ++q) idx32[q] = (uint32_t)m->indices[q];
+    for (uint64_t r = 0; r < m->rows; ++r)
+        for (uint64_t q = m->indptr[r]; q < m->indptr[r + 1]; ++q) rid32[q] = (uint32_t)r;
     HIP_TRY(hipMalloc((void **)&d->ptr, (m->rows + 1) * 8));
     if (hipMalloc((void **)&d->idx, std::max<uint64_t>(m->nnz, 1) * 4) != hipSuccess ||
-        hipMalloc((void **)&d->val, std::max<uint64_t>(m->nnz, 1) * 8) != hipSuccess) {
-        (void)hipFree(d->ptr);
-        if (d->idx) (void)hipFree(d->idx);
+        hipMalloc((void **)&d->val, std::max<uint64_t>(m->nnz, 1) * 8) != hipSuccess ||
+        hipMalloc((void **)&d->rowid, std::max<uint64_t>(m->nnz, 1) * 4) != hipSuccess) {
+        dev_free(d.release());
         return fail(SPADA_ERR_OOM, "hipMalloc failed for a %llu-nnz matrix", (unsigned long long)m->nnz);
     }
     const auto copy_in = [&]() -> int {
@@ -261,6 +274,7 @@ int dev_upload(spada_ctx *c, const spada_csr_view *m, spada_dev_csr **out)
         if (m->nnz) {
             HIP_TRY(hipMemcpyAsync(d->idx, idx32.data(), m->nnz * 4, hipMemcpyHostToDevice, c->stream));
             HIP_TRY(hipMemcpyAsync(d->val, m->data, m->nnz * 8, hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(d->rowid, rid32.data(), m->nnz * 4, hipMemcpyHostToDevice, c->stream));
         }
         HIP_TRY(hipStreamSynchronize(c->stream));
         return SPADA_OK;
@@ -463,6 +477,213 @@ int run_numeric(spada_ctx *c, uint64_t *d_ptr, uint32_t *d_idx, double *d_val)
     return SPADA_OK;
 }
 
+
+// ---- task pipeline ---------------------------------------------------------------------------------------------------
+float tev_ms(spada_ctx *c, int a, int b)
+{
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, c->tev[a], c->tev[b]) != hipSuccess) return 0.f;
+    return ms;
+}
+
+template <int MODE>
+void launch_task(spada_ctx *c, const TaskArgs &g)
+{
+    hipLaunchKernelGGL(k_task<MODE>, dim3(c->n_cu * 4), dim3(TK_BLOCK), task_lds(), c->stream, g);
+}
+
+TaskArgs task_args(spada_ctx *c, uint64_t *cptr, uint32_t *d_idx, double *d_val, uint64_t capacity)
+{
+    TaskArgs g;
+    g.aptr = c->A->ptr;
+    g.aval = c->A->val;
+    g.bidx = c->B->idx;
+    g.bval = c->B->val;
+    g.eb0 = c->eb0.as<uint64_t>();
+    g.elen = c->elen.as<uint32_t>();
+    g.r0 = c->r0;
+    g.nrows = c->nrows;
+    g.colbits = c->colbits;
+    g.row_cls = c->row_bin.as<uint8_t>();
+    g.row_kmin = c->row_kmin.as<uint32_t>();
+    g.row_kmax = c->row_kmax.as<uint32_t>();
+    g.tasks = c->t_tasks.as<TaskDesc>();
+    g.scr_col = c->t_scrcol.as<uint32_t>();
+    g.scr_val = c->t_scrval.as<double>();
+    g.cptr = cptr;
+    g.range_out = c->t_rangeout.as<uint64_t>();
+    g.status = c->t_status.as<unsigned long long>();
+    g.ctr = c->t_ctr.as<TaskCounters>();
+    g.c_idx = d_idx;
+    g.c_val = d_val;
+    g.capacity = capacity;
+    return g;
+}
+
+// Row statistics, BIG-row expansion, task list and the task kernel in MODE_COUNT (cptr = the context's C.indptr) or MODE_FUSED
+// (cptr / d_idx / d_val = the caller's buffers).  Nothing is read back before the end; workspaces whose size depends on the
+// data (tasks, range descriptors, scratch) keep their capacity from earlier calls, the kernels refuse to overrun them, and one
+// more run with the sizes they report follows when that happened.
+int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, double *d_val, uint64_t capacity)
+{
+    const spada_dev_csr *a = c->A, *b = c->B;
+    const uint32_t n = c->nrows;
+    hipStream_t s = c->stream;
+    int rc;
+    (void)hipGetLastError();   // an error an earlier call already reported must not be seen by the launch checks below
+    const size_t n1 = (size_t)n + 1;
+    if ((rc = c->row_nprod.ensure(n1 * 4, false, s, &c->ws_bytes))) return rc;
+    if ((rc = c->row_bin.ensure(n1, false, s, &c->ws_bytes))) return rc;
+    if ((rc = c->row_kmin.ensure(n1 * 4, false, s, &c->ws_bytes))) return rc;
+    if ((rc = c->row_kmax.ensure(n1 * 4, false, s, &c->ws_bytes))) return rc;
+    if ((rc = c->t_rowP.ensure(n1 * 8, false, s, &c->ws_bytes))) return rc;
+    if ((rc = c->t_rowm.ensure(n1 * 4, false, s, &c->ws_bytes))) return rc;
+    if ((rc = c->t_rowtmp.ensure(n1 * 4, false, s, &c->ws_bytes))) return rc;
+    if ((rc = c->t_big.ensure(n1 * 4, false, s, &c->ws_bytes))) return rc;
+    if ((rc = c->cptr.ensure(n1 * 8, false, s, &c->ws_bytes))) return rc;
+    if ((rc = c->t_ctr.ensure(sizeof(TaskCounters), false, s, &c->ws_bytes))) return rc;
+    if ((rc = c->eb0.ensure(std::max<uint64_t>(a->nnz, 1) * 8, false, s, &c->ws_bytes))) return rc;
+    if ((rc = c->elen.ensure(std::max<uint64_t>(a->nnz, 1) * 4, false, s, &c->ws_bytes))) return rc;
+    if ((rc = c->efl.ensure(std::max<uint64_t>(a->nnz, 1) * 8, false, s, &c->ws_bytes))) return rc;
+    const uint32_t ntiles = std::max<uint32_t>((n + CUT_TILE - 1) / CUT_TILE, 1);
+    if ((rc = c->t_tiles.ensure(((size_t)ntiles + 2) * 4, false, s, &c->ws_bytes))) return rc;
+    // composite hash keys of a batch: (local row << colbits) | column
+    uint32_t cb = 0;
+    while (cb < 32 && (1ull << cb) < b->cols) ++cb;
+    c->colbits = cb;
+    const uint32_t rmax = cb >= 32 ? 1u : (uint32_t)std::min<uint64_t>((1ull << (32 - cb)) - 1, TK_RMAX);
+    if (cptr == nullptr) cptr = c->cptr.as<uint64_t>();
+    TaskCounters *dc = c->t_ctr.as<TaskCounters>();
+    if (!c->t_cap_tasks) {
+        c->t_cap_tasks = n / 4 + 4096;
+        c->t_cap_tmp = 4096;
+        c->t_cap_scr = 1u << 20;
+    }
+    c->stats.pipeline_runs = 0;
+    for (int attempt = 0; attempt < 3; ++attempt) {
+        c->t_cap_tasks = std::max<uint64_t>(c->t_cap_tasks, (uint64_t)n / 4 + 4096);
+        if ((rc = c->t_tasks.ensure(c->t_cap_tasks * sizeof(TaskDesc), false, s, &c->ws_bytes))) return rc;
+        if ((rc = c->t_status.ensure(c->t_cap_tasks * 8, false, s, &c->ws_bytes))) return rc;
+        if ((rc = c->t_rangeout.ensure(c->t_cap_tasks * 8, false, s, &c->ws_bytes))) return rc;
+        if ((rc = c->t_tmp.ensure(c->t_cap_tmp * sizeof(TaskDesc), false, s, &c->ws_bytes))) return rc;
+        if ((rc = c->t_scrcol.ensure(c->t_cap_scr * 4, false, s, &c->ws_bytes))) return rc;
+        if ((rc = c->t_scrval.ensure(c->t_cap_scr * 8, false, s, &c->ws_bytes))) return rc;
+        // capacities the kernels may rely on (DevBuf over-allocates; use what was asked for)
+        const uint32_t cap_tasks = (uint32_t)std::min<uint64_t>(c->t_cap_tasks, 0xFFFFFFF0u);
+        const uint32_t cap_tmp = (uint32_t)std::min<uint64_t>(c->t_cap_tmp, 0xFFFFFFF0u);
+        ++c->stats.pipeline_runs;
+        HIP_TRY(hipEventRecord(c->tev[0], s));
+        HIP_TRY(hipMemsetAsync(dc, 0, sizeof(TaskCounters), s));
+        if (n) {
+            HIP_TRY(hipMemsetAsync(c->t_rowP.p, 0, (size_t)n * 8, s));
+            HIP_TRY(hipMemsetAsync(c->row_kmin.p, 0xFF, (size_t)n * 4, s));
+            HIP_TRY(hipMemsetAsync(c->row_kmax.p, 0, (size_t)n * 4, s));
+            const uint32_t gent = (uint32_t)std::min<uint64_t>((a->nnz + 255) / 256 + 1, (uint64_t)c->n_cu * 8 * 4);
+            hipLaunchKernelGGL(k_entry_stats, dim3(gent), dim3(256), 0, s, a->ptr, a->idx, a->rowid, b->ptr, b->idx, c->r0, n,
+                               c->eb0.as<uint64_t>(), c->elen.as<uint32_t>(), c->t_rowP.as<unsigned long long>(),
+                               c->row_kmin.as<uint32_t>(), c->row_kmax.as<uint32_t>());
+            hipLaunchKernelGGL(k_row_class, dim3(std::min<uint32_t>((n + 255) / 256, c->n_cu * 8)), dim3(256), 0, s, a->ptr, c->r0,
+                               n, rmax, c->t_rowP.as<unsigned long long>(), c->row_nprod.as<uint32_t>(), c->row_bin.as<uint8_t>(),
+                               c->t_rowm.as<uint32_t>(), c->t_big.as<uint32_t>(), dc);
+            HIP_TRY(hipGetLastError());
+        }
+        HIP_TRY(hipEventRecord(c->tev[1], s));
+        if (n) {
+            hipLaunchKernelGGL(k_big_expand, dim3(c->n_cu * 4), dim3(TK_BLOCK), BX_LDS, s, a->ptr, a->val, b->idx, b->val,
+                               c->eb0.as<uint64_t>(), c->elen.as<uint32_t>(), c->r0, c->t_big.as<uint32_t>(),
+                               c->row_nprod.as<uint32_t>(), c->row_kmin.as<uint32_t>(), c->row_kmax.as<uint32_t>(),
+                               c->t_rowm.as<uint32_t>(), c->t_rowtmp.as<uint32_t>(), c->t_tmp.as<TaskDesc>(), cap_tmp,
+                               c->t_scrcol.as<uint32_t>(), c->t_scrval.as<double>(), c->t_cap_scr, dc);
+            HIP_TRY(hipGetLastError());
+        }
+        HIP_TRY(hipEventRecord(c->tev[2], s));
+        if (n) {
+            hipLaunchKernelGGL(k_cut1, dim3(ntiles), dim3(256), 0, s, c->row_bin.as<uint8_t>(), c->row_nprod.as<uint32_t>(),
+                               c->t_rowm.as<uint32_t>(), n, rmax, c->t_tiles.as<uint32_t>());
+            hipLaunchKernelGGL(k_cut2, dim3(1), dim3(256), 0, s, c->t_tiles.as<uint32_t>(), ntiles, cap_tasks, dc);
+            hipLaunchKernelGGL(k_cut3, dim3(ntiles), dim3(256), 0, s, c->row_bin.as<uint8_t>(), c->row_nprod.as<uint32_t>(),
+                               c->t_rowm.as<uint32_t>(), c->t_rowtmp.as<uint32_t>(), n, rmax, c->t_tiles.as<uint32_t>(),
+                               c->t_tmp.as<TaskDesc>(), c->t_tasks.as<TaskDesc>(), cap_tasks, dc);
+            HIP_TRY(hipGetLastError());
+        }
+        HIP_TRY(hipMemsetAsync(c->t_status.p, 0, (size_t)cap_tasks * 8, s));
+        HIP_TRY(hipEventRecord(c->tev[3], s));
+        if (n) {
+            const TaskArgs g = task_args(c, cptr, d_idx, d_val, capacity);
+            if (mode == MODE_COUNT) launch_task<MODE_COUNT>(c, g);
+            else launch_task<MODE_FUSED>(c, g);
+            HIP_TRY(hipGetLastError());
+        } else {
+            HIP_TRY(hipMemsetAsync(cptr, 0, 8, s));
+        }
+        HIP_TRY(hipEventRecord(c->tev[4], s));
+        HIP_TRY(hipMemcpyAsync(c->h_tctr, dc, sizeof(TaskCounters), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        const TaskCounters &h = *c->h_tctr;
+        if (!h.abort_flag) break;
+        if (attempt == 2) return fail(SPADA_ERR_HIP, "task pipeline: workspaces still too small after two retries (flag %u)", h.abort_flag);
+        if (h.abort_flag & 4u) return fail(SPADA_ERR_UNSUPPORTED, "a row of C has 2^32 or more products");
+        c->t_cap_scr = std::max<uint64_t>(c->t_cap_scr, h.nprod_big + h.nprod_big / 16 + 1024);
+        c->t_cap_tmp = std::max<uint64_t>(c->t_cap_tmp, (uint64_t)h.tmp_cursor + h.tmp_cursor / 16 + 1024);
+        c->t_cap_tasks = std::max<uint64_t>(c->t_cap_tasks, (uint64_t)h.need_tasks + h.need_tasks / 16 + 1024);
+    }
+    const TaskCounters &h = *c->h_tctr;
+    c->nnz_c = n ? h.nnz_c : 0;
+    spada_stats &st = c->stats;
+    st.rows = n;
+    st.a_nnz = h.a_nnz;
+    st.b_nnz = b->nnz;
+    st.nprod = h.nprod;
+    st.c_nnz = c->nnz_c;
+    st.bytes_read = ((uint64_t)n + 1) * 8 + h.a_nnz * 12 + h.a_nnz * 16 + h.nprod * 12;
+    st.bytes_write = ((uint64_t)n + 1) * 8 + c->nnz_c * 12;
+    st.ms_row_stats = tev_ms(c, 0, 1);
+    st.ms_big_expand = tev_ms(c, 1, 2);
+    st.ms_cut = tev_ms(c, 2, 3);
+    st.ms_task = tev_ms(c, 3, 4);
+    for (int k = 0; k < N_CLS; ++k) {
+        st.cls_rows[k] = st.num_bin_rows[k] = st.sym_bin_rows[k] = h.cls_rows[k];
+        st.cls_prod[k] = st.num_bin_prod[k] = st.sym_bin_prod[k] = h.cls_prod[k];
+    }
+    if (SPADA_TASK_DBG)
+        std::fprintf(stderr, "[task dbg] tasks %u  loop cycles/WG %.0f  accumulate %.1f%%  chain %.1f%%  emit %.1f%%  windows/task %.2f  spins/task %.2f  waits/task %.2f  mean distance of the awaited task %.1f\n",
+                     h.ntasks, (double)h.dbg[3] / (c->n_cu * 4.0), 100.0 * h.dbg[4] / std::max<double>(1, h.dbg[3]),
+                     100.0 * h.dbg[0] / std::max<double>(1, h.dbg[3]), 100.0 * h.dbg[5] / std::max<double>(1, h.dbg[3]),
+                     (double)h.dbg[1] / std::max(1u, h.ntasks), (double)h.dbg[2] / std::max(1u, h.ntasks),
+                     (double)h.dbg[7] / std::max(1u, h.ntasks), (double)h.dbg[6] / std::max<double>(1, h.dbg[7]));
+    st.n_tasks = h.ntasks;
+    st.multi_pass_tasks = h.multi_pass_tasks;
+    st.scratch_products = h.nprod_big;
+    st.spill_rows = h.n_big;
+    st.workspace_bytes = c->ws_bytes;
+    if (mode == MODE_COUNT) {
+        st.ms_symbolic_call = tev_ms(c, 0, 4);
+        st.ms_symbolic = st.ms_task;
+    } else {
+        st.ms_fused_call = tev_ms(c, 0, 4);
+        st.ms_numeric = st.ms_task;
+    }
+    return SPADA_OK;
+}
+
+int task_numeric(spada_ctx *c, uint64_t *d_ptr, uint32_t *d_idx, double *d_val)
+{
+    hipStream_t s = c->stream;
+    HIP_TRY(hipEventRecord(c->tev[0], s));
+    HIP_TRY(hipMemcpyAsync(d_ptr, c->cptr.p, ((size_t)c->nrows + 1) * 8, hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipMemsetAsync(c->t_ctr.as<TaskCounters>()->ticket, 0, sizeof(TaskCounters::ticket), s));
+    if (c->nrows) {
+        const TaskArgs g = task_args(c, c->cptr.as<uint64_t>(), d_idx, d_val, c->nnz_c);
+        launch_task<MODE_NUMERIC>(c, g);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipEventRecord(c->tev[4], s));
+    HIP_TRY(hipStreamSynchronize(s));
+    c->stats.ms_numeric = c->stats.ms_numeric_call = c->stats.ms_task = tev_ms(c, 0, 4);
+    c->stats.workspace_bytes = c->ws_bytes;
+    return SPADA_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -531,6 +752,11 @@ int spada_create(const spada_options *opts, spada_ctx **out)
         if (rc0) return rc0;
     }
     HIP_TRY(hipHostMalloc((void **)&c->h_counters, sizeof(Counters), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void **)&c->h_tctr, sizeof(TaskCounters), hipHostMallocDefault));
+    for (auto &e : c->tev) HIP_TRY(hipEventCreate(&e));
+    c->n_cu = (uint32_t)std::max(1, prop.multiProcessorCount);
+    if (const char *e = std::getenv("SPADA_PIPELINE")) c->use_tasks = std::strcmp(e, "legacy") != 0;
+    if (o.accumulator == SPADA_ACC_SORT_MERGE) c->use_tasks = false;   // the sort-merge accumulator still runs on the per-bin kernels
     HIP_TRY(hipHostMalloc((void **)&c->h_u64, 64, hipHostMallocDefault));
     int rc;
     if ((rc = allow_lds(k_sym_hash<512, 14>, sym_lds<512, 14>()))) return rc;
@@ -559,6 +785,10 @@ int spada_create(const spada_options *opts, spada_ctx **out)
     if ((rc = allow_lds(k_num_merge<512>, 4 * ((num_merge_wave_bytes<512>() + 15) & ~(size_t)15)))) return rc;
     if ((rc = allow_lds(k_num_merge<1024>, 4 * ((num_merge_wave_bytes<1024>() + 15) & ~(size_t)15)))) return rc;
     if ((rc = allow_lds(k_num_flat<1024, 1, 13, 6144, 128, true, 1>, num_flat_lds<1024, 1, 13, 6144, 128>()))) return rc;
+    if ((rc = allow_lds(k_task<MODE_COUNT>, task_lds()))) return rc;
+    if ((rc = allow_lds(k_task<MODE_NUMERIC>, task_lds()))) return rc;
+    if ((rc = allow_lds(k_task<MODE_FUSED>, task_lds()))) return rc;
+    if ((rc = allow_lds(k_big_expand, BX_LDS))) return rc;
     if ((rc = allow_lds(k_sym_bitmap, LDS_MAX))) return rc;
     if ((rc = allow_lds(k_num_bitmap<true>, LDS_MAX))) return rc;
     if ((rc = allow_lds(k_num_bitmap<false>, LDS_MAX))) return rc;
@@ -575,8 +805,13 @@ void spada_destroy(spada_ctx *c)
     if (c->hB != c->hA) dev_free(c->hB);
     for (DevBuf *b : {&c->row_nprod, &c->row_nnzc, &c->row_bin, &c->sym_rows, &c->num_rows, &c->counters, &c->cptr,
                       &c->tile_sums, &c->bitmaps, &c->slabs, &c->own_idx, &c->own_val, &c->own_ptr, &c->wide_idx,
-                      &c->eb0, &c->elen, &c->efl, &c->row_kmin, &c->row_kmax, &c->batch_sym, &c->batch_num, &c->tile_w, &c->dbg})
+                      &c->eb0, &c->elen, &c->efl, &c->row_kmin, &c->row_kmax, &c->batch_sym, &c->batch_num, &c->tile_w, &c->dbg,
+                      &c->t_rowP, &c->t_rowm, &c->t_rowtmp, &c->t_big, &c->t_tiles, &c->t_tmp, &c->t_tasks, &c->t_status, &c->t_rangeout,
+                      &c->t_scrcol, &c->t_scrval, &c->t_ctr})
         b->release();
+    if (c->h_tctr) (void)hipHostFree(c->h_tctr);
+    for (auto &e : c->tev)
+        if (e) (void)hipEventDestroy(e);
     if (c->h_counters) (void)hipHostFree(c->h_counters);
     if (c->h_u64) (void)hipHostFree(c->h_u64);
     for (auto &e : c->ev)
@@ -629,6 +864,13 @@ int spada_dev_spgemm_symbolic(spada_ctx *c, const spada_dev_csr *a, const spada_
     c->nrows = (uint32_t)(row_end - row_begin);
     c->nnz_c = 0;
     std::memset(&c->stats, 0, sizeof c->stats);
+    if (c->use_tasks) {
+        const int rc_t = task_pipeline(c, MODE_COUNT, nullptr, nullptr, nullptr, 0);
+        if (rc_t) return rc_t;
+        *nnz_c = c->nnz_c;
+        c->have_symbolic = true;
+        return SPADA_OK;
+    }
     {
         const size_t base = bm_lds_bytes(b->cols, 0);
         c->bm_fits = base <= LDS_MAX;
@@ -864,7 +1106,60 @@ int spada_dev_spgemm_numeric(spada_ctx *c, void *d_c_indptr, void *d_c_indices, 
     if (!d_c_indptr || (c->nnz_c && (!d_c_indices || !d_c_data)))
         return fail(SPADA_ERR_INVALID, "spada_dev_spgemm_numeric: null output pointer");
     HIP_TRY(hipSetDevice(c->device));
+    if (c->use_tasks) return task_numeric(c, (uint64_t *)d_c_indptr, (uint32_t *)d_c_indices, (double *)d_c_data);
     return run_numeric(c, (uint64_t *)d_c_indptr, (uint32_t *)d_c_indices, (double *)d_c_data);
+}
+
+int spada_dev_spgemm_fused(spada_ctx *c, const spada_dev_csr *a, const spada_dev_csr *b, uint64_t row_begin, uint64_t row_end,
+                           void *d_c_indptr, void *d_c_indices, void *d_c_data, uint64_t capacity, uint64_t *nnz_c)
+{
+    if (!c) return fail(SPADA_ERR_STATE, "spada_dev_spgemm_fused: no engine context (no GPU?)");
+    if (!a || !b || !nnz_c || !d_c_indptr || (capacity && (!d_c_indices || !d_c_data)))
+        return fail(SPADA_ERR_INVALID, "spada_dev_spgemm_fused: null argument");
+    if (a->cols != b->rows)
+        return fail(SPADA_ERR_INVALID, "inner dimensions differ: A is %llux%llu, B is %llux%llu", (unsigned long long)a->rows,
+                    (unsigned long long)a->cols, (unsigned long long)b->rows, (unsigned long long)b->cols);
+    if (row_begin > row_end || row_end > a->rows) return fail(SPADA_ERR_INVALID, "bad row range");
+    if (!c->use_tasks) return fail(SPADA_ERR_UNSUPPORTED, "the one-pass entry point needs the task pipeline (LDS-hash accumulator)");
+    HIP_TRY(hipSetDevice(c->device));
+    c->have_symbolic = false;
+    c->cur = c->stream;
+    c->A = a;
+    c->B = b;
+    c->r0 = row_begin;
+    c->nrows = (uint32_t)(row_end - row_begin);
+    c->nnz_c = 0;
+    std::memset(&c->stats, 0, sizeof c->stats);
+    int rc = task_pipeline(c, MODE_FUSED, (uint64_t *)d_c_indptr, (uint32_t *)d_c_indices, (double *)d_c_data, capacity);
+    if (rc) return rc;
+    *nnz_c = c->nnz_c;
+    if (c->h_tctr->cap_overflow) {
+        // C.indptr is complete: keep it, so that a numeric call into large enough buffers can follow
+        HIP_TRY(hipMemcpyAsync(c->cptr.p, d_c_indptr, ((size_t)c->nrows + 1) * 8, hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        c->have_symbolic = true;    // task list, scratch and range offsets are those of a finished symbolic phase
+        return fail(SPADA_ERR_CAPACITY, "nnz(C) = %llu exceeds the capacity of %llu entries", (unsigned long long)c->nnz_c,
+                    (unsigned long long)capacity);
+    }
+    return SPADA_OK;
+}
+
+int spada_dev_spgemm_fused_owned(spada_ctx *c, const spada_dev_csr *a, const spada_dev_csr *b, uint64_t row_begin,
+                                 uint64_t row_end, uint64_t capacity, void **d_c_indptr, void **d_c_indices, void **d_c_data,
+                                 uint64_t *nnz_c)
+{
+    if (!c) return fail(SPADA_ERR_STATE, "spada_dev_spgemm_fused_owned: no engine context (no GPU?)");
+    if (!a || !d_c_indptr || !d_c_indices || !d_c_data || !nnz_c) return fail(SPADA_ERR_INVALID, "null argument");
+    if (row_begin > row_end || row_end > a->rows) return fail(SPADA_ERR_INVALID, "bad row range");
+    HIP_TRY(hipSetDevice(c->device));
+    int rc;
+    if ((rc = c->own_ptr.ensure((size_t)(row_end - row_begin + 1) * 8, false, c->stream, &c->ws_bytes))) return rc;
+    if ((rc = c->own_idx.ensure(std::max<uint64_t>(capacity, 1) * 4, false, c->stream, &c->ws_bytes))) return rc;
+    if ((rc = c->own_val.ensure(std::max<uint64_t>(capacity, 1) * 8, false, c->stream, &c->ws_bytes))) return rc;
+    *d_c_indptr = c->own_ptr.p;
+    *d_c_indices = c->own_idx.p;
+    *d_c_data = c->own_val.p;
+    return spada_dev_spgemm_fused(c, a, b, row_begin, row_end, c->own_ptr.p, c->own_idx.p, c->own_val.p, capacity, nnz_c);
 }
 
 int spada_dev_spgemm_numeric_owned(spada_ctx *c, void **d_c_indptr, void **d_c_indices, void **d_c_data)
@@ -877,7 +1172,9 @@ int spada_dev_spgemm_numeric_owned(spada_ctx *c, void **d_c_indptr, void **d_c_i
     if ((rc = c->own_ptr.ensure(((size_t)c->nrows + 1) * 8, false, c->stream, &c->ws_bytes))) return rc;
     if ((rc = c->own_idx.ensure(std::max<uint64_t>(c->nnz_c, 1) * 4, false, c->stream, &c->ws_bytes))) return rc;
     if ((rc = c->own_val.ensure(std::max<uint64_t>(c->nnz_c, 1) * 8, false, c->stream, &c->ws_bytes))) return rc;
-    if ((rc = run_numeric(c, c->own_ptr.as<uint64_t>(), c->own_idx.as<uint32_t>(), c->own_val.as<double>()))) return rc;
+    if (c->use_tasks) rc = task_numeric(c, c->own_ptr.as<uint64_t>(), c->own_idx.as<uint32_t>(), c->own_val.as<double>());
+    else rc = run_numeric(c, c->own_ptr.as<uint64_t>(), c->own_idx.as<uint32_t>(), c->own_val.as<double>());
+    if (rc) return rc;
     *d_c_indptr = c->own_ptr.p;
     *d_c_indices = c->own_idx.p;
     *d_c_data = c->own_val.p;
@@ -922,6 +1219,34 @@ int spada_spgemm_symbolic(spada_ctx *c, const spada_csr_view *a, const spada_csr
     if (same) c->hB = c->hA;
     else if ((rc = spada_dev_csr_upload(c, b, &c->hB))) return rc;
     return spada_dev_spgemm_symbolic(c, c->hA, c->hB, 0, a->rows, nnz_c);
+}
+
+int spada_spgemm_fused(spada_ctx *c, const spada_csr_view *a, const spada_csr_view *b, uint64_t capacity, uint64_t *c_indptr,
+                       uint64_t *c_indices, double *c_data, uint64_t *nnz_c)
+{
+    if (!c) return fail(SPADA_ERR_STATE, "spada_spgemm_fused: no engine context (no GPU?)");
+    if (!a || !b || !nnz_c || !c_indptr) return fail(SPADA_ERR_INVALID, "spada_spgemm_fused: null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    c->have_symbolic = false;
+    dev_free(c->hA);
+    if (c->hB != c->hA) dev_free(c->hB);
+    c->hA = c->hB = nullptr;
+    int rc = spada_dev_csr_upload(c, a, &c->hA);
+    if (rc) return rc;
+    const bool same = a->indptr == b->indptr && a->indices == b->indices && a->data == b->data && a->rows == b->rows &&
+                      a->cols == b->cols;
+    if (same) c->hB = c->hA;
+    else if ((rc = spada_dev_csr_upload(c, b, &c->hB))) return rc;
+    void *dp, *di, *dv;
+    rc = spada_dev_spgemm_fused_owned(c, c->hA, c->hB, 0, a->rows, capacity, &dp, &di, &dv, nnz_c);
+    if (rc == SPADA_ERR_CAPACITY) {
+        const std::string msg = spada_last_error();
+        const int rc2 = spada_dev_download_c(c, dp, nullptr, nullptr, c->nrows, 0, c_indptr, nullptr, nullptr);
+        if (rc2) return rc2;
+        return fail(SPADA_ERR_CAPACITY, "%s", msg.c_str());
+    }
+    if (rc) return rc;
+    return spada_dev_download_c(c, dp, di, dv, c->nrows, c->nnz_c, c_indptr, c_indices, c_data);
 }
 
 int spada_spgemm_numeric(spada_ctx *c, uint64_t *c_indptr, uint64_t *c_indices, double *c_data)

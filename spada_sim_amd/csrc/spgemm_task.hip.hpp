@@ -1,0 +1,1163 @@
+// gfx950 kernels, part 3: the TASK pipeline -- one persistent kernel computes all of C in row order.
+//
+// What it replaces in the reference (citations into /root/reference/src): Scheduler::next_block / next_window
+// (scheduler.rs:296-379, :482-606) become a device-built task list; the PE datapath multiply -> sort -> merge
+// (simulator.rs:86-230) and the partial-fiber merging (scheduler.rs:381-480, adder_tree.rs:145-188) become one LDS
+// accumulator per task; psum write-back and result assembly (simulator.rs:955-1062) become the chained output offsets.
+//
+//   rows of C            ->  classes by products P_i: EMPTY | COPY (one A entry: C_i = a * B_k) | SMALL (P <= 512, shares a
+//                            batch with its neighbours) | SOLO (P <= 1536: a batch of its own) | BIG (larger)
+//   BIG rows             ->  k_big_expand: histogram of the row's products over <= 1024 column buckets, buckets merged into
+//                            column RANGES of < 1536 products, products scattered into HBM scratch range by range (the
+//                            "spill" of rows whose accumulator does not fit LDS); every range becomes a task of its own
+//   task list            ->  k_cut1/2/3: consecutive non-BIG rows are cut into batches of < 1536 products; tasks are numbered in
+//                            output order (row, then column range)
+//   k_task               ->  persistent workgroups take tasks by ticket.  A task expands its products (flat walk over the A
+//                            entries of its rows, or a stream over its scratch slice), accumulates them in a 2048-slot LDS
+//                            hash table (ds_cmpst / ds_add_f64), counts the distinct outputs per row, obtains the position
+//                            of its slice of C from the tasks before it by a decoupled look-back over per-task status words,
+//                            and emits its outputs in (row, column) order (monotone buckets + in-bucket rank).
+//                            MODE COUNT   : symbolic phase of the two-phase ABI -- counts only, writes C.indptr
+//                            MODE NUMERIC : numeric phase after COUNT -- C.indptr known, no chain
+//                            MODE FUSED   : one pass, C written into an upper-bound buffer, C.indptr produced by the chain
+// Every workgroup uses the same 39 KiB of LDS (4 per CU): nothing needs a CU of its own.
+#pragma once
+#include "spgemm_flat.hip.hpp"
+
+namespace spada {
+
+constexpr uint8_t CLS_EMPTY = 0, CLS_COPY = 1, CLS_SMALL = 2, CLS_SOLO = 3, CLS_BIG = 4;
+constexpr int N_CLS = 5;
+constexpr int TK_BLOCK = 256, TK_EPT = 2, TK_LOG_T = 11, TK_T = 1 << TK_LOG_T, TK_NOUT = 1536, TK_RMAX = 128;
+constexpr uint32_t TK_CAP = 1024;        // BIG rows: light column ranges are cut every TK_CAP products
+constexpr uint32_t TK_SMALL_MAX = 512;   // class boundary SMALL | SOLO (statistics only: both are packed into batches)
+constexpr uint32_t TK_SOLO_MAX = 1536;   // 0.75 of the table: products one task hashes at most; rows above are BIG
+constexpr uint32_t BX_HEAVY_C = 512;
+constexpr int TK_NQ = 16;                // ticket queues: task t belongs to queue t % TK_NQ, workgroup b serves queue b % TK_NQ
+constexpr int BX_NB = 1024;              // column buckets of the big-row histogram
+constexpr uint32_t BX_HEAVY = BX_HEAVY_C; // a bucket with more products is a range of its own
+static_assert(TK_CAP + BX_HEAVY_C <= TK_SOLO_MAX && TK_SOLO_MAX <= TK_NOUT && TK_NOUT * 4 <= TK_T * 3, "table load <= 0.75");
+
+struct TaskDesc {
+    uint32_t kind;      // TASK_BATCH: rows [row, row of the next task) | TASK_RANGE: columns [col_lo, col_hi] of BIG row `row`
+    uint32_t row;
+    uint32_t np;        // RANGE: products of the slice
+    uint32_t first;     // RANGE: 1 = first range of its row (writes C.indptr[row])
+    uint64_t src;       // RANGE: first product of the slice in the scratch arrays
+    uint32_t col_lo, col_hi;
+};
+constexpr uint32_t TASK_BATCH = 1, TASK_RANGE = 2;
+
+// device counters of one pipeline run (zeroed at its start)
+struct TaskCounters {
+    unsigned long long nprod, a_nnz, nprod_big;       // of the row range
+    unsigned long long scratch_cursor;                // products handed out in the scratch arrays
+    unsigned long long nnz_c;                         // written by the last task (COUNT / FUSED)
+    unsigned long long cls_rows[N_CLS], cls_prod[N_CLS];
+    uint32_t n_big, tmp_cursor, ntasks, pad0;
+    uint32_t abort_flag;                              // a workspace was too small: results invalid, sizes below say what is needed
+    uint32_t cap_overflow;                            // FUSED: nnz(C) exceeded the caller's capacity (C.indptr is complete)
+    uint32_t need_tmp, need_tasks;
+    uint32_t multi_pass_tasks, pad;
+    uint32_t ticket[TK_NQ * 32];  // TK_NQ ticket counters, one per 128-byte line (a single hot word sustains ~88 atomics / us)
+    unsigned long long dbg[8];   // SPADA_TASK_DBG builds: [0] cycles in the chain, [1] look-back windows, [2] spin retries, [3] cycles
+                                 // of the task loop, [4] cycles before the chain (expand + accumulate), [5] cycles after it (emit)
+};
+
+__device__ inline uint8_t row_class(uint64_t P, uint32_t L, uint32_t rmax)
+{
+    if (P == 0) return CLS_EMPTY;
+    if (L == 1) return CLS_COPY;
+    if (P <= TK_SMALL_MAX && rmax > 1) return CLS_SMALL;
+    if (P <= TK_SOLO_MAX) return CLS_SOLO;
+    return CLS_BIG;
+}
+// ---- 1. entry descriptors + row statistics ---------------------------------------------------------------------------------
+// k_entry_stats: one lane per A entry, 64 consecutive entries per wave and round, whatever the row lengths are (the row of an
+// entry comes from A.rowid).  Per entry: the irregular 16-byte B.indptr gather of the path, done exactly once -> eb0 / elen
+// (begin, length of the selected B row), and the row's first / last column.  Entries of one row are adjacent lanes: a
+// segmented wave scan adds them up, and the last lane of every run adds the run to the row's totals (row_P, row_kmin,
+// row_kmax, preset to 0 / max / 0) with one device atomic each -- ~1 atomic triple per row, none of them contended.
+// k_row_class: one lane per row: class, statistics, the list of BIG rows.
+__global__ __launch_bounds__(256) void k_entry_stats(const uint64_t *__restrict__ aptr, const uint32_t *__restrict__ aidx,
+                                                     const uint32_t *__restrict__ arow, const uint64_t *__restrict__ bptr,
+                                                     const uint32_t *__restrict__ bidx, uint64_t r0, uint32_t nrows,
+                                                     uint64_t *__restrict__ eb0, uint32_t *__restrict__ elen,
+                                                     unsigned long long *__restrict__ row_P, uint32_t *__restrict__ row_kmin,
+                                                     uint32_t *__restrict__ row_kmax)
+{
+    const uint64_t e0 = aptr[r0], e1 = aptr[r0 + nrows];
+    const int lane = threadIdx.x & 63;
+    for (uint64_t q0 = e0 + (uint64_t)blockIdx.x * 256 + (threadIdx.x & ~63); q0 < e1; q0 += (uint64_t)gridDim.x * 256) {
+        const uint64_t q = q0 + lane;
+        uint32_t row = 0xFFFFFFFFu, mn = 0xFFFFFFFFu, mx = 0;
+        unsigned long long len = 0;
+        if (q < e1) {
+            const uint32_t k = aidx[q];
+            row = arow[q] - (uint32_t)r0;
+            const uint64_t b0 = bptr[k], b1 = bptr[k + 1];
+            eb0[q] = b0;
+            len = b1 - b0;
+            elen[q] = (uint32_t)len;
+            if (b1 > b0) {
+                mn = bidx[b0];
+                mx = bidx[b1 - 1];
+            }
+        }
+        // segmented inclusive scan over runs of equal row
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t r2 = __shfl_up(row, o);
+            const unsigned long long l2 = __shfl_up(len, o);
+            const uint32_t n2 = __shfl_up(mn, o), x2 = __shfl_up(mx, o);
+            if (lane >= o && r2 == row) {
+                len += l2;
+                mn = min(mn, n2);
+                mx = max(mx, x2);
+            }
+        }
+        const uint32_t rnext = __shfl_down(row, 1);
+        const bool tail = row != 0xFFFFFFFFu && (lane == 63 || rnext != row);
+        if (tail && len) {
+            atomicAdd(&row_P[row], len);
+            atomicMin(&row_kmin[row], mn);
+            atomicMax(&row_kmax[row], mx);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_row_class(const uint64_t *__restrict__ aptr, uint64_t r0, uint32_t nrows, uint32_t rmax,
+                                                   const unsigned long long *__restrict__ row_P, uint32_t *__restrict__ row_nprod,
+                                                   uint8_t *__restrict__ row_cls, uint32_t *__restrict__ row_m,
+                                                   uint32_t *__restrict__ big_rows, TaskCounters *__restrict__ ctr)
+{
+    __shared__ unsigned long long s_rows[N_CLS], s_prod[N_CLS], s_tot;
+    if (threadIdx.x < N_CLS) s_rows[threadIdx.x] = s_prod[threadIdx.x] = 0;
+    if (threadIdx.x == 0) s_tot = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    unsigned long long c_rows[N_CLS] = {0, 0, 0, 0, 0}, c_prod[N_CLS] = {0, 0, 0, 0, 0}, tot_l = 0;
+    for (uint32_t tile = blockIdx.x * 256; tile < nrows; tile += gridDim.x * 256) {
+        const uint32_t i = tile + threadIdx.x;
+        uint8_t cls = CLS_EMPTY;
+        if (i < nrows) {
+            const unsigned long long P = row_P[i];
+            const uint32_t L = (uint32_t)(aptr[r0 + i + 1] - aptr[r0 + i]);
+            cls = row_class(P, L, rmax);
+            row_nprod[i] = P > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)P;
+            row_cls[i] = cls;
+            row_m[i] = 0;
+            c_rows[cls] += 1;
+            c_prod[cls] += P;
+            tot_l += L;
+        }
+        // BIG rows: one global atomic per wave
+        const unsigned long long bm = __ballot(i < nrows && cls == CLS_BIG);
+        if (bm) {
+            uint32_t base = 0;
+            if (lane == __ffsll((long long)bm) - 1) base = atomicAdd(&ctr->n_big, (uint32_t)__popcll(bm));
+            base = __shfl(base, __ffsll((long long)bm) - 1);
+            if (i < nrows && cls == CLS_BIG) big_rows[base + (uint32_t)__popcll(bm & ((1ull << lane) - 1ull))] = i;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < N_CLS; ++k) {
+        const unsigned long long r = wave_sum_u64(c_rows[k]), p = wave_sum_u64(c_prod[k]);
+        if (lane == 0 && r) {
+            atomicAdd(&s_rows[k], r);
+            atomicAdd(&s_prod[k], p);
+        }
+    }
+    const unsigned long long wl = wave_sum_u64(tot_l);
+    if (lane == 0 && wl) atomicAdd(&s_tot, wl);
+    __syncthreads();
+    if (threadIdx.x < N_CLS && s_rows[threadIdx.x]) {
+        atomicAdd(&ctr->cls_rows[threadIdx.x], s_rows[threadIdx.x]);
+        atomicAdd(&ctr->cls_prod[threadIdx.x], s_prod[threadIdx.x]);
+        atomicAdd(&ctr->nprod, s_prod[threadIdx.x]);
+        if (threadIdx.x == CLS_BIG) atomicAdd(&ctr->nprod_big, s_prod[threadIdx.x]);
+    }
+    if (threadIdx.x == 0 && s_tot) atomicAdd(&ctr->a_nnz, s_tot);
+}
+
+// ---- 2. BIG rows: histogram, column ranges, scatter into HBM scratch -----------------------------------------------------
+// One workgroup per BIG row.  Pass 1 walks the row's products (column indices only) and counts them in BX_NB column
+// buckets of width 2^wshift over [kmin, kmax].  Buckets are then grouped into ranges: a bucket with more than BX_HEAVY
+// products is a range of its own, the others are grouped by floor(prefix / TK_CAP) -- a light range holds fewer than
+// TK_CAP + BX_HEAVY = 1536 products, i.e. it fits one task's table whatever its outputs are; a heavy range holds at most
+// 2^wshift distinct columns and is split further by the task itself if both exceed the table (k_task, multi-pass).  Pass 2
+// walks the products again and stores (column, a * b) at the bucket's cursor: afterwards the scratch slice of every range is
+// contiguous.  Range descriptors go to `tmp` (bump allocated), their number to row_m[row]; k_cut3 copies them into the
+// task list in row order.
+// LDS: 256 B hdr | cnt u32[NB] | pre u32[NB + 1] | aux u32[NB + 1] | rfirst u32[NB + 1] | rows (s_re[2], s_a0[1]) | walk scratch
+constexpr size_t BX_LDS = 256 + (size_t)BX_NB * 4 + (size_t)(BX_NB + 1) * 4 * 3 + 64 + flat_walk_bytes<TK_BLOCK, TK_EPT, true>() + 16;
+
+__global__ __launch_bounds__(TK_BLOCK) void k_big_expand(const uint64_t *__restrict__ aptr, const double *__restrict__ aval,
+                                                         const uint32_t *__restrict__ bidx, const double *__restrict__ bval,
+                                                         const uint64_t *__restrict__ eb0, const uint32_t *__restrict__ elen,
+                                                         uint64_t r0, const uint32_t *__restrict__ big_rows,
+                                                         const uint32_t *__restrict__ row_nprod,
+                                                         const uint32_t *__restrict__ row_kmin, const uint32_t *__restrict__ row_kmax,
+                                                         uint32_t *__restrict__ row_m, uint32_t *__restrict__ row_tmp,
+                                                         TaskDesc *__restrict__ tmp, uint32_t tmp_cap,
+                                                         uint32_t *__restrict__ scr_col, double *__restrict__ scr_val,
+                                                         uint64_t scr_cap, TaskCounters *__restrict__ ctr)
+{
+    constexpr int NB = BX_NB, BPT = NB / TK_BLOCK, U = SPADA_FLAT_U;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t *hdr = (uint32_t *)smem;
+    uint32_t *cnt = (uint32_t *)(smem + 256);
+    uint32_t *pre = cnt + NB;          // exclusive prefix of cnt, pre[NB] = P
+    uint32_t *aux = pre + NB + 1;      // start flags -> range numbers; later: nonempty flags -> compact numbers
+    uint32_t *rfirst = aux + NB + 1;   // first bucket of range r, rfirst[NR] = NB
+    uint32_t *s_re = rfirst + NB + 1;  // [2]
+    uint64_t *s_a0 = (uint64_t *)(((uintptr_t)(s_re + 2) + 7) & ~(uintptr_t)7);
+    unsigned char *scratch = (unsigned char *)(s_a0 + 1);
+    scratch = (unsigned char *)(((uintptr_t)scratch + 15) & ~(uintptr_t)15);
+    const int tid = threadIdx.x;
+    const uint32_t nbig = ctr->n_big;
+    for (uint32_t slot = blockIdx.x; slot < nbig; slot += gridDim.x) {
+        const uint32_t row = big_rows[slot];
+        if (row_nprod[row] == 0xFFFFFFFFu) {   // 2^32 or more products in one row: the 32-bit bucket counters would wrap
+            if (tid == 0) atomicOr(&ctr->abort_flag, 4u);
+            continue;
+        }
+        const uint64_t a0 = aptr[r0 + row], a1 = aptr[r0 + row + 1];
+        const uint32_t E = (uint32_t)(a1 - a0);
+        const uint32_t kmin = row_kmin[row], kmax = row_kmax[row];
+        uint32_t wshift = 0;
+        while (((kmax - kmin) >> wshift) >= (uint32_t)NB) ++wshift;
+        for (int b = tid; b < NB; b += TK_BLOCK) cnt[b] = 0;
+        if (tid == 0) {
+            s_re[0] = 0;
+            s_re[1] = E;
+            s_a0[0] = a0;
+        }
+        __syncthreads();
+        // pass 1: histogram
+        flat_walk<TK_BLOCK, TK_EPT, 1, false, U>(s_re, s_a0, 1u, E, eb0, elen, nullptr, bidx, nullptr, scratch, hdr,
+                                                 [&](uint32_t(&col)[U], uint32_t(&plr)[U], double(&)[U], uint32_t(&)[U]) {
+#pragma unroll
+                                                     for (int u = 0; u < U; ++u)
+                                                         if (plr[u] != LR_NONE) atomicAdd(&cnt[(col[u] - kmin) >> wshift], 1u);
+                                                 });
+        __syncthreads();
+        for (int b = tid; b < NB; b += TK_BLOCK) pre[b] = cnt[b];
+        __syncthreads();
+        group_exclusive_scan<TK_BLOCK, NB>(pre, tid, hdr + 2);
+        if (tid == TK_BLOCK - 1) pre[NB] = pre[NB - 1] + cnt[NB - 1];
+        __syncthreads();
+        // range starts
+#pragma unroll
+        for (int k = 0; k < BPT; ++k) {
+            const int b = tid * BPT + k;
+            bool st = b == 0 || cnt[b] > BX_HEAVY;
+            if (b > 0) st = st || cnt[b - 1] > BX_HEAVY || (pre[b] / TK_CAP) != (pre[b - 1] / TK_CAP);
+            aux[b] = st ? 1u : 0u;
+        }
+        __syncthreads();
+        uint32_t stf[BPT];
+#pragma unroll
+        for (int k = 0; k < BPT; ++k) stf[k] = aux[tid * BPT + k];
+        __syncthreads();
+        group_exclusive_scan<TK_BLOCK, NB>(aux, tid, hdr + 2);
+#pragma unroll
+        for (int k = 0; k < BPT; ++k)
+            if (stf[k]) rfirst[aux[tid * BPT + k]] = tid * BPT + k;
+        if (tid == TK_BLOCK - 1) {
+            const uint32_t NR = aux[NB - 1] + stf[BPT - 1];
+            rfirst[NR] = NB;
+            hdr[40] = NR;
+        }
+        __syncthreads();
+        const uint32_t NR = hdr[40];
+        // non-empty ranges, compacted
+        uint32_t nef[BPT];
+#pragma unroll
+        for (int k = 0; k < BPT; ++k) {
+            const uint32_t r = tid * BPT + k;
+            nef[k] = (r < NR && pre[rfirst[r + 1]] > pre[rfirst[r]]) ? 1u : 0u;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < BPT; ++k) aux[tid * BPT + k] = nef[k];
+        __syncthreads();
+        group_exclusive_scan<TK_BLOCK, NB>(aux, tid, hdr + 2);
+        if (tid == TK_BLOCK - 1) {
+            const uint32_t m = aux[NB - 1] + nef[BPT - 1];
+            const unsigned long long P = pre[NB];
+            const uint32_t tb = atomicAdd(&ctr->tmp_cursor, m);
+            const unsigned long long sb = atomicAdd(&ctr->scratch_cursor, P);
+            hdr[41] = m;
+            hdr[42] = tb;
+            hdr[43] = (uint32_t)sb;
+            hdr[44] = (uint32_t)(sb >> 32);
+            const bool ok = (unsigned long long)tb + m <= tmp_cap && sb + P <= scr_cap;
+            hdr[45] = ok ? 1u : 0u;
+            if (!ok) atomicOr(&ctr->abort_flag, 1u);
+            row_m[row] = m;
+            row_tmp[row] = tb;
+        }
+        __syncthreads();
+        const uint32_t tb = hdr[42];
+        const uint64_t sb = ((uint64_t)hdr[44] << 32) | hdr[43];
+        const bool ok = hdr[45] != 0;
+        if (ok) {
+#pragma unroll
+            for (int k = 0; k < BPT; ++k)
+                if (nef[k]) {
+                    const uint32_t r = tid * BPT + k, f0 = rfirst[r], f1 = rfirst[r + 1];
+                    TaskDesc d;
+                    d.kind = TASK_RANGE;
+                    d.row = row;
+                    d.np = pre[f1] - pre[f0];
+                    d.first = aux[r] == 0 ? 1u : 0u;
+                    d.src = sb + pre[f0];
+                    d.col_lo = kmin + (f0 << wshift);
+                    const uint64_t hi = (uint64_t)kmin + ((uint64_t)f1 << wshift) - 1ull;
+                    d.col_hi = hi > kmax ? kmax : (uint32_t)hi;
+                    tmp[tb + aux[r]] = d;
+                }
+        }
+        __syncthreads();
+        // pass 2: scatter; cnt becomes the cursor of every bucket
+        for (int b = tid; b < NB; b += TK_BLOCK) cnt[b] = pre[b];
+        __syncthreads();
+        if (ok)
+            flat_walk<TK_BLOCK, TK_EPT, 1, true, U>(s_re, s_a0, 1u, E, eb0, elen, aval, bidx, bval, scratch, hdr,
+                                                    [&](uint32_t(&col)[U], uint32_t(&plr)[U], double(&v)[U], uint32_t(&)[U]) {
+#pragma unroll
+                                                        for (int u = 0; u < U; ++u)
+                                                            if (plr[u] != LR_NONE) {
+                                                                const uint32_t p = atomicAdd(&cnt[(col[u] - kmin) >> wshift], 1u);
+                                                                scr_col[sb + p] = col[u];
+                                                                scr_val[sb + p] = v[u];
+                                                            }
+                                                    });
+        __syncthreads();
+    }
+}
+
+// ---- 3. the cut: rows -> tasks in output order ---------------------------------------------------------------------------
+// Tiles of CUT_TILE consecutive rows.  A BIG row is row_m[i] range tasks of its own.  The other rows are packed greedily, in
+// row order, into batches that are as full as the table allows: a batch is a maximal run of rows with at most TK_SOLO_MAX
+// products to hash (COPY rows do not count: they never touch the table), at most `rmax` rows and at most CUT_COPY_MAX copied
+// products.  Full batches mean fewer tasks and -- what matters to the chain -- tasks of equal length.  nxt[i] (first row
+// after a batch that starts at row i) is found for all rows in parallel by binary search over the tile's prefix sums; one
+// thread then follows the chain from the tile's first row (batches do not cross tiles).
+constexpr int CUT_ITEMS = 8, CUT_TILE = 256 * CUT_ITEMS;
+constexpr uint32_t CUT_COPY_MAX = 8192;
+
+__device__ inline uint32_t block_scan_excl_u32(uint32_t v, uint32_t *s_w /*[4]*/, uint32_t *total)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(inc, o);
+        if (lane >= o) inc += t;
+    }
+    __syncthreads();
+    if (lane == 63) s_w[w] = inc;
+    __syncthreads();
+    uint32_t add = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (k < w) add += s_w[k];
+        tot += s_w[k];
+    }
+    *total = tot;
+    return inc - v + add;
+}
+
+struct CutRow {
+    uint32_t t[CUT_ITEMS];      // tasks started by the row
+    uint32_t kind[CUT_ITEMS];   // 0 none, 1 batch start, 2 BIG
+};
+struct CutLds {
+    uint32_t pc[CUT_TILE + 1], pw[CUT_TILE + 1];   // prefix sums: products to hash, products to copy
+    uint32_t nxt[CUT_TILE];
+    uint8_t mark[CUT_TILE];
+    uint32_t s_w[4];
+};
+
+// tasks started by every row of the tile; returns the exclusive prefix of this thread's first row and the tile total
+__device__ inline uint32_t cut_tile(const uint8_t *__restrict__ row_cls, const uint32_t *__restrict__ row_nprod,
+                                    const uint32_t *__restrict__ row_m, uint32_t n, uint32_t rmax, CutLds &L, CutRow &cr,
+                                    uint32_t *tile_total)
+{
+    const uint32_t tile_base = blockIdx.x * CUT_TILE, base = tile_base + threadIdx.x * CUT_ITEMS;
+    const uint32_t cnt = min((uint32_t)CUT_TILE, n - tile_base);
+    uint8_t cls[CUT_ITEMS];
+    uint32_t c[CUT_ITEMS], w[CUT_ITEMS], sc = 0, sw = 0;
+#pragma unroll
+    for (int j = 0; j < CUT_ITEMS; ++j) {
+        const uint32_t i = base + j;
+        cls[j] = i < n ? row_cls[i] : CLS_EMPTY;
+        const uint32_t P = i < n ? row_nprod[i] : 0u;
+        c[j] = cls[j] == CLS_BIG ? TK_SOLO_MAX + 1 : ((cls[j] == CLS_SMALL || cls[j] == CLS_SOLO) ? P : 0u);
+        w[j] = cls[j] == CLS_COPY ? min(P, CUT_COPY_MAX) : 0u;
+        L.mark[threadIdx.x * CUT_ITEMS + j] = 0;
+        sc += c[j];
+        sw += w[j];
+    }
+    uint32_t tot;
+    uint32_t ec = block_scan_excl_u32(sc, L.s_w, &tot);
+    __syncthreads();
+    uint32_t ew = block_scan_excl_u32(sw, L.s_w, &tot);
+#pragma unroll
+    for (int j = 0; j < CUT_ITEMS; ++j) {
+        L.pc[threadIdx.x * CUT_ITEMS + j] = ec;
+        L.pw[threadIdx.x * CUT_ITEMS + j] = ew;
+        ec += c[j];
+        ew += w[j];
+    }
+    if (threadIdx.x == 255) {
+        L.pc[CUT_TILE] = ec;
+        L.pw[CUT_TILE] = ew;
+    }
+    __syncthreads();
+    // nxt[i]: largest j <= cnt with pc[j] - pc[i] <= TK_SOLO_MAX, pw[j] - pw[i] <= CUT_COPY_MAX, j - i <= rmax (j >= i + 1 always)
+#pragma unroll
+    for (int j = 0; j < CUT_ITEMS; ++j) {
+        const uint32_t li = threadIdx.x * CUT_ITEMS + j;
+        uint32_t nx = li + 1;
+        if (li < cnt && cls[j] != CLS_BIG) {
+            const uint32_t limc = L.pc[li] + TK_SOLO_MAX, limw = L.pw[li] + CUT_COPY_MAX;
+            uint32_t lo = li + 1, hi = min(cnt, li + rmax);   // invariant: lo is feasible
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi + 1) >> 1;
+                if (L.pc[mid] <= limc && L.pw[mid] <= limw) lo = mid;
+                else hi = mid - 1;
+            }
+            nx = lo;
+        }
+        L.nxt[li] = nx;
+    }
+    __syncthreads();
+    // batch starts: every run of non-BIG rows is walked from its first row (the tile's first row, or the row after a BIG
+    // row) by the thread that owns that row; BIG rows mark themselves
+#pragma unroll
+    for (int j = 0; j < CUT_ITEMS; ++j) {
+        const uint32_t li = threadIdx.x * CUT_ITEMS + j;
+        if (li >= cnt) continue;
+        if (cls[j] == CLS_BIG) {
+            L.mark[li] = 1;
+        } else if (li == 0 || L.pc[li] - L.pc[li - 1] > TK_SOLO_MAX) {   // the row before is BIG
+            for (uint32_t i = li; i < cnt && L.pc[i + 1] - L.pc[i] <= TK_SOLO_MAX; i = L.nxt[i]) L.mark[i] = 1;
+        }
+    }
+    __syncthreads();
+    uint32_t local = 0;
+#pragma unroll
+    for (int j = 0; j < CUT_ITEMS; ++j) {
+        const uint32_t i = base + j;
+        cr.t[j] = 0;
+        cr.kind[j] = 0;
+        if (i < n && L.mark[threadIdx.x * CUT_ITEMS + j]) {
+            cr.kind[j] = cls[j] == CLS_BIG ? 2u : 1u;
+            cr.t[j] = cls[j] == CLS_BIG ? row_m[i] : 1u;
+        }
+        local += cr.t[j];
+    }
+    __syncthreads();
+    return block_scan_excl_u32(local, L.s_w, tile_total);
+}
+
+__global__ __launch_bounds__(256) void k_cut1(const uint8_t *__restrict__ row_cls, const uint32_t *__restrict__ row_nprod,
+                                              const uint32_t *__restrict__ row_m, uint32_t n, uint32_t rmax,
+                                              uint32_t *__restrict__ tile_tasks)
+{
+    __shared__ CutLds L;
+    CutRow cr;
+    uint32_t tot;
+    (void)cut_tile(row_cls, row_nprod, row_m, n, rmax, L, cr, &tot);
+    if (threadIdx.x == 0) tile_tasks[blockIdx.x] = tot;
+}
+
+// single workgroup: exclusive scan of the tile totals in place; total -> ctr->ntasks
+__global__ __launch_bounds__(256) void k_cut2(uint32_t *__restrict__ tile_tasks, uint32_t ntiles, uint32_t task_cap,
+                                              TaskCounters *__restrict__ ctr)
+{
+    __shared__ uint32_t s_w[4];
+    uint32_t carry = 0;
+    for (uint32_t b = 0; b < ntiles; b += 256) {
+        const uint32_t i = b + threadIdx.x;
+        const uint32_t v = i < ntiles ? tile_tasks[i] : 0u;
+        uint32_t tot;
+        const uint32_t ex = block_scan_excl_u32(v, s_w, &tot);
+        if (i < ntiles) tile_tasks[i] = carry + ex;
+        carry += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        ctr->ntasks = carry;
+        ctr->need_tasks = carry;
+        if (carry > task_cap) atomicOr(&ctr->abort_flag, 2u);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_cut3(const uint8_t *__restrict__ row_cls, const uint32_t *__restrict__ row_nprod,
+                                              const uint32_t *__restrict__ row_m, const uint32_t *__restrict__ row_tmp,
+                                              uint32_t n, uint32_t rmax, const uint32_t *__restrict__ tile_tasks,
+                                              const TaskDesc *__restrict__ tmp, TaskDesc *__restrict__ tasks, uint32_t task_cap,
+                                              const TaskCounters *__restrict__ ctr)
+{
+    __shared__ CutLds L;
+    __shared__ uint32_t s_nbig;
+    if (threadIdx.x == 0) s_nbig = 0;
+    CutRow cr;
+    uint32_t tot;
+    uint32_t idx = cut_tile(row_cls, row_nprod, row_m, n, rmax, L, cr, &tot) + tile_tasks[blockIdx.x];
+    if (ctr->abort_flag) return;   // a workspace overflowed upstream: nothing below may be trusted
+    const uint32_t base = blockIdx.x * CUT_TILE + threadIdx.x * CUT_ITEMS;
+    uint32_t kb[CUT_ITEMS], idxb[CUT_ITEMS];
+#pragma unroll
+    for (int j = 0; j < CUT_ITEMS; ++j) {
+        kb[j] = 0xFFFFFFFFu;
+        idxb[j] = 0;
+        if (cr.kind[j] == 1 && idx < task_cap) {
+            TaskDesc d;
+            d.kind = TASK_BATCH;
+            d.row = base + j;
+            d.np = 0;
+            d.first = 0;
+            d.src = 0;
+            d.col_lo = d.col_hi = 0;
+            tasks[idx] = d;
+        } else if (cr.kind[j] == 2 && cr.t[j]) {
+            kb[j] = atomicAdd(&s_nbig, 1u);
+            idxb[j] = idx;
+        }
+        idx += cr.t[j];
+    }
+    __syncthreads();   // every thread is done with the cut arrays: they now hold the tile's BIG rows
+    uint32_t *b_first = L.pc, *b_tb = L.pw, *b_pre = L.nxt;   // first task | first descriptor in tmp | range tasks -> their prefix
+#pragma unroll
+    for (int j = 0; j < CUT_ITEMS; ++j)
+        if (kb[j] != 0xFFFFFFFFu) {
+            b_first[kb[j]] = idxb[j];
+            b_tb[kb[j]] = row_tmp[base + j];
+            b_pre[kb[j]] = cr.t[j];
+        }
+    __syncthreads();
+    // the range descriptors of the tile's BIG rows, copied by the whole workgroup: descriptor q of the concatenation belongs
+    // to the BIG row k with pre[k] <= q < pre[k + 1]
+    const uint32_t nb = s_nbig;
+    uint32_t M = 0;
+    for (uint32_t b0 = 0; b0 < nb; b0 += 256) {
+        const uint32_t k = b0 + threadIdx.x;
+        uint32_t tot2;
+        const uint32_t ex = block_scan_excl_u32(k < nb ? b_pre[k] : 0u, L.s_w, &tot2);
+        __syncthreads();
+        if (k < nb) b_pre[k] = M + ex;
+        M += tot2;
+        __syncthreads();
+    }
+    for (uint32_t q = threadIdx.x; q < M; q += 256) {
+        uint32_t lo = 0, hi = nb - 1;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi + 1) >> 1;
+            if (b_pre[mid] <= q) lo = mid;
+            else hi = mid - 1;
+        }
+        const uint32_t off = q - b_pre[lo];
+        if (b_first[lo] + off < task_cap) tasks[b_first[lo] + off] = tmp[b_tb[lo] + off];
+    }
+}
+
+// ---- 4. the task kernel ------------------------------------------------------------------------------------------------
+constexpr int MODE_COUNT = 0, MODE_NUMERIC = 1, MODE_FUSED = 2;
+constexpr unsigned long long ST_AGG = 1ull << 62, ST_INC = 2ull << 62, ST_MASK = 3ull << 62;
+
+struct TaskArgs {
+    const uint64_t *aptr;
+    const double *aval;
+    const uint32_t *bidx;
+    const double *bval;
+    const uint64_t *eb0;
+    const uint32_t *elen;
+    uint64_t r0;
+    uint32_t nrows;
+    uint32_t colbits;
+    const uint8_t *row_cls;
+    const uint32_t *row_kmin, *row_kmax;
+    const TaskDesc *tasks;
+    const uint32_t *scr_col;
+    const double *scr_val;
+    uint64_t *cptr;                 // nrows + 1: COUNT / FUSED write it, NUMERIC reads it
+    uint64_t *range_out;            // per task: first output of a RANGE task (COUNT writes, NUMERIC reads)
+    unsigned long long *status;     // per task: chain words, zeroed before the launch
+    TaskCounters *ctr;
+    uint32_t *c_idx;
+    double *c_val;
+    uint64_t capacity;              // FUSED: entries the caller's C buffers hold
+};
+
+// LDS: 256 B hdr | table: keys u32[T], vals f64[T] (re-used after accumulation as lk u32[NOUT], lv f64[NOUT])
+//      | region 2: bcnt u32[NOUT], aliased by the walk scratch (disjoint phases)
+//      | rows: s_row RowEmit[RMAX + 1], s_a0 u64[RMAX], s_out u64[RMAX], s_re u32[RMAX + 1], s_cnt u32[RMAX]
+__host__ __device__ constexpr size_t task_region2()
+{
+    return (flat_walk_bytes<TK_BLOCK, TK_EPT, true>() > (size_t)TK_NOUT * 4 ? flat_walk_bytes<TK_BLOCK, TK_EPT, true>() : (size_t)TK_NOUT * 4) + 16;
+}
+__host__ __device__ constexpr size_t task_lds()
+{
+    return 256 + ((size_t)12 << TK_LOG_T) + ((task_region2() + 15) & ~(size_t)15) + (size_t)(TK_RMAX + 1) * 16 + (size_t)TK_RMAX * 16 +
+           (size_t)(TK_RMAX + 1) * 4 + (size_t)TK_RMAX * 4 + 32;
+}
+
+// Position of this task's slice of C: sum of the counts of all tasks before it.  Decoupled look-back (one wave): the task
+// publishes its own count (AGG), then walks back over the status words of its predecessors, 64 at a time, adding AGG counts
+// until it meets an inclusive prefix (INC); finally it publishes its own inclusive prefix.  Status words are single 8-byte
+// agent-scope atomics (flag | value): no ordering between separate words is needed.  Tasks are taken by ticket, so every
+// predecessor has been started by a resident workgroup and never waits for a later task: the wait is bounded.
+#ifndef SPADA_TASK_DBG
+#define SPADA_TASK_DBG 0
+#endif
+// chain_publish: the task's own count, as soon as it is known (thread 0).  chain_lookback: the exclusive prefix, as late as it is
+// needed (all threads) -- the LDS half of the emission sits between the two, so the wait for predecessors that are still
+// accumulating is mostly over by the time the look-back starts.
+__device__ inline void chain_publish(unsigned long long *status, uint32_t t, unsigned long long count)
+{
+    if (threadIdx.x == 0)
+        __hip_atomic_store(&status[t], (t == 0 ? ST_INC : ST_AGG) | count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ inline unsigned long long chain_lookback(unsigned long long *status, uint32_t t, unsigned long long count, uint32_t *hdr,
+                                                    TaskCounters *ctr)
+{
+    const int tid = threadIdx.x, lane = tid & 63;
+    unsigned long long dbg_win = 0, dbg_spin = 0;
+    if (tid < 64) {
+        if (t == 0) {
+            if (lane == 0) {
+                hdr[48] = 0;
+                hdr[49] = 0;
+            }
+        } else {
+            unsigned long long excl = 0;
+            long long pos = (long long)t - 1;   // nearest predecessor not yet accounted for
+            for (;;) {
+                const long long idx = pos - lane;
+                unsigned long long s = ST_INC;   // before task 0: inclusive prefix 0
+                if (idx >= 0) s = __hip_atomic_load(&status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long m_inc = __ballot((s & ST_MASK) == ST_INC), m_empty = __ballot((s & ST_MASK) == 0);
+                const int first_inc = m_inc ? __ffsll((long long)m_inc) - 1 : 64;
+                const unsigned long long relevant = first_inc >= 63 ? ~0ull : ((2ull << first_inc) - 1ull);
+                ++dbg_win;
+                if (m_empty & relevant) {
+                    // wait for the nearest missing predecessor (it started last, it tends to publish last) with ONE lane and a
+                    // growing pause: a thousand workgroups re-reading whole windows would slow down the very tasks they wait for
+                    const int who = __ffsll((long long)(m_empty & relevant)) - 1;
+                    unsigned long long spins = 0;
+                    if (lane == who) {
+                        uint32_t pause = 0;
+                        while ((__hip_atomic_load(&status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & ST_MASK) == 0) {
+                            ++spins;
+                            __builtin_amdgcn_s_sleep(8);
+                            if (pause < 6) ++pause;
+                            for (uint32_t z = 0; z < pause; ++z) __builtin_amdgcn_s_sleep(16);
+                        }
+                    }
+                    dbg_spin += __shfl(spins, who);
+                    continue;
+                }
+                unsigned long long v = lane <= first_inc ? (s & ~ST_MASK) : 0ull;
+                v = wave_sum_u64(v);
+                excl += v;
+                if (first_inc < 64) break;
+                pos -= 64;
+            }
+            if (lane == 0) {
+                __hip_atomic_store(&status[t], ST_INC | (excl + count), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                hdr[48] = (uint32_t)excl;
+                hdr[49] = (uint32_t)(excl >> 32);
+                if (SPADA_TASK_DBG) {
+                    atomicAdd(&ctr->dbg[1], dbg_win);
+                    atomicAdd(&ctr->dbg[2], dbg_spin);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const unsigned long long base = ((unsigned long long)hdr[49] << 32) | hdr[48];
+    __syncthreads();
+    return base;
+}
+
+// Ordered emission of the table (all waves): every occupied slot -> bucket = boff[lr] + floor((col - kmin) * n / span), monotone
+// inside a row, rows laid out in order, so bucket order IS the order of the task's outputs up to permutations inside a bucket;
+// count, scan, scatter into bucket order (the lists re-use the table's LDS), rank inside the bucket -- all in LDS; then
+// `resolve()` supplies the position of the task's slice of C (the chain look-back, or 0 when s_out is absolute; NO_STORE = the
+// caller's buffers are too small) and the outputs are stored.  Returns what resolve() returned.
+// s_row[lr] = {boff, n, kmin, scale}, s_out[lr] = first output of the row relative to that position.  NO = outputs in the table.
+constexpr unsigned long long NO_STORE = ~0ull;
+template <bool SINGLE_ROW, class Resolve>
+__device__ inline unsigned long long emit_table(unsigned char *smem, uint32_t NO, uint32_t colbits, uint32_t *__restrict__ c_idx,
+                                                double *__restrict__ c_val, Resolve &&resolve)
+{
+    constexpr int BLOCK = TK_BLOCK, T = TK_T, NOUT = TK_NOUT, SPT = T / BLOCK, OPT = NOUT / BLOCK;
+    uint32_t *hdr = (uint32_t *)smem;
+    uint32_t *keys = (uint32_t *)(smem + 256);
+    double *vals = (double *)(keys + T);
+    uint32_t *lk = keys;
+    double *lv = (double *)(smem + 256 + (((size_t)NOUT * 4 + 7) & ~(size_t)7));
+    unsigned char *region2 = smem + 256 + ((size_t)12 << TK_LOG_T);
+    uint32_t *bcnt = (uint32_t *)region2;
+    const RowEmit *s_row = (const RowEmit *)(region2 + ((task_region2() + 15) & ~(size_t)15));
+    const uint64_t *s_out = (const uint64_t *)(s_row + TK_RMAX + 1) + TK_RMAX;
+    const int tid = threadIdx.x;
+    const uint32_t colmask = colbits >= 32 ? 0xFFFFFFFFu : ((1u << colbits) - 1u);
+    for (int s = tid; s < NOUT; s += BLOCK) bcnt[s] = 0;
+    __syncthreads();
+    uint32_t myk[SPT];
+    uint16_t myb[SPT];
+#pragma unroll
+    for (int i = 0; i < SPT; ++i) myk[i] = keys[tid + i * BLOCK];
+    RowEmit r0e;
+    if constexpr (SINGLE_ROW) r0e = s_row[0];
+#pragma unroll
+    for (int i = 0; i < SPT; ++i) {
+        myb[i] = 0;
+        if (myk[i] != EMPTY_KEY) {
+            const uint32_t lr = (SINGLE_ROW || colbits >= 32) ? 0u : (myk[i] >> colbits), col = myk[i] & colmask;
+            const RowEmit rw = SINGLE_ROW ? r0e : s_row[lr];
+            uint32_t bk = (uint32_t)((float)(col - rw.kmin) * rw.scale);
+            bk = bk < rw.n ? bk : rw.n - 1;
+            myb[i] = (uint16_t)(rw.boff + bk);
+            atomicAdd(&bcnt[myb[i]], 1u);
+        }
+    }
+    double myv[SPT];
+#pragma unroll
+    for (int i = 0; i < SPT; ++i) myv[i] = vals[tid + i * BLOCK];
+    __syncthreads();
+    group_exclusive_scan<BLOCK, NOUT>(bcnt, tid, hdr + 2);   // ends with a barrier: table fully read by now
+#pragma unroll
+    for (int i = 0; i < SPT; ++i)
+        if (myk[i] != EMPTY_KEY) {
+            const uint32_t p = atomicAdd(&bcnt[myb[i]], 1u);   // afterwards bcnt[b] = end of bucket b
+            lk[p] = myk[i];
+            lv[p] = myv[i];
+        }
+    __syncthreads();
+    uint32_t ecol[OPT];
+    uint64_t epos[OPT];
+    double evl[OPT];
+#pragma unroll
+    for (int w = 0; w < OPT; ++w) {
+        const uint32_t p = tid + w * BLOCK;
+        ecol[w] = 0;
+        epos[w] = 0;
+        evl[w] = 0.0;
+        if (p < NO) {
+            const uint32_t k = lk[p];
+            const uint32_t lr = (SINGLE_ROW || colbits >= 32) ? 0u : (k >> colbits), col = k & colmask;
+            const RowEmit rw = SINGLE_ROW ? r0e : s_row[lr];
+            uint32_t bk = (uint32_t)((float)(col - rw.kmin) * rw.scale);
+            bk = rw.boff + (bk < rw.n ? bk : rw.n - 1);
+            const uint32_t lo = bk ? bcnt[bk - 1] : 0u, hi = bcnt[bk];
+            uint32_t r = lo;
+            for (uint32_t j = lo; j < hi; ++j) r += (lk[j] < k) ? 1u : 0u;
+            epos[w] = s_out[lr] + (r - rw.boff);
+            ecol[w] = col;
+            evl[w] = lv[p];
+        }
+    }
+    const unsigned long long base = resolve();   // all threads; contains barriers
+    if (base != NO_STORE) {
+#pragma unroll
+        for (int w = 0; w < OPT; ++w)
+            if (tid + w * BLOCK < NO) {
+                c_idx[base + epos[w]] = ecol[w];
+                c_val[base + epos[w]] = evl[w];
+            }
+    }
+    __syncthreads();
+    return base;
+}
+
+__device__ inline void table_clear(unsigned char *smem)
+{
+    uint4 *k4 = (uint4 *)(smem + 256);
+    for (int s = threadIdx.x; s < TK_T / 4; s += TK_BLOCK) k4[s] = make_uint4(EMPTY_KEY, EMPTY_KEY, EMPTY_KEY, EMPTY_KEY);
+    double2 *v2 = (double2 *)(smem + 256 + (size_t)TK_T * 4);
+    for (int s = threadIdx.x; s < TK_T / 2; s += TK_BLOCK) v2[s] = make_double2(0.0, 0.0);
+}
+
+// insert `key`, add `v`; returns true when the key was new
+template <bool VALUES>
+__device__ inline bool table_insert(uint32_t *keys, double *vals, uint32_t key, double v)
+{
+    uint32_t h = hash_slot<TK_LOG_T>(key);
+    bool isnew = false;
+    for (;;) {
+        const uint32_t o = atomicCAS(&keys[h], EMPTY_KEY, key);
+        if (o == EMPTY_KEY) { isnew = true; break; }
+        if (o == key) break;
+        h = (h + 1) & (TK_T - 1);
+    }
+    if constexpr (VALUES) atomicAdd(&vals[h], v);   // simulator.rs:213-218 (order differs)
+    return isnew;
+}
+
+// RANGE task: accumulate the products of the scratch slice whose column lies in [lo, hi]; returns the number of distinct columns
+template <bool VALUES>
+__device__ inline uint32_t range_accumulate(unsigned char *smem, const uint32_t *__restrict__ scr_col,
+                                            const double *__restrict__ scr_val, uint64_t src, uint32_t np, uint32_t lo, uint32_t hi,
+                                            bool filter)
+{
+    uint32_t *hdr = (uint32_t *)smem;
+    uint32_t *keys = (uint32_t *)(smem + 256);
+    double *vals = (double *)(keys + TK_T);
+    table_clear(smem);
+    __syncthreads();
+    uint32_t mine = 0;
+    constexpr int U = 4;
+    for (uint32_t p0 = threadIdx.x; p0 < np; p0 += U * TK_BLOCK) {
+        uint32_t c[U];
+        double v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t p = p0 + u * TK_BLOCK;
+            c[u] = p < np ? scr_col[src + p] : EMPTY_KEY;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t p = p0 + u * TK_BLOCK;
+            v[u] = 0.0;
+            if constexpr (VALUES) v[u] = p < np ? scr_val[src + p] : 0.0;
+            if (filter && (c[u] < lo || c[u] > hi)) c[u] = EMPTY_KEY;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (c[u] != EMPTY_KEY) mine += table_insert<VALUES>(keys, vals, c[u], v[u]) ? 1u : 0u;
+    }
+    const uint32_t n = group_sum<TK_BLOCK>(mine, hdr);
+    __syncthreads();
+    return n;
+}
+
+__device__ inline uint32_t range_count_products(unsigned char *smem, const uint32_t *__restrict__ scr_col, uint64_t src, uint32_t np,
+                                                uint32_t lo, uint32_t hi)
+{
+    uint32_t mine = 0;
+    for (uint32_t p = threadIdx.x; p < np; p += TK_BLOCK) {
+        const uint32_t c = scr_col[src + p];
+        mine += (c >= lo && c <= hi) ? 1u : 0u;
+    }
+    const uint32_t n = group_sum<TK_BLOCK>(mine, (uint32_t *)smem);
+    __syncthreads();
+    return n;
+}
+
+// Multi-pass RANGE task: the slice may hold more distinct columns than the table takes (a heavy bucket wider than TK_SOLO_MAX
+// columns: only matrices with more than BX_NB * TK_SOLO_MAX = 1.5 M columns can produce one).  Depth-first halving of the column
+// range, ascending; a leaf holds <= TK_SOLO_MAX products or <= TK_SOLO_MAX columns, so it fits.  The walk is deterministic: it is
+// run once to count (the chain needs the task's total before anything is stored) and once more to emit.
+// `stack` = 2 * 40 words of LDS that nothing else uses during a RANGE task.
+template <bool EMIT>
+__device__ inline uint32_t range_dfs(unsigned char *smem, uint32_t *stack, RowEmit *s_row, uint64_t *s_out, const TaskDesc &td,
+                                     const uint32_t *__restrict__ scr_col, const double *__restrict__ scr_val,
+                                     unsigned long long base, uint32_t *__restrict__ c_idx, double *__restrict__ c_val)
+{
+    const int tid = threadIdx.x;
+    uint32_t total = 0, sp = 1;
+    if (tid == 0) {
+        stack[0] = td.col_lo;
+        stack[1] = td.col_hi;
+    }
+    __syncthreads();
+    while (sp) {
+        --sp;
+        const uint32_t lo = stack[2 * sp], hi = stack[2 * sp + 1];
+        __syncthreads();
+        const uint32_t cntp = range_count_products(smem, scr_col, td.src, td.np, lo, hi);
+        if (cntp == 0) continue;
+        if (cntp > TK_SOLO_MAX && hi - lo >= TK_SOLO_MAX) {
+            const uint32_t mid = lo + (hi - lo) / 2;
+            if (tid == 0) {   // upper half below the lower half: the lower half is popped first
+                stack[2 * sp] = mid + 1;
+                stack[2 * sp + 1] = hi;
+                stack[2 * sp + 2] = lo;
+                stack[2 * sp + 3] = mid;
+            }
+            sp += 2;
+            __syncthreads();
+            continue;
+        }
+        const uint32_t nl = range_accumulate<EMIT>(smem, scr_col, scr_val, td.src, td.np, lo, hi, true);
+        if constexpr (EMIT) {
+            if (nl) {
+                if (tid == 0) {
+                    s_row[0] = RowEmit{0u, nl, lo, (float)nl / ((float)(hi - lo) + 1.0f)};
+                    s_out[0] = base + total;
+                }
+                __syncthreads();
+                (void)emit_table<true>(smem, nl, 32u, c_idx, c_val, []() -> unsigned long long { return 0ull; });
+            }
+        }
+        total += nl;
+    }
+    return total;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(TK_BLOCK, 4) void k_task(const TaskArgs g)
+{
+    constexpr int BLOCK = TK_BLOCK, EPT = TK_EPT, T = TK_T, RMAX = TK_RMAX, U = SPADA_FLAT_U;
+    constexpr bool VALUES = MODE != MODE_COUNT;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t *hdr = (uint32_t *)smem;
+    uint32_t *keys = (uint32_t *)(smem + 256);
+    double *vals = (double *)(keys + T);
+    unsigned char *region2 = smem + 256 + ((size_t)12 << TK_LOG_T);
+    unsigned char *rows = region2 + ((task_region2() + 15) & ~(size_t)15);
+    RowEmit *s_row = (RowEmit *)rows;
+    uint64_t *s_a0 = (uint64_t *)(s_row + RMAX + 1);
+    uint64_t *s_out = s_a0 + RMAX;
+    uint32_t *s_re = (uint32_t *)(s_out + RMAX);
+    uint32_t *s_cnt = s_re + RMAX + 1;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const uint32_t ntasks = g.ctr->ntasks;
+    if (g.ctr->abort_flag) return;
+
+    // Tasks are taken by ticket, in (almost) chain order: queue q hands out tasks q, q + NQ, q + 2 NQ, ...  The smallest task that
+    // is not finished is either running -- it waits for finished tasks only -- or the next one of its queue, whose workgroups
+    // all hold smaller, hence finished, tasks and are free to take it: no cycle of waiting workgroups can form as long as
+    // every queue has a resident workgroup, which a grid of at least TK_NQ workgroups dispatched in order guarantees.
+    uint32_t *my_ticket = &g.ctr->ticket[(blockIdx.x % TK_NQ) * 32];
+    if (tid == 0) hdr[50] = atomicAdd(my_ticket, 1u) * TK_NQ + blockIdx.x % TK_NQ;
+    __syncthreads();
+    uint32_t t = hdr[50];
+    __syncthreads();
+    unsigned long long dbg_t0 = SPADA_TASK_DBG ? __builtin_amdgcn_s_memtime() : 0, dbg_acc = 0, dbg_chain = 0, dbg_emit = 0;
+    while (t < ntasks) {
+        unsigned long long dbg_a = SPADA_TASK_DBG ? __builtin_amdgcn_s_memtime() : 0, dbg_b = dbg_a, dbg_c = dbg_a;
+        // (a ticket taken ahead of time would sit unstarted in the chain while this workgroup waits for its own
+        // predecessors, and every later task would wait for it: tickets are taken when the work starts)
+        const TaskDesc td = g.tasks[t];
+        if (td.kind == TASK_BATCH) {
+            const uint32_t rb = td.row;
+            const uint32_t re = t + 1 < ntasks ? g.tasks[t + 1].row : g.nrows;
+            const uint32_t R = re - rb;   // 1 .. RMAX
+            // ---- rows of the batch ------------------------------------------------------------------------------------
+            uint32_t L = 0, n = 0, kmin = 0, kmax = 0, rid = 0, clen = 0;
+            uint64_t cb0 = 0, c0 = 0;
+            double cav = 0.0;
+            uint8_t cls = CLS_EMPTY;
+            if ((uint32_t)tid < R) {
+                rid = rb + tid;
+                const uint64_t a0 = g.aptr[g.r0 + rid], a1 = g.aptr[g.r0 + rid + 1];
+                cls = g.row_cls[rid];
+                s_a0[tid] = a0;
+                s_cnt[tid] = 0;
+                if (cls == CLS_SMALL || cls == CLS_SOLO) {
+                    L = (uint32_t)(a1 - a0);
+                    kmin = g.row_kmin[rid];
+                    kmax = g.row_kmax[rid];
+                } else if (cls == CLS_COPY) {
+                    cb0 = g.eb0[a0];
+                    clen = g.elen[a0];
+                    if constexpr (VALUES) cav = g.aval[a0];
+                }
+                if constexpr (MODE == MODE_NUMERIC) {
+                    c0 = g.cptr[rid];
+                    n = (uint32_t)(g.cptr[rid + 1] - c0);
+                }
+            }
+            uint32_t E;
+            const uint32_t exl = group_scan_excl<BLOCK>(L, tid, hdr + 2, &E);
+            if ((uint32_t)tid < R) s_re[tid] = exl;
+            if (tid == 0) s_re[R] = E;
+            if (E) table_clear(smem);
+            __syncthreads();
+            // ---- expand - scale - accumulate (simulator.rs:86-111, :199-230) ---------------------------------------------
+            if (E)
+                flat_walk<BLOCK, EPT, RMAX, VALUES, U>(
+                    s_re, s_a0, R, E, g.eb0, g.elen, g.aval, g.bidx, g.bval, region2, hdr,
+                    [&](uint32_t(&col)[U], uint32_t(&plr)[U], double(&v)[U], uint32_t(&)[U]) {
+                        uint32_t key[U], h[U], old[U];
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            key[u] = compose_key(plr[u], col[u], g.colbits);
+                            h[u] = hash_slot<TK_LOG_T>(key[u]);
+                            old[u] = key[u];
+                            if (plr[u] != LR_NONE) old[u] = atomicCAS(&keys[h[u]], EMPTY_KEY, key[u]);
+                        }
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            bool isnew = old[u] == EMPTY_KEY;
+                            if (!isnew && old[u] != key[u]) {
+                                for (;;) {
+                                    h[u] = (h[u] + 1) & (T - 1);
+                                    const uint32_t o = atomicCAS(&keys[h[u]], EMPTY_KEY, key[u]);
+                                    if (o == EMPTY_KEY) { isnew = true; break; }
+                                    if (o == key[u]) break;
+                                }
+                            }
+                            if constexpr (MODE != MODE_NUMERIC) segmented_count_add(plr[u], isnew, s_cnt, lane);
+                        }
+                        if constexpr (VALUES) {
+#pragma unroll
+                            for (int u = 0; u < U; ++u)
+                                if (plr[u] != LR_NONE) atomicAdd(&vals[h[u]], v[u]);   // simulator.rs:213-218
+                        }
+                    });
+            __syncthreads();
+            // ---- outputs per row, offsets inside the batch ------------------------------------------------------------------
+            const bool hashed = cls == CLS_SMALL || cls == CLS_SOLO;
+            if constexpr (MODE != MODE_NUMERIC) n = hashed ? s_cnt[tid < RMAX ? tid : 0] : (cls == CLS_COPY ? clen : 0u);
+            unsigned long long tot64;
+            const unsigned long long ex64 = group_scan_excl_u64<BLOCK>(((unsigned long long)n << 32) | (hashed ? n : 0u), tid,
+                                                                       (unsigned long long *)(hdr + 4), &tot64);
+            const uint32_t boff = (uint32_t)ex64, ooff = (uint32_t)(ex64 >> 32);
+            const uint32_t NO = (uint32_t)tot64, total = (uint32_t)(tot64 >> 32);
+            __syncthreads();
+            // ---- chain: publish the count now, look back as late as possible ------------------------------------------------
+            if (SPADA_TASK_DBG) dbg_b = dbg_c = __builtin_amdgcn_s_memtime();
+            if constexpr (MODE != MODE_NUMERIC) chain_publish(g.status, t, total);
+            unsigned long long dbg_w = 0;
+            auto resolve = [&]() -> unsigned long long {
+                if constexpr (MODE == MODE_NUMERIC) {
+                    return 0ull;
+                } else {
+                    const unsigned long long w0 = SPADA_TASK_DBG ? __builtin_amdgcn_s_memtime() : 0;
+                    const unsigned long long b0 = chain_lookback(g.status, t, total, hdr, g.ctr);
+                    if (SPADA_TASK_DBG) dbg_w = __builtin_amdgcn_s_memtime() - w0;
+                    if ((uint32_t)tid < R) g.cptr[rid] = b0 + ooff;
+                    if (t == ntasks - 1 && tid == 0) {
+                        g.cptr[g.nrows] = b0 + total;
+                        g.ctr->nnz_c = b0 + total;
+                    }
+                    if constexpr (MODE == MODE_FUSED) {
+                        if (b0 + total > g.capacity) {
+                            if (tid == 0) atomicOr(&g.ctr->cap_overflow, 1u);
+                            return NO_STORE;
+                        }
+                    }
+                    return b0;
+                }
+            };
+            unsigned long long base;
+            if (MODE != MODE_COUNT && NO) {
+                // s_out: first output of the row relative to the task's slice (NUMERIC: absolute, the slice starts at 0)
+                if ((uint32_t)tid < R) {
+                    s_row[tid] = RowEmit{boff, hashed ? n : 0u, kmin, (float)n / ((float)(kmax - kmin) + 1.0f)};
+                    s_out[tid] = MODE == MODE_NUMERIC ? c0 : (uint64_t)ooff;
+                }
+                __syncthreads();
+                base = emit_table<false>(smem, NO, g.colbits, g.c_idx, g.c_val, resolve);
+            } else {
+                base = resolve();
+            }
+            if (SPADA_TASK_DBG) dbg_c = dbg_b + dbg_w;
+            if constexpr (MODE != MODE_NUMERIC) c0 = base + ooff;
+            if (MODE != MODE_COUNT && base != NO_STORE) {
+                // COPY rows: C_i = a * B_k, already ascending (one lane per short row, the whole wave for longer ones)
+                const bool copy = (uint32_t)tid < R && cls == CLS_COPY;
+                if (copy && clen <= COPY_SHORT) {
+                    for (uint32_t q = 0; q < clen; q += 4) {
+                        uint32_t k4[4];
+                        double v4[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const uint32_t qq = q + u < clen ? q + u : clen - 1;
+                            k4[u] = g.bidx[cb0 + qq];
+                            v4[u] = g.bval[cb0 + qq];
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            if (q + u < clen) {
+                                g.c_idx[c0 + q + u] = k4[u];
+                                g.c_val[c0 + q + u] = cav * v4[u];
+                            }
+                    }
+                }
+                unsigned long long mask = __ballot(copy && clen > COPY_SHORT);
+                while (mask) {
+                    const int src = __ffsll((long long)mask) - 1;
+                    mask &= mask - 1;
+                    const uint64_t sb0 = __shfl(cb0, src), sc0 = __shfl(c0, src);
+                    const uint32_t slen = __shfl(clen, src);
+                    const double sav = __shfl(cav, src);
+                    for (uint32_t q = lane; q < slen; q += 64) {
+                        g.c_idx[sc0 + q] = g.bidx[sb0 + q];
+                        g.c_val[sc0 + q] = sav * g.bval[sb0 + q];
+                    }
+                }
+            }
+        } else {
+            // ---- RANGE task: columns [col_lo, col_hi] of a BIG row, products in the scratch slice -----------------------------
+            // Single pass when the slice cannot overflow the table (<= TK_SOLO_MAX products or columns), else range_dfs.
+            const bool single = td.np <= TK_SOLO_MAX || td.col_hi - td.col_lo < TK_SOLO_MAX;
+            uint32_t total;
+            if (single) {
+                total = range_accumulate<VALUES>(smem, g.scr_col, g.scr_val, td.src, td.np, td.col_lo, td.col_hi, false);
+            } else {
+                if (tid == 0) atomicAdd(&g.ctr->multi_pass_tasks, 1u);
+                total = range_dfs<false>(smem, s_re, s_row, s_out, td, g.scr_col, g.scr_val, 0ull, nullptr, nullptr);
+            }
+            if (SPADA_TASK_DBG) dbg_b = dbg_c = __builtin_amdgcn_s_memtime();
+            if constexpr (MODE != MODE_NUMERIC) chain_publish(g.status, t, total);
+            unsigned long long dbg_w = 0;
+            auto resolve = [&]() -> unsigned long long {
+                if constexpr (MODE == MODE_NUMERIC) {
+                    return g.range_out[t];
+                } else {
+                    const unsigned long long w0 = SPADA_TASK_DBG ? __builtin_amdgcn_s_memtime() : 0;
+                    const unsigned long long b0 = chain_lookback(g.status, t, total, hdr, g.ctr);
+                    if (SPADA_TASK_DBG) dbg_w = __builtin_amdgcn_s_memtime() - w0;
+                    if (tid == 0) {
+                        if (td.first) g.cptr[td.row] = b0;
+                        g.range_out[t] = b0;
+                        if (t == ntasks - 1) {
+                            g.cptr[g.nrows] = b0 + total;
+                            g.ctr->nnz_c = b0 + total;
+                        }
+                    }
+                    if constexpr (MODE == MODE_FUSED) {
+                        if (b0 + total > g.capacity) {
+                            if (tid == 0) atomicOr(&g.ctr->cap_overflow, 1u);
+                            return NO_STORE;
+                        }
+                    }
+                    return b0;
+                }
+            };
+            if (MODE != MODE_COUNT && single && total) {
+                if (tid == 0) {
+                    s_row[0] = RowEmit{0u, total, td.col_lo, (float)total / ((float)(td.col_hi - td.col_lo) + 1.0f)};
+                    s_out[0] = 0;
+                }
+                __syncthreads();
+                (void)emit_table<true>(smem, total, 32u, g.c_idx, g.c_val, resolve);
+            } else {
+                const unsigned long long base = resolve();
+                if (MODE != MODE_COUNT && !single && base != NO_STORE)
+                    (void)range_dfs<true>(smem, s_re, s_row, s_out, td, g.scr_col, g.scr_val, base, g.c_idx, g.c_val);
+            }
+            if (SPADA_TASK_DBG) dbg_c = dbg_b + dbg_w;
+        }
+        __syncthreads();
+        if (tid == 0) hdr[50] = atomicAdd(my_ticket, 1u) * TK_NQ + blockIdx.x % TK_NQ;
+        __syncthreads();
+        t = hdr[50];
+        __syncthreads();
+        if (SPADA_TASK_DBG) {
+            const unsigned long long e = __builtin_amdgcn_s_memtime();
+            dbg_acc += dbg_b - dbg_a;
+            dbg_chain += dbg_c - dbg_b;
+            dbg_emit += e - dbg_c;
+        }
+    }
+    if (SPADA_TASK_DBG && tid == 0) {
+        atomicAdd(&g.ctr->dbg[0], dbg_chain);
+        atomicAdd(&g.ctr->dbg[3], __builtin_amdgcn_s_memtime() - dbg_t0);
+        atomicAdd(&g.ctr->dbg[4], dbg_acc);
+        atomicAdd(&g.ctr->dbg[5], dbg_emit);
+    }
+}
+
+}  // namespace spada

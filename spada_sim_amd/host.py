@@ -240,6 +240,36 @@ class Engine:
         """Device pointers (ints) of caller-allocated u64[rows+1], u32[nnz], f64[nnz]."""
         check(self._L.spada_dev_spgemm_numeric(self._ctx, _ffi.vp(d_indptr), _ffi.vp(d_indices), _ffi.vp(d_data)))
 
+    def fused(self, da, db, row_begin, row_end, d_indptr, d_indices, d_data, capacity):
+        """One-pass SpGEMM into caller buffers of `capacity` entries (any upper bound of nnz(C)); returns nnz(C)."""
+        nnz = ctypes.c_uint64(0)
+        check(self._L.spada_dev_spgemm_fused(self._ctx, da, db, row_begin, row_end, _ffi.vp(d_indptr), _ffi.vp(d_indices),
+                                             _ffi.vp(d_data), capacity, ctypes.byref(nnz)))
+        return nnz.value
+
+    def fused_owned(self, da, db, row_begin, row_end, capacity):
+        """One-pass SpGEMM into context-owned device buffers; returns (d_indptr, d_indices, d_data, nnz)."""
+        p, i, v, nnz = _ffi.vp(), _ffi.vp(), _ffi.vp(), ctypes.c_uint64(0)
+        check(self._L.spada_dev_spgemm_fused_owned(self._ctx, da, db, row_begin, row_end, capacity, ctypes.byref(p),
+                                                   ctypes.byref(i), ctypes.byref(v), ctypes.byref(nnz)))
+        return p.value, i.value, v.value, nnz.value
+
+    def spgemm_fused(self, a, b, capacity=None):
+        """C = A * B in one pass through spada_spgemm_fused (host pointers); capacity defaults to the product count."""
+        if capacity is None:
+            capacity = count_products(a, b, 0, a.shape[0])
+        nnz = ctypes.c_uint64(0)
+        va = a.view()
+        vb = va if b is a else b.view()
+        c_indptr = np.zeros(a.shape[0] + 1, np.uint64)
+        c_indices = np.zeros(max(capacity, 1), np.uint64)
+        c_data = np.zeros(max(capacity, 1), np.float64)
+        check(self._L.spada_spgemm_fused(self._ctx, ctypes.byref(va), ctypes.byref(vb), capacity,
+                                         c_indptr.ctypes.data_as(_ffi.u64p), c_indices.ctypes.data_as(_ffi.u64p),
+                                         c_data.ctypes.data_as(_ffi.f64p), ctypes.byref(nnz)))
+        n = nnz.value
+        return CsMat((a.shape[0], b.shape[1]), c_indptr, c_indices[:n].copy(), c_data[:n].copy())
+
     def numeric_owned(self):
         p, i, v = _ffi.vp(), _ffi.vp(), _ffi.vp()
         check(self._L.spada_dev_spgemm_numeric_owned(self._ctx, ctypes.byref(p), ctypes.byref(i), ctypes.byref(v)))

@@ -1,0 +1,154 @@
+"""GPU (-m gpu): the task pipeline's one-pass entry point (spada_dev_spgemm_fused) and its special paths, through the
+C ABI, against the CPU oracle.  Bar as in test_gpu_parity.py: structure bit-exact, values within 1e-9 relative."""
+import numpy as np
+import pytest
+
+from conftest import assert_parity, to_oracle
+from fuzz_cases import random_case
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-9
+
+
+def fused(engine, a, b, capacity=None, r0=0, r1=None):
+    """C = A[r0:r1] * B by the one-pass entry point into context-owned device buffers of `capacity` entries."""
+    import spada_sim_amd as S
+    r1 = a.shape[0] if r1 is None else r1
+    da = engine.upload(a)
+    db = da if b is a else engine.upload(b)
+    try:
+        if capacity is None:
+            capacity = S.count_products(a, b, r0, r1)
+        p, i, v, nnz = engine.fused_owned(da, db, r0, r1, capacity)
+        st = engine.stats()
+        return engine.download(p, i, v, r1 - r0, nnz, b.shape[1]), st
+    finally:
+        engine.free(da)
+        if db is not da:
+            engine.free(db)
+
+
+GEN = [
+    ("uniform_small", 5, 2000, 6, 1),
+    ("rmat_s12", 0, 12, 8, 2),
+    ("rmat_s14", 0, 14, 16, 3),          # long rows: BIG rows, many range tasks
+    ("webbase_like_50k", 1, 50000, 155000, 4),
+    ("cop20k_like_20k", 2, 20000, 0, 5),
+    ("cage12_like_20k", 3, 20000, 0, 6),
+    ("mc2depi_like", 4, 779 * 40, 0, 7),
+]
+
+
+@pytest.mark.parametrize("name,kind,p0,p1,seed", GEN)
+def test_fused_generated_workloads(engine, name, kind, p0, p1, seed):
+    import spada_sim_amd as S
+    m = S.generate(kind, p0, p1, seed)
+    c, st = fused(engine, m, m)
+    a = to_oracle(m)
+    ref = oracle.spgemm_spa(a, a)
+    assert assert_parity(c, ref, a, a, RTOL) == 0
+    assert st["nprod"] == oracle.count_products(a, a) and st["c_nnz"] == ref.nnz
+    assert sum(st["cls_rows"]) == m.shape[0] and sum(st["cls_prod"]) == st["nprod"]
+    assert st["scratch_products"] == st["cls_prod"][4]
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_fused_random_sweep(engine, seed):
+    a, b, desc = random_case(seed)
+    c, _ = fused(engine, a, b)
+    ao, bo = to_oracle(a), to_oracle(b)
+    ref = oracle.spgemm_sortmerge(ao, bo)
+    assert_parity(c, ref, ao, bo, RTOL)
+
+
+def test_fused_capacity_error_then_numeric(engine):
+    """capacity < nnz(C): SPADA_ERR_CAPACITY, C.indptr and nnz(C) complete; a numeric call into large enough buffers follows."""
+    import spada_sim_amd as S
+    m = S.generate(S.GEN_RMAT, 11, 8, 5)
+    a = to_oracle(m)
+    ref = oracle.spgemm_spa(a, a)
+    with pytest.raises(S.SpadaError) as e:
+        fused(engine, m, m, capacity=ref.nnz // 2)
+    assert e.value.code == 9 and str(ref.nnz) in str(e.value)
+    # the same through the device API, keeping the handles alive for the numeric call
+    da = engine.upload(m)
+    with pytest.raises(S.SpadaError) as e:
+        engine.fused_owned(da, da, 0, m.shape[0], 16)
+    assert e.value.code == 9
+    p, i, v = engine.numeric_owned()
+    c = engine.download(p, i, v, m.shape[0], ref.nnz, m.shape[1])
+    assert_parity(c, ref, a, a, RTOL)
+    engine.free(da)
+    # host-pointer form: indptr and nnz(C) come back with the error, spada_spgemm_numeric completes the product
+    with pytest.raises(S.SpadaError) as e:
+        engine.spgemm_fused(m, m, capacity=10)
+    assert e.value.code == 9
+    assert_parity(engine.spgemm_fused(m, m), ref, a, a, RTOL)
+
+
+def test_fused_row_blocks(engine):
+    """Row ranges (the A-row block of one GPU): every block's C.indptr starts at 0 and the blocks concatenate."""
+    import spada_sim_amd as S
+    m = S.generate(S.GEN_WEBBASE_LIKE, 30000, 95000, 8)
+    a = to_oracle(m)
+    ref = oracle.spgemm_spa(a, a)
+    bounds = [0, 1, 7000, 7000, 19999, 30000]
+    pos = 0
+    for r0, r1 in zip(bounds[:-1], bounds[1:]):
+        c, _ = fused(engine, m, m, r0=r0, r1=r1)
+        lo, hi = int(ref.indptr[r0]), int(ref.indptr[r1])
+        assert np.array_equal(c.indptr, ref.indptr[r0:r1 + 1] - ref.indptr[r0])
+        assert np.array_equal(c.indices, ref.indices[lo:hi])
+        assert np.all(np.abs(c.data - ref.data[lo:hi]) <= RTOL * np.abs(ref.data[lo:hi]))
+        pos += c.nnz()
+    assert pos == ref.nnz
+
+
+def test_multi_pass_range_tasks(engine):
+    """More than 1.5 M columns and a BIG row whose products crowd into one histogram bucket wider than the table: the range
+    task has to halve its column range (stats.multi_pass_tasks > 0); also rows with many entries and short B rows."""
+    import spada_sim_amd as S
+    rng = np.random.default_rng(3)
+    cols = 6_000_000
+    k = 4000
+    # B: row j has 6 entries inside a 40 000-column window + 2 far outliers
+    bi, bv, bptr = [], [], [0]
+    for j in range(k):
+        c = np.unique(np.concatenate([3_000_000 + rng.integers(0, 40_000, 6), rng.integers(0, cols, 2)]))
+        bi.append(c)
+        bv.append(rng.uniform(0.1, 1.0, len(c)))
+        bptr.append(bptr[-1] + len(c))
+    b = S.CsMat((k, cols), np.array(bptr, np.uint64), np.concatenate(bi).astype(np.uint64), np.concatenate(bv))
+    # A: row 0 selects every B row (32 000 products, ~24 000 of them in one 5 859-column-wide bucket range), the others few
+    ai, av, aptr = [np.arange(k)], [rng.uniform(0.1, 1.0, k)], [0, k]
+    for r in range(1, 40):
+        c = np.unique(rng.integers(0, k, int(rng.integers(0, 700))))
+        ai.append(c)
+        av.append(rng.uniform(0.1, 1.0, len(c)))
+        aptr.append(aptr[-1] + len(c))
+    a = S.CsMat((40, k), np.array(aptr, np.uint64), np.concatenate(ai).astype(np.uint64), np.concatenate(av))
+    ao, bo = to_oracle(a), to_oracle(b)
+    ref = oracle.spgemm_sortmerge(ao, bo)
+    c, st = fused(engine, a, b)
+    assert_parity(c, ref, ao, bo, RTOL)
+    assert st["multi_pass_tasks"] > 0 and st["cls_rows"][4] > 0
+    # and through the two-phase contract
+    c2 = engine.spgemm(a, b)
+    assert_parity(c2, ref, ao, bo, RTOL)
+
+
+def test_workspace_growth_reruns_once(engine):
+    """A fresh context sizes its task list / scratch from the first run's counters and runs the pipeline again (at most once)."""
+    import spada_sim_amd as S
+    eng = S.Engine()
+    try:
+        m = S.generate(S.GEN_RMAT, 13, 16, 4)
+        c, st = fused(eng, m, m)
+        a = to_oracle(m)
+        assert_parity(c, oracle.spgemm_spa(a, a), a, a, RTOL)
+        assert st["pipeline_runs"] in (1, 2)
+        c, st = fused(eng, m, m)
+        assert st["pipeline_runs"] == 1
+    finally:
+        eng.close()

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """bench.py -- nnz(C)/s of A*A SpGEMM on MI355X, with roofline and CPU baseline (contract: see DESIGN.md).
 
-One "step" = one complete SpGEMM of the workload: symbolic phase, allocation of C, numeric phase and
+One "step" = one complete SpGEMM of the workload: allocation of C, the one-pass task pipeline (row statistics, spill
+of the big rows, task list, task kernel; `--two-phase` times the symbolic + numeric contract instead) and
 (for N > 1) the allgatherv of the C row blocks.  Inputs (A, B = A) are resident in HBM before the
 timed region starts; the timed region is bracketed by a barrier + torch.cuda.synchronize() on both sides
 and the max over ranks is taken.
@@ -81,20 +82,10 @@ def cpu_baseline(a, budget_s=12.0):
                       f"oracle SPA variant, OpenMP {nt} threads"}
 
 
-def pick_traffic(traffic, tmpl_suffix):
-    """hbm_bytes_per_launch of the k_num_flat instantiation whose template list ends with `tmpl_suffix`."""
-    if not traffic:
-        return None
-    for name, v in traffic.items():
-        if name.startswith("k_num_flat<") and name.endswith(tmpl_suffix):
-            return v["hbm_bytes_per_launch"]
-    return None
-
-
 def load_traffic(workload):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/r01_traffic_<workload>.json,
-    written by scripts/collect_traffic.sh on the GPU box); None when that file is absent."""
-    path = os.path.join(ROOT, "profiles", f"r01_traffic_{workload}.json")
+    """HBM bytes per launch of every kernel from the committed PMC passes (profiles/r02_traffic_<workload>.json, written by
+    scripts/collect_traffic.sh on the GPU box); (None, None) when that file is absent."""
+    path = os.path.join(ROOT, "profiles", f"r02_traffic_{workload}.json")
     if not os.path.exists(path):
         return None, None
     with open(path) as f:
@@ -110,6 +101,7 @@ def main():
     ap.add_argument("--workload", default="webbase-1M")
     ap.add_argument("--accumulator", default="lds_hash", choices=["lds_hash", "sort_merge"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--two-phase", action="store_true", help="time spada_dev_spgemm_symbolic + _numeric instead of the one-pass entry point")
     ap.add_argument("--chunk-products", type=float, default=0,
                     help="stream C in A-row chunks of about this many products (0 = automatic: chunk when the product "
                          "count of a rank exceeds 3e9, i.e. when C would not fit next to the inputs)")
@@ -163,6 +155,8 @@ def main():
             chunk_bounds.insert(0, r0)
         if chunk_bounds[-1] != r1:
             chunk_bounds.append(r1)
+    one_pass = not args.two_phase and args.accumulator == "lds_hash"
+    cap = my_products      # capacity of the C buffers of the one-pass entry point: one entry per product at most
     checksum = torch.zeros(1, dtype=torch.float64, device=dev)
     gather_s = [0.0]   # seconds spent in the allgatherv of C (N > 1), timed steps only
 
@@ -180,25 +174,33 @@ def main():
 
             def consume(b0, b1, nnz, st):
                 checksum.add_(bufs["v"][:nnz].sum())
-                for k in agg:
+                for k in ("c_nnz", "nprod", "bytes_read", "bytes_write"):
                     agg[k] += st[k]
                 for k, v in st.items():
                     if k.startswith("ms_"):
                         tms[k] = tms.get(k, 0.0) + v
-                for k in ("num_bin_rows", "num_bin_prod", "num_bin_entries", "num_bin_nnz"):
+                for k in ("cls_rows", "cls_prod"):
                     agg[k] = [x + y for x, y in zip(agg.get(k, [0] * len(st[k])), st[k])]
+                agg["n_tasks"] = agg.get("n_tasks", 0) + st["n_tasks"]
 
             nnz = eng.spgemm_row_chunks(da, da, chunk_bounds, alloc, consume)
             st = dict(agg)
             st.update(tms)
             return st, nnz, None
-        c_ptr = torch.empty(r1 - r0 + 1, dtype=torch.int64, device=dev)       # size known before the symbolic phase
-        nnz = eng.symbolic(da, da, r0, r1)
-        # C's values and column indices: one allocation (values first: 8-byte aligned), sized by the symbolic result
-        buf = torch.empty(max(nnz, 1) * 12, dtype=torch.uint8, device=dev)
-        c_val = buf[:max(nnz, 1) * 8].view(torch.float64)
-        c_idx = buf[max(nnz, 1) * 8:].view(torch.int32)
-        eng.numeric(c_ptr.data_ptr(), c_idx.data_ptr(), c_val.data_ptr())     # returns after its stream has drained
+        c_ptr = torch.empty(r1 - r0 + 1, dtype=torch.int64, device=dev)
+        if one_pass:
+            # C's values and column indices: one allocation sized by the product count of the row block -- an upper bound of
+            # nnz(C) the host knows before anything runs on the GPU (values first: 8-byte aligned)
+            buf = torch.empty(max(cap, 1) * 12, dtype=torch.uint8, device=dev)
+            c_val = buf[:max(cap, 1) * 8].view(torch.float64)
+            c_idx = buf[max(cap, 1) * 8:].view(torch.int32)
+            nnz = eng.fused(da, da, r0, r1, c_ptr.data_ptr(), c_idx.data_ptr(), c_val.data_ptr(), cap)
+        else:
+            nnz = eng.symbolic(da, da, r0, r1)
+            buf = torch.empty(max(nnz, 1) * 12, dtype=torch.uint8, device=dev)
+            c_val = buf[:max(nnz, 1) * 8].view(torch.float64)
+            c_idx = buf[max(nnz, 1) * 8:].view(torch.int32)
+            eng.numeric(c_ptr.data_ptr(), c_idx.data_ptr(), c_val.data_ptr())     # returns after its stream has drained
         st = eng.stats()
         if world > 1:
             tg = time.perf_counter()
@@ -220,11 +222,11 @@ def main():
     gather_s[0] = 0.0
     t0 = time.perf_counter()
     acc = {}
+    TIMES = ("ms_fused_call", "ms_symbolic_call", "ms_numeric_call", "ms_row_stats", "ms_big_expand", "ms_cut", "ms_task")
     for _ in range(args.steps):
         st, nnz_local, _ = step()
-        for k in ("ms_symbolic_call", "ms_numeric_call", "ms_row_stats", "ms_binning", "ms_symbolic", "ms_scan",
-                  "ms_numeric", "ms_sym_flat", "ms_num_flat", "ms_num_mid"):
-            acc[k] = acc.get(k, 0.0) + st[k]
+        for k in TIMES:
+            acc[k] = acc.get(k, 0.0) + st.get(k, 0.0)
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -241,24 +243,26 @@ def main():
     if rank == 0:
         K = args.steps
         ms_step = elapsed / K * 1e3
-        dev_ms = (acc["ms_symbolic_call"] + acc["ms_numeric_call"]) / K      # rank 0, HIP events on the engine stream
+        ms = {k: v / K for k, v in acc.items()}
+        # device time of one SpGEMM on rank 0 (HIP events on the engine stream)
+        dev_ms = ms["ms_fused_call"] if one_pass and chunk_bounds is None else ms["ms_symbolic_call"] + ms["ms_numeric_call"]
         pipe_gbs = st["bytes_read"] / (dev_ms * 1e-3) / 1e9
-        # dominant kernel: the flat-batch numeric kernel k_num_flat, timed by HIP events on the stream it runs on.  It is
-        # launched twice per step: shared batches of consecutive rows (bin 2) and list mode, one mid row per batch (bin 7);
-        # the launch with the larger algorithmic byte count is reported as `roofline`, the other under `roofline.other`.
-        def launch(bin_id, ms_key, label, tmpl):
-            r_, p_, e_, n_ = (st[k][bin_id] for k in ("num_bin_rows", "num_bin_prod", "num_bin_entries", "num_bin_nnz"))
-            rd, wr, ms = 12 * p_ + 28 * e_ + 8 * r_, 12 * n_ + 8 * r_, acc[ms_key] / K
-            return {"label": label, "tmpl": tmpl, "ms": ms, "read": rd, "write": wr, "gbs": rd / (ms * 1e-3) / 1e9 if ms > 0 else 0.0,
-                    "units": {"rows": r_, "products": p_, "a_entries": e_, "nnz_c": n_}}
-        cands = [launch(2, "ms_num_flat", "shared batches of consecutive rows (nnz(C_i) <= 512)", "false, 1>"),
-                 launch(7, "ms_num_mid", "list mode, one row per batch (768 < nnz(C_i) <= 1536)", "true, 1>")]
-        if args.accumulator == "sort_merge":
-            cands = cands[:1]
-        cands.sort(key=lambda d: -d["read"])
-        dom = cands[0]
-        achieved, k_ms, k_read, k_write = dom["gbs"], dom["ms"], dom["read"], dom["write"]
+        # Dominant kernel: k_task -- the persistent task kernel that expands, scales, accumulates and orders every product of
+        # the step (all rows; 60-70 % of the device time).  Its average duration comes from HIP events recorded around it on
+        # the stream it is launched on; its algorithmic bytes are those of the whole step (12 B per product,
+        # 28 B per A entry, 8 B per row read; 12 B per nnz(C) written), the other kernels are listed under `kernels`.
+        k_ms = ms["ms_task"] if chunk_bounds is None else dev_ms
+        achieved = st["bytes_read"] / (k_ms * 1e-3) / 1e9
         traffic, traffic_src = load_traffic(args.workload)
+        cls_names = ["empty", "copy (one A entry)", "small", "solo", "big (spilled to HBM scratch)"]
+        kernels = [
+            {"kernel": "k_entry_stats + k_row_class (B-row descriptors, products per row, row classes)", "ms": ms["ms_row_stats"]},
+            {"kernel": "k_big_expand (big rows: column histogram, ranges, products scattered into HBM scratch)", "ms": ms["ms_big_expand"],
+             "products": st["cls_prod"][4] if "cls_prod" in st else None},
+            {"kernel": "k_cut1/2/3 (task list)", "ms": ms["ms_cut"]},
+            {"kernel": "k_task (expand - scale - accumulate - order, all rows)", "ms": ms["ms_task"], "products": nprod_total if world == 1 else st["nprod"],
+             "tasks": st.get("n_tasks")},
+        ]
         out = {
             "metric": "nnz(C)/sec on A*A SpGEMM",
             "value": nnz_total / (elapsed / K),
@@ -280,30 +284,30 @@ def main():
                         "(N-1)/N of 12 B x nnz(C) over xGMI, which bounds strong scaling once that exceeds the compute time"},
             "config": {"workload": f"{args.workload} A*A", "rows": rows, "nnz_a": a.nnz(), "products": nprod_total,
                        "nnz_c": nnz_total, "accumulator": args.accumulator,
+                       "entry_point": "spada_dev_spgemm_fused (one pass, C buffers sized by the product count)" if one_pass
+                                      else "spada_dev_spgemm_symbolic + spada_dev_spgemm_numeric",
                        "parallelism": f"row-block x{world}, B replicated" +
                                       (f", C streamed in {len(chunk_bounds) - 1} row chunks per rank and not gathered"
                                        if chunk_bounds is not None else (", allgatherv of C" if world > 1 else ""))},
             "roofline": {
                 "bound": "hbm",
-                "kernel": ("k_num_sortmerge (sort-merge accumulator over the rows with <= 1024 products)"
-                           if args.accumulator == "sort_merge" else
-                           "k_num_flat (flat-batch numeric: expand - scale - accumulate - order), " + dom["label"]) +
-                          "; average duration per step by HIP events on its stream, rank 0",
+                "kernel": "k_task (persistent task kernel: expand - scale - LDS-hash accumulate - ordered emission of every row of C); "
+                          "average duration per step by HIP events on its stream, rank 0",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": pick_traffic(traffic, dom["tmpl"]) if args.accumulator != "sort_merge" else None,
+                "traffic": (traffic or {}).get("k_task", {}).get("hbm_bytes_per_launch"),
                 "traffic_source": os.path.relpath(traffic_src, ROOT) if traffic else None,
                 "kernel_ms": k_ms,
-                "kernel_units": dom["units"],
-                "other": [{"kernel": "k_num_flat, " + o["label"], "kernel_ms": o["ms"], "achieved": o["gbs"],
-                           "frac": o["gbs"] / HBM_PEAK_GBS, "kernel_units": o["units"]} for o in cands[1:]],
-                "kernel_algorithmic_bytes_read": k_read,
-                "kernel_algorithmic_bytes_write": k_write,
+                "kernel_algorithmic_bytes_read": st["bytes_read"],
+                "kernel_algorithmic_bytes_write": st["bytes_write"],
+                "kernels": kernels,
+                "row_classes": ({cls_names[k]: {"rows": st["cls_rows"][k], "products": st["cls_prod"][k]} for k in range(5)}
+                                if "cls_rows" in st else None),
                 "pipeline": {"achieved": pipe_gbs, "frac": pipe_gbs / HBM_PEAK_GBS, "device_ms_per_step": dev_ms,
                              "algorithmic_bytes_read": st["bytes_read"], "algorithmic_bytes_write": st["bytes_write"],
-                             "phase_ms": {k: v / K for k, v in acc.items()}},
+                             "phase_ms": ms},
             },
         }
         if not args.no_cpu_baseline and world == 1:

@@ -132,7 +132,7 @@ struct spada_ctx {
     uint64_t *h_u64 = nullptr;        // pinned
     // task pipeline (spgemm_task.hip.hpp): the default; SPADA_PIPELINE=legacy selects the round-1 per-bin kernels
     bool use_tasks = true;
-    DevBuf t_rowP, t_rowm, t_rowtmp, t_big, t_tiles, t_tmp, t_tasks, t_status, t_rangeout, t_scrcol, t_scrval, t_ctr;
+    DevBuf t_rowP, t_rowm, t_rowt, t_rowtmp, t_big, t_tiles, t_tmp, t_tasks, t_status, t_rangeout, t_scrcol, t_scrval, t_ctr;
     uint64_t t_cap_tmp = 0, t_cap_tasks = 0, t_cap_scr = 0;
     TaskCounters *h_tctr = nullptr;   // pinned
     hipEvent_t tev[6] = {};
@@ -538,6 +538,7 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
     if ((rc = c->row_kmax.ensure(n1 * 4, false, s, &c->ws_bytes))) return rc;
     if ((rc = c->t_rowP.ensure(n1 * 8, false, s, &c->ws_bytes))) return rc;
     if ((rc = c->t_rowm.ensure(n1 * 4, false, s, &c->ws_bytes))) return rc;
+    if ((rc = c->t_rowt.ensure(n1 * 4, false, s, &c->ws_bytes))) return rc;
     if ((rc = c->t_rowtmp.ensure(n1 * 4, false, s, &c->ws_bytes))) return rc;
     if ((rc = c->t_big.ensure(n1 * 4, false, s, &c->ws_bytes))) return rc;
     if ((rc = c->cptr.ensure(n1 * 8, false, s, &c->ws_bytes))) return rc;
@@ -582,14 +583,14 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
             hipLaunchKernelGGL(k_entry_stats, dim3(gent), dim3(256), 0, s, a->ptr, a->idx, a->rowid, b->ptr, b->idx, c->r0, n,
                                c->eb0.as<uint64_t>(), c->elen.as<uint32_t>(), c->t_rowP.as<unsigned long long>(),
                                c->row_kmin.as<uint32_t>(), c->row_kmax.as<uint32_t>());
-            hipLaunchKernelGGL(k_row_class, dim3(std::min<uint32_t>((n + 255) / 256, c->n_cu * 8)), dim3(256), 0, s, a->ptr, c->r0,
+            hipLaunchKernelGGL(k_row_class, dim3(std::min<uint32_t>((n + 255) / 256, c->n_cu)), dim3(256), 0, s, a->ptr, c->r0,
                                n, rmax, c->t_rowP.as<unsigned long long>(), c->row_nprod.as<uint32_t>(), c->row_bin.as<uint8_t>(),
                                c->t_rowm.as<uint32_t>(), c->t_big.as<uint32_t>(), dc);
             HIP_TRY(hipGetLastError());
         }
         HIP_TRY(hipEventRecord(c->tev[1], s));
         if (n) {
-            hipLaunchKernelGGL(k_big_expand, dim3(c->n_cu * 4), dim3(TK_BLOCK), BX_LDS, s, a->ptr, a->val, b->idx, b->val,
+            hipLaunchKernelGGL(k_big_expand, dim3(c->n_cu * 5), dim3(TK_BLOCK), BX_LDS, s, a->ptr, a->val, b->idx, b->val,
                                c->eb0.as<uint64_t>(), c->elen.as<uint32_t>(), c->r0, c->t_big.as<uint32_t>(),
                                c->row_nprod.as<uint32_t>(), c->row_kmin.as<uint32_t>(), c->row_kmax.as<uint32_t>(),
                                c->t_rowm.as<uint32_t>(), c->t_rowtmp.as<uint32_t>(), c->t_tmp.as<TaskDesc>(), cap_tmp,
@@ -599,10 +600,10 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
         HIP_TRY(hipEventRecord(c->tev[2], s));
         if (n) {
             hipLaunchKernelGGL(k_cut1, dim3(ntiles), dim3(256), 0, s, c->row_bin.as<uint8_t>(), c->row_nprod.as<uint32_t>(),
-                               c->t_rowm.as<uint32_t>(), n, rmax, c->t_tiles.as<uint32_t>());
+                               c->t_rowm.as<uint32_t>(), n, rmax, c->t_tiles.as<uint32_t>(), c->t_rowt.as<uint32_t>());
             hipLaunchKernelGGL(k_cut2, dim3(1), dim3(256), 0, s, c->t_tiles.as<uint32_t>(), ntiles, cap_tasks, dc);
-            hipLaunchKernelGGL(k_cut3, dim3(ntiles), dim3(256), 0, s, c->row_bin.as<uint8_t>(), c->row_nprod.as<uint32_t>(),
-                               c->t_rowm.as<uint32_t>(), c->t_rowtmp.as<uint32_t>(), n, rmax, c->t_tiles.as<uint32_t>(),
+            hipLaunchKernelGGL(k_cut3, dim3(ntiles), dim3(256), 0, s, c->row_bin.as<uint8_t>(), c->t_rowt.as<uint32_t>(),
+                               c->t_rowtmp.as<uint32_t>(), n, c->t_tiles.as<uint32_t>(),
                                c->t_tmp.as<TaskDesc>(), c->t_tasks.as<TaskDesc>(), cap_tasks, dc);
             HIP_TRY(hipGetLastError());
         }
@@ -619,7 +620,10 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
         HIP_TRY(hipEventRecord(c->tev[4], s));
         HIP_TRY(hipMemcpyAsync(c->h_tctr, dc, sizeof(TaskCounters), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
-        const TaskCounters &h = *c->h_tctr;
+        TaskCounters &h = *c->h_tctr;
+        h.nprod = 0;
+        for (int k = 0; k < N_CLS; ++k) h.nprod += h.cls_prod[k];
+        h.nprod_big = h.cls_prod[CLS_BIG];
         if (!h.abort_flag) break;
         if (attempt == 2) return fail(SPADA_ERR_HIP, "task pipeline: workspaces still too small after two retries (flag %u)", h.abort_flag);
         if (h.abort_flag & 4u) return fail(SPADA_ERR_UNSUPPORTED, "a row of C has 2^32 or more products");
@@ -806,7 +810,7 @@ void spada_destroy(spada_ctx *c)
     for (DevBuf *b : {&c->row_nprod, &c->row_nnzc, &c->row_bin, &c->sym_rows, &c->num_rows, &c->counters, &c->cptr,
                       &c->tile_sums, &c->bitmaps, &c->slabs, &c->own_idx, &c->own_val, &c->own_ptr, &c->wide_idx,
                       &c->eb0, &c->elen, &c->efl, &c->row_kmin, &c->row_kmax, &c->batch_sym, &c->batch_num, &c->tile_w, &c->dbg,
-                      &c->t_rowP, &c->t_rowm, &c->t_rowtmp, &c->t_big, &c->t_tiles, &c->t_tmp, &c->t_tasks, &c->t_status, &c->t_rangeout,
+                      &c->t_rowP, &c->t_rowm, &c->t_rowt, &c->t_rowtmp, &c->t_big, &c->t_tiles, &c->t_tmp, &c->t_tasks, &c->t_status, &c->t_rangeout,
                       &c->t_scrcol, &c->t_scrval, &c->t_ctr})
         b->release();
     if (c->h_tctr) (void)hipHostFree(c->h_tctr);

@@ -54,7 +54,7 @@ struct TaskCounters {
     unsigned long long scratch_cursor;                // products handed out in the scratch arrays
     unsigned long long nnz_c;                         // written by the last task (COUNT / FUSED)
     unsigned long long cls_rows[N_CLS], cls_prod[N_CLS];
-    uint32_t n_big, tmp_cursor, ntasks, pad0;
+    uint32_t n_big, tmp_cursor, ntasks, big_cursor;
     uint32_t abort_flag;                              // a workspace was too small: results invalid, sizes below say what is needed
     uint32_t cap_overflow;                            // FUSED: nnz(C) exceeded the caller's capacity (C.indptr is complete)
     uint32_t need_tmp, need_tasks;
@@ -147,8 +147,11 @@ __global__ __launch_bounds__(256) void k_row_class(const uint64_t *__restrict__ 
             row_nprod[i] = P > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)P;
             row_cls[i] = cls;
             row_m[i] = 0;
-            c_rows[cls] += 1;
-            c_prod[cls] += P;
+#pragma unroll
+            for (int k = 0; k < N_CLS; ++k) {   // (a run-time index would push the counters out of the registers)
+                c_rows[k] += cls == k ? 1ull : 0ull;
+                c_prod[k] += cls == k ? P : 0ull;
+            }
             tot_l += L;
         }
         // BIG rows: one global atomic per wave
@@ -172,10 +175,9 @@ __global__ __launch_bounds__(256) void k_row_class(const uint64_t *__restrict__ 
     if (lane == 0 && wl) atomicAdd(&s_tot, wl);
     __syncthreads();
     if (threadIdx.x < N_CLS && s_rows[threadIdx.x]) {
+        // (few workgroups, few atomics: one hot word takes ~90 atomics per microsecond; nprod / nprod_big = sums of cls_prod)
         atomicAdd(&ctr->cls_rows[threadIdx.x], s_rows[threadIdx.x]);
         atomicAdd(&ctr->cls_prod[threadIdx.x], s_prod[threadIdx.x]);
-        atomicAdd(&ctr->nprod, s_prod[threadIdx.x]);
-        if (threadIdx.x == CLS_BIG) atomicAdd(&ctr->nprod_big, s_prod[threadIdx.x]);
     }
     if (threadIdx.x == 0 && s_tot) atomicAdd(&ctr->a_nnz, s_tot);
 }
@@ -216,7 +218,13 @@ __global__ __launch_bounds__(TK_BLOCK) void k_big_expand(const uint64_t *__restr
     scratch = (unsigned char *)(((uintptr_t)scratch + 15) & ~(uintptr_t)15);
     const int tid = threadIdx.x;
     const uint32_t nbig = ctr->n_big;
-    for (uint32_t slot = blockIdx.x; slot < nbig; slot += gridDim.x) {
+    for (;;) {
+        // rows differ in size by orders of magnitude: dequeue dynamically (one device atomic per row)
+        if (tid == 0) hdr[46] = atomicAdd(&ctr->big_cursor, 1u);
+        __syncthreads();
+        const uint32_t slot = hdr[46];
+        __syncthreads();
+        if (slot >= nbig) break;
         const uint32_t row = big_rows[slot];
         if (row_nprod[row] == 0xFFFFFFFFu) {   // 2^32 or more products in one row: the 32-bit bucket counters would wrap
             if (tid == 0) atomicOr(&ctr->abort_flag, 4u);
@@ -464,15 +472,20 @@ __device__ inline uint32_t cut_tile(const uint8_t *__restrict__ row_cls, const u
     return block_scan_excl_u32(local, L.s_w, tile_total);
 }
 
+// k_cut1: tasks started by every row -> row_t (0: none; BIG rows: their range tasks; else 1) and the tile totals
 __global__ __launch_bounds__(256) void k_cut1(const uint8_t *__restrict__ row_cls, const uint32_t *__restrict__ row_nprod,
                                               const uint32_t *__restrict__ row_m, uint32_t n, uint32_t rmax,
-                                              uint32_t *__restrict__ tile_tasks)
+                                              uint32_t *__restrict__ tile_tasks, uint32_t *__restrict__ row_t)
 {
     __shared__ CutLds L;
     CutRow cr;
     uint32_t tot;
     (void)cut_tile(row_cls, row_nprod, row_m, n, rmax, L, cr, &tot);
     if (threadIdx.x == 0) tile_tasks[blockIdx.x] = tot;
+    const uint32_t base = blockIdx.x * CUT_TILE + threadIdx.x * CUT_ITEMS;
+#pragma unroll
+    for (int j = 0; j < CUT_ITEMS; ++j)
+        if (base + j < n) row_t[base + j] = cr.t[j];
 }
 
 // single workgroup: exclusive scan of the tile totals in place; total -> ctr->ntasks
@@ -497,18 +510,28 @@ __global__ __launch_bounds__(256) void k_cut2(uint32_t *__restrict__ tile_tasks,
     }
 }
 
-__global__ __launch_bounds__(256) void k_cut3(const uint8_t *__restrict__ row_cls, const uint32_t *__restrict__ row_nprod,
-                                              const uint32_t *__restrict__ row_m, const uint32_t *__restrict__ row_tmp,
-                                              uint32_t n, uint32_t rmax, const uint32_t *__restrict__ tile_tasks,
-                                              const TaskDesc *__restrict__ tmp, TaskDesc *__restrict__ tasks, uint32_t task_cap,
+// k_cut3: task descriptors at their final place: tile offset + prefix of row_t inside the tile
+__global__ __launch_bounds__(256) void k_cut3(const uint8_t *__restrict__ row_cls, const uint32_t *__restrict__ row_t,
+                                              const uint32_t *__restrict__ row_tmp, uint32_t n,
+                                              const uint32_t *__restrict__ tile_tasks, const TaskDesc *__restrict__ tmp,
+                                              TaskDesc *__restrict__ tasks, uint32_t task_cap,
                                               const TaskCounters *__restrict__ ctr)
 {
     __shared__ CutLds L;
     __shared__ uint32_t s_nbig;
     if (threadIdx.x == 0) s_nbig = 0;
     CutRow cr;
-    uint32_t tot;
-    uint32_t idx = cut_tile(row_cls, row_nprod, row_m, n, rmax, L, cr, &tot) + tile_tasks[blockIdx.x];
+    uint32_t tot, local = 0;
+    {
+        const uint32_t b = blockIdx.x * CUT_TILE + threadIdx.x * CUT_ITEMS;
+#pragma unroll
+        for (int j = 0; j < CUT_ITEMS; ++j) {
+            cr.t[j] = b + j < n ? row_t[b + j] : 0u;
+            cr.kind[j] = cr.t[j] == 0 ? 0u : (row_cls[b + j] == CLS_BIG ? 2u : 1u);
+            local += cr.t[j];
+        }
+    }
+    uint32_t idx = block_scan_excl_u32(local, L.s_w, &tot) + tile_tasks[blockIdx.x];
     if (ctr->abort_flag) return;   // a workspace overflowed upstream: nothing below may be trusted
     const uint32_t base = blockIdx.x * CUT_TILE + threadIdx.x * CUT_ITEMS;
     uint32_t kb[CUT_ITEMS], idxb[CUT_ITEMS];
@@ -935,8 +958,9 @@ __global__ __launch_bounds__(TK_BLOCK, 4) void k_task(const TaskArgs g)
     unsigned long long dbg_t0 = SPADA_TASK_DBG ? __builtin_amdgcn_s_memtime() : 0, dbg_acc = 0, dbg_chain = 0, dbg_emit = 0;
     while (t < ntasks) {
         unsigned long long dbg_a = SPADA_TASK_DBG ? __builtin_amdgcn_s_memtime() : 0, dbg_b = dbg_a, dbg_c = dbg_a;
-        // (a ticket taken ahead of time would sit unstarted in the chain while this workgroup waits for its own
-        // predecessors, and every later task would wait for it: tickets are taken when the work starts)
+        // (tickets are taken when the work starts: one taken earlier -- even only across this task's stores, to hide its
+        // round trip -- sits unstarted in the chain, every later task waits for it, and the pipeline loses more than the
+        // round trip it saved: measured +6 % on the web surrogate, +30 % on R-MAT 16)
         const TaskDesc td = g.tasks[t];
         if (td.kind == TASK_BATCH) {
             const uint32_t rb = td.row;

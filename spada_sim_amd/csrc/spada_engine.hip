@@ -655,6 +655,11 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
                      100.0 * h.dbg[0] / std::max<double>(1, h.dbg[3]), 100.0 * h.dbg[5] / std::max<double>(1, h.dbg[3]),
                      (double)h.dbg[1] / std::max(1u, h.ntasks), (double)h.dbg[2] / std::max(1u, h.ntasks),
                      (double)h.dbg[7] / std::max(1u, h.ntasks), (double)h.dbg[6] / std::max<double>(1, h.dbg[7]));
+    if (SPADA_TASK_DBG && h.dbg[15])
+        std::fprintf(stderr, "[batch dbg] %llu batches, cycles each: descriptor %.0f | rows+scan+clear %.0f | walk %.0f | counts+publish %.0f | "
+                     "emit (LDS, look-back wait, stores) %.0f | copy rows %.0f | ticket %.0f\n", h.dbg[15], (double)h.dbg[8] / h.dbg[15],
+                     (double)h.dbg[9] / h.dbg[15], (double)h.dbg[10] / h.dbg[15], (double)h.dbg[11] / h.dbg[15],
+                     (double)h.dbg[12] / h.dbg[15], (double)h.dbg[13] / h.dbg[15], (double)h.dbg[14] / h.dbg[15]);
     st.n_tasks = h.ntasks;
     st.multi_pass_tasks = h.multi_pass_tasks;
     st.scratch_products = h.nprod_big;

@@ -24,6 +24,10 @@
 #pragma once
 #include "spgemm_flat.hip.hpp"
 
+#ifndef SPADA_TASK_DBG
+#define SPADA_TASK_DBG 0   /* 1 (scripts/build_dbg.sh): phase cycle counters of k_big_expand / k_task, printed to stderr */
+#endif
+
 namespace spada {
 
 constexpr uint8_t CLS_EMPTY = 0, CLS_COPY = 1, CLS_SMALL = 2, CLS_SOLO = 3, CLS_BIG = 4;
@@ -60,7 +64,7 @@ struct TaskCounters {
     uint32_t need_tmp, need_tasks;
     uint32_t multi_pass_tasks, pad;
     uint32_t ticket[TK_NQ * 32];  // TK_NQ ticket counters, one per 128-byte line (a single hot word sustains ~88 atomics / us)
-    unsigned long long dbg[8];   // SPADA_TASK_DBG builds: [0] cycles in the chain, [1] look-back windows, [2] spin retries, [3] cycles
+    unsigned long long dbg[16];  // SPADA_TASK_DBG builds: [0] cycles in the chain, [1] look-back windows, [2] spin retries, [3] cycles
                                  // of the task loop, [4] cycles before the chain (expand + accumulate), [5] cycles after it (emit)
 };
 
@@ -243,6 +247,9 @@ __global__ __launch_bounds__(TK_BLOCK) void k_big_expand(const uint64_t *__restr
         }
         __syncthreads();
         // pass 1: histogram
+#ifdef BX_SKIP_HIST
+        if (false)
+#endif
         flat_walk<TK_BLOCK, TK_EPT, 1, false, U>(s_re, s_a0, 1u, E, eb0, elen, nullptr, bidx, nullptr, scratch, hdr,
                                                  [&](uint32_t(&col)[U], uint32_t(&plr)[U], double(&)[U], uint32_t(&)[U]) {
 #pragma unroll
@@ -331,7 +338,11 @@ __global__ __launch_bounds__(TK_BLOCK) void k_big_expand(const uint64_t *__restr
         // pass 2: scatter; cnt becomes the cursor of every bucket
         for (int b = tid; b < NB; b += TK_BLOCK) cnt[b] = pre[b];
         __syncthreads();
+#ifdef BX_SKIP_SCATTER
+        if (false)
+#else
         if (ok)
+#endif
             flat_walk<TK_BLOCK, TK_EPT, 1, true, U>(s_re, s_a0, 1u, E, eb0, elen, aval, bidx, bval, scratch, hdr,
                                                     [&](uint32_t(&col)[U], uint32_t(&plr)[U], double(&v)[U], uint32_t(&)[U]) {
 #pragma unroll
@@ -635,9 +646,6 @@ __host__ __device__ constexpr size_t task_lds()
 // until it meets an inclusive prefix (INC); finally it publishes its own inclusive prefix.  Status words are single 8-byte
 // agent-scope atomics (flag | value): no ordering between separate words is needed.  Tasks are taken by ticket, so every
 // predecessor has been started by a resident workgroup and never waits for a later task: the wait is bounded.
-#ifndef SPADA_TASK_DBG
-#define SPADA_TASK_DBG 0
-#endif
 // chain_publish: the task's own count, as soon as it is known (thread 0).  chain_lookback: the exclusive prefix, as late as it is
 // needed (all threads) -- the LDS half of the emission sits between the two, so the wait for predecessors that are still
 // accumulating is mostly over by the time the look-back starts.
@@ -956,16 +964,20 @@ __global__ __launch_bounds__(TK_BLOCK, 4) void k_task(const TaskArgs g)
     uint32_t t = hdr[50];
     __syncthreads();
     unsigned long long dbg_t0 = SPADA_TASK_DBG ? __builtin_amdgcn_s_memtime() : 0, dbg_acc = 0, dbg_chain = 0, dbg_emit = 0;
+    unsigned long long dbg_ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     while (t < ntasks) {
         unsigned long long dbg_a = SPADA_TASK_DBG ? __builtin_amdgcn_s_memtime() : 0, dbg_b = dbg_a, dbg_c = dbg_a;
         // (tickets are taken when the work starts: one taken earlier -- even only across this task's stores, to hide its
         // round trip -- sits unstarted in the chain, every later task waits for it, and the pipeline loses more than the
         // round trip it saved: measured +6 % on the web surrogate, +30 % on R-MAT 16)
         const TaskDesc td = g.tasks[t];
+        unsigned long long ph_prev = dbg_a;
+#define PHASE(i) do { if (SPADA_TASK_DBG && tid == 0) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); dbg_ph[i] += n_ - ph_prev; ph_prev = n_; } } while (0)
         if (td.kind == TASK_BATCH) {
             const uint32_t rb = td.row;
             const uint32_t re = t + 1 < ntasks ? g.tasks[t + 1].row : g.nrows;
             const uint32_t R = re - rb;   // 1 .. RMAX
+            PHASE(0);
             // ---- rows of the batch ------------------------------------------------------------------------------------
             uint32_t L = 0, n = 0, kmin = 0, kmax = 0, rid = 0, clen = 0;
             uint64_t cb0 = 0, c0 = 0;
@@ -997,6 +1009,7 @@ __global__ __launch_bounds__(TK_BLOCK, 4) void k_task(const TaskArgs g)
             if (tid == 0) s_re[R] = E;
             if (E) table_clear(smem);
             __syncthreads();
+            PHASE(1);
             // ---- expand - scale - accumulate (simulator.rs:86-111, :199-230) ---------------------------------------------
             if (E)
                 flat_walk<BLOCK, EPT, RMAX, VALUES, U>(
@@ -1030,6 +1043,7 @@ __global__ __launch_bounds__(TK_BLOCK, 4) void k_task(const TaskArgs g)
                         }
                     });
             __syncthreads();
+            PHASE(2);
             // ---- outputs per row, offsets inside the batch ------------------------------------------------------------------
             const bool hashed = cls == CLS_SMALL || cls == CLS_SOLO;
             if constexpr (MODE != MODE_NUMERIC) n = hashed ? s_cnt[tid < RMAX ? tid : 0] : (cls == CLS_COPY ? clen : 0u);
@@ -1042,6 +1056,7 @@ __global__ __launch_bounds__(TK_BLOCK, 4) void k_task(const TaskArgs g)
             // ---- chain: publish the count now, look back as late as possible ------------------------------------------------
             if (SPADA_TASK_DBG) dbg_b = dbg_c = __builtin_amdgcn_s_memtime();
             if constexpr (MODE != MODE_NUMERIC) chain_publish(g.status, t, total);
+            PHASE(3);
             unsigned long long dbg_w = 0;
             auto resolve = [&]() -> unsigned long long {
                 if constexpr (MODE == MODE_NUMERIC) {
@@ -1077,38 +1092,51 @@ __global__ __launch_bounds__(TK_BLOCK, 4) void k_task(const TaskArgs g)
                 base = resolve();
             }
             if (SPADA_TASK_DBG) dbg_c = dbg_b + dbg_w;
+            PHASE(4);
             if constexpr (MODE != MODE_NUMERIC) c0 = base + ooff;
             if (MODE != MODE_COUNT && base != NO_STORE) {
-                // COPY rows: C_i = a * B_k, already ascending (one lane per short row, the whole wave for longer ones)
+                // COPY rows: C_i = a * B_k, already ascending.  Their products form one flat list (prefix sums of the row
+                // lengths in LDS, region 2 is free by now): every lane copies products, whatever the row lengths are.
+                uint32_t *s_cpre = (uint32_t *)region2;                       // [RMAX + 1]
+                uint64_t *s_cb0 = (uint64_t *)(region2 + (RMAX + 2) * 4);     // [RMAX]  (8-byte aligned: RMAX is even)
+                double *s_cav = (double *)(s_cb0 + RMAX);
+                uint64_t *s_cc0 = (uint64_t *)(s_cav + RMAX);
                 const bool copy = (uint32_t)tid < R && cls == CLS_COPY;
-                if (copy && clen <= COPY_SHORT) {
-                    for (uint32_t q = 0; q < clen; q += 4) {
-                        uint32_t k4[4];
+                uint32_t Cp;
+                const uint32_t cex = group_scan_excl<BLOCK>(copy ? clen : 0u, tid, hdr + 2, &Cp);
+                if (Cp) {   // uniform
+                    if ((uint32_t)tid < R) {
+                        s_cpre[tid] = cex;
+                        s_cb0[tid] = cb0;
+                        s_cav[tid] = cav;
+                        s_cc0[tid] = c0;
+                    }
+                    if (tid == 0) s_cpre[R] = Cp;
+                    __syncthreads();
+                    for (uint32_t p0 = tid; p0 < Cp; p0 += 4 * BLOCK) {
+                        uint32_t k4[4], off4[4], lr4[4];
                         double v4[4];
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {
-                            const uint32_t qq = q + u < clen ? q + u : clen - 1;
-                            k4[u] = g.bidx[cb0 + qq];
-                            v4[u] = g.bval[cb0 + qq];
+                            const uint32_t p = min(p0 + u * BLOCK, Cp - 1);
+                            uint32_t lo = 0;   // largest lr with s_cpre[lr] <= p (rows without copy products repeat a value)
+#pragma unroll
+                            for (int step = RMAX / 2; step >= 1; step >>= 1)
+                                if (lo + step < R && s_cpre[lo + step] <= p) lo += step;
+                            lr4[u] = lo;
+                            off4[u] = p - s_cpre[lo];
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            k4[u] = g.bidx[s_cb0[lr4[u]] + off4[u]];
+                            v4[u] = g.bval[s_cb0[lr4[u]] + off4[u]];
                         }
 #pragma unroll
                         for (int u = 0; u < 4; ++u)
-                            if (q + u < clen) {
-                                g.c_idx[c0 + q + u] = k4[u];
-                                g.c_val[c0 + q + u] = cav * v4[u];
+                            if (p0 + u * BLOCK < Cp) {
+                                g.c_idx[s_cc0[lr4[u]] + off4[u]] = k4[u];
+                                g.c_val[s_cc0[lr4[u]] + off4[u]] = s_cav[lr4[u]] * v4[u];
                             }
-                    }
-                }
-                unsigned long long mask = __ballot(copy && clen > COPY_SHORT);
-                while (mask) {
-                    const int src = __ffsll((long long)mask) - 1;
-                    mask &= mask - 1;
-                    const uint64_t sb0 = __shfl(cb0, src), sc0 = __shfl(c0, src);
-                    const uint32_t slen = __shfl(clen, src);
-                    const double sav = __shfl(cav, src);
-                    for (uint32_t q = lane; q < slen; q += 64) {
-                        g.c_idx[sc0 + q] = g.bidx[sb0 + q];
-                        g.c_val[sc0 + q] = sav * g.bval[sb0 + q];
                     }
                 }
             }
@@ -1165,10 +1193,16 @@ __global__ __launch_bounds__(TK_BLOCK, 4) void k_task(const TaskArgs g)
             if (SPADA_TASK_DBG) dbg_c = dbg_b + dbg_w;
         }
         __syncthreads();
+        if (td.kind == TASK_BATCH) {
+            PHASE(5);
+            if (SPADA_TASK_DBG && tid == 0) dbg_ph[7] += 1;
+        }
         if (tid == 0) hdr[50] = atomicAdd(my_ticket, 1u) * TK_NQ + blockIdx.x % TK_NQ;
         __syncthreads();
         t = hdr[50];
         __syncthreads();
+        if (td.kind == TASK_BATCH) PHASE(6);
+#undef PHASE
         if (SPADA_TASK_DBG) {
             const unsigned long long e = __builtin_amdgcn_s_memtime();
             dbg_acc += dbg_b - dbg_a;
@@ -1181,6 +1215,8 @@ __global__ __launch_bounds__(TK_BLOCK, 4) void k_task(const TaskArgs g)
         atomicAdd(&g.ctr->dbg[3], __builtin_amdgcn_s_memtime() - dbg_t0);
         atomicAdd(&g.ctr->dbg[4], dbg_acc);
         atomicAdd(&g.ctr->dbg[5], dbg_emit);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) atomicAdd(&g.ctr->dbg[8 + k], dbg_ph[k]);
     }
 }
 

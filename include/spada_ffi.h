@@ -62,8 +62,9 @@ typedef struct spada_csr_view {
 
 /* Per-row accumulator used by the numeric phase (BASELINE.json configs[2] compares the two). */
 enum spada_accumulator {
-    SPADA_ACC_LDS_HASH = 0,   /* LDS hash accumulator + rank sort (default) */
-    SPADA_ACC_SORT_MERGE = 1  /* expand to LDS, bitonic sort by column, segmented sum */
+    SPADA_ACC_LDS_HASH = 0,   /* LDS hash accumulator + ordered emission (default) */
+    SPADA_ACC_SORT_MERGE = 1  /* products to LDS, bitonic sort by (column, k), runs added left to right: bit-identical to a
+                                 sequential sort-merge; same tasks as the hash variant */
 };
 
 typedef struct spada_options {
@@ -73,9 +74,7 @@ typedef struct spada_options {
     int32_t flags;            /* reserved, 0 */
 } spada_options;
 
-#define SPADA_N_BINS 12
-
-/* Replaces get_exec_cycle / get_*_mat_stat (simulator.rs:1008-1032) with measured quantities. */
+/* Replaces get_exec_cycle / get_*_mat_stat (simulator.rs:1008-1032) with measured quantities of the last call(s). */
 typedef struct spada_stats {
     uint64_t rows;            /* C rows computed by the last call (row range length) */
     uint64_t a_nnz;           /* A nonzeros inside the row range */
@@ -84,37 +83,22 @@ typedef struct spada_stats {
     uint64_t c_nnz;
     uint64_t bytes_read;      /* algorithmic: (m+1)*8 + a_nnz*12 + a_nnz*16 + nprod*12    */
     uint64_t bytes_write;     /* algorithmic: (m+1)*8 + c_nnz*12 */
-    double ms_symbolic_call;  /* hipEvent time of the whole symbolic call on the engine stream */
-    double ms_numeric_call;   /* hipEvent time of the whole numeric call */
-    double ms_row_stats;      /* phases (hipEvents on the engine stream) */
-    double ms_binning;
-    double ms_symbolic;
-    double ms_scan;
-    double ms_numeric;
-    uint64_t sym_bin_rows[SPADA_N_BINS];   /* rows per symbolic bin */
-    uint64_t num_bin_rows[SPADA_N_BINS];   /* rows per numeric bin */
-    uint64_t spill_rows;      /* rows that took the global-memory (spill) path */
-    uint64_t workspace_bytes; /* device scratch owned by the context */
-    /* per numeric bin: products, nnz(C) and A entries of its rows (algorithmic bytes of one kernel =
-     * 12 * prod + 28 * entries + 8 * rows read, 12 * nnz written) */
-    uint64_t num_bin_prod[SPADA_N_BINS];
-    uint64_t num_bin_nnz[SPADA_N_BINS];
-    uint64_t num_bin_entries[SPADA_N_BINS];
-    uint64_t sym_bin_prod[SPADA_N_BINS];
-    double ms_sym_flat;       /* duration of the flat-batch symbolic kernel (hipEvents on its stream) */
-    double ms_num_flat;       /* duration of the flat-batch numeric kernel (shared batches of consecutive rows) */
-    double ms_num_mid;        /* duration of its list-mode launch (one "mid" row per batch) */
-    /* task pipeline (the default): one persistent kernel, tasks in output order */
+    /* HIP-event times on the engine stream, milliseconds */
+    double ms_symbolic_call;  /* whole spada_dev_spgemm_symbolic call (row statistics ... counting task kernel) */
+    double ms_numeric_call;   /* whole spada_dev_spgemm_numeric call */
     double ms_fused_call;     /* whole one-pass call (spada_dev_spgemm_fused) */
-    double ms_big_expand;     /* BIG rows: column histogram + scatter of their products into HBM scratch */
+    double ms_row_stats;      /* B-row descriptors, products per row, row classes */
+    double ms_big_expand;     /* BIG rows: column histogram + scatter of their products into HBM scratch (the spill path) */
     double ms_cut;            /* task list (three scan kernels) */
     double ms_task;           /* the task kernel of the last call (count, numeric or one-pass) */
-    uint64_t cls_rows[8];     /* rows per class: 0 EMPTY, 1 COPY (one A entry), 2 SMALL, 3 SOLO, 4 BIG */
+    uint64_t cls_rows[8];     /* rows per class: 0 EMPTY, 1 COPY (one A entry), 2 SMALL, 3 SOLO, 4 BIG (spilled) */
     uint64_t cls_prod[8];     /* products per class */
-    uint64_t n_tasks;         /* tasks of the last run */
+    uint64_t n_tasks;         /* tasks of the last pipeline run */
     uint64_t multi_pass_tasks;/* range tasks that had to halve their column range (more distinct columns than the table takes) */
     uint64_t scratch_products;/* products spilled to HBM scratch (= products of the BIG rows) */
+    uint64_t spill_rows;      /* rows that took the HBM spill path (= BIG rows) */
     uint64_t pipeline_runs;   /* 2 when a workspace had to grow and the pipeline was run again */
+    uint64_t workspace_bytes; /* device scratch owned by the context */
 } spada_stats;
 
 typedef struct spada_ctx spada_ctx;          /* engine context: one GPU, one stream, scratch */

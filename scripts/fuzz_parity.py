@@ -24,12 +24,12 @@ def main():
         ref = oracle.spgemm_sortmerge(ao, bo)
         for e in engines:
             try:
-                c = e.spgemm(a, b)
-                assert_parity(c, ref, ao, bo, 1e-9)
+                assert_parity(e.spgemm(a, b), ref, ao, bo, 1e-9)            # two-phase contract
+                assert_parity(e.spgemm_fused(a, b), ref, ao, bo, 1e-9)      # one-pass entry point
             except AssertionError as ex:
                 bad += 1
                 print("FAIL", desc, "nnzC", ref.nnz, str(ex)[:200])
-    print(f"{ncases} cases x 2 accumulators, {bad} failures")
+    print(f"{ncases} cases x 2 accumulators x 2 entry points, {bad} failures")
     return 1 if bad else 0
 
 

@@ -9,8 +9,6 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SPADA_LIB_PATH") or os.path.join(_HERE, "lib", "libspada_spgemm.so")   # env: development A/B builds
 
-SPADA_N_BINS = 12
-
 u64 = ctypes.c_uint64
 u64p = ctypes.POINTER(ctypes.c_uint64)
 f64p = ctypes.POINTER(ctypes.c_double)
@@ -38,17 +36,11 @@ class Options(ctypes.Structure):
 class Stats(ctypes.Structure):
     _fields_ = [("rows", u64), ("a_nnz", u64), ("b_nnz", u64), ("nprod", u64), ("c_nnz", u64),
                 ("bytes_read", u64), ("bytes_write", u64),
-                ("ms_symbolic_call", ctypes.c_double), ("ms_numeric_call", ctypes.c_double),
-                ("ms_row_stats", ctypes.c_double), ("ms_binning", ctypes.c_double),
-                ("ms_symbolic", ctypes.c_double), ("ms_scan", ctypes.c_double), ("ms_numeric", ctypes.c_double),
-                ("sym_bin_rows", u64 * SPADA_N_BINS), ("num_bin_rows", u64 * SPADA_N_BINS),
-                ("spill_rows", u64), ("workspace_bytes", u64),
-                ("num_bin_prod", u64 * SPADA_N_BINS), ("num_bin_nnz", u64 * SPADA_N_BINS),
-                ("num_bin_entries", u64 * SPADA_N_BINS), ("sym_bin_prod", u64 * SPADA_N_BINS),
-                ("ms_sym_flat", ctypes.c_double), ("ms_num_flat", ctypes.c_double), ("ms_num_mid", ctypes.c_double),
-                ("ms_fused_call", ctypes.c_double), ("ms_big_expand", ctypes.c_double), ("ms_cut", ctypes.c_double),
+                ("ms_symbolic_call", ctypes.c_double), ("ms_numeric_call", ctypes.c_double), ("ms_fused_call", ctypes.c_double),
+                ("ms_row_stats", ctypes.c_double), ("ms_big_expand", ctypes.c_double), ("ms_cut", ctypes.c_double),
                 ("ms_task", ctypes.c_double), ("cls_rows", u64 * 8), ("cls_prod", u64 * 8), ("n_tasks", u64),
-                ("multi_pass_tasks", u64), ("scratch_products", u64), ("pipeline_runs", u64)]
+                ("multi_pass_tasks", u64), ("scratch_products", u64), ("spill_rows", u64), ("pipeline_runs", u64),
+                ("workspace_bytes", u64)]
 
     def as_dict(self):
         d = {}

@@ -191,7 +191,7 @@ int main(int argc, char **argv)
             const spada_stats &st = cycle_simu.stats();
             const double ms = st.ms_symbolic_call + st.ms_numeric_call;
             std::fprintf(stderr, "engine: rows %llu nnz(A) %llu products %llu nnz(C) %llu | symbolic %.3f ms numeric %.3f ms | "
-                                 "%.3f G nnz(C)/s, algorithmic read %.1f GB/s (%.2f%% of 8 TB/s), spill rows %llu\n",
+                                 "%.3f G nnz(C)/s, algorithmic read %.1f GB/s (%.2f%% of 8 TB/s), rows spilled to HBM scratch %llu\n",
                          (unsigned long long)st.rows, (unsigned long long)st.a_nnz, (unsigned long long)st.nprod,
                          (unsigned long long)st.c_nnz, st.ms_symbolic_call, st.ms_numeric_call, st.c_nnz / ms / 1e6,
                          st.bytes_read / ms / 1e6, st.bytes_read / ms / 1e6 / 8000.0 * 100.0, (unsigned long long)st.spill_rows);

@@ -1,5 +1,5 @@
-// Device half of libspada_spgemm.so: engine context, HBM-resident CSR, the two-phase SpGEMM pipeline
-// and its C ABI (include/spada_ffi.h).  The seam it replaces is Simulator::new / execute /
+// Device half of libspada_spgemm.so: engine context, HBM-resident CSR, the task pipeline of spgemm_task.hip.hpp (two-phase
+// and one-pass entry points) and its C ABI (include/spada_ffi.h).  The seam it replaces is Simulator::new / execute /
 // get_exec_result of the reference (simulator.rs:431-507, :509-890, :1034-1062).
 //
 // There is no CPU fallback in this file: every compute entry point needs a gfx950 device.
@@ -14,7 +14,6 @@
 #include <vector>
 
 #include "spada_internal.hpp"
-#include "spgemm_flat.hip.hpp"
 #include "spgemm_task.hip.hpp"
 
 using namespace spada;
@@ -33,7 +32,6 @@ struct spada_dev_csr {
     uint32_t *idx = nullptr;
     double *val = nullptr;
     uint32_t *rowid = nullptr;   // row of every entry: lets the row statistics run entry-parallel whatever the row lengths are
-    DevCsrView view() const { return DevCsrView{ptr, idx, val, nullptr, nullptr}; }
 };
 
 namespace {
@@ -69,74 +67,29 @@ struct DevBuf {
     T *as() const { return (T *)p; }
 };
 
-// device counter block, zeroed at the start of every symbolic call
-struct Counters {
-    uint32_t sym_counts[SPADA_N_BINS];
-    uint32_t sym_cursor[SPADA_N_BINS];
-    uint32_t num_counts[SPADA_N_BINS];
-    uint32_t num_cursor[SPADA_N_BINS];
-    unsigned long long totals[2];   // nprod, a_nnz of the row range
-    uint32_t nb_sym, nb_num;        // number of flat batches (symbolic / numeric)
-    uint32_t queue[4];              // dynamic dequeue cursors of the huge-row kernels
-    unsigned long long num_sums[3 * SPADA_N_BINS];   // per numeric bin: products | nnz(C) | A entries
-    unsigned long long sym_prod[SPADA_N_BINS];
-};
-
-enum { EV_SYM_BEGIN, EV_STATS, EV_BINNED, EV_SYM, EV_SCAN, EV_NUM_BEGIN, EV_NUM_END, EV_SFLAT_0, EV_SFLAT_1, EV_NFLAT_0, EV_NFLAT_1, EV_NMID_0, EV_NMID_1, EV_COUNT };
-
 }  // namespace
 
 struct spada_ctx {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;     // everything of one SpGEMM is queued on this stream, in order
     int accumulator = SPADA_ACC_LDS_HASH;
-    hipEvent_t ev[EV_COUNT] = {};
-    // independent bins run concurrently: one side stream per bin, forked from / joined to `stream`
-    hipStream_t side[SPADA_N_BINS] = {};
-    hipEvent_t ev_fork = nullptr, ev_join[SPADA_N_BINS] = {};
-    hipStream_t cur = nullptr;        // stream the launch helpers use
-    bool merge_on = false;            // SPADA_MERGE=1: multiway-merge class (k_num_merge) for rows with <= 8 long B rows; measured
-                                      // neutral on the webbase surrogate (1.77 ms either way), so off by default
-    size_t lds_pad = 0;               // SPADA_LDS_PAD=<bytes>: occupancy experiments (fewer flat workgroups per CU)
-    bool flat_big = false;            // SPADA_FLAT_BIG=1: flat kernel (list mode) instead of k_num_hash for rows above the mid class
-    bool sort_huge = false;           // SPADA_SORT_HUGE=1
-    int flat_cfg = 1;                 // SPADA_FLAT_CFG: 0 = 256 threads x 4 entries, 1 = 512 x 2, 2 = 1024 x 1
-    int dbg_g = 0;                    // SPADA_DBG_G=<G>: phase timestamps of k_num_hash<G,*> into `dbg`
-    DevBuf dbg;
-    bool serial_bins = false;         // SPADA_SERIAL_BINS=1: one stream, for per-kernel profiling
-    // state carried from symbolic to numeric
+    uint32_t n_cu = 256;
+    hipEvent_t tev[6] = {};           // phase boundaries of the last pipeline run
+    // state carried from the symbolic to the numeric call
     bool have_symbolic = false;
     const spada_dev_csr *A = nullptr, *B = nullptr;
     uint64_t r0 = 0;
     uint32_t nrows = 0;
     uint64_t nnz_c = 0;
-    uint32_t h_sym_counts[SPADA_N_BINS] = {}, h_num_counts[SPADA_N_BINS] = {};
-    unsigned long long h_sym_prod[SPADA_N_BINS] = {};
-    uint32_t h_nb_sym = 1;
-    // workspace
+    uint32_t colbits = 0;
+    // workspace (grow only): per row | per A entry | task pipeline | buffers handed out by the *_owned entry points
     size_t ws_bytes = 0;
-    DevBuf row_nprod, row_nnzc, row_bin, sym_rows, num_rows, counters, cptr, tile_sums, bitmaps, slabs;
+    DevBuf row_nprod, row_bin, row_kmin, row_kmax, cptr, t_rowP, t_rowm, t_rowt, t_rowtmp, t_big, t_tiles;
+    DevBuf eb0, elen;
+    DevBuf t_tmp, t_tasks, t_status, t_rangeout, t_scrcol, t_scrval, t_scrseq, t_ctr;
     DevBuf own_idx, own_val, own_ptr, wide_idx;
-    DevBuf efl;   // per A entry: first / last column of the selected B row
-    DevBuf eb0, elen, row_kmin, row_kmax, batch_sym, batch_num, tile_w;
-    uint32_t colbits = 0, rmax_eff = 0, num_flat_max = 0;
-    bool flat_on = false;
-    DevCsrView a_view() const
-    {
-        return DevCsrView{A->ptr, A->idx, A->val, eb0.as<uint64_t>(), elen.as<uint32_t>()};
-    }
-    uint64_t spill_slabs = 0, spill_cols = 0;
-    bool bm_fits = false;             // LDS column bitmap fits for the current B
-    uint32_t bm_vcap = 0;             // value-row capacity of k_num_bitmap<true> (0 = variant unused)
-    Counters *h_counters = nullptr;   // pinned
-    uint64_t *h_u64 = nullptr;        // pinned
-    // task pipeline (spgemm_task.hip.hpp): the default; SPADA_PIPELINE=legacy selects the round-1 per-bin kernels
-    bool use_tasks = true;
-    DevBuf t_rowP, t_rowm, t_rowt, t_rowtmp, t_big, t_tiles, t_tmp, t_tasks, t_status, t_rangeout, t_scrcol, t_scrval, t_ctr;
-    uint64_t t_cap_tmp = 0, t_cap_tasks = 0, t_cap_scr = 0;
+    uint64_t t_cap_tmp = 0, t_cap_tasks = 0, t_cap_scr = 0;   // capacities the kernels may rely on
     TaskCounters *h_tctr = nullptr;   // pinned
-    hipEvent_t tev[6] = {};
-    uint32_t n_cu = 256;
     // matrices uploaded by the host-pointer API
     spada_dev_csr *hA = nullptr, *hB = nullptr;
     spada_stats stats = {};
@@ -149,93 +102,6 @@ int allow_lds(K kernel, size_t bytes)
 {
     HIP_TRY(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     return SPADA_OK;
-}
-
-template <int G, int LOG_T>
-constexpr size_t sym_lds() { return 128 + (size_t)((G <= 64 ? 256 : G) / G) * sym_row_bytes<G, LOG_T>(); }
-template <int G, int LOG_T>
-constexpr size_t num_lds() { return 128 + (size_t)((G <= 64 ? 256 : G) / G) * num_row_bytes<G, LOG_T>(); }
-
-template <int G, int LOG_T>
-int launch_sym(spada_ctx *c, uint32_t off, uint32_t n)
-{
-    if (!n) return SPADA_OK;
-    constexpr int BLOCK = G <= 64 ? 256 : G;
-    constexpr int RPB = BLOCK / G;
-    const uint32_t grid = (n + RPB - 1) / RPB;
-    hipLaunchKernelGGL((k_sym_hash<G, LOG_T>), dim3(grid), dim3(BLOCK), (sym_lds<G, LOG_T>()), c->cur, c->a_view(),
-                       c->B->view(), c->r0, c->sym_rows.as<uint32_t>() + off, n, c->row_nnzc.as<uint32_t>());
-    HIP_TRY(hipGetLastError());
-    return SPADA_OK;
-}
-
-template <int G, int LOG_T>
-int launch_num(spada_ctx *c, uint32_t off, uint32_t n, uint32_t *c_idx, double *c_val)
-{
-    if (!n) return SPADA_OK;
-    constexpr int BLOCK = G <= 64 ? 256 : G;
-    constexpr int RPB = BLOCK / G;
-    const uint32_t grid = (n + RPB - 1) / RPB;
-    hipLaunchKernelGGL((k_num_hash<G, LOG_T>), dim3(grid), dim3(BLOCK), (num_lds<G, LOG_T>()), c->cur, c->a_view(),
-                       c->B->view(), c->r0, c->num_rows.as<uint32_t>() + off, n, c->cptr.as<uint64_t>(), c_idx, c_val,
-                       (G == c->dbg_g) ? c->dbg.as<unsigned long long>() : nullptr, c->row_kmin.as<uint32_t>(),
-                       c->row_kmax.as<uint32_t>());
-    HIP_TRY(hipGetLastError());
-    return SPADA_OK;
-}
-
-int ensure_spill(spada_ctx *c, uint32_t rows_in_bin, bool need_slabs)
-{
-    const uint64_t cols = c->B->cols;
-    const uint64_t nslab = std::min<uint64_t>(rows_in_bin, 512);
-    const uint64_t words = ((cols + 31) / 32 + 3) & ~3ull;
-    if (c->spill_cols != cols || c->spill_slabs < nslab) {
-        // geometry changed: drop and re-zero
-        c->ws_bytes -= c->bitmaps.cap + c->slabs.cap;
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        c->bitmaps.release();
-        c->slabs.release();
-        c->spill_cols = cols;
-        c->spill_slabs = nslab;
-    }
-    int rc = c->bitmaps.ensure(c->spill_slabs * words * 4, true, c->stream, &c->ws_bytes);
-    if (rc) return rc;
-    if (need_slabs) rc = c->slabs.ensure(c->spill_slabs * words * 4, false, c->stream, &c->ws_bytes);
-    return rc;
-}
-
-// fork: side stream `k` starts after everything queued on the main stream so far
-int fork_to(spada_ctx *c, int k)
-{
-    if (c->serial_bins) return SPADA_OK;
-    HIP_TRY(hipStreamWaitEvent(c->side[k], c->ev_fork, 0));
-    c->cur = c->side[k];
-    return SPADA_OK;
-}
-// join: the main stream continues after side stream `k`
-int join_from(spada_ctx *c, int k)
-{
-    if (c->serial_bins) return SPADA_OK;
-    HIP_TRY(hipEventRecord(c->ev_join[k], c->side[k]));
-    HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join[k], 0));
-    c->cur = c->stream;
-    return SPADA_OK;
-}
-
-constexpr size_t LDS_MAX = 160 * 1024;
-
-// persistent grid for the LDS bitmap kernels: as many workgroups as the LDS footprint admits per CU
-uint32_t bm_grid(uint32_t rows, size_t lds)
-{
-    const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(4, LDS_MAX / lds));
-    return std::min<uint32_t>(rows, 256u * per_cu);
-}
-
-float ev_ms(spada_ctx *c, int a, int b)
-{
-    float ms = 0;
-    if (hipEventElapsedTime(&ms, c->ev[a], c->ev[b]) != hipSuccess) return 0.f;
-    return ms;
 }
 
 void dev_free(spada_dev_csr *m)
@@ -287,197 +153,6 @@ int dev_upload(spada_ctx *c, const spada_csr_view *m, spada_dev_csr **out)
     return SPADA_OK;
 }
 
-// flat-batch kernel configurations: <BLOCK, LOG_T, NOUT, RMAX>; cap = 2 * flat_max, NOUT >= cap + flat_max
-#ifndef SPADA_NF_LARGE   // default: four 256-thread workgroups per CU, 2048-slot tables (A/B: -7 % numeric time on the regular surrogates vs two 512-thread workgroups with 4096-slot tables = SPADA_NF_LARGE)
-constexpr int NF_LOG_T = 11, NF_NOUT = 1536, NF_RMAX = 128;
-constexpr uint32_t NUM_FLAT_MAX = 512, NUM_FLAT_CAP = 1024;
-#define NF_CFG_LIST(X) X(256, 2)
-#else
-constexpr int NF_LOG_T = 12, NF_NOUT = 3072, NF_RMAX = 256;
-constexpr uint32_t NUM_FLAT_MAX = 1024, NUM_FLAT_CAP = 2048;
-#define NF_CFG_LIST(X) X(256, 4) X(512, 2) X(1024, 1)
-#endif
-#ifndef SPADA_SF_LARGE   /* default: 256-thread workgroups, 4096-key tables (A/B: -17..21 % symbolic time) */
-constexpr int SF_RMAX = 128;
-#define SF_CFG_LIST(X) X(256, 2)
-#else
-constexpr int SF_RMAX = 256;
-#define SF_CFG_LIST(X) X(256, 4) X(512, 2) X(1024, 1)
-#endif
-static_assert(NF_NOUT >= NUM_FLAT_CAP + NUM_FLAT_MAX, "a batch weighs less than cap + flat_max");
-static_assert((1u << SYM_FLAT_LOG_T) * 3 >= (SYM_FLAT_CAP + SYM_FLAT_MAX) * 4, "symbolic table load <= 0.75");
-
-uint32_t flat_grid(uint64_t nb_upper, size_t lds)
-{
-    const uint64_t per_cu = std::max<size_t>(1, std::min<size_t>(8, LDS_MAX / lds));
-    return (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(nb_upper, 256ull * per_cu * 4));
-}
-
-int run_numeric(spada_ctx *c, uint64_t *d_ptr, uint32_t *d_idx, double *d_val)
-{
-    c->cur = c->stream;   // an earlier call may have failed between a fork and its join
-    if (c->dbg.p && c->dbg_g != 2) HIP_TRY(hipMemsetAsync(c->dbg.p, 0, 64 * 16 * 8, c->stream));
-    HIP_TRY(hipEventRecord(c->ev[EV_NUM_BEGIN], c->stream));
-    HIP_TRY(hipMemcpyAsync(d_ptr, c->cptr.p, ((size_t)c->nrows + 1) * 8, hipMemcpyDeviceToDevice, c->stream));
-    const uint32_t *cnt = c->h_num_counts;
-    uint32_t off[SPADA_N_BINS + 1];
-    off[0] = 0;
-    for (int b = 0; b < SPADA_N_BINS; ++b) off[b + 1] = off[b] + (b == BIN_EMPTY || b == BIN_FLAT ? 0u : cnt[b]);
-    int rc;
-    Counters *dc = c->counters.as<Counters>();
-    // the dequeue cursors of the huge-row kernels: a numeric call may be repeated after one symbolic call
-    HIP_TRY(hipMemsetAsync(dc->queue, 0, sizeof dc->queue, c->stream));
-    // spill slabs are (re)allocated and zeroed on the engine stream BEFORE the fork event, so the side stream sees them
-    if (cnt[NUM2_BIN_SPILL] && !c->bm_fits && (rc = ensure_spill(c, cnt[NUM2_BIN_SPILL], true))) return rc;
-    HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
-    // heaviest bins first; every bin on its own stream
-    if (cnt[NUM2_BIN_SPILL]) {
-        const uint32_t nsp = cnt[NUM2_BIN_SPILL];
-        if (c->bm_fits) {
-            if ((rc = fork_to(c, NUM2_BIN_SPILL))) return rc;
-            const size_t lds = bm_lds_bytes(c->B->cols, 0);
-            hipLaunchKernelGGL(k_num_bitmap<false>, dim3(bm_grid(nsp, lds)), dim3(BM_BLOCK), lds, c->cur, c->a_view(),
-                               c->B->view(), c->r0, c->num_rows.as<uint32_t>() + off[NUM2_BIN_SPILL], nsp, c->B->cols, 0u,
-                               c->cptr.as<uint64_t>(), d_idx, d_val, &dc->queue[0]);
-        } else {
-            if ((rc = fork_to(c, NUM2_BIN_SPILL))) return rc;
-            const uint64_t words = ((c->B->cols + 31) / 32 + 3) & ~3ull;
-            const uint32_t grid = (uint32_t)std::min<uint64_t>(nsp, c->spill_slabs);
-            hipLaunchKernelGGL(k_num_spill, dim3(grid), dim3(SPILL_BLOCK), 0, c->cur, c->a_view(), c->B->view(), c->r0,
-                               c->num_rows.as<uint32_t>() + off[NUM2_BIN_SPILL], nsp, c->bitmaps.as<uint32_t>(),
-                               c->slabs.as<uint32_t>(), words, c->cptr.as<uint64_t>(), d_idx, d_val);
-        }
-        HIP_TRY(hipGetLastError());
-        if ((rc = join_from(c, NUM2_BIN_SPILL))) return rc;
-    }
-    if (cnt[NUM2_BIN_BMV]) {
-        const uint32_t nb = cnt[NUM2_BIN_BMV];
-        if ((rc = fork_to(c, NUM2_BIN_BMV))) return rc;
-        const size_t lds = bm_lds_bytes(c->B->cols, c->bm_vcap);
-        hipLaunchKernelGGL(k_num_bitmap<true>, dim3(bm_grid(nb, lds)), dim3(BM_BLOCK), lds, c->cur, c->a_view(),
-                           c->B->view(), c->r0, c->num_rows.as<uint32_t>() + off[NUM2_BIN_BMV], nb, c->B->cols, c->bm_vcap,
-                           c->cptr.as<uint64_t>(), d_idx, d_val, &dc->queue[1]);
-        HIP_TRY(hipGetLastError());
-        if ((rc = join_from(c, NUM2_BIN_BMV))) return rc;
-    }
-#define NUM_BIN(BIN, G, LT)                                                            \
-    if (cnt[BIN]) {                                                                    \
-        if ((rc = fork_to(c, BIN))) return rc;                                         \
-        if ((rc = launch_num<G, LT>(c, off[BIN], cnt[BIN], d_idx, d_val))) return rc;  \
-        if ((rc = join_from(c, BIN))) return rc;                                       \
-    }
-    if (c->flat_on && c->flat_big) {
-        // A/B (measured 20 % slower than the per-row kernels below): rows above the mid class through the flat kernel, one row per
-        // 1024-thread workgroup, 8192-slot table (list mode)
-        for (int bin : {NUM2_BIN_6K, NUM2_BIN_2K})
-            if (cnt[bin]) {
-                if ((rc = fork_to(c, bin))) return rc;
-                constexpr size_t lds = num_flat_lds<1024, 1, 13, 6144, 128>();
-                hipLaunchKernelGGL((k_num_flat<1024, 1, 13, 6144, 128, true, 1>), dim3(flat_grid(cnt[bin], lds)), dim3(1024), lds,
-                                   c->cur, c->A->ptr, c->A->val, c->B->idx, c->B->val, c->eb0.as<uint64_t>(),
-                                   c->elen.as<uint32_t>(), c->r0, c->nrows, c->row_bin.as<uint8_t>(),
-                                   c->row_kmin.as<uint32_t>(), c->row_kmax.as<uint32_t>(), c->cptr.as<uint64_t>(),
-                                   c->batch_num.as<uint32_t>(), &dc->num_counts[bin], c->colbits, d_idx, d_val,
-                                   (unsigned long long *)nullptr, c->num_rows.as<uint32_t>() + off[bin], (uint32_t)bin);
-                HIP_TRY(hipGetLastError());
-                if ((rc = join_from(c, bin))) return rc;
-            }
-    } else {
-        NUM_BIN(NUM2_BIN_6K, 1024, 13)
-        NUM_BIN(NUM2_BIN_2K, 256, 12)
-    }
-#undef NUM_BIN
-    if (cnt[BIN_FLAT] && c->accumulator == SPADA_ACC_SORT_MERGE) {
-        // sort-merge accumulator: the rows of the symbolic (product-weighted) batches
-        if ((rc = fork_to(c, BIN_FLAT))) return rc;
-        constexpr size_t lds = num_sm_lds<1024, 1, SF_RMAX>();
-        HIP_TRY(hipEventRecord(c->ev[EV_NFLAT_0], c->cur));
-        hipLaunchKernelGGL((k_num_sortmerge<1024, 1, SF_RMAX>), dim3(flat_grid(c->h_nb_sym, lds)), dim3(1024), lds, c->cur,
-                           c->A->ptr, c->A->val, c->B->idx, c->B->val, c->eb0.as<uint64_t>(), c->elen.as<uint32_t>(), c->r0,
-                           c->nrows, c->row_bin.as<uint8_t>(), c->cptr.as<uint64_t>(), c->batch_sym.as<uint32_t>(),
-                           &dc->nb_sym, c->colbits, d_idx, d_val);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipEventRecord(c->ev[EV_NFLAT_1], c->cur));
-        if ((rc = join_from(c, BIN_FLAT))) return rc;
-    } else if (cnt[BIN_FLAT]) {
-        if ((rc = fork_to(c, BIN_FLAT))) return rc;
-#define LAUNCH_NUM_FLAT(BL, EP, LS, RP)                                                                                             \
-    {                                                                                                                        \
-        const size_t lds = num_flat_lds<BL, EP, NF_LOG_T, NF_NOUT, NF_RMAX>() + c->lds_pad;                                  \
-        hipLaunchKernelGGL((k_num_flat<BL, EP, NF_LOG_T, NF_NOUT, NF_RMAX, LS, RP>), dim3(flat_grid(nf_batches, lds)),                \
-                           dim3(BL), lds, c->cur, c->A->ptr, c->A->val, c->B->idx, c->B->val, c->eb0.as<uint64_t>(),          \
-                           c->elen.as<uint32_t>(), c->r0, c->nrows, c->row_bin.as<uint8_t>(), c->row_kmin.as<uint32_t>(),     \
-                           c->row_kmax.as<uint32_t>(), c->cptr.as<uint64_t>(), c->batch_num.as<uint32_t>(), nf_nb,            \
-                           c->colbits, d_idx, d_val, nf_dbg, nf_list, nf_bin);                                               \
-    }
-#ifndef SPADA_NF_LARGE
-#define NUM_FLAT_DISPATCH(LS, RP) LAUNCH_NUM_FLAT(256, 2, LS, RP)
-#else
-#define NUM_FLAT_DISPATCH(LS, RP)                          \
-    if (c->flat_cfg == 0) LAUNCH_NUM_FLAT(256, 4, LS, RP)  \
-    else if (c->flat_cfg == 1) LAUNCH_NUM_FLAT(512, 2, LS, RP) \
-    else LAUNCH_NUM_FLAT(1024, 1, LS, RP)
-#endif
-        HIP_TRY(hipEventRecord(c->ev[EV_NFLAT_0], c->cur));
-        {
-            const uint64_t nf_batches = c->h_counters->nb_num;
-            const uint32_t *nf_nb = &dc->nb_num, *nf_list = nullptr;
-            const uint32_t nf_bin = BIN_FLAT;
-            unsigned long long *nf_dbg = c->dbg_g == 1 ? c->dbg.as<unsigned long long>() : nullptr;
-            NUM_FLAT_DISPATCH(false, 1)
-        }
-        HIP_TRY(hipEventRecord(c->ev[EV_NFLAT_1], c->cur));
-        HIP_TRY(hipGetLastError());
-        if ((rc = join_from(c, BIN_FLAT))) return rc;
-    }
-    for (int pass = 0; pass < 2; ++pass) {   // mid rows from their row lists: one row per batch, or two of the lower half
-        const int bin = pass == 0 ? NUM2_BIN_MID : NUM2_BIN_MID2;
-        if (!cnt[bin]) continue;
-        if ((rc = fork_to(c, bin))) return rc;
-        const uint64_t nf_batches = (cnt[bin] + pass) / (pass + 1);
-        const uint32_t *nf_nb = &dc->num_counts[bin], *nf_list = c->num_rows.as<uint32_t>() + off[bin];
-        const uint32_t nf_bin = (uint32_t)bin;
-        unsigned long long *nf_dbg = nullptr;
-        if (pass == 0) HIP_TRY(hipEventRecord(c->ev[EV_NMID_0], c->cur));
-        if (pass == 0) { NUM_FLAT_DISPATCH(true, 1) } else { NUM_FLAT_DISPATCH(true, 2) }
-        HIP_TRY(hipGetLastError());
-        if (pass == 0) HIP_TRY(hipEventRecord(c->ev[EV_NMID_1], c->cur));
-        if ((rc = join_from(c, bin))) return rc;
-    }
-#undef LAUNCH_NUM_FLAT
-#define LAUNCH_MERGE(BIN, PM)                                                                                               \
-    if (cnt[BIN]) {                                                                                                        \
-        if ((rc = fork_to(c, BIN))) return rc;                                                                             \
-        constexpr size_t lds = 4 * ((num_merge_wave_bytes<PM>() + 15) & ~(size_t)15);                                      \
-        const uint32_t grid = (uint32_t)std::min<uint64_t>((cnt[BIN] + 3) / 4, 256ull * (LDS_MAX / lds) * 4);               \
-        hipLaunchKernelGGL(k_num_merge<PM>, dim3(grid), dim3(256), lds, c->cur, c->A->ptr, c->A->val, c->B->idx, c->B->val,  \
-                           c->eb0.as<uint64_t>(), c->elen.as<uint32_t>(), c->r0, c->num_rows.as<uint32_t>() + off[BIN],     \
-                           cnt[BIN], c->cptr.as<uint64_t>(), d_idx, d_val);                                               \
-        HIP_TRY(hipGetLastError());                                                                                        \
-        if ((rc = join_from(c, BIN))) return rc;                                                                           \
-    }
-    LAUNCH_MERGE(NUM2_BIN_MERGE_L, 1024)
-    LAUNCH_MERGE(NUM2_BIN_MERGE_S, 512)
-#undef LAUNCH_MERGE
-    if (cnt[BIN_COPY]) {
-        if ((rc = fork_to(c, BIN_COPY))) return rc;
-        const uint32_t grid = std::min<uint32_t>((c->nrows + 255) / 256, 256u * 8 * 4);
-        hipLaunchKernelGGL(k_num_copy2, dim3(grid), dim3(256), 0, c->cur, c->A->ptr, c->A->val, c->B->idx, c->B->val,
-                           c->eb0.as<uint64_t>(), c->elen.as<uint32_t>(), c->r0, c->nrows, c->row_bin.as<uint8_t>(),
-                           c->cptr.as<uint64_t>(), d_idx, d_val);
-        HIP_TRY(hipGetLastError());
-        if ((rc = join_from(c, BIN_COPY))) return rc;
-    }
-    HIP_TRY(hipEventRecord(c->ev[EV_NUM_END], c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    c->stats.ms_numeric = c->stats.ms_numeric_call = ev_ms(c, EV_NUM_BEGIN, EV_NUM_END);
-    c->stats.ms_num_flat = cnt[BIN_FLAT] ? ev_ms(c, EV_NFLAT_0, EV_NFLAT_1) : 0.0;
-    c->stats.ms_num_mid = cnt[NUM2_BIN_MID] ? ev_ms(c, EV_NMID_0, EV_NMID_1) : 0.0;
-    c->stats.workspace_bytes = c->ws_bytes;
-    return SPADA_OK;
-}
-
-
 // ---- task pipeline ---------------------------------------------------------------------------------------------------
 float tev_ms(spada_ctx *c, int a, int b)
 {
@@ -489,7 +164,10 @@ float tev_ms(spada_ctx *c, int a, int b)
 template <int MODE>
 void launch_task(spada_ctx *c, const TaskArgs &g)
 {
-    hipLaunchKernelGGL(k_task<MODE>, dim3(c->n_cu * 4), dim3(TK_BLOCK), task_lds(), c->stream, g);
+    if (c->accumulator == SPADA_ACC_SORT_MERGE)
+        hipLaunchKernelGGL(k_task_sm<MODE>, dim3(c->n_cu * 3), dim3(TK_BLOCK), task_sm_lds(), c->stream, g);
+    else
+        hipLaunchKernelGGL(k_task<MODE>, dim3(c->n_cu * 4), dim3(TK_BLOCK), task_lds(), c->stream, g);
 }
 
 TaskArgs task_args(spada_ctx *c, uint64_t *cptr, uint32_t *d_idx, double *d_val, uint64_t capacity)
@@ -510,6 +188,7 @@ TaskArgs task_args(spada_ctx *c, uint64_t *cptr, uint32_t *d_idx, double *d_val,
     g.tasks = c->t_tasks.as<TaskDesc>();
     g.scr_col = c->t_scrcol.as<uint32_t>();
     g.scr_val = c->t_scrval.as<double>();
+    g.scr_seq = c->accumulator == SPADA_ACC_SORT_MERGE ? c->t_scrseq.as<uint32_t>() : nullptr;
     g.cptr = cptr;
     g.range_out = c->t_rangeout.as<uint64_t>();
     g.status = c->t_status.as<unsigned long long>();
@@ -545,7 +224,6 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
     if ((rc = c->t_ctr.ensure(sizeof(TaskCounters), false, s, &c->ws_bytes))) return rc;
     if ((rc = c->eb0.ensure(std::max<uint64_t>(a->nnz, 1) * 8, false, s, &c->ws_bytes))) return rc;
     if ((rc = c->elen.ensure(std::max<uint64_t>(a->nnz, 1) * 4, false, s, &c->ws_bytes))) return rc;
-    if ((rc = c->efl.ensure(std::max<uint64_t>(a->nnz, 1) * 8, false, s, &c->ws_bytes))) return rc;
     const uint32_t ntiles = std::max<uint32_t>((n + CUT_TILE - 1) / CUT_TILE, 1);
     if ((rc = c->t_tiles.ensure(((size_t)ntiles + 2) * 4, false, s, &c->ws_bytes))) return rc;
     // composite hash keys of a batch: (local row << colbits) | column
@@ -564,11 +242,12 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
     for (int attempt = 0; attempt < 3; ++attempt) {
         c->t_cap_tasks = std::max<uint64_t>(c->t_cap_tasks, (uint64_t)n / 4 + 4096);
         if ((rc = c->t_tasks.ensure(c->t_cap_tasks * sizeof(TaskDesc), false, s, &c->ws_bytes))) return rc;
-        if ((rc = c->t_status.ensure(c->t_cap_tasks * 8, false, s, &c->ws_bytes))) return rc;
+        if ((rc = c->t_status.ensure(c->t_cap_tasks * 8 * ST_STRIDE, false, s, &c->ws_bytes))) return rc;
         if ((rc = c->t_rangeout.ensure(c->t_cap_tasks * 8, false, s, &c->ws_bytes))) return rc;
         if ((rc = c->t_tmp.ensure(c->t_cap_tmp * sizeof(TaskDesc), false, s, &c->ws_bytes))) return rc;
         if ((rc = c->t_scrcol.ensure(c->t_cap_scr * 4, false, s, &c->ws_bytes))) return rc;
         if ((rc = c->t_scrval.ensure(c->t_cap_scr * 8, false, s, &c->ws_bytes))) return rc;
+        if (c->accumulator == SPADA_ACC_SORT_MERGE && (rc = c->t_scrseq.ensure(c->t_cap_scr * 4, false, s, &c->ws_bytes))) return rc;
         // capacities the kernels may rely on (DevBuf over-allocates; use what was asked for)
         const uint32_t cap_tasks = (uint32_t)std::min<uint64_t>(c->t_cap_tasks, 0xFFFFFFF0u);
         const uint32_t cap_tmp = (uint32_t)std::min<uint64_t>(c->t_cap_tmp, 0xFFFFFFF0u);
@@ -594,7 +273,8 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
                                c->eb0.as<uint64_t>(), c->elen.as<uint32_t>(), c->r0, c->t_big.as<uint32_t>(),
                                c->row_nprod.as<uint32_t>(), c->row_kmin.as<uint32_t>(), c->row_kmax.as<uint32_t>(),
                                c->t_rowm.as<uint32_t>(), c->t_rowtmp.as<uint32_t>(), c->t_tmp.as<TaskDesc>(), cap_tmp,
-                               c->t_scrcol.as<uint32_t>(), c->t_scrval.as<double>(), c->t_cap_scr, dc);
+                               c->t_scrcol.as<uint32_t>(), c->t_scrval.as<double>(),
+                               c->accumulator == SPADA_ACC_SORT_MERGE ? c->t_scrseq.as<uint32_t>() : (uint32_t *)nullptr, c->t_cap_scr, dc);
             HIP_TRY(hipGetLastError());
         }
         HIP_TRY(hipEventRecord(c->tev[2], s));
@@ -607,7 +287,7 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
                                c->t_tmp.as<TaskDesc>(), c->t_tasks.as<TaskDesc>(), cap_tasks, dc);
             HIP_TRY(hipGetLastError());
         }
-        HIP_TRY(hipMemsetAsync(c->t_status.p, 0, (size_t)cap_tasks * 8, s));
+        HIP_TRY(hipMemsetAsync(c->t_status.p, 0, (size_t)cap_tasks * 8 * ST_STRIDE, s));
         HIP_TRY(hipEventRecord(c->tev[3], s));
         if (n) {
             const TaskArgs g = task_args(c, cptr, d_idx, d_val, capacity);
@@ -646,8 +326,8 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
     st.ms_cut = tev_ms(c, 2, 3);
     st.ms_task = tev_ms(c, 3, 4);
     for (int k = 0; k < N_CLS; ++k) {
-        st.cls_rows[k] = st.num_bin_rows[k] = st.sym_bin_rows[k] = h.cls_rows[k];
-        st.cls_prod[k] = st.num_bin_prod[k] = st.sym_bin_prod[k] = h.cls_prod[k];
+        st.cls_rows[k] = h.cls_rows[k];
+        st.cls_prod[k] = h.cls_prod[k];
     }
     if (SPADA_TASK_DBG)
         std::fprintf(stderr, "[task dbg] tasks %u  loop cycles/WG %.0f  accumulate %.1f%%  chain %.1f%%  emit %.1f%%  windows/task %.2f  spins/task %.2f  waits/task %.2f  mean distance of the awaited task %.1f\n",
@@ -667,10 +347,8 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
     st.workspace_bytes = c->ws_bytes;
     if (mode == MODE_COUNT) {
         st.ms_symbolic_call = tev_ms(c, 0, 4);
-        st.ms_symbolic = st.ms_task;
     } else {
         st.ms_fused_call = tev_ms(c, 0, 4);
-        st.ms_numeric = st.ms_task;
     }
     return SPADA_OK;
 }
@@ -688,7 +366,7 @@ int task_numeric(spada_ctx *c, uint64_t *d_ptr, uint32_t *d_idx, double *d_val)
     }
     HIP_TRY(hipEventRecord(c->tev[4], s));
     HIP_TRY(hipStreamSynchronize(s));
-    c->stats.ms_numeric = c->stats.ms_numeric_call = c->stats.ms_task = tev_ms(c, 0, 4);
+    c->stats.ms_numeric_call = c->stats.ms_task = tev_ms(c, 0, 4);
     c->stats.workspace_bytes = c->ws_bytes;
     return SPADA_OK;
 }
@@ -739,68 +417,17 @@ int spada_create(const spada_options *opts, spada_ctx **out)
     c->device = dev;
     c->accumulator = o.accumulator;
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    for (auto &e : c->ev) HIP_TRY(hipEventCreate(&e));
-    {
-        // the one-workgroup-per-CU kernels (large / huge rows) need a whole CU's LDS: give their streams priority, otherwise
-        // the many small workgroups of the flat kernels keep every CU partly occupied and starve them until the end
-        int prio_lo = 0, prio_hi = 0;
-        HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-        const bool use_prio = !(std::getenv("SPADA_NO_PRIO") && std::getenv("SPADA_NO_PRIO")[0] == '1');
-        for (int k = 0; k < SPADA_N_BINS; ++k) {
-            const bool big = k == NUM2_BIN_6K || k == NUM2_BIN_2K || k == NUM2_BIN_BMV || k == NUM2_BIN_SPILL;
-            HIP_TRY(hipStreamCreateWithPriority(&c->side[k], hipStreamNonBlocking, big && use_prio ? prio_hi : 0));   // 0 = default priority
-        }
-    }
-    HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-    for (auto &e : c->ev_join) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    c->cur = c->stream;
-    if (const char *e = std::getenv("SPADA_SERIAL_BINS")) c->serial_bins = e[0] == '1';
-    if (const char *e = std::getenv("SPADA_DBG_G")) {
-        c->dbg_g = atoi(e);
-        int rc0 = c->dbg.ensure(64 * 16 * 8, true, c->stream, &c->ws_bytes);
-        if (rc0) return rc0;
-    }
-    HIP_TRY(hipHostMalloc((void **)&c->h_counters, sizeof(Counters), hipHostMallocDefault));
     HIP_TRY(hipHostMalloc((void **)&c->h_tctr, sizeof(TaskCounters), hipHostMallocDefault));
     for (auto &e : c->tev) HIP_TRY(hipEventCreate(&e));
     c->n_cu = (uint32_t)std::max(1, prop.multiProcessorCount);
-    if (const char *e = std::getenv("SPADA_PIPELINE")) c->use_tasks = std::strcmp(e, "legacy") != 0;
-    if (o.accumulator == SPADA_ACC_SORT_MERGE) c->use_tasks = false;   // the sort-merge accumulator still runs on the per-bin kernels
-    HIP_TRY(hipHostMalloc((void **)&c->h_u64, 64, hipHostMallocDefault));
     int rc;
-    if ((rc = allow_lds(k_sym_hash<512, 14>, sym_lds<512, 14>()))) return rc;
-    if ((rc = allow_lds(k_sym_hash<1024, 15>, sym_lds<1024, 15>()))) return rc;
-    if ((rc = allow_lds(k_num_hash<256, 12>, num_lds<256, 12>()))) return rc;
-    if ((rc = allow_lds(k_num_hash<1024, 13>, num_lds<1024, 13>()))) return rc;
-#define ALLOW_FLAT(BL, EP)                                                                                                   \
-    if ((rc = allow_lds(k_sym_flat<BL, EP, SYM_FLAT_LOG_T, SF_RMAX, false, 1>, sym_flat_lds<BL, EP, SYM_FLAT_LOG_T, SF_RMAX>()))) return rc; \
-    if ((rc = allow_lds(k_sym_flat<BL, EP, SYM_FLAT_LOG_T, SF_RMAX, true, 1>, sym_flat_lds<BL, EP, SYM_FLAT_LOG_T, SF_RMAX>()))) return rc; \
-    if ((rc = allow_lds(k_sym_flat<BL, EP, SYM_FLAT_LOG_T, SF_RMAX, true, 2>, sym_flat_lds<BL, EP, SYM_FLAT_LOG_T, SF_RMAX>()))) return rc;
-
-    SF_CFG_LIST(ALLOW_FLAT)
-#undef ALLOW_FLAT
-#define ALLOW_NFLAT(BL, EP)                                                                                                  \
-    if ((rc = allow_lds(k_num_flat<BL, EP, NF_LOG_T, NF_NOUT, NF_RMAX, false, 1>, LDS_MAX))) return rc; \
-    if ((rc = allow_lds(k_num_flat<BL, EP, NF_LOG_T, NF_NOUT, NF_RMAX, true, 1>, LDS_MAX))) return rc; \
-    if ((rc = allow_lds(k_num_flat<BL, EP, NF_LOG_T, NF_NOUT, NF_RMAX, true, 2>, LDS_MAX))) return rc;
-    NF_CFG_LIST(ALLOW_NFLAT)
-#undef ALLOW_NFLAT
-    if ((rc = allow_lds(k_num_sortmerge<1024, 1, SF_RMAX>, num_sm_lds<1024, 1, SF_RMAX>()))) return rc;
-    if (const char *e = std::getenv("SPADA_FLAT_CFG")) c->flat_cfg = atoi(e);
-    if (const char *e = std::getenv("SPADA_SORT_HUGE")) c->sort_huge = e[0] == '1';
-    if (const char *e = std::getenv("SPADA_FLAT_BIG")) c->flat_big = e[0] == '1';
-    if (const char *e = std::getenv("SPADA_LDS_PAD")) c->lds_pad = (size_t)atol(e);
-    if (const char *e = std::getenv("SPADA_MERGE")) c->merge_on = e[0] == '1';
-    if ((rc = allow_lds(k_num_merge<512>, 4 * ((num_merge_wave_bytes<512>() + 15) & ~(size_t)15)))) return rc;
-    if ((rc = allow_lds(k_num_merge<1024>, 4 * ((num_merge_wave_bytes<1024>() + 15) & ~(size_t)15)))) return rc;
-    if ((rc = allow_lds(k_num_flat<1024, 1, 13, 6144, 128, true, 1>, num_flat_lds<1024, 1, 13, 6144, 128>()))) return rc;
     if ((rc = allow_lds(k_task<MODE_COUNT>, task_lds()))) return rc;
     if ((rc = allow_lds(k_task<MODE_NUMERIC>, task_lds()))) return rc;
     if ((rc = allow_lds(k_task<MODE_FUSED>, task_lds()))) return rc;
+    if ((rc = allow_lds(k_task_sm<MODE_COUNT>, task_sm_lds()))) return rc;
+    if ((rc = allow_lds(k_task_sm<MODE_NUMERIC>, task_sm_lds()))) return rc;
+    if ((rc = allow_lds(k_task_sm<MODE_FUSED>, task_sm_lds()))) return rc;
     if ((rc = allow_lds(k_big_expand, BX_LDS))) return rc;
-    if ((rc = allow_lds(k_sym_bitmap, LDS_MAX))) return rc;
-    if ((rc = allow_lds(k_num_bitmap<true>, LDS_MAX))) return rc;
-    if ((rc = allow_lds(k_num_bitmap<false>, LDS_MAX))) return rc;
     *out = c.release();
     return SPADA_OK;
 }
@@ -812,24 +439,13 @@ void spada_destroy(spada_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     dev_free(c->hA);
     if (c->hB != c->hA) dev_free(c->hB);
-    for (DevBuf *b : {&c->row_nprod, &c->row_nnzc, &c->row_bin, &c->sym_rows, &c->num_rows, &c->counters, &c->cptr,
-                      &c->tile_sums, &c->bitmaps, &c->slabs, &c->own_idx, &c->own_val, &c->own_ptr, &c->wide_idx,
-                      &c->eb0, &c->elen, &c->efl, &c->row_kmin, &c->row_kmax, &c->batch_sym, &c->batch_num, &c->tile_w, &c->dbg,
-                      &c->t_rowP, &c->t_rowm, &c->t_rowt, &c->t_rowtmp, &c->t_big, &c->t_tiles, &c->t_tmp, &c->t_tasks, &c->t_status, &c->t_rangeout,
-                      &c->t_scrcol, &c->t_scrval, &c->t_ctr})
+    for (DevBuf *b : {&c->row_nprod, &c->row_bin, &c->row_kmin, &c->row_kmax, &c->cptr, &c->t_rowP, &c->t_rowm, &c->t_rowt, &c->t_rowtmp,
+                      &c->t_big, &c->t_tiles, &c->eb0, &c->elen, &c->t_tmp, &c->t_tasks, &c->t_status, &c->t_rangeout, &c->t_scrcol,
+                      &c->t_scrval, &c->t_scrseq, &c->t_ctr, &c->own_idx, &c->own_val, &c->own_ptr, &c->wide_idx})
         b->release();
     if (c->h_tctr) (void)hipHostFree(c->h_tctr);
     for (auto &e : c->tev)
         if (e) (void)hipEventDestroy(e);
-    if (c->h_counters) (void)hipHostFree(c->h_counters);
-    if (c->h_u64) (void)hipHostFree(c->h_u64);
-    for (auto &e : c->ev)
-        if (e) (void)hipEventDestroy(e);
-    for (auto &e : c->ev_join)
-        if (e) (void)hipEventDestroy(e);
-    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-    for (auto &st : c->side)
-        if (st) (void)hipStreamDestroy(st);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -866,245 +482,16 @@ int spada_dev_spgemm_symbolic(spada_ctx *c, const spada_dev_csr *a, const spada_
     if (row_begin > row_end || row_end > a->rows) return fail(SPADA_ERR_INVALID, "bad row range");
     HIP_TRY(hipSetDevice(c->device));
     c->have_symbolic = false;
-    c->cur = c->stream;
     c->A = a;
     c->B = b;
     c->r0 = row_begin;
     c->nrows = (uint32_t)(row_end - row_begin);
     c->nnz_c = 0;
     std::memset(&c->stats, 0, sizeof c->stats);
-    if (c->use_tasks) {
-        const int rc_t = task_pipeline(c, MODE_COUNT, nullptr, nullptr, nullptr, 0);
-        if (rc_t) return rc_t;
-        *nnz_c = c->nnz_c;
-        c->have_symbolic = true;
-        return SPADA_OK;
-    }
-    {
-        const size_t base = bm_lds_bytes(b->cols, 0);
-        c->bm_fits = base <= LDS_MAX;
-        c->bm_vcap = 0;
-        if (c->bm_fits && LDS_MAX - base >= 8192 * 8) c->bm_vcap = (uint32_t)std::min<size_t>(16384, (LDS_MAX - base) / 8);
-    }
-    const uint32_t n = c->nrows;
-    hipStream_t s = c->stream;
-    int rc;
-    const size_t n1 = (size_t)n + 1;
-    if ((rc = c->row_nprod.ensure(n1 * 4, false, s, &c->ws_bytes))) return rc;
-    if ((rc = c->row_nnzc.ensure(n1 * 4, false, s, &c->ws_bytes))) return rc;
-    if ((rc = c->row_bin.ensure(n1, false, s, &c->ws_bytes))) return rc;
-    if ((rc = c->row_kmin.ensure(n1 * 4, false, s, &c->ws_bytes))) return rc;
-    if ((rc = c->row_kmax.ensure(n1 * 4, false, s, &c->ws_bytes))) return rc;
-    if ((rc = c->sym_rows.ensure(n1 * 4, false, s, &c->ws_bytes))) return rc;
-    if ((rc = c->num_rows.ensure(n1 * 4, false, s, &c->ws_bytes))) return rc;
-    if ((rc = c->cptr.ensure(n1 * 8, false, s, &c->ws_bytes))) return rc;
-    if ((rc = c->counters.ensure(sizeof(Counters), false, s, &c->ws_bytes))) return rc;
-    if ((rc = c->eb0.ensure(std::max<uint64_t>(a->nnz, 1) * 8, false, s, &c->ws_bytes))) return rc;
-    if ((rc = c->elen.ensure(std::max<uint64_t>(a->nnz, 1) * 4, false, s, &c->ws_bytes))) return rc;
-    if ((rc = c->efl.ensure(std::max<uint64_t>(a->nnz, 1) * 8, false, s, &c->ws_bytes))) return rc;
-    // batch b starts at row batch_first[b]; b <= sum of weights / cap <= rows (a row weighs at most cap)
-    if ((rc = c->batch_sym.ensure((n1 + 4) * 4, false, s, &c->ws_bytes))) return rc;
-    if ((rc = c->batch_num.ensure((n1 + 4) * 4, false, s, &c->ws_bytes))) return rc;
-    const uint32_t ntiles = std::max<uint32_t>((n + SCAN_TILE - 1) / SCAN_TILE, 1);
-    if ((rc = c->tile_sums.ensure(((size_t)ntiles + 2) * 8, false, s, &c->ws_bytes))) return rc;
-    if ((rc = c->tile_w.ensure(((size_t)ntiles + 2) * 8, false, s, &c->ws_bytes))) return rc;
-    Counters *dc = c->counters.as<Counters>();
-
-    // composite hash keys of the flat batches: (local row << colbits) | column
-    {
-        uint32_t cb = 0;
-        while (cb < 32 && (1ull << cb) < b->cols) ++cb;
-        c->colbits = cb;
-        const uint64_t lim = cb >= 32 ? 1 : std::min<uint64_t>((1ull << (32 - cb)) - 1, 256);
-        c->rmax_eff = (uint32_t)lim;
-        c->flat_on = lim >= 4;
-        c->num_flat_max = c->flat_on ? NUM_FLAT_MAX : 0;
-    }
-    const uint32_t rmax = std::max<uint32_t>(c->rmax_eff, 4);
-    const uint32_t rmax_s = std::min<uint32_t>(rmax, SF_RMAX);
-    const CutParams cut_sym{SYM_FLAT_CAP, (SYM_FLAT_CAP + rmax_s - 1) / rmax_s, 0, 0, 0, 0};
-    const bool sort_merge = c->accumulator == SPADA_ACC_SORT_MERGE && c->flat_on;
-    const uint32_t rmax_n = std::min<uint32_t>(rmax, NF_RMAX);
-    const CutParams cut_num{NUM_FLAT_CAP, (NUM_FLAT_CAP + rmax_n - 1) / rmax_n, c->num_flat_max, c->bm_vcap,
-                            sort_merge ? SYM_FLAT_MAX : 0u, c->merge_on && c->colbits <= 21 ? 1024u : 0u};
-
-    if (c->dbg.p && c->dbg_g == 2) HIP_TRY(hipMemsetAsync(c->dbg.p, 0, 64 * 16 * 8, s));
-    HIP_TRY(hipEventRecord(c->ev[EV_SYM_BEGIN], s));
-    HIP_TRY(hipMemsetAsync(dc, 0, sizeof(Counters), s));
-    const uint32_t g256 = (n + 255) / 256, gsc = (n + 256 * SC_ITEMS - 1) / (256 * SC_ITEMS);
-    if (n) {
-        const uint32_t gent = (uint32_t)std::min<uint64_t>((a->nnz + 255) / 256 + 1, 256u * 8 * 8);
-        hipLaunchKernelGGL(k_entry_desc, dim3(gent), dim3(256), 0, s, a->ptr, a->idx, b->ptr, b->idx, c->r0, n,
-                           c->eb0.as<uint64_t>(), c->elen.as<uint32_t>(), c->efl.as<uint2>());
-        hipLaunchKernelGGL(k_row_stats2, dim3(std::min<uint32_t>(g256, 2048)), dim3(256), 0, s, a->ptr, c->elen.as<uint32_t>(),
-                           c->efl.as<uint2>(), c->r0, n, c->row_nprod.as<uint32_t>(), c->row_nnzc.as<uint32_t>(),
-                           c->row_bin.as<uint8_t>(), c->row_kmin.as<uint32_t>(), c->row_kmax.as<uint32_t>(), dc->sym_counts,
-                           dc->totals, dc->sym_prod, c->flat_on ? 1 : 0);
-        HIP_TRY(hipGetLastError());
-    }
-    HIP_TRY(hipEventRecord(c->ev[EV_STATS], s));
-    HIP_TRY(hipMemcpyAsync(c->h_counters, dc, sizeof(Counters), hipMemcpyDeviceToHost, s));
-    if (n) {
-        hipLaunchKernelGGL(k_bin_scatter2, dim3(gsc), dim3(256), 0, s, c->row_bin.as<uint8_t>(), n, dc->sym_counts,
-                           dc->sym_cursor, c->sym_rows.as<uint32_t>());
-        hipLaunchKernelGGL(k_cut_tile_sums<0>, dim3(ntiles), dim3(SCAN_BLOCK), 0, s, a->ptr, c->r0, n,
-                           c->row_nprod.as<uint32_t>(), c->row_nnzc.as<uint32_t>(), c->row_bin.as<uint8_t>(), cut_sym,
-                           c->tile_sums.as<uint64_t>(), c->tile_w.as<uint64_t>());
-        hipLaunchKernelGGL(k_cut_scan_tiles, dim3(1), dim3(SCAN_BLOCK), 0, s, c->tile_sums.as<uint64_t>(),
-                           c->tile_w.as<uint64_t>(), ntiles, cut_sym.cap, 0, &dc->nb_sym);
-        hipLaunchKernelGGL(k_cut_apply<0>, dim3(ntiles), dim3(SCAN_BLOCK), 0, s, a->ptr, c->r0, n,
-                           c->row_nprod.as<uint32_t>(), c->row_nnzc.as<uint32_t>(), c->row_bin.as<uint8_t>(), cut_sym,
-                           c->tile_sums.as<uint64_t>(), c->tile_w.as<uint64_t>(), ntiles, (uint64_t *)nullptr,
-                           (uint8_t *)nullptr, (uint32_t *)nullptr, (unsigned long long *)nullptr,
-                           c->batch_sym.as<uint32_t>());
-        HIP_TRY(hipGetLastError());
-    }
-    HIP_TRY(hipEventRecord(c->ev[EV_BINNED], s));
-    HIP_TRY(hipStreamSynchronize(s));
-    std::memcpy(c->h_sym_counts, c->h_counters->sym_counts, sizeof c->h_sym_counts);
-    std::memcpy(c->h_sym_prod, c->h_counters->sym_prod, sizeof c->h_sym_prod);
-    const uint64_t nprod = c->h_counters->totals[0], a_nnz = c->h_counters->totals[1];
-
-    {
-        const uint32_t *cnt = c->h_sym_counts;
-        uint32_t off[SPADA_N_BINS + 1];
-        off[0] = 0;
-        for (int k = 0; k < SPADA_N_BINS; ++k) off[k + 1] = off[k] + (k == BIN_EMPTY || k == BIN_FLAT ? 0u : cnt[k]);
-        if (cnt[SYM2_BIN_SPILL] && !c->bm_fits && (rc = ensure_spill(c, cnt[SYM2_BIN_SPILL], false))) return rc;
-        HIP_TRY(hipEventRecord(c->ev_fork, s));
-        if (cnt[SYM2_BIN_SPILL]) {
-            const uint32_t nsp = cnt[SYM2_BIN_SPILL];
-            if (c->bm_fits) {
-                if ((rc = fork_to(c, SYM2_BIN_SPILL))) return rc;
-                const size_t lds = bm_lds_bytes(b->cols, 0);
-                hipLaunchKernelGGL(k_sym_bitmap, dim3(bm_grid(nsp, lds)), dim3(BM_BLOCK), lds, c->cur, c->a_view(), b->view(),
-                                   c->r0, c->sym_rows.as<uint32_t>() + off[SYM2_BIN_SPILL], nsp, b->cols,
-                                   c->row_nnzc.as<uint32_t>());
-            } else {
-                if ((rc = fork_to(c, SYM2_BIN_SPILL))) return rc;
-                const uint64_t words = ((b->cols + 31) / 32 + 3) & ~3ull;
-                const uint32_t grid = (uint32_t)std::min<uint64_t>(nsp, c->spill_slabs);
-                hipLaunchKernelGGL(k_sym_spill, dim3(grid), dim3(SPILL_BLOCK), 0, c->cur, c->a_view(), b->view(), c->r0,
-                                   c->sym_rows.as<uint32_t>() + off[SYM2_BIN_SPILL], nsp, c->bitmaps.as<uint32_t>(), words,
-                                   c->row_nnzc.as<uint32_t>());
-            }
-            HIP_TRY(hipGetLastError());
-            if ((rc = join_from(c, SYM2_BIN_SPILL))) return rc;
-        }
-#define SYM_BIN(BIN, G, LT)                                                   \
-    if (cnt[BIN]) {                                                           \
-        if ((rc = fork_to(c, BIN))) return rc;                                \
-        if ((rc = launch_sym<G, LT>(c, off[BIN], cnt[BIN]))) return rc;       \
-        if ((rc = join_from(c, BIN))) return rc;                              \
-    }
-        SYM_BIN(SYM2_BIN_24K, 1024, 15)
-        SYM_BIN(SYM2_BIN_8K, 512, 14)
-#undef SYM_BIN
-        if (cnt[BIN_FLAT]) {
-            if ((rc = fork_to(c, BIN_FLAT))) return rc;
-            const uint64_t nb_upper = (nprod + (uint64_t)n * cut_sym.minw) / cut_sym.cap + 1;
-#define LAUNCH_SYM_FLAT(BL, EP, LS, RP)                                                                                             \
-    {                                                                                                                        \
-        constexpr size_t lds = sym_flat_lds<BL, EP, SYM_FLAT_LOG_T, SF_RMAX>();                                              \
-        hipLaunchKernelGGL((k_sym_flat<BL, EP, SYM_FLAT_LOG_T, SF_RMAX, LS, RP>), dim3(flat_grid(sf_batches, lds)), dim3(BL), lds,    \
-                           c->cur, a->ptr, b->idx, c->eb0.as<uint64_t>(), c->elen.as<uint32_t>(), c->r0, n,                   \
-                           c->row_bin.as<uint8_t>(), c->batch_sym.as<uint32_t>(), sf_nb, c->colbits,                         \
-                           c->row_nnzc.as<uint32_t>(), sf_list, sf_bin, sf_dbg);                                             \
-    }
-#ifndef SPADA_SF_LARGE   /* default: 256-thread workgroups, 4096-key tables (A/B: -17..21 % symbolic time) */
-#define SYM_FLAT_DISPATCH(LS, RP) LAUNCH_SYM_FLAT(256, 2, LS, RP)
-#else
-#define SYM_FLAT_DISPATCH(LS, RP)                          \
-    if (c->flat_cfg == 0) LAUNCH_SYM_FLAT(256, 4, LS, RP)  \
-    else if (c->flat_cfg == 1) LAUNCH_SYM_FLAT(512, 2, LS, RP) \
-    else LAUNCH_SYM_FLAT(1024, 1, LS, RP)
-#endif
-            HIP_TRY(hipEventRecord(c->ev[EV_SFLAT_0], c->cur));
-            {
-                const uint64_t sf_batches = nb_upper;
-                const uint32_t *sf_nb = &dc->nb_sym, *sf_list = nullptr;
-                const uint32_t sf_bin = BIN_FLAT;
-                unsigned long long *sf_dbg = c->dbg_g == 2 ? c->dbg.as<unsigned long long>() : nullptr;
-                SYM_FLAT_DISPATCH(false, 1)
-            }
-            HIP_TRY(hipEventRecord(c->ev[EV_SFLAT_1], c->cur));
-            HIP_TRY(hipGetLastError());
-            if ((rc = join_from(c, BIN_FLAT))) return rc;
-        }
-        for (int pass = 0; pass < 2; ++pass) {   // mid rows from their row lists: one row per batch, or two of the lower half
-            const int bin = pass == 0 ? SYM2_BIN_MID : SYM2_BIN_MID2;
-            if (!cnt[bin]) continue;
-            if ((rc = fork_to(c, bin))) return rc;
-            const uint64_t sf_batches = (cnt[bin] + pass) / (pass + 1);
-            const uint32_t *sf_nb = &dc->sym_counts[bin], *sf_list = c->sym_rows.as<uint32_t>() + off[bin];
-            const uint32_t sf_bin = (uint32_t)bin;
-            unsigned long long *sf_dbg = nullptr;
-            if (pass == 0) { SYM_FLAT_DISPATCH(true, 1) } else { SYM_FLAT_DISPATCH(true, 2) }
-            HIP_TRY(hipGetLastError());
-            if ((rc = join_from(c, bin))) return rc;
-        }
-#undef LAUNCH_SYM_FLAT
-    }
-    HIP_TRY(hipEventRecord(c->ev[EV_SYM], s));
-
-    // nnz(C_i) -> cptr, numeric classification, numeric batch cut, per-row bin lists
-    hipLaunchKernelGGL(k_cut_tile_sums<1>, dim3(ntiles), dim3(SCAN_BLOCK), 0, s, a->ptr, c->r0, n, c->row_nprod.as<uint32_t>(),
-                       c->row_nnzc.as<uint32_t>(), c->row_bin.as<uint8_t>(), cut_num, c->tile_sums.as<uint64_t>(),
-                       c->tile_w.as<uint64_t>());
-    hipLaunchKernelGGL(k_cut_scan_tiles, dim3(1), dim3(SCAN_BLOCK), 0, s, c->tile_sums.as<uint64_t>(), c->tile_w.as<uint64_t>(),
-                       ntiles, cut_num.cap, 1, &dc->nb_num);
-    hipLaunchKernelGGL(k_cut_apply<1>, dim3(ntiles), dim3(SCAN_BLOCK), 0, s, a->ptr, c->r0, n, c->row_nprod.as<uint32_t>(),
-                       c->row_nnzc.as<uint32_t>(), c->row_bin.as<uint8_t>(), cut_num, c->tile_sums.as<uint64_t>(),
-                       c->tile_w.as<uint64_t>(), ntiles, c->cptr.as<uint64_t>(), c->row_bin.as<uint8_t>(), dc->num_counts,
-                       dc->num_sums, c->batch_num.as<uint32_t>());
-    HIP_TRY(hipGetLastError());
-    if (n) {
-        hipLaunchKernelGGL(k_bin_scatter2, dim3(gsc), dim3(256), 0, s, c->row_bin.as<uint8_t>(), n, dc->num_counts,
-                           dc->num_cursor, c->num_rows.as<uint32_t>());
-        // largest-first order of the huge rows (k_sort_rows_desc) measured -85 us on the serialised bitmap kernel but
-        // nothing on the concurrent pipeline (other bins fill the idle CUs) while costing 16 us here: opt-in
-        if (c->sort_huge)
-            for (int hb : {NUM2_BIN_SPILL, NUM2_BIN_BMV})
-                hipLaunchKernelGGL(k_sort_rows_desc, dim3(1), dim3(1024), 0, s, c->num_rows.as<uint32_t>(), dc->num_counts,
-                                   hb, c->row_nprod.as<uint32_t>());
-        HIP_TRY(hipGetLastError());
-    }
-    HIP_TRY(hipMemcpyAsync(c->h_counters, dc, sizeof(Counters), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(c->h_u64, c->cptr.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipEventRecord(c->ev[EV_SCAN], s));
-    HIP_TRY(hipStreamSynchronize(s));
-    std::memcpy(c->h_num_counts, c->h_counters->num_counts, sizeof c->h_num_counts);
-    c->nnz_c = c->h_u64[0];
-    c->h_nb_sym = std::max<uint32_t>(c->h_counters->nb_sym, 1);
+    const int rc_t = task_pipeline(c, MODE_COUNT, nullptr, nullptr, nullptr, 0);
+    if (rc_t) return rc_t;
     *nnz_c = c->nnz_c;
     c->have_symbolic = true;
-
-    spada_stats &st = c->stats;
-    st.rows = n;
-    st.a_nnz = a_nnz;
-    st.b_nnz = b->nnz;
-    st.nprod = nprod;
-    st.c_nnz = c->nnz_c;
-    st.bytes_read = ((uint64_t)n + 1) * 8 + a_nnz * 12 + a_nnz * 16 + nprod * 12;
-    st.bytes_write = ((uint64_t)n + 1) * 8 + c->nnz_c * 12;
-    st.ms_row_stats = ev_ms(c, EV_SYM_BEGIN, EV_STATS);
-    st.ms_binning = ev_ms(c, EV_STATS, EV_BINNED);
-    st.ms_symbolic = ev_ms(c, EV_BINNED, EV_SYM);
-    st.ms_scan = ev_ms(c, EV_SYM, EV_SCAN);
-    st.ms_symbolic_call = ev_ms(c, EV_SYM_BEGIN, EV_SCAN);
-    for (int k = 0; k < SPADA_N_BINS; ++k) {
-        st.sym_bin_rows[k] = c->h_sym_counts[k];
-        st.num_bin_rows[k] = c->h_num_counts[k];
-    }
-    for (int k = 0; k < SPADA_N_BINS; ++k) {
-        st.num_bin_prod[k] = c->h_counters->num_sums[k];
-        st.num_bin_nnz[k] = c->h_counters->num_sums[SPADA_N_BINS + k];
-        st.num_bin_entries[k] = c->h_counters->num_sums[2 * SPADA_N_BINS + k];
-        st.sym_bin_prod[k] = c->h_sym_prod[k];
-    }
-    st.ms_sym_flat = c->h_sym_counts[BIN_FLAT] ? ev_ms(c, EV_SFLAT_0, EV_SFLAT_1) : 0.0;
-    st.spill_rows = c->h_sym_counts[SYM2_BIN_SPILL] + c->h_num_counts[NUM2_BIN_SPILL] + c->h_num_counts[NUM2_BIN_BMV];
-    st.workspace_bytes = c->ws_bytes;
     return SPADA_OK;
 }
 
@@ -1115,8 +502,7 @@ int spada_dev_spgemm_numeric(spada_ctx *c, void *d_c_indptr, void *d_c_indices, 
     if (!d_c_indptr || (c->nnz_c && (!d_c_indices || !d_c_data)))
         return fail(SPADA_ERR_INVALID, "spada_dev_spgemm_numeric: null output pointer");
     HIP_TRY(hipSetDevice(c->device));
-    if (c->use_tasks) return task_numeric(c, (uint64_t *)d_c_indptr, (uint32_t *)d_c_indices, (double *)d_c_data);
-    return run_numeric(c, (uint64_t *)d_c_indptr, (uint32_t *)d_c_indices, (double *)d_c_data);
+    return task_numeric(c, (uint64_t *)d_c_indptr, (uint32_t *)d_c_indices, (double *)d_c_data);
 }
 
 int spada_dev_spgemm_fused(spada_ctx *c, const spada_dev_csr *a, const spada_dev_csr *b, uint64_t row_begin, uint64_t row_end,
@@ -1129,10 +515,8 @@ int spada_dev_spgemm_fused(spada_ctx *c, const spada_dev_csr *a, const spada_dev
         return fail(SPADA_ERR_INVALID, "inner dimensions differ: A is %llux%llu, B is %llux%llu", (unsigned long long)a->rows,
                     (unsigned long long)a->cols, (unsigned long long)b->rows, (unsigned long long)b->cols);
     if (row_begin > row_end || row_end > a->rows) return fail(SPADA_ERR_INVALID, "bad row range");
-    if (!c->use_tasks) return fail(SPADA_ERR_UNSUPPORTED, "the one-pass entry point needs the task pipeline (LDS-hash accumulator)");
     HIP_TRY(hipSetDevice(c->device));
     c->have_symbolic = false;
-    c->cur = c->stream;
     c->A = a;
     c->B = b;
     c->r0 = row_begin;
@@ -1181,9 +565,7 @@ int spada_dev_spgemm_numeric_owned(spada_ctx *c, void **d_c_indptr, void **d_c_i
     if ((rc = c->own_ptr.ensure(((size_t)c->nrows + 1) * 8, false, c->stream, &c->ws_bytes))) return rc;
     if ((rc = c->own_idx.ensure(std::max<uint64_t>(c->nnz_c, 1) * 4, false, c->stream, &c->ws_bytes))) return rc;
     if ((rc = c->own_val.ensure(std::max<uint64_t>(c->nnz_c, 1) * 8, false, c->stream, &c->ws_bytes))) return rc;
-    if (c->use_tasks) rc = task_numeric(c, c->own_ptr.as<uint64_t>(), c->own_idx.as<uint32_t>(), c->own_val.as<double>());
-    else rc = run_numeric(c, c->own_ptr.as<uint64_t>(), c->own_idx.as<uint32_t>(), c->own_val.as<double>());
-    if (rc) return rc;
+    if ((rc = task_numeric(c, c->own_ptr.as<uint64_t>(), c->own_idx.as<uint32_t>(), c->own_val.as<double>()))) return rc;
     *d_c_indptr = c->own_ptr.p;
     *d_c_indices = c->own_idx.p;
     *d_c_data = c->own_val.p;
@@ -1266,14 +648,6 @@ int spada_spgemm_numeric(spada_ctx *c, uint64_t *c_indptr, uint64_t *c_indices, 
     int rc = spada_dev_spgemm_numeric_owned(c, &dp, &di, &dv);
     if (rc) return rc;
     return spada_dev_download_c(c, dp, di, dv, c->nrows, c->nnz_c, c_indptr, c_indices, c_data);
-}
-
-// development aid (scripts/phase_timing.py): s_memtime stamps written by the kernels when SPADA_DBG_G is set
-int spada_debug_read(spada_ctx *c, unsigned long long *out, uint64_t n)
-{
-    if (!c || !c->dbg.p) return fail(SPADA_ERR_STATE, "no debug buffer");
-    HIP_TRY(hipMemcpy(out, c->dbg.p, std::min<uint64_t>(n, 64 * 16) * 8, hipMemcpyDeviceToHost));
-    return SPADA_OK;
 }
 
 int spada_get_stats(const spada_ctx *c, spada_stats *out)

@@ -1,0 +1,418 @@
+// gfx950 (MI355X, CDNA4) device helpers shared by the kernels of the task pipeline (spgemm_task.hip.hpp): wave / workgroup
+// scans and reductions, the LDS hash slot, and the FLAT PRODUCT WALK -- the balanced expansion of the products of a run of
+// A entries that every kernel of the path uses (row-wise expand step of the reference: scheduler.rs:482-606 window fetch,
+// simulator.rs:892-953 B-fiber streaming, simulator.rs:86-111 multiplier).  64-wide wavefronts throughout; no MFMA: this path
+// is irregular gather-accumulate, bounded by memory latency, LDS throughput and HBM bandwidth.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "spada_ffi.h"
+
+namespace spada {
+
+constexpr uint32_t EMPTY_KEY = 0xFFFFFFFFu;
+
+__device__ inline uint64_t wave_sum_u64(uint64_t v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// Synchronise the G lanes that share one row.  G >= 128 means the group is the whole workgroup.
+// For G <= 64 the group lives inside one wavefront, which executes in lock step; only the LDS
+// traffic has to be ordered.
+template <int G>
+__device__ inline void group_sync()
+{
+    if constexpr (G >= 128) {
+        __syncthreads();
+    } else {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+}
+
+// Sum over the group.  `hdr` is a per-workgroup LDS word used when the group spans several waves.
+template <int G>
+__device__ inline uint32_t group_sum(uint32_t v, uint32_t *hdr)
+{
+    if constexpr (G <= 64) {
+#pragma unroll
+        for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        return v;
+    } else {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        __syncthreads();
+        if (threadIdx.x == 0) *hdr = 0;
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) atomicAdd(hdr, v);
+        __syncthreads();
+        return *hdr;
+    }
+}
+template <int G>
+__device__ inline uint32_t group_max(uint32_t v, uint32_t *hdr)
+{
+    if constexpr (G <= 64) {
+#pragma unroll
+        for (int o = G / 2; o > 0; o >>= 1) v = max(v, (uint32_t)__shfl_xor(v, o));
+        return v;
+    } else {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v = max(v, (uint32_t)__shfl_xor(v, o));
+        __syncthreads();
+        if (threadIdx.x == 0) *hdr = 0;
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) atomicMax(hdr, v);
+        __syncthreads();
+        return *hdr;
+    }
+}
+
+// In-place exclusive scan of arr[0..N) by the G lanes of a group; N is a multiple of G.
+// `wtot` = LDS scratch for per-wave totals (>= G/64 words), only used when G > 64.
+template <int G, int N>
+__device__ inline void group_exclusive_scan(uint32_t *arr, int gl, uint32_t *wtot)
+{
+    constexpr int PER = N / G;
+    static_assert(N % G == 0, "scan length must be a multiple of the group size");
+    uint32_t loc[PER];
+    uint32_t tot = 0;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        loc[j] = arr[gl * PER + j];
+        tot += loc[j];
+    }
+    // inclusive scan of `tot` across the lanes of the group
+    uint32_t inc = tot;
+    constexpr int W = G < 64 ? G : 64;
+    const int wl = (G < 64) ? gl : (gl & 63);
+#pragma unroll
+    for (int o = 1; o < W; o <<= 1) {
+        uint32_t t = __shfl_up(inc, o, W);
+        if (wl >= o) inc += t;
+    }
+    uint32_t base = inc - tot;
+    if constexpr (G > 64) {
+        const int w = gl >> 6;
+        __syncthreads();
+        if (wl == 63) wtot[w] = inc;
+        __syncthreads();
+        uint32_t add = 0;
+        for (int k = 0; k < w; ++k) add += wtot[k];
+        base += add;
+    }
+    group_sync<G>();
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        arr[gl * PER + j] = base;
+        base += loc[j];
+    }
+    group_sync<G>();
+}
+
+template <int LOG_T>
+__device__ inline uint32_t hash_slot(uint32_t col)
+{
+    return (col * 0x9E3779B1u) >> (32 - LOG_T);
+}
+
+// exclusive scan of one u32 per lane across the group; *total = group sum
+template <int G>
+__device__ inline uint32_t group_scan_excl(uint32_t v, int gl, uint32_t *wtot, uint32_t *total)
+{
+    constexpr int W = G < 64 ? G : 64;
+    const int wl = (G < 64) ? gl : (gl & 63);
+    uint32_t inc = v;
+#pragma unroll
+    for (int o = 1; o < W; o <<= 1) {
+        uint32_t t = __shfl_up(inc, o, W);
+        if (wl >= o) inc += t;
+    }
+    if constexpr (G <= 64) {
+        *total = __shfl(inc, W - 1, W);
+        return inc - v;
+    } else {
+        const int w = gl >> 6;
+        __syncthreads();
+        if (wl == 63) wtot[w] = inc;
+        __syncthreads();
+        uint32_t add = 0, tot = 0;
+#pragma unroll
+        for (int k = 0; k < G / 64; ++k) {
+            const uint32_t t = wtot[k];
+            if (k < w) add += t;
+            tot += t;
+        }
+        *total = tot;
+        return inc - v + add;
+    }
+}
+
+// exclusive scan of one u64 per thread across a workgroup of G threads (G a multiple of 64); *total = sum
+template <int G>
+__device__ inline unsigned long long group_scan_excl_u64(unsigned long long v, int gl, unsigned long long *wtot,
+                                                         unsigned long long *total)
+{
+    static_assert(G % 64 == 0 && G >= 64, "whole waves");
+    const int wl = gl & 63, w = gl >> 6;
+    unsigned long long inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned long long t = __shfl_up(inc, o);
+        if (wl >= o) inc += t;
+    }
+    __syncthreads();
+    if (wl == 63) wtot[w] = inc;
+    __syncthreads();
+    unsigned long long add = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < G / 64; ++k) {
+        const unsigned long long t = wtot[k];
+        if (k < w) add += t;
+        tot += t;
+    }
+    *total = tot;
+    return inc - v + add;
+}
+
+constexpr uint32_t LR_NONE = 0xFFFFFFFFu;
+
+// Within one wave the products handled by adjacent lanes belong to non-decreasing local rows; every run of
+// equal `lr` adds its number of new keys to s_cnt[lr] with ONE LDS atomic (a per-lane atomic would serialise
+// 64-fold on the same address).  Must be called by all lanes of the wave.
+__device__ inline void segmented_count_add(uint32_t lr, bool isnew, uint32_t *s_cnt, int lane)
+{
+    const uint32_t prev = __shfl_up(lr, 1);
+    const bool head = lane == 0 || prev != lr;
+    const unsigned long long hm = __ballot(head), nm = __ballot(isnew);
+    if (head && lr != LR_NONE) {
+        const unsigned long long from = ~0ull << lane;                              // lanes >= this one
+        const unsigned long long above = lane == 63 ? 0ull : (hm & (~0ull << (lane + 1)));
+        const unsigned long long upto = above ? ((1ull << (__ffsll((long long)above) - 1)) - 1ull) : ~0ull;
+        const uint32_t c = (uint32_t)__popcll(nm & from & upto);
+        if (c) atomicAdd(&s_cnt[lr], c);
+    }
+}
+
+// ---- the flat product walk -----------------------------------------------------------------------------------------
+// The A entries of the batch's flat rows are taken ECH = BLOCK * EPT at a time (each thread EPT consecutive
+// entries: descriptor (begin, length) of the selected B row, the A value, the local row).  Entries that select an
+// empty B row are dropped; one packed exclusive scan numbers the surviving entries and the products of the chunk
+// densely.  Products are handled in windows of PWIN: every entry sets the bit of its first product in a window
+// bitmap ("head bits"), one wave turns the word popcounts into prefix counts, and the owner entry of product p
+// is   prefix[word(p)] + popcount(bits(word(p)) up to p) - 1   -- two broadcast LDS reads instead of a binary
+// search.  Each wave takes 64 CONSECUTIVE products at a time (adjacent lanes read adjacent B entries, and the
+// lanes of a wave hit the same or neighbouring entry records), U such segments per thread and round, so that U
+// independent gathers and U independent first-probe LDS atomics are in flight.
+// LDS scratch: entry records {pack = (begin - offset) mod 2^48 | local row << 48, a value} | bm u64[PWIN / 64] |
+// bpre u32[PWIN / 64]
+constexpr int FLAT_PWIN = 8192;
+#ifndef SPADA_FLAT_U
+#define SPADA_FLAT_U 4
+#endif
+constexpr unsigned long long M48 = 0xFFFFFFFFFFFFull;
+
+struct __attribute__((aligned(16))) EntryRecNum {
+    uint64_t pack;
+    double av;
+};
+
+template <int BLOCK, int EPT, bool NUMERIC>
+__host__ __device__ constexpr size_t flat_walk_bytes()
+{
+    return (size_t)BLOCK * EPT * (NUMERIC ? 16 : 8) + (size_t)(FLAT_PWIN / 64) * 12 + 16;
+}
+
+template <int BLOCK, int EPT, int RMAX, bool NUMERIC, int U, class F>
+__device__ inline void flat_walk(const uint32_t *s_re, const uint64_t *s_a0, uint32_t R, uint32_t E,
+                                 const uint64_t *__restrict__ eb0, const uint32_t *__restrict__ elen,
+                                 const double *__restrict__ aval, const uint32_t *__restrict__ bidx,
+                                 const double *__restrict__ bval, unsigned char *scratch, uint32_t *hdr, F &&f)
+{
+    uint32_t pbase = 0;   // products of the chunks already walked
+    constexpr int ECH = BLOCK * EPT;
+    constexpr int NW = BLOCK / 64;
+    constexpr int PWORDS = FLAT_PWIN / 64;
+    static_assert(PWORDS % 64 == 0 || PWORDS == 64 || PWORDS == 128, "prefix pass: whole words per lane");
+    constexpr int WPL = PWORDS / 64;   // bitmap words per lane of the prefix wave
+    EntryRecNum *w_ent = (EntryRecNum *)scratch;
+    uint64_t *w_pack = (uint64_t *)scratch;
+    unsigned long long *bm = (unsigned long long *)(scratch + (size_t)ECH * (NUMERIC ? 16 : 8));
+    uint32_t *bpre = (uint32_t *)(bm + PWORDS);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const unsigned long long lane_bit = 1ull << lane;
+    for (uint32_t chunk = 0; chunk < E; chunk += ECH) {
+        uint64_t b0[EPT];
+        uint32_t len[EPT], lr[EPT], off[EPT];
+        double av[EPT];
+        {
+            uint32_t ee[EPT];
+#pragma unroll
+            for (int i = 0; i < EPT; ++i) {
+                ee[i] = chunk + tid * EPT + i;
+                lr[i] = 0;
+            }
+#pragma unroll
+            for (int step = RMAX / 2; step >= 1; step >>= 1) {   // EPT row searches in lock step
+                uint32_t o[EPT];
+#pragma unroll
+                for (int i = 0; i < EPT; ++i) o[i] = lr[i] + step < R ? s_re[lr[i] + step] : 0xFFFFFFFFu;
+#pragma unroll
+                for (int i = 0; i < EPT; ++i) lr[i] += o[i] <= ee[i] ? step : 0;
+            }
+#pragma unroll
+            for (int i = 0; i < EPT; ++i) {
+                b0[i] = 0;
+                len[i] = 0;
+                av[i] = 0.0;
+                if (ee[i] < E) {
+                    const uint64_t a = s_a0[lr[i]] + (ee[i] - s_re[lr[i]]);
+                    b0[i] = eb0[a];
+                    len[i] = elen[a];
+                    if constexpr (NUMERIC) av[i] = aval[a];
+                }
+            }
+        }
+        // packed scan: (entries with products) << 32 | products
+        unsigned long long mine = 0;
+#pragma unroll
+        for (int i = 0; i < EPT; ++i) mine += len[i] ? ((1ull << 32) | len[i]) : 0ull;
+        unsigned long long tot64;
+        unsigned long long ex64 = group_scan_excl_u64<BLOCK>(mine, tid, (unsigned long long *)(hdr + 4), &tot64);
+        const uint32_t total = (uint32_t)tot64;
+        {
+            uint32_t ci = (uint32_t)(ex64 >> 32), po = (uint32_t)ex64;
+#pragma unroll
+            for (int i = 0; i < EPT; ++i) {
+                off[i] = po;
+                if (len[i]) {
+                    const uint64_t pack = ((b0[i] - po) & M48) | ((uint64_t)lr[i] << 48);
+                    if constexpr (NUMERIC) w_ent[ci] = EntryRecNum{pack, av[i]};
+                    else w_pack[ci] = pack;
+                    ++ci;
+                    po += len[i];
+                }
+            }
+        }
+        for (uint32_t lo = 0; lo < total; lo += FLAT_PWIN) {
+            const uint32_t hi = min(lo + (uint32_t)FLAT_PWIN, total);
+            if (tid < PWORDS) bm[tid] = 0ull;
+            if (tid == 0) hdr[0] = 0;
+            __syncthreads();
+            uint32_t before = 0;
+#pragma unroll
+            for (int i = 0; i < EPT; ++i)
+                if (len[i]) {
+                    if (off[i] >= lo && off[i] < hi) {
+                        const uint32_t d = off[i] - lo;
+                        atomicOr((uint32_t *)bm + (d >> 5), 1u << (d & 31));
+                    }
+                    before += off[i] < lo ? 1u : 0u;
+                }
+            if (lo) {   // entries whose first product lies before this window (uniform branch)
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o);
+                if (lane == 0 && before) atomicAdd(&hdr[0], before);
+            }
+            __syncthreads();
+            if (wave == 0) {
+                uint32_t c[WPL], sum = 0;
+#pragma unroll
+                for (int k = 0; k < WPL; ++k) {
+                    c[k] = (uint32_t)__popcll(bm[lane * WPL + k]);
+                    sum += c[k];
+                }
+                uint32_t inc = sum;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const uint32_t t = __shfl_up(inc, o);
+                    if (lane >= o) inc += t;
+                }
+                uint32_t run = hdr[0] + inc - sum;
+#pragma unroll
+                for (int k = 0; k < WPL; ++k) {
+                    bpre[lane * WPL + k] = run;
+                    run += c[k];
+                }
+            }
+            __syncthreads();
+            for (uint32_t base = lo; base < hi; base += U * BLOCK) {   // uniform trip count over the workgroup
+                uint32_t col[U], plr[U];
+                double v[U];
+                uint32_t pp[U], j[U];
+                bool act[U];
+                // lane l of a segment holds product seg + l, i.e. bit l of one bitmap word (lo, base and the segments are
+                // multiples of 64): the word and its prefix are wave-uniform reads, the rank is a v_mbcnt pair.  Lanes past
+                // the end fall back to product 0 of entry 0 (a valid address; their result is discarded).
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const uint32_t seg = base + (u * NW + wave_u) * 64;      // wave-uniform
+                    const uint32_t p = seg + lane;
+                    act[u] = p < hi;
+                    const uint32_t w = min((seg - lo) >> 6, (uint32_t)PWORDS - 1u);
+                    const unsigned long long bits = bm[w];
+                    const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(bits >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bits, 0u));
+                    const uint32_t self = (bits & lane_bit) ? 1u : 0u;
+                    j[u] = act[u] ? bpre[w] + below + self - 1u : 0u;
+                    pp[u] = act[u] ? p : 0u;
+                }
+                uint64_t q[U];
+                double a_[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    uint64_t pack;
+                    a_[u] = 0.0;
+                    if constexpr (NUMERIC) {
+                        const EntryRecNum er = w_ent[j[u]];
+                        pack = er.pack;
+                        a_[u] = er.av;
+                    } else {
+                        pack = w_pack[j[u]];
+                    }
+                    q[u] = ((pack & M48) + pp[u]) & M48;
+                    plr[u] = act[u] ? (uint32_t)(pack >> 48) : LR_NONE;
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) col[u] = bidx[q[u]];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    v[u] = 0.0;
+                    if constexpr (NUMERIC) v[u] = a_[u] * bval[q[u]];   // simulator.rs:100-101
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) pp[u] += pbase;
+                f(col, plr, v, pp);
+            }
+            __syncthreads();
+        }
+        pbase += total;
+    }
+}
+
+__device__ inline uint32_t compose_key(uint32_t lr, uint32_t col, uint32_t colbits)
+{
+    return colbits >= 32 ? col : ((lr << colbits) | col);
+}
+
+// per-row parameters of the ordered emission, one 16-byte LDS read per lookup
+struct __attribute__((aligned(16))) RowEmit {
+    uint32_t boff;    // first bucket (= first output slot inside the batch) of the row
+    uint32_t n;       // nnz(C row)
+    uint32_t kmin;    // smallest column that can occur
+    float scale;      // n / (kmax - kmin + 1)
+};
+
+// widen u32 column indices to the ABI's u64 (usize)
+__global__ __launch_bounds__(256) void k_widen_u32(const uint32_t *__restrict__ in, uint64_t n, uint64_t *__restrict__ out)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        out[i] = in[i];
+}
+
+}  // namespace spada

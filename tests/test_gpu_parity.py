@@ -83,12 +83,19 @@ def test_generated_workloads_match_oracle(engine, name, kind, p0, p1, seed):
 
 
 def test_spill_path_is_exercised(engine):
-    """R-MAT scale 14, degree 16: hub rows exceed every LDS bin (SURVEY 7 hard part 3)."""
+    """R-MAT scale 14, degree 16: hub rows whose accumulator does not fit LDS (SURVEY 7 hard part 3) are BIG rows: their
+    products are spilled to HBM scratch, column range by column range, and the counters say how many."""
     import spada_sim_amd as S
     m = S.generate(S.GEN_RMAT, 14, 16, 3)
     engine.spgemm(m, m)
     st = engine.stats()
-    assert st["spill_rows"] > 0
+    ao = to_oracle(m)
+    lens = np.diff(m.indptr.astype(np.int64))
+    prod = np.array([lens[m.indices[int(m.indptr[r]):int(m.indptr[r + 1])].astype(np.int64)].sum() for r in range(m.shape[0])])
+    big = (prod > 1536) & (lens > 1)
+    assert st["spill_rows"] == st["cls_rows"][4] == int(big.sum()) > 0
+    assert st["scratch_products"] == st["cls_prod"][4] == int(prod[big].sum())
+    assert st["n_tasks"] > st["spill_rows"]
 
 
 def test_empty_and_ragged_inputs(engine):
@@ -186,11 +193,12 @@ def test_sort_merge_generated_workloads(engine_sm, name, kind, p0, p1, seed):
     a = to_oracle(m)
     ref = oracle.spgemm_sortmerge(a, a)
     assert assert_parity(c, ref, a, a, RTOL) == 0
+    # every row -- batches and the column ranges of BIG rows alike -- is added in ascending k like the CPU restatement
+    # (simulator.rs:209-220 adds left to right): values are bit-identical, not just within 1e-9
+    assert np.array_equal(c.data, ref.data)
     st = engine_sm.stats()
-    if sum(st["num_bin_rows"][3:8]) == 0:   # bins 8, 9 (multiway merge) also add in ascending k
-        # every row went through the copy or the sort-merge kernel, which add in ascending k like the CPU
-        # restatement (simulator.rs:209-220 adds left to right): values are bit-identical, not just within 1e-9
-        assert np.array_equal(c.data, ref.data)
+    if name == "rmat_s12":
+        assert st["cls_rows"][4] > 0      # BIG rows took the same sort-merge accumulator
 
 
 # ---- flat-batch pipeline: edge cases of the batch cut, the composite keys and the bucket order ---------------------
@@ -279,49 +287,28 @@ def test_stats_account_for_every_product(engine):
     st = engine.stats()
     ao = to_oracle(m)
     assert st["nprod"] == oracle.count_products(ao, ao)
-    assert sum(st["num_bin_rows"]) == m.shape[0] and sum(st["sym_bin_rows"]) == m.shape[0]
-    assert sum(st["num_bin_nnz"]) == c.nnz() == st["c_nnz"]
-    assert sum(st["num_bin_entries"]) + 0 <= m.nnz()          # rows with an empty C row are not counted
-    assert sum(st["num_bin_prod"]) == st["nprod"]
+    assert sum(st["cls_rows"]) == m.shape[0] and sum(st["cls_prod"]) == st["nprod"]
+    assert c.nnz() == st["c_nnz"] and st["a_nnz"] == m.nnz()
     assert st["bytes_read"] == (m.shape[0] + 1) * 8 + m.nnz() * 28 + st["nprod"] * 12
+    assert st["bytes_write"] == (m.shape[0] + 1) * 8 + st["c_nnz"] * 12
 
 
-def test_multiway_merge_class(monkeypatch):
-    """SPADA_MERGE=1 routes rows with <= 8 long B rows through k_num_merge (one wavefront per row: merge-path tree +
-    adder, the reference's adder_tree.rs datapath).  It adds in ascending k, so its rows are bit-identical to the
-    sequential restatement."""
+def test_sort_merge_full_size_webbase(engine_sm):
+    """configs[2]: the sort-merge accumulator over the SAME rows as the hash variant, at the full size of the webbase-1M
+    surrogate (51.7 M nnz(C)): structure bit-exact, values bit-identical to the sequential sort-merge."""
     import spada_sim_amd as S
-    monkeypatch.setenv("SPADA_MERGE", "1")
-    eng = S.Engine()
-    try:
-        rng = np.random.default_rng(11)
-        n = 4000
-        hubs = rng.choice(n, size=60, replace=False)
-
-        def cols(r, k):
-            if r in set(hubs.tolist()):
-                return rng.integers(0, n, size=300)          # long rows: the B rows the others select
-            return rng.choice(hubs, size=k)                    # few entries, all pointing at long rows
-
-        m = _random_csr(rng, n, n, rng.integers(1, 9, size=n), cols)
-        c = eng.spgemm(m, m)
-        ao = to_oracle(m)
-        ref = oracle.spgemm_sortmerge(ao, ao)
-        assert assert_parity(c, ref, ao, ao, RTOL) == 0
-        st = eng.stats()
-        merged = st["num_bin_rows"][8] + st["num_bin_rows"][9]
-        assert merged > 1000
-        # rows of the merge and copy classes are bit-identical
-        ip = ref.indptr.astype(np.int64)
-        L = np.diff(m.indptr.astype(np.int64))
-        P = np.array([sum(int(m.indptr[k + 1] - m.indptr[k]) for k in m.indices[int(m.indptr[r]):int(m.indptr[r + 1])])
-                      for r in range(n)])
-        sel = np.nonzero((L >= 2) & (L <= 8) & (P >= 96) & (P <= 1024))[0]
-        assert len(sel) == merged
-        for r in sel[:500]:
-            assert np.array_equal(c.data[ip[r]:ip[r + 1]], ref.data[ip[r]:ip[r + 1]])
-    finally:
-        eng.close()
+    m = S.generate(S.GEN_WEBBASE_LIKE, 0, 0, 12347)
+    d = engine_sm.upload(m)
+    nnz = engine_sm.symbolic(d, d, 0, m.shape[0])
+    p, i, v = engine_sm.numeric_owned()
+    c = engine_sm.download(p, i, v, m.shape[0], nnz, m.shape[1])
+    st = engine_sm.stats()
+    engine_sm.free(d)
+    ao = to_oracle(m)
+    ref = oracle.spgemm_spa(ao, ao)       # bit-identical to oracle.spgemm_sortmerge (test_oracle_golden.py)
+    assert np.array_equal(c.indptr, ref.indptr) and np.array_equal(c.indices, ref.indices)
+    assert np.array_equal(c.data, ref.data)
+    assert st["cls_rows"][4] > 4000 and sum(st["cls_rows"]) == m.shape[0]
 
 
 @pytest.mark.parametrize("seed", range(24))
@@ -338,7 +325,7 @@ def test_random_parity_sweep(engine, engine_sm, seed):
 @pytest.mark.parametrize("kind,name", [(1, "webbase-1M surrogate"), (2, "cop20k_A surrogate"), (4, "mc2depi surrogate")])
 def test_bench_workloads_at_full_size(engine, kind, name):
     """The workloads bench.py times, at BASELINE.json's full sizes, against the oracle (structure bit-exact, values within
-    1e-9): 67 M / 29 M / 5 M nnz(C).  The oracle's OpenMP SPA variant finishes them in seconds."""
+    1e-9): 51.7 M / 18.5 M / 5.2 M nnz(C).  The oracle's OpenMP SPA variant finishes them in seconds."""
     import spada_sim_amd as S
     seeds = {1: 12347, 2: 12346, 4: 12349}
     m = S.generate(kind, 0, 0, seeds[kind])

@@ -152,3 +152,32 @@ def test_workspace_growth_reruns_once(engine):
         assert st["pipeline_runs"] == 1
     finally:
         eng.close()
+
+
+def test_one_output_with_thousands_of_products():
+    """A row whose 5000 entries all select B rows that contain column 7: one output entry is the sum of 5000 products, more
+    than a task's table / sorting network holds at once.  Hash accumulator: within 1e-9; sort-merge: bit-identical (the run
+    is added in ascending k across the pieces)."""
+    import spada_sim_amd as S
+    rng = np.random.default_rng(17)
+    k, cols = 5000, 3000
+    bi, bv, bptr = [], [], [0]
+    for j in range(k):
+        c = np.unique(np.concatenate([[7], rng.integers(0, cols, 3)]))
+        bi.append(c)
+        bv.append(rng.uniform(-1.0, 1.0, len(c)))
+        bptr.append(bptr[-1] + len(c))
+    b = S.CsMat((k, cols), np.array(bptr, np.uint64), np.concatenate(bi).astype(np.uint64), np.concatenate(bv))
+    a = S.CsMat((2, k), np.array([0, k, k + 3], np.uint64), np.concatenate([np.arange(k), [1, 5, 9]]).astype(np.uint64),
+                rng.uniform(-1.0, 1.0, k + 3))
+    ao, bo = to_oracle(a), to_oracle(b)
+    ref = oracle.spgemm_sortmerge(ao, bo)
+    for acc in (S.ACC_LDS_HASH, S.ACC_SORT_MERGE):
+        eng = S.Engine(accumulator=acc)
+        try:
+            for c in (eng.spgemm(a, b), eng.spgemm_fused(a, b)):
+                assert_parity(c, ref, ao, bo, RTOL)
+                if acc == S.ACC_SORT_MERGE:
+                    assert np.array_equal(c.data, ref.data)
+        finally:
+            eng.close()

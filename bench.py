@@ -102,6 +102,14 @@ def main():
     ap.add_argument("--accumulator", default="lds_hash", choices=["lds_hash", "sort_merge"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--two-phase", action="store_true", help="time spada_dev_spgemm_symbolic + _numeric instead of the one-pass entry point")
+    ap.add_argument("--exchange", default="overlap", choices=["overlap", "after", "torch"],
+                    help="N > 1: how the C row blocks are replicated -- overlap: libspada_comm.so, two-phase, every finished piece "
+                         "of the own block is broadcast (RCCL) while the next is computed; after: one-pass SpGEMM of the block, then "
+                         "the RCCL allgatherv of libspada_comm.so; torch: the same allgatherv through torch.distributed")
+    ap.add_argument("--exchange-chunks", type=int, default=4)
+    ap.add_argument("--exercise-exchange", action="store_true",
+                    help="N = 1 only: run both libspada_comm.so exchange forms on a one-rank RCCL communicator, check them against the "
+                         "plain one-pass result and exit (the code path the driver's multi-GPU runs take, on the one GPU a builder has)")
     ap.add_argument("--chunk-products", type=float, default=0,
                     help="stream C in A-row chunks of about this many products (0 = automatic: chunk when the product "
                          "count of a rank exceeds 3e9, i.e. when C would not fit next to the inputs)")
@@ -158,7 +166,50 @@ def main():
     one_pass = not args.two_phase and args.accumulator == "lds_hash"
     cap = my_products      # capacity of the C buffers of the one-pass entry point: one entry per product at most
     checksum = torch.zeros(1, dtype=torch.float64, device=dev)
-    gather_s = [0.0]   # seconds spent in the allgatherv of C (N > 1), timed steps only
+    gather_s = [0.0]   # seconds spent in the allgatherv of C (N > 1, exchange after the compute), timed steps only
+    exchange = args.exchange if world > 1 and chunk_bounds is None else None
+    if exchange in ("overlap", "after") and (backend != "nccl" or args.accumulator != "lds_hash" and exchange == "after"):
+        exchange = "torch"     # several ranks per GPU (gloo validation runs): RCCL refuses that
+    comm = None
+    if exchange in ("overlap", "after"):
+        # the 128-byte RCCL id travels from rank 0 through the process group that launched us
+        uid = [S.Comm.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        comm = S.Comm(uid[0], rank, world, local_rank)
+
+    def exchange_native(mode):
+        """One step at N > 1 through libspada_comm.so; returns (stats, local nnz, (indptr, indices, data) of the whole C)."""
+        if mode == "overlap":
+            rows_r, nnz_r = comm.dist_symbolic(eng, da, da, r0, r1, args.exchange_chunks)
+            st = eng.stats()
+            total, trows = int(nnz_r.sum()), int(rows_r.sum())
+            f_ptr = torch.empty(trows + 1, dtype=torch.int64, device=dev)
+            fbuf = torch.empty(max(total, 1) * 12, dtype=torch.uint8, device=dev)
+            f_val = fbuf[:max(total, 1) * 8].view(torch.float64)
+            f_idx = fbuf[max(total, 1) * 8:].view(torch.int32)
+            torch.cuda.synchronize()
+            comm.dist_numeric(eng, f_ptr.data_ptr(), f_idx.data_ptr(), f_val.data_ptr())
+            st.update({k: v for k, v in eng.stats().items() if k in ("ms_numeric_call",)})
+            return st, int(nnz_r[rank]), (f_ptr, f_idx[:total], f_val[:total])
+        c_ptr = torch.empty(r1 - r0 + 1, dtype=torch.int64, device=dev)
+        buf = torch.empty(max(cap, 1) * 12, dtype=torch.uint8, device=dev)
+        c_val = buf[:max(cap, 1) * 8].view(torch.float64)
+        c_idx = buf[max(cap, 1) * 8:].view(torch.int32)
+        torch.cuda.synchronize()
+        nnz = eng.fused(da, da, r0, r1, c_ptr.data_ptr(), c_idx.data_ptr(), c_val.data_ptr(), cap)
+        st = eng.stats()
+        tg = time.perf_counter()
+        rows_r, nnz_r = comm.allgather_counts(r1 - r0, nnz)
+        total, trows = int(nnz_r.sum()), int(rows_r.sum())
+        f_ptr = torch.empty(trows + 1, dtype=torch.int64, device=dev)
+        fbuf = torch.empty(max(total, 1) * 12, dtype=torch.uint8, device=dev)
+        f_val = fbuf[:max(total, 1) * 8].view(torch.float64)
+        f_idx = fbuf[max(total, 1) * 8:].view(torch.int32)
+        torch.cuda.synchronize()
+        comm.allgatherv_c(c_ptr.data_ptr(), c_idx.data_ptr(), c_val.data_ptr(), rows_r, nnz_r, f_ptr.data_ptr(), f_idx.data_ptr(),
+                          f_val.data_ptr())
+        gather_s[0] += time.perf_counter() - tg
+        return st, nnz, (f_ptr, f_idx[:total], f_val[:total])
 
     def step():
         if chunk_bounds is not None:
@@ -187,6 +238,8 @@ def main():
             st = dict(agg)
             st.update(tms)
             return st, nnz, None
+        if comm is not None:
+            return exchange_native(exchange)
         c_ptr = torch.empty(r1 - r0 + 1, dtype=torch.int64, device=dev)
         if one_pass:
             # C's values and column indices: one allocation sized by the product count of the row block -- an upper bound of
@@ -216,9 +269,53 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    if args.exercise_exchange:
+        if world != 1:
+            raise SystemExit("--exercise-exchange is a single-process check")
+        comm = S.Comm(S.Comm.unique_id(), 0, 1, local_rank)
+        comm_saved, comm = comm, None
+        _, nnz, (p0, i0, v0) = step()
+        comm = comm_saved
+        for mode in ("overlap", "after"):
+            _, n2, (fp, fi, fv) = exchange_native(mode)
+            assert n2 == nnz and torch.equal(fp, p0) and torch.equal(fi, i0[:nnz]) and torch.allclose(fv, v0[:nnz], rtol=1e-9, atol=0), mode
+        print(json.dumps({"exercise_exchange": "ok", "nnz_c": nnz, "modes": ["overlap", "after"]}))
+        comm.close()
+        eng.free(da)
+        eng.close()
+        return
     for _ in range(args.warmup):
         step()
     sync()
+    compute_only_s = None
+    if world > 1 and chunk_bounds is None:
+        # (a) the native exchange against the torch.distributed one, once, on the device: nnz, column and value checksums
+        if comm is not None:
+            _, _, (fp, fi, fv) = exchange_native(exchange)
+            c_ptr = torch.empty(r1 - r0 + 1, dtype=torch.int64, device=dev)
+            nnz = eng.symbolic(da, da, r0, r1)
+            c_idx = torch.empty(max(nnz, 1), dtype=torch.int32, device=dev)
+            c_val = torch.empty(max(nnz, 1), dtype=torch.float64, device=dev)
+            eng.numeric(c_ptr.data_ptr(), c_idx.data_ptr(), c_val.data_ptr())
+            tp, ti, tv = parallel.allgatherv_c(c_ptr, c_idx[:nnz], c_val[:nnz])
+            ok = (fi.numel() == ti.numel() and bool(torch.equal(fp, tp)) and bool(torch.equal(fi, ti)) and
+                  bool(torch.allclose(fv, tv, rtol=1e-9, atol=0)))
+            if not ok:
+                raise SystemExit(f"rank {rank}: libspada_comm.so ({exchange}) and torch.distributed disagree on the gathered C")
+            del fp, fi, fv, tp, ti, tv
+        # (b) the block computation alone (C left sharded), same number of steps: what the exchange is compared with
+        sync()
+        tc = time.perf_counter()
+        for _ in range(args.steps):
+            c_ptr = torch.empty(r1 - r0 + 1, dtype=torch.int64, device=dev)
+            buf = torch.empty(max(cap, 1) * 12, dtype=torch.uint8, device=dev)
+            if one_pass:
+                eng.fused(da, da, r0, r1, c_ptr.data_ptr(), buf[max(cap, 1) * 8:].data_ptr(), buf.data_ptr(), cap)
+            else:
+                nnz = eng.symbolic(da, da, r0, r1)
+                eng.numeric(c_ptr.data_ptr(), buf[max(cap, 1) * 8:].data_ptr(), buf.data_ptr())
+        sync()
+        compute_only_s = time.perf_counter() - tc
     gather_s[0] = 0.0
     t0 = time.perf_counter()
     acc = {}
@@ -231,7 +328,8 @@ def main():
     elapsed = time.perf_counter() - t0
     if world > 1:
         rdev = dev if dist.get_backend() == "nccl" else torch.device("cpu")
-        t = torch.tensor([elapsed, elapsed - gather_s[0], gather_s[0]], dtype=torch.float64, device=rdev)
+        t = torch.tensor([elapsed, compute_only_s if compute_only_s is not None else elapsed - gather_s[0], gather_s[0]],
+                         dtype=torch.float64, device=rdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, compute_max_s, gather_max_s = (float(x) for x in t.tolist())
         tot = torch.tensor([st["c_nnz"], st["nprod"], st["bytes_read"], st["bytes_write"]], dtype=torch.int64, device=rdev)
@@ -245,13 +343,13 @@ def main():
         ms_step = elapsed / K * 1e3
         ms = {k: v / K for k, v in acc.items()}
         # device time of one SpGEMM on rank 0 (HIP events on the engine stream)
-        dev_ms = ms["ms_fused_call"] if one_pass and chunk_bounds is None else ms["ms_symbolic_call"] + ms["ms_numeric_call"]
+        dev_ms = ms["ms_fused_call"] if ms["ms_fused_call"] > 0 else ms["ms_symbolic_call"] + ms["ms_numeric_call"]
         pipe_gbs = st["bytes_read"] / (dev_ms * 1e-3) / 1e9
         # Dominant kernel: k_task -- the persistent task kernel that expands, scales, accumulates and orders every product of
         # the step (all rows; 60-70 % of the device time).  Its average duration comes from HIP events recorded around it on
         # the stream it is launched on; its algorithmic bytes are those of the whole step (12 B per product,
         # 28 B per A entry, 8 B per row read; 12 B per nnz(C) written), the other kernels are listed under `kernels`.
-        k_ms = ms["ms_task"] if chunk_bounds is None else dev_ms
+        k_ms = ms["ms_task"] if chunk_bounds is None and ms["ms_fused_call"] > 0 else dev_ms
         achieved = st["bytes_read"] / (k_ms * 1e-3) / 1e9
         traffic, traffic_src = load_traffic(args.workload)
         cls_names = ["empty", "copy (one A entry)", "small", "solo", "big (spilled to HBM scratch)"]
@@ -277,8 +375,12 @@ def main():
             "dtype": "f64",
             "data": data_desc,
             "multi_gpu": None if world == 1 else {
-                "allgatherv_ms_per_step": gather_max_s / K * 1e3,          # max over ranks
-                "compute_ms_per_step": compute_max_s / K * 1e3,            # max over ranks: everything but the gather
+                "exchange": {"overlap": "libspada_comm.so: two-phase, finished pieces of the own block broadcast (RCCL) while the next "
+                                        f"is computed, {args.exchange_chunks} pieces", "after": "libspada_comm.so: RCCL allgatherv after the "
+                                        "one-pass SpGEMM of the block", "torch": "torch.distributed allgatherv after the SpGEMM of the block",
+                             None: "none (C streamed in row chunks, not gathered)"}[exchange],
+                "allgatherv_ms_per_step": gather_max_s / K * 1e3 if exchange != "overlap" else None,   # max over ranks
+                "compute_ms_per_step": compute_max_s / K * 1e3,            # max over ranks: the block SpGEMM alone, timed separately
                 "value_compute_only": nnz_total / (compute_max_s / K),     # nnz(C)/s with C left sharded by row block
                 "note": "value includes the allgatherv that replicates C on every rank (north_star); every GPU must take in "
                         "(N-1)/N of 12 B x nnz(C) over xGMI, which bounds strong scaling once that exceeds the compute time"},
@@ -313,6 +415,8 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(a)
         print(json.dumps(out))
+    if comm is not None:
+        comm.close()
     eng.free(da)
     eng.close()
     if world > 1:

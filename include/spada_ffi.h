@@ -137,6 +137,15 @@ void spada_dev_csr_free(spada_ctx *ctx, spada_dev_csr *m);
 int spada_dev_spgemm_symbolic(spada_ctx *ctx, const spada_dev_csr *a, const spada_dev_csr *b,
                               uint64_t row_begin, uint64_t row_end, uint64_t *nnz_c);
 int spada_dev_spgemm_numeric(spada_ctx *ctx, void *d_c_indptr, void *d_c_indices, void *d_c_data);
+/* Numeric phase in pieces, for callers that overlap the exchange of finished parts of C with the computation of the rest
+ * (libspada_comm.so does: spada_comm.h).  After a symbolic call: _plan cuts the task list into `chunks` pieces and returns the
+ * C entries each completes, chunk_pos[k] .. chunk_pos[k + 1] (chunks + 1 values, ascending, last = nnz(C)); _chunk queues piece k
+ * on the engine stream WITHOUT waiting and hands back an event (hipEvent_t) that fires when its entries are in place;
+ * _indptr queues the copy of C.indptr; _synchronize waits for everything queued. */
+int spada_dev_spgemm_numeric_plan(spada_ctx *ctx, uint32_t chunks, uint64_t *chunk_pos);
+int spada_dev_spgemm_numeric_chunk(spada_ctx *ctx, uint32_t k, void *d_c_indices, void *d_c_data, void **done_event);
+int spada_dev_spgemm_indptr(spada_ctx *ctx, void *d_c_indptr);
+int spada_dev_synchronize(spada_ctx *ctx);
 /* One-pass SpGEMM (additive to the two-phase contract): no symbolic phase.  The caller supplies C buffers of `capacity`
  * entries -- any upper bound of nnz(C), e.g. spada_count_products (one product per entry at most) -- and receives
  * C.indptr, the first *nnz_c entries of indices / data, and *nnz_c.  SPADA_ERR_CAPACITY when capacity < nnz(C): indptr and

@@ -71,6 +71,10 @@ SIGNATURES = {
     "spada_dev_csr_free": (None, [vp, vp]),
     "spada_dev_spgemm_symbolic": (ctypes.c_int, [vp, vp, vp, u64, u64, u64p]),
     "spada_dev_spgemm_numeric": (ctypes.c_int, [vp, vp, vp, vp]),
+    "spada_dev_spgemm_numeric_plan": (ctypes.c_int, [vp, ctypes.c_uint32, u64p]),
+    "spada_dev_spgemm_numeric_chunk": (ctypes.c_int, [vp, ctypes.c_uint32, vp, vp, ctypes.POINTER(vp)]),
+    "spada_dev_spgemm_indptr": (ctypes.c_int, [vp, vp]),
+    "spada_dev_synchronize": (ctypes.c_int, [vp]),
     "spada_dev_spgemm_fused": (ctypes.c_int, [vp, vp, vp, u64, u64, vp, vp, vp, u64, u64p]),
     "spada_dev_spgemm_fused_owned": (ctypes.c_int, [vp, vp, vp, u64, u64, u64, ctypes.POINTER(vp), ctypes.POINTER(vp),
                                                     ctypes.POINTER(vp), u64p]),
@@ -92,7 +96,39 @@ SIGNATURES = {
     "spada_config_parse": (ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(Config)]),
 }
 
+# libspada_comm.so (include/spada_comm.h): the RCCL exchange; loaded on demand, it pulls in librccl
+COMM_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libspada_comm.so")
+COMM_ID_BYTES = 128
+COMM_SIGNATURES = {
+    "spada_comm_get_unique_id": (ctypes.c_int, [vp]),
+    "spada_comm_create": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(vp)]),
+    "spada_comm_destroy": (None, [vp]),
+    "spada_comm_rank": (ctypes.c_int, [vp]),
+    "spada_comm_size": (ctypes.c_int, [vp]),
+    "spada_comm_allgather_counts": (ctypes.c_int, [vp, u64, u64, u64p, u64p]),
+    "spada_comm_allgatherv_c": (ctypes.c_int, [vp, vp, vp, vp, u64p, u64p, vp, vp, vp]),
+    "spada_dist_spgemm_symbolic": (ctypes.c_int, [vp, vp, vp, vp, u64, u64, ctypes.c_uint32, u64p, u64p]),
+    "spada_dist_spgemm_numeric": (ctypes.c_int, [vp, vp, vp, vp, vp]),
+}
+
 _lib = None
+_comm_lib = None
+
+
+def comm_lib():
+    """Load libspada_comm.so (once).  Raises ImportError if it has not been built."""
+    global _comm_lib
+    if _comm_lib is None:
+        lib()
+        if not os.path.exists(COMM_LIB_PATH):
+            raise ImportError(f"{COMM_LIB_PATH} is missing: build it with `make -C spada_sim_amd/csrc`")
+        L = ctypes.CDLL(COMM_LIB_PATH)
+        for name, (res, args) in COMM_SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _comm_lib = L
+    return _comm_lib
 
 
 def lib():

@@ -90,6 +90,10 @@ struct spada_ctx {
     DevBuf own_idx, own_val, own_ptr, wide_idx;
     uint64_t t_cap_tmp = 0, t_cap_tasks = 0, t_cap_scr = 0;   // capacities the kernels may rely on
     TaskCounters *h_tctr = nullptr;   // pinned
+    // numeric phase in pieces (spada_dev_spgemm_numeric_plan / _chunk): task boundaries, one event per piece
+    std::vector<uint32_t> chunk_task;
+    std::vector<hipEvent_t> chunk_ev;
+    DevBuf t_chunk;
     // matrices uploaded by the host-pointer API
     spada_dev_csr *hA = nullptr, *hB = nullptr;
     spada_stats stats = {};
@@ -196,6 +200,8 @@ TaskArgs task_args(spada_ctx *c, uint64_t *cptr, uint32_t *d_idx, double *d_val,
     g.c_idx = d_idx;
     g.c_val = d_val;
     g.capacity = capacity;
+    g.task_lo = 0;
+    g.task_hi = 0xFFFFFFFFu;
     return g;
 }
 
@@ -446,6 +452,9 @@ void spada_destroy(spada_ctx *c)
     if (c->h_tctr) (void)hipHostFree(c->h_tctr);
     for (auto &e : c->tev)
         if (e) (void)hipEventDestroy(e);
+    for (auto &e : c->chunk_ev)
+        if (e) (void)hipEventDestroy(e);
+    c->t_chunk.release();
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -503,6 +512,76 @@ int spada_dev_spgemm_numeric(spada_ctx *c, void *d_c_indptr, void *d_c_indices, 
         return fail(SPADA_ERR_INVALID, "spada_dev_spgemm_numeric: null output pointer");
     HIP_TRY(hipSetDevice(c->device));
     return task_numeric(c, (uint64_t *)d_c_indptr, (uint32_t *)d_c_indices, (double *)d_c_data);
+}
+
+int spada_dev_spgemm_numeric_plan(spada_ctx *c, uint32_t chunks, uint64_t *chunk_pos)
+{
+    if (!c) return fail(SPADA_ERR_STATE, "spada_dev_spgemm_numeric_plan: no engine context (no GPU?)");
+    if (!c->have_symbolic) return fail(SPADA_ERR_STATE, "numeric plan requested without a preceding symbolic phase");
+    if (!chunks || chunks > 4096 || !chunk_pos) return fail(SPADA_ERR_INVALID, "spada_dev_spgemm_numeric_plan: 1 .. 4096 chunks");
+    HIP_TRY(hipSetDevice(c->device));
+    const uint32_t nt = c->nrows ? c->h_tctr->ntasks : 0;
+    c->chunk_task.assign(chunks + 1, 0);
+    for (uint32_t k = 0; k <= chunks; ++k) c->chunk_task[k] = (uint32_t)((uint64_t)nt * k / chunks);
+    while (c->chunk_ev.size() < chunks) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        c->chunk_ev.push_back(e);
+    }
+    if (!c->nrows) {
+        for (uint32_t k = 0; k <= chunks; ++k) chunk_pos[k] = 0;
+        return SPADA_OK;
+    }
+    int rc = c->t_chunk.ensure((size_t)(chunks + 1) * 12, false, c->stream, &c->ws_bytes);
+    if (rc) return rc;
+    uint64_t *d_pos = c->t_chunk.as<uint64_t>();
+    uint32_t *d_t = (uint32_t *)(d_pos + chunks + 1);
+    HIP_TRY(hipMemcpyAsync(d_t, c->chunk_task.data(), (size_t)(chunks + 1) * 4, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_task_positions, dim3((chunks + 256) / 256), dim3(256), 0, c->stream, c->t_tasks.as<TaskDesc>(),
+                       c->cptr.as<uint64_t>(), c->t_rangeout.as<uint64_t>(), c->t_ctr.as<TaskCounters>(), c->nrows, d_t, chunks + 1,
+                       d_pos);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(chunk_pos, d_pos, (size_t)(chunks + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return SPADA_OK;
+}
+
+int spada_dev_spgemm_numeric_chunk(spada_ctx *c, uint32_t k, void *d_c_indices, void *d_c_data, void **done_event)
+{
+    if (!c) return fail(SPADA_ERR_STATE, "spada_dev_spgemm_numeric_chunk: no engine context (no GPU?)");
+    if (!c->have_symbolic || c->chunk_task.size() < 2 || k + 1 >= c->chunk_task.size())
+        return fail(SPADA_ERR_STATE, "spada_dev_spgemm_numeric_chunk: no plan, or chunk %u outside it", k);
+    if (c->nnz_c && (!d_c_indices || !d_c_data)) return fail(SPADA_ERR_INVALID, "null output pointer");
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    if (c->nrows && c->chunk_task[k + 1] > c->chunk_task[k]) {
+        HIP_TRY(hipMemsetAsync(c->t_ctr.as<TaskCounters>()->ticket, 0, sizeof(TaskCounters::ticket), s));
+        TaskArgs g = task_args(c, c->cptr.as<uint64_t>(), (uint32_t *)d_c_indices, (double *)d_c_data, c->nnz_c);
+        g.task_lo = c->chunk_task[k];
+        g.task_hi = c->chunk_task[k + 1];
+        launch_task<MODE_NUMERIC>(c, g);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipEventRecord(c->chunk_ev[k], s));
+    if (done_event) *done_event = (void *)c->chunk_ev[k];
+    return SPADA_OK;
+}
+
+int spada_dev_spgemm_indptr(spada_ctx *c, void *d_c_indptr)
+{
+    if (!c) return fail(SPADA_ERR_STATE, "spada_dev_spgemm_indptr: no engine context (no GPU?)");
+    if (!c->have_symbolic || !d_c_indptr) return fail(SPADA_ERR_STATE, "C.indptr requested without a preceding symbolic phase");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpyAsync(d_c_indptr, c->cptr.p, ((size_t)c->nrows + 1) * 8, hipMemcpyDeviceToDevice, c->stream));
+    return SPADA_OK;
+}
+
+int spada_dev_synchronize(spada_ctx *c)
+{
+    if (!c) return fail(SPADA_ERR_STATE, "spada_dev_synchronize: no engine context (no GPU?)");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return SPADA_OK;
 }
 
 int spada_dev_spgemm_fused(spada_ctx *c, const spada_dev_csr *a, const spada_dev_csr *b, uint64_t row_begin, uint64_t row_end,

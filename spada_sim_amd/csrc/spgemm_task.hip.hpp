@@ -633,7 +633,21 @@ struct TaskArgs {
     uint32_t *c_idx;
     double *c_val;
     uint64_t capacity;              // FUSED: entries the caller's C buffers hold
+    uint32_t task_lo, task_hi;      // tasks [task_lo, min(task_hi, all)) are run (NUMERIC in chunks; otherwise 0, 0xFFFFFFFF)
 };
+
+// first output position of tasks t[0 .. n) (t[k] == number of tasks: nnz(C)) after a COUNT run: the chunk boundaries of a
+// numeric phase that is run in pieces (spada_dev_spgemm_numeric_plan)
+__global__ void k_task_positions(const TaskDesc *__restrict__ tasks, const uint64_t *__restrict__ cptr,
+                                 const uint64_t *__restrict__ range_out, const TaskCounters *__restrict__ ctr, uint32_t nrows,
+                                 const uint32_t *__restrict__ t, uint32_t n, uint64_t *__restrict__ pos)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const uint32_t ti = t[k];
+    if (ti >= ctr->ntasks) pos[k] = cptr[nrows];
+    else pos[k] = tasks[ti].kind == TASK_BATCH ? cptr[tasks[ti].row] : range_out[ti];
+}
 
 // LDS: 256 B hdr | table: keys u32[T], vals f64[T] (re-used after accumulation as lk u32[NOUT], lv f64[NOUT])
 //      | region 2: bcnt u32[NOUT], aliased by the walk scratch (disjoint phases)
@@ -958,7 +972,7 @@ __global__ __launch_bounds__(TK_BLOCK, 4) void k_task(const TaskArgs g)
     uint32_t *s_re = (uint32_t *)(s_out + RMAX);
     uint32_t *s_cnt = s_re + RMAX + 1;
     const int tid = threadIdx.x, lane = tid & 63;
-    const uint32_t ntasks = g.ctr->ntasks;
+    const uint32_t ntasks = g.ctr->ntasks, task_end = min(ntasks, g.task_hi);
     if (g.ctr->abort_flag) return;
 
     // Tasks are taken by ticket, in (almost) chain order: queue q hands out tasks q, q + NQ, q + 2 NQ, ...  The smallest task that
@@ -966,13 +980,13 @@ __global__ __launch_bounds__(TK_BLOCK, 4) void k_task(const TaskArgs g)
     // all hold smaller, hence finished, tasks and are free to take it: no cycle of waiting workgroups can form as long as
     // every queue has a resident workgroup, which a grid of at least TK_NQ workgroups dispatched in order guarantees.
     uint32_t *my_ticket = &g.ctr->ticket[(blockIdx.x % TK_NQ) * 32];
-    if (tid == 0) hdr[50] = atomicAdd(my_ticket, 1u) * TK_NQ + blockIdx.x % TK_NQ;
+    if (tid == 0) hdr[50] = g.task_lo + atomicAdd(my_ticket, 1u) * TK_NQ + blockIdx.x % TK_NQ;
     __syncthreads();
     uint32_t t = hdr[50];
     __syncthreads();
     unsigned long long dbg_t0 = SPADA_TASK_DBG ? __builtin_amdgcn_s_memtime() : 0, dbg_acc = 0, dbg_chain = 0, dbg_emit = 0;
     unsigned long long dbg_ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    while (t < ntasks) {
+    while (t < task_end) {
         unsigned long long dbg_a = SPADA_TASK_DBG ? __builtin_amdgcn_s_memtime() : 0, dbg_b = dbg_a, dbg_c = dbg_a;
         // (tickets are taken when the work starts: one taken earlier -- even only across this task's stores, to hide its
         // round trip -- sits unstarted in the chain, every later task waits for it, and the pipeline loses more than the
@@ -1204,7 +1218,7 @@ __global__ __launch_bounds__(TK_BLOCK, 4) void k_task(const TaskArgs g)
             PHASE(5);
             if (SPADA_TASK_DBG && tid == 0) dbg_ph[7] += 1;
         }
-        if (tid == 0) hdr[50] = atomicAdd(my_ticket, 1u) * TK_NQ + blockIdx.x % TK_NQ;
+        if (tid == 0) hdr[50] = g.task_lo + atomicAdd(my_ticket, 1u) * TK_NQ + blockIdx.x % TK_NQ;
         __syncthreads();
         t = hdr[50];
         __syncthreads();
@@ -1314,11 +1328,11 @@ __global__ __launch_bounds__(TK_BLOCK, 3) void k_task_sm(const TaskArgs g)
     uint32_t *s_re = (uint32_t *)(s_out + RMAX);
     uint32_t *s_cnt = s_re + RMAX + 1;
     const int tid = threadIdx.x;
-    const uint32_t ntasks = g.ctr->ntasks;
+    const uint32_t ntasks = g.ctr->ntasks, task_end = min(ntasks, g.task_hi);
     if (g.ctr->abort_flag) return;
     const uint32_t colmask = g.colbits >= 32 ? 0xFFFFFFFFu : ((1u << g.colbits) - 1u);
     uint32_t *my_ticket = &g.ctr->ticket[(blockIdx.x % TK_NQ) * 32];
-    if (tid == 0) hdr[50] = atomicAdd(my_ticket, 1u) * TK_NQ + blockIdx.x % TK_NQ;
+    if (tid == 0) hdr[50] = g.task_lo + atomicAdd(my_ticket, 1u) * TK_NQ + blockIdx.x % TK_NQ;
     __syncthreads();
     uint32_t t = hdr[50];
     __syncthreads();
@@ -1339,7 +1353,7 @@ __global__ __launch_bounds__(TK_BLOCK, 3) void k_task_sm(const TaskArgs g)
         }
     };
 
-    while (t < ntasks) {
+    while (t < task_end) {
         const TaskDesc td = g.tasks[t];
         if (td.kind == TASK_BATCH) {
             const uint32_t rb = td.row;
@@ -1640,7 +1654,7 @@ __global__ __launch_bounds__(TK_BLOCK, 3) void k_task_sm(const TaskArgs g)
             }
         }
         __syncthreads();
-        if (tid == 0) hdr[50] = atomicAdd(my_ticket, 1u) * TK_NQ + blockIdx.x % TK_NQ;
+        if (tid == 0) hdr[50] = g.task_lo + atomicAdd(my_ticket, 1u) * TK_NQ + blockIdx.x % TK_NQ;
         __syncthreads();
         t = hdr[50];
         __syncthreads();

@@ -307,6 +307,51 @@ class Engine:
         return st.as_dict()
 
 
+class Comm:
+    """One RCCL communicator per process / GPU (libspada_comm.so, include/spada_comm.h): the allgatherv of the C row blocks.
+    `unique_id()` is called on rank 0 and its 128 bytes are handed to the other ranks by the launcher."""
+
+    @staticmethod
+    def unique_id():
+        buf = ctypes.create_string_buffer(_ffi.COMM_ID_BYTES)
+        check(_ffi.comm_lib().spada_comm_get_unique_id(buf))
+        return buf.raw
+
+    def __init__(self, uid, rank, nranks, device):
+        self._L = _ffi.comm_lib()
+        self._h = _ffi.vp()
+        self.rank, self.nranks = int(rank), int(nranks)
+        check(self._L.spada_comm_create(ctypes.c_char_p(bytes(uid)), self.rank, self.nranks, int(device), ctypes.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            self._L.spada_comm_destroy(self._h)
+            self._h = _ffi.vp()
+
+    def allgather_counts(self, rows, nnz):
+        r = np.zeros(self.nranks, np.uint64)
+        n = np.zeros(self.nranks, np.uint64)
+        check(self._L.spada_comm_allgather_counts(self._h, int(rows), int(nnz), r.ctypes.data_as(_ffi.u64p), n.ctypes.data_as(_ffi.u64p)))
+        return r, n
+
+    def allgatherv_c(self, d_indptr, d_indices, d_data, rows, nnz, d_full_indptr, d_full_indices, d_full_data):
+        """Device pointers (ints); rows / nnz = the arrays allgather_counts returned."""
+        check(self._L.spada_comm_allgatherv_c(self._h, _ffi.vp(d_indptr), _ffi.vp(d_indices), _ffi.vp(d_data),
+                                              rows.ctypes.data_as(_ffi.u64p), nnz.ctypes.data_as(_ffi.u64p),
+                                              _ffi.vp(d_full_indptr), _ffi.vp(d_full_indices), _ffi.vp(d_full_data)))
+
+    def dist_symbolic(self, engine, da, db, row_begin, row_end, chunks):
+        r = np.zeros(self.nranks, np.uint64)
+        n = np.zeros(self.nranks, np.uint64)
+        check(self._L.spada_dist_spgemm_symbolic(engine._ctx, self._h, da, db, int(row_begin), int(row_end), int(chunks),
+                                                 r.ctypes.data_as(_ffi.u64p), n.ctypes.data_as(_ffi.u64p)))
+        return r, n
+
+    def dist_numeric(self, engine, d_full_indptr, d_full_indices, d_full_data):
+        check(self._L.spada_dist_spgemm_numeric(engine._ctx, self._h, _ffi.vp(d_full_indptr), _ffi.vp(d_full_indices),
+                                                _ffi.vp(d_full_data)))
+
+
 class Simulator:
     """Drop-in for the reference's Simulator: same constructor arguments (simulator.rs:431-448); the
     accelerator-model parameters are accepted and kept but do not steer the GPU kernels."""

@@ -181,3 +181,64 @@ def test_one_output_with_thousands_of_products():
                     assert np.array_equal(c.data, ref.data)
         finally:
             eng.close()
+
+
+def test_numeric_in_chunks(engine):
+    """spada_dev_spgemm_numeric_plan / _chunk: the numeric phase in pieces (what the overlapped exchange uses) fills exactly the
+    entries its plan announces, piece by piece, and the pieces add up to the product."""
+    import ctypes
+    import spada_sim_amd as S
+    from spada_sim_amd import _ffi
+    m = S.generate(S.GEN_RMAT, 12, 12, 21)
+    a = to_oracle(m)
+    ref = oracle.spgemm_spa(a, a)
+    d = engine.upload(m)
+    nnz = engine.symbolic(d, d, 0, m.shape[0])
+    p, i, v = engine.numeric_owned()          # reference run; also provides device buffers of the right size
+    L = _ffi.lib()
+    K = 5
+    pos = np.zeros(K + 1, np.uint64)
+    _ffi.check(L.spada_dev_spgemm_numeric_plan(engine._ctx, K, pos.ctypes.data_as(_ffi.u64p)))
+    assert pos[0] == 0 and pos[-1] == nnz == ref.nnz and np.all(np.diff(pos.astype(np.int64)) >= 0)
+    for k in [3, 0, 4, 1, 2]:                 # pieces are independent: any order
+        ev = _ffi.vp()
+        _ffi.check(L.spada_dev_spgemm_numeric_chunk(engine._ctx, k, _ffi.vp(i), _ffi.vp(v), ctypes.byref(ev)))
+        assert ev.value
+    _ffi.check(L.spada_dev_synchronize(engine._ctx))
+    c = engine.download(p, i, v, m.shape[0], nnz, m.shape[1])
+    engine.free(d)
+    assert_parity(c, ref, a, a, RTOL)
+
+
+def test_rccl_exchange_single_rank(engine):
+    """libspada_comm.so on a one-rank RCCL communicator (all this box has): both forms -- allgatherv after a one-pass SpGEMM and
+    the distributed two-phase call with the overlapped, chunked exchange -- must reproduce the product in the caller's buffers.
+    The N > 1 logic is covered by tests/test_multi_rank_gloo.py (same offsets arithmetic) and by the driver's 8-GPU run."""
+    import spada_sim_amd as S
+    m = S.generate(S.GEN_WEBBASE_LIKE, 40000, 125000, 3)
+    a = to_oracle(m)
+    ref = oracle.spgemm_spa(a, a)
+    comm = S.Comm(S.Comm.unique_id(), 0, 1, 0)
+    d = engine.upload(m)
+    try:
+        cap = S.count_products(m, m, 0, m.shape[0])
+        p, i, v, nnz = engine.fused_owned(d, d, 0, m.shape[0], cap)
+        rows_r, nnz_r = comm.allgather_counts(m.shape[0], nnz)
+        assert list(rows_r) == [m.shape[0]] and list(nnz_r) == [ref.nnz]
+        # receive buffers: a second engine's owned buffers stand in for the caller's allocator
+        eng2 = S.Engine()
+        d2 = eng2.upload(m)
+        fp, fi, fv, _ = eng2.fused_owned(d2, d2, 0, 1, cap)      # buffers of `cap` entries, contents irrelevant
+        fp = eng2.fused_owned(d2, d2, 0, m.shape[0], cap)[0]      # indptr buffer of rows + 1 entries
+        comm.allgatherv_c(p, i, v, rows_r, nnz_r, fp, fi, fv)
+        assert_parity(eng2.download(fp, fi, fv, m.shape[0], ref.nnz, m.shape[1]), ref, a, a, RTOL)
+        # distributed two-phase call, 4 pieces
+        rows_r, nnz_r = comm.dist_symbolic(engine, d, d, 0, m.shape[0], 4)
+        assert list(nnz_r) == [ref.nnz]
+        comm.dist_numeric(engine, fp, fi, fv)
+        assert_parity(eng2.download(fp, fi, fv, m.shape[0], ref.nnz, m.shape[1]), ref, a, a, RTOL)
+        eng2.free(d2)
+        eng2.close()
+    finally:
+        engine.free(d)
+        comm.close()

@@ -32,6 +32,18 @@ def test_library_exports_every_symbol_of_the_header():
     assert _ffi.lib().spada_abi_version() == 3
 
 
+def test_comm_library_exports_every_symbol_of_its_header():
+    """include/spada_comm.h (RCCL exchange) against libspada_comm.so and the binding; no collective is called here."""
+    hdr = open(os.path.join(ROOT, "include", "spada_comm.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(spada_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) == 9
+    L = ctypes.CDLL(_ffi.COMM_LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(L, name), f"{name} declared in spada_comm.h but not exported"
+    assert declared == set(_ffi.COMM_SIGNATURES), declared ^ set(_ffi.COMM_SIGNATURES)
+
+
 def test_struct_layouts_match_the_header():
     assert ctypes.sizeof(_ffi.CsrView) == 48
     assert ctypes.sizeof(_ffi.Options) == 16

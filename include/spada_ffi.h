@@ -121,6 +121,11 @@ void spada_destroy(spada_ctx *ctx);
  * C rows are ascending, columns ascending and unique, explicit zeros kept (simulator.rs:1034-1062). */
 int spada_spgemm_symbolic(spada_ctx *ctx, const spada_csr_view *a, const spada_csr_view *b, uint64_t *nnz_c);
 int spada_spgemm_numeric(spada_ctx *ctx, uint64_t *c_indptr, uint64_t *c_indices, double *c_data);
+/* symbolic phase with -p / --preprocess: A's rows are reordered on the device first (enum spada_reorder below), rowmap (A.rows
+ * entries, may be NULL) receives row_remap (storage.rs:157); the numeric call that follows maps the rows of the product back,
+ * so C comes out in the original row order, identical to the plain call (main.rs:60-63, simulator.rs:1039-1055). */
+int spada_spgemm_symbolic_reordered(spada_ctx *ctx, const spada_csr_view *a, const spada_csr_view *b, int key, uint64_t *nnz_c,
+                                    uint64_t *rowmap);
 /* one pass, host pointers: c_indices / c_data hold `capacity` entries (e.g. Vec::with_capacity(spada_count_products)),
  * *nnz_c receives nnz(C).  SPADA_ERR_CAPACITY: c_indptr and *nnz_c are valid; resize to *nnz_c and call
  * spada_spgemm_numeric. */
@@ -134,6 +139,18 @@ int spada_spgemm_fused(spada_ctx *ctx, const spada_csr_view *a, const spada_csr_
  * d_c_indices : uint32_t[nnz_c]     d_c_data : double[nnz_c]                                   */
 int spada_dev_csr_upload(spada_ctx *ctx, const spada_csr_view *m, spada_dev_csr **out);
 void spada_dev_csr_free(spada_ctx *ctx, spada_dev_csr *m);
+/* -p / --preprocess as a device pre-pass.  The reference sorts the rows of A by length before the simulator visits them
+ * (sort_by_length, preprocessing.rs:76-89; main.rs:60-63; stable, ascending) and maps the result rows back afterwards
+ * (simulator.rs:1039-1055), so C is unchanged.  spada_dev_csr_reorder returns the reordered A in HBM (to be freed with
+ * spada_dev_csr_free); key BY_PRODUCTS sorts by the number of products of a row instead (needs B), which is what balances
+ * the GPU work.  spada_dev_csr_rowmap: row i of the reordered matrix is original row rowmap[i] (row_remap, storage.rs:157).
+ * spada_dev_unpermute_c: the product of the reordered A (device CSR) -> C in the original row order (device, caller-allocated,
+ * same sizes). */
+enum spada_reorder { SPADA_REORDER_BY_LENGTH = 0, SPADA_REORDER_BY_PRODUCTS = 1 };
+int spada_dev_csr_reorder(spada_ctx *ctx, const spada_dev_csr *a, const spada_dev_csr *b, int key, spada_dev_csr **a_reordered);
+int spada_dev_csr_rowmap(spada_ctx *ctx, const spada_dev_csr *a_reordered, uint64_t *rowmap /* rows */);
+int spada_dev_unpermute_c(spada_ctx *ctx, const spada_dev_csr *a_reordered, const void *d_p_indptr, const void *d_p_indices,
+                          const void *d_p_data, void *d_c_indptr, void *d_c_indices, void *d_c_data);
 int spada_dev_spgemm_symbolic(spada_ctx *ctx, const spada_dev_csr *a, const spada_dev_csr *b,
                               uint64_t row_begin, uint64_t row_end, uint64_t *nnz_c);
 int spada_dev_spgemm_numeric(spada_ctx *ctx, void *d_c_indptr, void *d_c_indices, void *d_c_data);
@@ -172,7 +189,19 @@ int spada_get_stats(const spada_ctx *ctx, spada_stats *out);
 /* load_mm_mat (py2rust.rs:62-97): <dir>/<name>.mtx -> canonical CSR as scipy mmread(...).tocsr() */
 int spada_mtx_read(const char *path, spada_host_csr **out);
 /* C writer (the reference never persists C): coordinate real general, 1-based */
-int spada_mtx_write(const char *path, const spada_csr_view *m);
+int spada_mtx_write(const char *path, const spada_csr_view *m);   /* with a `% spada-sim checksum: ...` comment line */
+/* checksum of a CSR: FNV-1a 64 over indptr then indices (structure) and over the value bytes, plus the sequential sum and
+ * absolute sum of the values -- for cross-run parity and for comparing the C of 1 and 8 GPUs without shipping it */
+typedef struct spada_checksum {
+    uint64_t rows, cols, nnz;
+    uint64_t structure_hash, value_hash;
+    double value_sum, value_abs_sum;
+} spada_checksum;
+int spada_csr_checksum(const spada_csr_view *m, spada_checksum *out);
+int spada_checksum_format(const spada_checksum *cs, char *buf, size_t n);   /* the one-line text form */
+/* binary CSR dump (the three Vecs of CsrMatStorage as they are in memory, + header and checksums) and its reader */
+int spada_csr_write_bin(const char *path, const spada_csr_view *m);
+int spada_csr_read_bin(const char *path, spada_host_csr **out);
 int spada_host_csr_from_view(const spada_csr_view *m, spada_host_csr **out);   /* deep copy */
 int spada_host_csr_view(const spada_host_csr *m, spada_csr_view *out);
 void spada_host_csr_free(spada_host_csr *m);

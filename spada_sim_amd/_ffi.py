@@ -50,6 +50,11 @@ class Stats(ctypes.Structure):
         return d
 
 
+class Checksum(ctypes.Structure):
+    _fields_ = [("rows", u64), ("cols", u64), ("nnz", u64), ("structure_hash", u64), ("value_hash", u64),
+                ("value_sum", ctypes.c_double), ("value_abs_sum", ctypes.c_double)]
+
+
 class Config(ctypes.Structure):
     _fields_ = [("ss_filepath", ctypes.c_char * 1024), ("nn_filepath", ctypes.c_char * 1024),
                 ("pe_num", u64), ("at_num", u64), ("lane_num", u64), ("cache_size", u64), ("word_byte", u64),
@@ -66,9 +71,13 @@ SIGNATURES = {
     "spada_create": (ctypes.c_int, [ctypes.POINTER(Options), ctypes.POINTER(vp)]),
     "spada_destroy": (None, [vp]),
     "spada_spgemm_symbolic": (ctypes.c_int, [vp, ctypes.POINTER(CsrView), ctypes.POINTER(CsrView), u64p]),
+    "spada_spgemm_symbolic_reordered": (ctypes.c_int, [vp, ctypes.POINTER(CsrView), ctypes.POINTER(CsrView), ctypes.c_int, u64p, u64p]),
     "spada_spgemm_numeric": (ctypes.c_int, [vp, u64p, u64p, f64p]),
     "spada_dev_csr_upload": (ctypes.c_int, [vp, ctypes.POINTER(CsrView), ctypes.POINTER(vp)]),
     "spada_dev_csr_free": (None, [vp, vp]),
+    "spada_dev_csr_reorder": (ctypes.c_int, [vp, vp, vp, ctypes.c_int, ctypes.POINTER(vp)]),
+    "spada_dev_csr_rowmap": (ctypes.c_int, [vp, vp, u64p]),
+    "spada_dev_unpermute_c": (ctypes.c_int, [vp, vp, vp, vp, vp, vp, vp, vp]),
     "spada_dev_spgemm_symbolic": (ctypes.c_int, [vp, vp, vp, u64, u64, u64p]),
     "spada_dev_spgemm_numeric": (ctypes.c_int, [vp, vp, vp, vp]),
     "spada_dev_spgemm_numeric_plan": (ctypes.c_int, [vp, ctypes.c_uint32, u64p]),
@@ -84,6 +93,10 @@ SIGNATURES = {
     "spada_get_stats": (ctypes.c_int, [vp, ctypes.POINTER(Stats)]),
     "spada_mtx_read": (ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(vp)]),
     "spada_mtx_write": (ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(CsrView)]),
+    "spada_csr_checksum": (ctypes.c_int, [ctypes.POINTER(CsrView), ctypes.POINTER(Checksum)]),
+    "spada_checksum_format": (ctypes.c_int, [ctypes.POINTER(Checksum), ctypes.c_char_p, ctypes.c_size_t]),
+    "spada_csr_write_bin": (ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(CsrView)]),
+    "spada_csr_read_bin": (ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(vp)]),
     "spada_host_csr_from_view": (ctypes.c_int, [ctypes.POINTER(CsrView), ctypes.POINTER(vp)]),
     "spada_host_csr_view": (ctypes.c_int, [vp, ctypes.POINTER(CsrView)]),
     "spada_host_csr_free": (None, [vp]),

@@ -1,7 +1,7 @@
 // spada-sim: drop-in command line of the reference (main.rs:30-121, frontend.rs:52-75)
 //
 //   spada-sim <simulator> <accelerator> <category> <workload> <configuration> [-p|--preprocess]
-//             [--output C.mtx] [--accumulator lds_hash|sort_merge] [--stats]
+//             [--preprocess-by length|products] [--output C.mtx|C.bin] [--accumulator lds_hash|sort_merge] [--stats]
 //
 // e.g.  spada-sim accuratesimu spada ss cari config/config_1mb_row1.json
 //
@@ -93,8 +93,10 @@ static int usage(const char *msg)
 {
     std::fprintf(stderr,
                  "error: %s\n\nUSAGE:\n    spada-sim [FLAGS] <simulator> <accelerator> <category> <workload> <configuration>\n\n"
-                 "FLAGS:\n    -p, --preprocess    Preprocessing (row order only; C is unchanged)\n"
-                 "        --output <C.mtx>          write the product as MatrixMarket\n"
+                 "FLAGS:\n    -p, --preprocess    Preprocessing: rows of A sorted by length on the GPU, result mapped back (C is unchanged)\n"
+                 "        --preprocess-by <length|products>\n"
+                 "        --output <C.mtx|C.bin>    write the product as MatrixMarket, or as a binary CSR dump; prints its checksum\n"
+                 "        --checksum          print the checksum line of the product\n"
                  "        --accumulator <lds_hash|sort_merge>\n        --stats             print engine statistics to stderr\n\n"
                  "ARGS:\n    <simulator>        [possible values: AccurateSimu, TrafficModel, BReuseCounter]\n"
                  "    <accelerator>      [possible values: Ip, Op, MultiRow, Spada]\n"
@@ -107,18 +109,21 @@ static int usage(const char *msg)
 int main(int argc, char **argv)
 {
     std::vector<std::string> pos;
-    bool preprocess = false, want_stats = false;
-    std::string output, acc_name;
+    bool preprocess = false, want_stats = false, want_checksum = false;
+    std::string output, acc_name, preprocess_by = "length";
     for (int i = 1; i < argc; ++i) {
         std::string s = argv[i];
         if (s == "-p" || s == "--preprocess") preprocess = true;
         else if (s == "--stats") want_stats = true;
+        else if (s == "--checksum") want_checksum = true;
+        else if (s == "--preprocess-by" && i + 1 < argc) { preprocess = true; preprocess_by = argv[++i]; }
         else if (s == "--output" && i + 1 < argc) output = argv[++i];
         else if (s == "--accumulator" && i + 1 < argc) acc_name = argv[++i];
         else if (s == "-h" || s == "--help") { usage("help requested"); return 0; }
         else if (s.size() > 1 && s[0] == '-') return usage(("Found argument '" + s + "' which wasn't expected").c_str());
         else pos.push_back(s);
     }
+    if (preprocess_by != "length" && preprocess_by != "products") return usage("--preprocess-by must be length or products");
     if (pos.size() != 5) return usage("The following required arguments were not provided (need 5 positionals)");
     const std::string simulator = lower(pos[0]), accel = lower(pos[1]), category = lower(pos[2]);
     const std::string workload = pos[3], configuration = pos[4];
@@ -162,10 +167,10 @@ int main(int argc, char **argv)
             return 101;
         }
         auto drams = CsrMatStorage::init_with_gemm(gemm);
-        if (preprocess)
-            std::fprintf(stderr, "note: -p only reorders the rows the simulated PEs visit (preprocessing.rs:76-89); results are "
-                                 "mapped back (simulator.rs:1039-1055), so C is unchanged and the GPU binning already "
-                                 "groups rows by length\n");
+        if (preprocess) {   // main.rs:60-63
+            const int rowmap = preprocess_by == "products" ? sort_by_products(drams.first) : sort_by_length(drams.first);
+            drams.first.reorder_row(rowmap);
+        }
         const uint64_t output_base_addr = drams.second.indptr().size();
         uint64_t block_shape[2] = {cfg.block_shape[0], cfg.block_shape[1]};
         if (accelerator == Accelerator::Op) { block_shape[0] = cfg.lane_num; block_shape[1] = 1; }   // main.rs:67-72
@@ -196,9 +201,17 @@ int main(int argc, char **argv)
                          (unsigned long long)st.c_nnz, st.ms_symbolic_call, st.ms_numeric_call, st.c_nnz / ms / 1e6,
                          st.bytes_read / ms / 1e6, st.bytes_read / ms / 1e6 / 8000.0 * 100.0, (unsigned long long)st.spill_rows);
         }
-        if (!output.empty()) {
+        if (want_checksum || !output.empty()) {
             spada_csr_view v = cycle_simu.result_matrix().view();
-            check(spada_mtx_write(output.c_str(), &v));
+            spada_checksum cs;
+            char line[512];
+            check(spada_csr_checksum(&v, &cs));
+            check(spada_checksum_format(&cs, line, sizeof line));
+            std::printf("-----Checksum of the product matrix\n%s\n", line);
+            if (!output.empty()) {
+                const bool bin = output.size() > 4 && output.compare(output.size() - 4, 4, ".bin") == 0;
+                check(bin ? spada_csr_write_bin(output.c_str(), &v) : spada_mtx_write(output.c_str(), &v));
+            }
         }
     } catch (const Error &e) {
         std::fprintf(stderr, "error: %s\n", e.what());

@@ -4,6 +4,7 @@
 //
 // There is no CPU fallback in this file: every compute entry point needs a gfx950 device.
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
 
 #include <algorithm>
 #include <cstdio>
@@ -32,6 +33,7 @@ struct spada_dev_csr {
     uint32_t *idx = nullptr;
     double *val = nullptr;
     uint32_t *rowid = nullptr;   // row of every entry: lets the row statistics run entry-parallel whatever the row lengths are
+    uint32_t *rowmap = nullptr;  // reordered matrices (-p): row i holds original row rowmap[i] (storage.rs:156-157 row_remap)
 };
 
 namespace {
@@ -94,8 +96,9 @@ struct spada_ctx {
     std::vector<uint32_t> chunk_task;
     std::vector<hipEvent_t> chunk_ev;
     DevBuf t_chunk;
-    // matrices uploaded by the host-pointer API
-    spada_dev_csr *hA = nullptr, *hB = nullptr;
+    // matrices uploaded by the host-pointer API; hAr = A reordered by spada_spgemm_symbolic_reordered (-p)
+    spada_dev_csr *hA = nullptr, *hB = nullptr, *hAr = nullptr;
+    DevBuf un_ptr, un_idx, un_val;    // the product mapped back to the original row order
     spada_stats stats = {};
 };
 
@@ -115,6 +118,7 @@ void dev_free(spada_dev_csr *m)
     if (m->idx) (void)hipFree(m->idx);
     if (m->val) (void)hipFree(m->val);
     if (m->rowid) (void)hipFree(m->rowid);
+    if (m->rowmap) (void)hipFree(m->rowmap);
     delete m;
 }
 
@@ -155,6 +159,60 @@ int dev_upload(spada_ctx *c, const spada_csr_view *m, spada_dev_csr **out)
     }
     *out = d.release();
     return SPADA_OK;
+}
+
+
+// ---- row reordering (-p / --preprocess: preprocessing.rs:76-89, main.rs:60-63) and the map-back of the result
+// (simulator.rs:1039-1055) -------------------------------------------------------------------------------------------------
+// sort key of every row: its length, or its number of products (sum of the lengths of the B rows it selects)
+__global__ void k_reorder_keys(const uint64_t *__restrict__ aptr, const uint32_t *__restrict__ aidx, const uint64_t *__restrict__ bptr,
+                               uint32_t rows, int by_products, uint64_t *__restrict__ key, uint32_t *__restrict__ id)
+{
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < rows; i += gridDim.x * blockDim.x) {
+        uint64_t k = aptr[i + 1] - aptr[i];
+        if (by_products) {
+            k = 0;
+            for (uint64_t q = aptr[i]; q < aptr[i + 1]; ++q) k += bptr[aidx[q] + 1] - bptr[aidx[q]];
+        }
+        key[i] = k;
+        id[i] = i;
+    }
+}
+// lengths of the rows in their new order (len[i + 1] = length of original row map[i]); an inclusive scan makes it an indptr
+__global__ void k_gather_lengths(const uint64_t *__restrict__ ptr, const uint32_t *__restrict__ map, uint32_t rows,
+                                 uint64_t *__restrict__ len)
+{
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < rows; i += gridDim.x * blockDim.x) {
+        len[i + 1] = ptr[map[i] + 1] - ptr[map[i]];
+        if (i == 0) len[0] = 0;
+    }
+}
+// lengths of the rows back in original order from a product whose row i is original row map[i]
+__global__ void k_scatter_lengths(const uint64_t *__restrict__ pptr, const uint32_t *__restrict__ map, uint32_t rows,
+                                  uint64_t *__restrict__ len)
+{
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < rows; i += gridDim.x * blockDim.x) {
+        len[map[i] + 1] = pptr[i + 1] - pptr[i];
+        if (i == 0) len[0] = 0;
+    }
+}
+// copy rows: one wave per row; FORWARD: row i of dst = row map[i] of src; else row map[i] of dst = row i of src
+template <bool FORWARD, bool WITH_ROWID>
+__global__ __launch_bounds__(256) void k_move_rows(const uint64_t *__restrict__ sptr, const uint32_t *__restrict__ sidx,
+                                                   const double *__restrict__ sval, const uint64_t *__restrict__ dptr,
+                                                   uint32_t *__restrict__ didx, double *__restrict__ dval,
+                                                   uint32_t *__restrict__ drowid, const uint32_t *__restrict__ map, uint32_t rows)
+{
+    const int lane = threadIdx.x & 63;
+    for (uint32_t i = blockIdx.x * 4 + (threadIdx.x >> 6); i < rows; i += gridDim.x * 4) {
+        const uint32_t srow = FORWARD ? map[i] : i, drow = FORWARD ? i : map[i];
+        const uint64_t s0 = sptr[srow], n = sptr[srow + 1] - s0, d0 = dptr[drow];
+        for (uint64_t q = lane; q < n; q += 64) {
+            didx[d0 + q] = sidx[s0 + q];
+            dval[d0 + q] = sval[s0 + q];
+            if constexpr (WITH_ROWID) drowid[d0 + q] = drow;
+        }
+    }
 }
 
 // ---- task pipeline ---------------------------------------------------------------------------------------------------
@@ -445,6 +503,10 @@ void spada_destroy(spada_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     dev_free(c->hA);
     if (c->hB != c->hA) dev_free(c->hB);
+    dev_free(c->hAr);
+    c->un_ptr.release();
+    c->un_idx.release();
+    c->un_val.release();
     for (DevBuf *b : {&c->row_nprod, &c->row_bin, &c->row_kmin, &c->row_kmax, &c->cptr, &c->t_rowP, &c->t_rowm, &c->t_rowt, &c->t_rowtmp,
                       &c->t_big, &c->t_tiles, &c->eb0, &c->elen, &c->t_tmp, &c->t_tasks, &c->t_status, &c->t_rangeout, &c->t_scrcol,
                       &c->t_scrval, &c->t_scrseq, &c->t_ctr, &c->own_idx, &c->own_val, &c->own_ptr, &c->wide_idx})
@@ -478,6 +540,115 @@ void spada_dev_csr_free(spada_ctx *c, spada_dev_csr *m)
         if (c->A == m || c->B == m) c->have_symbolic = false;
     }
     dev_free(m);
+}
+
+int spada_dev_csr_reorder(spada_ctx *c, const spada_dev_csr *a, const spada_dev_csr *b, int key, spada_dev_csr **out)
+{
+    if (!c) return fail(SPADA_ERR_STATE, "spada_dev_csr_reorder: no engine context (no GPU?)");
+    if (!a || !out) return fail(SPADA_ERR_INVALID, "spada_dev_csr_reorder: null argument");
+    if (key != SPADA_REORDER_BY_LENGTH && key != SPADA_REORDER_BY_PRODUCTS) return fail(SPADA_ERR_INVALID, "unknown reorder key %d", key);
+    if (key == SPADA_REORDER_BY_PRODUCTS && (!b || a->cols != b->rows))
+        return fail(SPADA_ERR_INVALID, "reordering by products needs B with rows(B) == cols(A)");
+    *out = nullptr;
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const uint32_t rows = (uint32_t)a->rows;
+    auto d = std::make_unique<spada_dev_csr>();
+    d->rows = a->rows;
+    d->cols = a->cols;
+    d->nnz = a->nnz;
+    uint64_t *k_in = nullptr, *k_out = nullptr;
+    uint32_t *id_in = nullptr;
+    void *tmp = nullptr;
+    const auto body = [&]() -> int {
+        HIP_TRY(hipMalloc((void **)&d->ptr, ((size_t)rows + 1) * 8));
+        HIP_TRY(hipMalloc((void **)&d->idx, std::max<uint64_t>(a->nnz, 1) * 4));
+        HIP_TRY(hipMalloc((void **)&d->val, std::max<uint64_t>(a->nnz, 1) * 8));
+        HIP_TRY(hipMalloc((void **)&d->rowid, std::max<uint64_t>(a->nnz, 1) * 4));
+        HIP_TRY(hipMalloc((void **)&d->rowmap, std::max<size_t>(rows, 1) * 4));
+        HIP_TRY(hipMalloc((void **)&k_in, std::max<size_t>(rows, 1) * 8));
+        HIP_TRY(hipMalloc((void **)&k_out, std::max<size_t>(rows, 1) * 8));
+        HIP_TRY(hipMalloc((void **)&id_in, std::max<size_t>(rows, 1) * 4));
+        if (!rows) {
+            HIP_TRY(hipMemsetAsync(d->ptr, 0, 8, s));
+            return SPADA_OK;
+        }
+        const uint32_t grid = std::min<uint32_t>((rows + 255) / 256, c->n_cu * 8);
+        hipLaunchKernelGGL(k_reorder_keys, dim3(grid), dim3(256), 0, s, a->ptr, a->idx, b ? b->ptr : nullptr, rows,
+                           key == SPADA_REORDER_BY_PRODUCTS ? 1 : 0, k_in, id_in);
+        // stable ascending sort of the rows by key, as id_len_vector.sort_by(|a, b| a[1].cmp(&b[1])) (preprocessing.rs:82)
+        size_t tmp_bytes = 0;
+        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, k_in, k_out, id_in, d->rowmap, (int)rows, 0, 64, s));
+        HIP_TRY(hipMalloc(&tmp, std::max<size_t>(tmp_bytes, 16)));
+        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, k_in, k_out, id_in, d->rowmap, (int)rows, 0, 64, s));
+        HIP_TRY(hipFree(tmp));
+        tmp = nullptr;
+        hipLaunchKernelGGL(k_gather_lengths, dim3(grid), dim3(256), 0, s, a->ptr, d->rowmap, rows, d->ptr);
+        tmp_bytes = 0;
+        HIP_TRY(hipcub::DeviceScan::InclusiveSum(nullptr, tmp_bytes, d->ptr, d->ptr, (int)rows + 1, s));
+        HIP_TRY(hipMalloc(&tmp, std::max<size_t>(tmp_bytes, 16)));
+        HIP_TRY(hipcub::DeviceScan::InclusiveSum(tmp, tmp_bytes, d->ptr, d->ptr, (int)rows + 1, s));
+        hipLaunchKernelGGL((k_move_rows<true, true>), dim3(std::min<uint32_t>((rows + 3) / 4, c->n_cu * 16)), dim3(256), 0, s, a->ptr,
+                           a->idx, a->val, d->ptr, d->idx, d->val, d->rowid, d->rowmap, rows);
+        HIP_TRY(hipGetLastError());
+        return SPADA_OK;
+    };
+    int rc = body();
+    if (rc == SPADA_OK && hipStreamSynchronize(s) != hipSuccess) rc = fail(SPADA_ERR_HIP, "row reordering failed on the device");
+    for (void *p : {(void *)k_in, (void *)k_out, (void *)id_in, tmp})
+        if (p) (void)hipFree(p);
+    if (rc) {
+        dev_free(d.release());
+        return rc;
+    }
+    *out = d.release();
+    return SPADA_OK;
+}
+
+int spada_dev_unpermute_c(spada_ctx *c, const spada_dev_csr *a_reordered, const void *d_p_indptr, const void *d_p_indices,
+                          const void *d_p_data, void *d_c_indptr, void *d_c_indices, void *d_c_data)
+{
+    if (!c) return fail(SPADA_ERR_STATE, "spada_dev_unpermute_c: no engine context (no GPU?)");
+    if (!a_reordered || !a_reordered->rowmap) return fail(SPADA_ERR_INVALID, "spada_dev_unpermute_c: the matrix was not produced by spada_dev_csr_reorder");
+    if (!d_p_indptr || !d_c_indptr) return fail(SPADA_ERR_INVALID, "spada_dev_unpermute_c: null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const uint32_t rows = (uint32_t)a_reordered->rows;
+    if (!rows) {
+        HIP_TRY(hipMemsetAsync(d_c_indptr, 0, 8, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        return SPADA_OK;
+    }
+    const uint32_t grid = std::min<uint32_t>((rows + 255) / 256, c->n_cu * 8);
+    hipLaunchKernelGGL(k_scatter_lengths, dim3(grid), dim3(256), 0, s, (const uint64_t *)d_p_indptr, a_reordered->rowmap, rows,
+                       (uint64_t *)d_c_indptr);
+    size_t tmp_bytes = 0;
+    void *tmp = nullptr;
+    HIP_TRY(hipcub::DeviceScan::InclusiveSum(nullptr, tmp_bytes, (uint64_t *)d_c_indptr, (uint64_t *)d_c_indptr, (int)rows + 1, s));
+    HIP_TRY(hipMalloc(&tmp, std::max<size_t>(tmp_bytes, 16)));
+    hipError_t e = hipcub::DeviceScan::InclusiveSum(tmp, tmp_bytes, (uint64_t *)d_c_indptr, (uint64_t *)d_c_indptr, (int)rows + 1, s);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL((k_move_rows<false, false>), dim3(std::min<uint32_t>((rows + 3) / 4, c->n_cu * 16)), dim3(256), 0, s,
+                           (const uint64_t *)d_p_indptr, (const uint32_t *)d_p_indices, (const double *)d_p_data,
+                           (const uint64_t *)d_c_indptr, (uint32_t *)d_c_indices, (double *)d_c_data, (uint32_t *)nullptr,
+                           a_reordered->rowmap, rows);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(tmp);
+    if (e != hipSuccess) return fail(SPADA_ERR_HIP, "map-back of the reordered product failed: %s", hipGetErrorString(e));
+    return SPADA_OK;
+}
+
+int spada_dev_csr_rowmap(spada_ctx *c, const spada_dev_csr *a_reordered, uint64_t *rowmap)
+{
+    if (!c) return fail(SPADA_ERR_STATE, "spada_dev_csr_rowmap: no engine context (no GPU?)");
+    if (!a_reordered || !a_reordered->rowmap || !rowmap) return fail(SPADA_ERR_INVALID, "spada_dev_csr_rowmap: not a reordered matrix");
+    HIP_TRY(hipSetDevice(c->device));
+    std::vector<uint32_t> m32(a_reordered->rows);
+    HIP_TRY(hipMemcpy(m32.data(), a_reordered->rowmap, a_reordered->rows * 4, hipMemcpyDeviceToHost));
+    for (uint64_t i = 0; i < a_reordered->rows; ++i) rowmap[i] = m32[i];
+    return SPADA_OK;
 }
 
 int spada_dev_spgemm_symbolic(spada_ctx *c, const spada_dev_csr *a, const spada_dev_csr *b, uint64_t row_begin,
@@ -673,22 +844,42 @@ int spada_dev_download_c(spada_ctx *c, const void *d_c_indptr, const void *d_c_i
     return SPADA_OK;
 }
 
-int spada_spgemm_symbolic(spada_ctx *c, const spada_csr_view *a, const spada_csr_view *b, uint64_t *nnz_c)
+static int upload_pair(spada_ctx *c, const spada_csr_view *a, const spada_csr_view *b)
 {
-    if (!c) return fail(SPADA_ERR_STATE, "spada_spgemm_symbolic: no engine context (no GPU?)");
-    if (!a || !b || !nnz_c) return fail(SPADA_ERR_INVALID, "spada_spgemm_symbolic: null argument");
     HIP_TRY(hipSetDevice(c->device));
     c->have_symbolic = false;
     dev_free(c->hA);
     if (c->hB != c->hA) dev_free(c->hB);
-    c->hA = c->hB = nullptr;
+    dev_free(c->hAr);
+    c->hA = c->hB = c->hAr = nullptr;
     int rc = spada_dev_csr_upload(c, a, &c->hA);
     if (rc) return rc;
     const bool same = a->indptr == b->indptr && a->indices == b->indices && a->data == b->data && a->rows == b->rows &&
                       a->cols == b->cols;
     if (same) c->hB = c->hA;
     else if ((rc = spada_dev_csr_upload(c, b, &c->hB))) return rc;
+    return SPADA_OK;
+}
+
+int spada_spgemm_symbolic(spada_ctx *c, const spada_csr_view *a, const spada_csr_view *b, uint64_t *nnz_c)
+{
+    if (!c) return fail(SPADA_ERR_STATE, "spada_spgemm_symbolic: no engine context (no GPU?)");
+    if (!a || !b || !nnz_c) return fail(SPADA_ERR_INVALID, "spada_spgemm_symbolic: null argument");
+    int rc = upload_pair(c, a, b);
+    if (rc) return rc;
     return spada_dev_spgemm_symbolic(c, c->hA, c->hB, 0, a->rows, nnz_c);
+}
+
+int spada_spgemm_symbolic_reordered(spada_ctx *c, const spada_csr_view *a, const spada_csr_view *b, int key, uint64_t *nnz_c,
+                                    uint64_t *rowmap)
+{
+    if (!c) return fail(SPADA_ERR_STATE, "spada_spgemm_symbolic_reordered: no engine context (no GPU?)");
+    if (!a || !b || !nnz_c) return fail(SPADA_ERR_INVALID, "spada_spgemm_symbolic_reordered: null argument");
+    int rc = upload_pair(c, a, b);
+    if (rc) return rc;
+    if ((rc = spada_dev_csr_reorder(c, c->hA, c->hB, key, &c->hAr))) return rc;
+    if (rowmap && (rc = spada_dev_csr_rowmap(c, c->hAr, rowmap))) return rc;
+    return spada_dev_spgemm_symbolic(c, c->hAr, c->hB, 0, a->rows, nnz_c);
 }
 
 int spada_spgemm_fused(spada_ctx *c, const spada_csr_view *a, const spada_csr_view *b, uint64_t capacity, uint64_t *c_indptr,
@@ -726,6 +917,15 @@ int spada_spgemm_numeric(spada_ctx *c, uint64_t *c_indptr, uint64_t *c_indices, 
     void *dp, *di, *dv;
     int rc = spada_dev_spgemm_numeric_owned(c, &dp, &di, &dv);
     if (rc) return rc;
+    if (c->hAr && c->A == c->hAr) {   // rows were reordered (-p): map the product back (simulator.rs:1039-1055)
+        if ((rc = c->un_ptr.ensure(((size_t)c->nrows + 1) * 8, false, c->stream, &c->ws_bytes))) return rc;
+        if ((rc = c->un_idx.ensure(std::max<uint64_t>(c->nnz_c, 1) * 4, false, c->stream, &c->ws_bytes))) return rc;
+        if ((rc = c->un_val.ensure(std::max<uint64_t>(c->nnz_c, 1) * 8, false, c->stream, &c->ws_bytes))) return rc;
+        if ((rc = spada_dev_unpermute_c(c, c->hAr, dp, di, dv, c->un_ptr.p, c->un_idx.p, c->un_val.p))) return rc;
+        dp = c->un_ptr.p;
+        di = c->un_idx.p;
+        dv = c->un_val.p;
+    }
     return spada_dev_download_c(c, dp, di, dv, c->nrows, c->nnz_c, c_indptr, c_indices, c_data);
 }
 

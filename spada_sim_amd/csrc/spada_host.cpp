@@ -642,15 +642,119 @@ int spada_mtx_read(const char *path, spada_host_csr **out)
     return SPADA_OK;
 }
 
+// FNV-1a, 64 bit, over a byte range
+static uint64_t fnv1a(uint64_t h, const void *p, size_t n)
+{
+    const unsigned char *b = (const unsigned char *)p;
+    for (size_t i = 0; i < n; ++i) {
+        h ^= b[i];
+        h *= 0x100000001B3ull;
+    }
+    return h;
+}
+
+int spada_csr_checksum(const spada_csr_view *m, spada_checksum *out)
+{
+    if (!out) return fail(SPADA_ERR_INVALID, "spada_csr_checksum: null out");
+    int rc = validate(m, "spada_csr_checksum");
+    if (rc) return rc;
+    out->rows = m->rows;
+    out->cols = m->cols;
+    out->nnz = m->nnz;
+    uint64_t h = 0xCBF29CE484222325ull;
+    h = fnv1a(h, m->indptr, (m->rows + 1) * 8);
+    h = fnv1a(h, m->indices, m->nnz * 8);
+    out->structure_hash = h;
+    out->value_hash = fnv1a(0xCBF29CE484222325ull, m->data, m->nnz * 8);
+    double s = 0.0, sa = 0.0;
+    for (uint64_t q = 0; q < m->nnz; ++q) {   // in storage order, one rounding per addition
+        s += m->data[q];
+        sa += std::fabs(m->data[q]);
+    }
+    out->value_sum = s;
+    out->value_abs_sum = sa;
+    return SPADA_OK;
+}
+
+int spada_checksum_format(const spada_checksum *cs, char *buf, size_t n)
+{
+    if (!cs || !buf || !n) return fail(SPADA_ERR_INVALID, "spada_checksum_format: null argument");
+    std::snprintf(buf, n, "rows %llu cols %llu nnz %llu structure %016llx values %016llx sum %.17g abs_sum %.17g",
+                  (unsigned long long)cs->rows, (unsigned long long)cs->cols, (unsigned long long)cs->nnz,
+                  (unsigned long long)cs->structure_hash, (unsigned long long)cs->value_hash, cs->value_sum, cs->value_abs_sum);
+    return SPADA_OK;
+}
+
+// binary CSR dump: "SPADACSR" | version u64 | rows | cols | nnz | indptr u64[rows + 1] | indices u64[nnz] | data f64[nnz] |
+// structure_hash | value_hash   (little endian, the in-memory layout of CsrMatStorage's three Vecs, storage.rs:150-160)
+static const char BIN_MAGIC[8] = {'S', 'P', 'A', 'D', 'A', 'C', 'S', 'R'};
+
+int spada_csr_write_bin(const char *path, const spada_csr_view *m)
+{
+    if (!path) return fail(SPADA_ERR_INVALID, "spada_csr_write_bin: null path");
+    spada_checksum cs;
+    int rc = spada_csr_checksum(m, &cs);
+    if (rc) return rc;
+    FILE *f = std::fopen(path, "wb");
+    if (!f) return fail(SPADA_ERR_IO, "cannot create %s: %s", path, std::strerror(errno));
+    const uint64_t hdr[4] = {1, m->rows, m->cols, m->nnz}, tail[2] = {cs.structure_hash, cs.value_hash};
+    bool ok = std::fwrite(BIN_MAGIC, 1, 8, f) == 8 && std::fwrite(hdr, 8, 4, f) == 4 &&
+              std::fwrite(m->indptr, 8, m->rows + 1, f) == m->rows + 1 && std::fwrite(m->indices, 8, m->nnz, f) == m->nnz &&
+              std::fwrite(m->data, 8, m->nnz, f) == m->nnz && std::fwrite(tail, 8, 2, f) == 2;
+    if (std::fclose(f) != 0) ok = false;
+    if (!ok) return fail(SPADA_ERR_IO, "write to %s failed", path);
+    return SPADA_OK;
+}
+
+int spada_csr_read_bin(const char *path, spada_host_csr **out)
+{
+    if (!path || !out) return fail(SPADA_ERR_INVALID, "spada_csr_read_bin: null argument");
+    *out = nullptr;
+    FILE *f = std::fopen(path, "rb");
+    if (!f) return fail(SPADA_ERR_IO, "cannot open %s: %s", path, std::strerror(errno));
+    char magic[8];
+    uint64_t hdr[4], tail[2];
+    auto m = std::make_unique<spada_host_csr>();
+    bool ok = std::fread(magic, 1, 8, f) == 8 && std::memcmp(magic, BIN_MAGIC, 8) == 0 && std::fread(hdr, 8, 4, f) == 4 && hdr[0] == 1;
+    if (ok) {
+        m->rows = hdr[1];
+        m->cols = hdr[2];
+        if (hdr[1] > (1ull << 40) || hdr[3] > (1ull << 44)) ok = false;
+    }
+    if (ok) {
+        m->indptr.resize(hdr[1] + 1);
+        m->indices.resize(hdr[3]);
+        m->data.resize(hdr[3]);
+        ok = std::fread(m->indptr.data(), 8, hdr[1] + 1, f) == hdr[1] + 1 && std::fread(m->indices.data(), 8, hdr[3], f) == hdr[3] &&
+             std::fread(m->data.data(), 8, hdr[3], f) == hdr[3] && std::fread(tail, 8, 2, f) == 2;
+    }
+    std::fclose(f);
+    if (!ok) return fail(SPADA_ERR_PARSE, "%s is not a complete SPADACSR version 1 file", path);
+    const spada_csr_view v = view_of(*m);
+    spada_checksum cs;
+    if (spada_csr_checksum(&v, &cs)) {
+        const std::string why = spada_last_error();
+        return fail(SPADA_ERR_PARSE, "%s: corrupt CSR (%s)", path, why.c_str());
+    }
+    if (cs.structure_hash != tail[0] || cs.value_hash != tail[1]) return fail(SPADA_ERR_PARSE, "%s: checksum mismatch", path);
+    *out = m.release();
+    return SPADA_OK;
+}
+
 int spada_mtx_write(const char *path, const spada_csr_view *m)
 {
     if (!path) return fail(SPADA_ERR_INVALID, "spada_mtx_write: null path");
     int rc = validate(m, "spada_mtx_write");
     if (rc) return rc;
+    spada_checksum cs;
+    if ((rc = spada_csr_checksum(m, &cs))) return rc;
+    char line[512];
+    (void)spada_checksum_format(&cs, line, sizeof line);
     FILE *f = std::fopen(path, "wb");
     if (!f) return fail(SPADA_ERR_IO, "cannot create %s: %s", path, std::strerror(errno));
-    std::fprintf(f, "%%%%MatrixMarket matrix coordinate real general\n%llu %llu %llu\n", (unsigned long long)m->rows,
-                 (unsigned long long)m->cols, (unsigned long long)m->nnz);
+    // the checksum travels as a MatrixMarket comment: any reader skips it, `spada-sim --checksum` prints the same line
+    std::fprintf(f, "%%%%MatrixMarket matrix coordinate real general\n%% spada-sim checksum: %s\n%llu %llu %llu\n", line,
+                 (unsigned long long)m->rows, (unsigned long long)m->cols, (unsigned long long)m->nnz);
     for (uint64_t r = 0; r < m->rows; ++r)
         for (uint64_t q = m->indptr[r]; q < m->indptr[r + 1]; ++q)
             std::fprintf(f, "%llu %llu %.17g\n", (unsigned long long)r + 1, (unsigned long long)m->indices[q] + 1, m->data[q]);

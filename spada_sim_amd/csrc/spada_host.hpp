@@ -116,7 +116,21 @@ struct CsrMatStorage {
     }
     uint64_t row_num() const { return mat->nrows; }
     const std::vector<uint64_t> &indptr() const { return mat->indptr; }
+    // storage.rs:156-157, :252-255.  The order is computed by the device pre-pass of Simulator::execute (key = what
+    // sort_by_length / sort_by_products asked for); row_remap holds it afterwards.
+    bool remapped = false;
+    int reorder_key = SPADA_REORDER_BY_LENGTH;
+    std::vector<uint64_t> row_remap;
+    void reorder_row(int key)
+    {
+        remapped = true;
+        reorder_key = key;
+    }
 };
+// preprocessing.rs:76-89 (rows of A by ascending length, stable) and its product-aware sibling: both return the key the
+// device pre-pass sorts by
+inline int sort_by_length(const CsrMatStorage &) { return SPADA_REORDER_BY_LENGTH; }
+inline int sort_by_products(const CsrMatStorage &) { return SPADA_REORDER_BY_PRODUCTS; }
 
 enum class Accelerator { Ip, Op, MultiRow, Spada };
 
@@ -143,7 +157,12 @@ public:
     {
         spada_csr_view va = a_->mat->view(), vb = b_->mat->view();
         uint64_t nnz = 0;
-        check(spada_spgemm_symbolic(ctx_, &va, &vb, &nnz));
+        if (a_->remapped) {   // main.rs:60-63: -p; the product is mapped back by the numeric call (simulator.rs:1039-1055)
+            a_->row_remap.assign(va.rows, 0);
+            check(spada_spgemm_symbolic_reordered(ctx_, &va, &vb, a_->reorder_key, &nnz, a_->row_remap.data()));
+        } else {
+            check(spada_spgemm_symbolic(ctx_, &va, &vb, &nnz));
+        }
         c_.nrows = va.rows;
         c_.ncols = vb.cols;
         c_.indptr.assign(va.rows + 1, 0);

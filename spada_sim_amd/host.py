@@ -24,6 +24,8 @@ from ._ffi import SpadaError, check
 
 ACC_LDS_HASH = 0
 ACC_SORT_MERGE = 1
+REORDER_BY_LENGTH = 0      # sort_by_length, preprocessing.rs:76-89 (what -p does in the reference)
+REORDER_BY_PRODUCTS = 1    # rows sorted by their number of products (GPU load balance)
 
 GEN_RMAT, GEN_WEBBASE_LIKE, GEN_COP20K_LIKE, GEN_CAGE12_LIKE, GEN_MC2DEPI_LIKE, GEN_UNIFORM = range(6)
 
@@ -92,6 +94,26 @@ def load_mm_mat(dir_path, gemm_nm):
 
 def write_mm_mat(path, mat):
     check(_ffi.lib().spada_mtx_write(str(path).encode(), ctypes.byref(mat.view())))
+
+
+def write_bin(path, mat):
+    """Binary CSR dump (SPADACSR version 1: header, the three arrays, checksums)."""
+    check(_ffi.lib().spada_csr_write_bin(str(path).encode(), ctypes.byref(mat.view())))
+
+
+def read_bin(path):
+    h = _ffi.vp()
+    check(_ffi.lib().spada_csr_read_bin(str(path).encode(), ctypes.byref(h)))
+    return CsMat._from_handle(h)
+
+
+def checksum(mat):
+    """(dict, one-line text) -- the line `spada-sim --checksum` prints and the .mtx writer embeds."""
+    cs = _ffi.Checksum()
+    check(_ffi.lib().spada_csr_checksum(ctypes.byref(mat.view()), ctypes.byref(cs)))
+    buf = ctypes.create_string_buffer(512)
+    check(_ffi.lib().spada_checksum_format(ctypes.byref(cs), buf, 512))
+    return {n: getattr(cs, n) for n, _ in cs._fields_}, buf.value.decode()
 
 
 def generate(kind, p0=0, p1=0, seed=0):
@@ -167,6 +189,8 @@ class CsrMatStorage:
         self.mat_shape = [mat.shape[1], mat.shape[0]]
         self.read_count = 0
         self.write_count = 0
+        self.remapped = False
+        self.row_remap = {}
         self._mat = mat
 
     @classmethod
@@ -177,6 +201,13 @@ class CsrMatStorage:
     def row_num(self):
         return len(self.indptr) - 1
 
+    def reorder_row(self, rowmap):
+        """storage.rs:252-255: mark the storage as remapped.  `rowmap` is what sort_by_length / sort_by_products returned: the
+        order itself is computed on the device when the simulator executes, row_remap holds it afterwards."""
+        self.remapped = True
+        self._reorder_key = rowmap.key
+        self.row_remap = rowmap
+
     def view(self):
         return self._mat.view()
 
@@ -185,6 +216,25 @@ class CsrMatStorage:
             raise SpadaError(1, f"Invalid row_ptr: {row_ptr}")
         s, t = int(self.indptr[row_ptr]), int(self.indptr[row_ptr + 1])
         return CsrRow(row_ptr, self.data[s:t], self.indices[s:t])
+
+
+class RowMap(dict):
+    """Result of sort_by_length / sort_by_products: new position -> original row (HashMap<usize, usize> in the reference).  It
+    is filled by the device pre-pass of the run that uses it."""
+
+    def __init__(self, key):
+        super().__init__()
+        self.key = key
+
+
+def sort_by_length(amat):
+    """preprocessing.rs:76-89: rows of A in ascending order of their length (stable)."""
+    return RowMap(REORDER_BY_LENGTH)
+
+
+def sort_by_products(amat):
+    """Like sort_by_length, by the number of products of a row (sum of the lengths of the B rows it selects)."""
+    return RowMap(REORDER_BY_PRODUCTS)
 
 
 class Engine:
@@ -208,12 +258,19 @@ class Engine:
             pass
 
     # -- host-pointer two-phase path (the drop-in seam) --
-    def spgemm(self, a, b):
-        """C = A * B through spada_spgemm_symbolic / spada_spgemm_numeric; returns a CsMat."""
+    def spgemm(self, a, b, reorder=None):
+        """C = A * B through spada_spgemm_symbolic / spada_spgemm_numeric; returns a CsMat.  reorder = REORDER_BY_LENGTH /
+        REORDER_BY_PRODUCTS: the -p pre-pass (rows of A reordered on the device, product mapped back; C is the same);
+        the row map is left in self.last_rowmap."""
         nnz = ctypes.c_uint64(0)
         va = a.view()
         vb = va if b is a else b.view()
-        check(self._L.spada_spgemm_symbolic(self._ctx, ctypes.byref(va), ctypes.byref(vb), ctypes.byref(nnz)))
+        if reorder is not None:
+            self.last_rowmap = np.zeros(a.shape[0], np.uint64)
+            check(self._L.spada_spgemm_symbolic_reordered(self._ctx, ctypes.byref(va), ctypes.byref(vb), int(reorder),
+                                                          ctypes.byref(nnz), self.last_rowmap.ctypes.data_as(_ffi.u64p)))
+        else:
+            check(self._L.spada_spgemm_symbolic(self._ctx, ctypes.byref(va), ctypes.byref(vb), ctypes.byref(nnz)))
         n = nnz.value
         c_indptr = np.zeros(a.shape[0] + 1, np.uint64)
         c_indices = np.zeros(n, np.uint64)
@@ -370,7 +427,10 @@ class Simulator:
 
     def execute(self):
         a, b = self.a_matrix._mat, self.b_matrix._mat
-        self._c = self._engine.spgemm(a, a if self.b_matrix is self.a_matrix else b)
+        key = getattr(self.a_matrix, "_reorder_key", None) if getattr(self.a_matrix, "remapped", False) else None
+        self._c = self._engine.spgemm(a, a if self.b_matrix is self.a_matrix else b, reorder=key)
+        if key is not None:     # row_remap as the reference keeps it (storage.rs:157); the result rows are already mapped back
+            self.a_matrix.row_remap.update({i: int(r) for i, r in enumerate(self._engine.last_rowmap)})
         self._stats = self._engine.stats()
 
     def get_exec_result(self):

@@ -227,3 +227,78 @@ def test_product_path_does_not_touch_the_oracle():
             if f.endswith((".py", ".cpp", ".hpp", ".hip", "Makefile")):
                 text = open(os.path.join(d, f), errors="replace").read()
                 assert "oracle" not in text.replace("oracle_rowwise", ""), f"{f} mentions the oracle"
+
+
+def test_checksum_and_binary_dump_round_trip(tmp_path):
+    """C writer: binary CSR dump + checksum line; the .mtx writer embeds the same line as a comment."""
+    m = S.generate(S.GEN_RMAT, 9, 6, 3)
+    cs, line = S.checksum(m)
+    assert cs["rows"] == m.shape[0] and cs["nnz"] == m.nnz() and f"nnz {m.nnz()} " in line
+    assert abs(cs["value_sum"] - float(np.sum(m.data))) <= 1e-9 * cs["value_abs_sum"]
+    p = tmp_path / "m.bin"
+    S.write_bin(p, m)
+    assert p.stat().st_size == 8 + 4 * 8 + (m.shape[0] + 1) * 8 + m.nnz() * 16 + 16
+    r = S.read_bin(p)
+    assert r.shape == m.shape and np.array_equal(r.indptr, m.indptr) and np.array_equal(r.indices, m.indices)
+    assert np.array_equal(r.data, m.data) and S.checksum(r)[1] == line
+    raw = bytearray(p.read_bytes())
+    raw[8 + 32 + (m.shape[0] + 1) * 8 + 3] ^= 1          # flip one bit of a column index
+    p.write_bytes(bytes(raw))
+    with pytest.raises(S.SpadaError) as e:
+        S.read_bin(p)
+    assert e.value.code == 6
+    raw[8 + 32 + (m.shape[0] + 1) * 8 + 3] ^= 1
+    raw[-16 - 5] ^= 4                                      # and one bit of the last value: structure fine, checksum not
+    p.write_bytes(bytes(raw))
+    with pytest.raises(S.SpadaError) as e:
+        S.read_bin(p)
+    assert e.value.code == 6 and "checksum mismatch" in str(e.value)
+    (tmp_path / "short.bin").write_bytes(bytes(raw[:100]))
+    with pytest.raises(S.SpadaError):
+        S.read_bin(tmp_path / "short.bin")
+    q = tmp_path / "m.mtx"
+    S.write_mm_mat(q, m)
+    text = q.read_text().splitlines()
+    assert text[1] == "% spada-sim checksum: " + line
+    back = S.load_mm_mat(str(tmp_path), "m")
+    assert S.checksum(back)[1] == line                   # %.17g round-trips every value
+    m2 = S.CsMat(m.shape, m.indptr, m.indices, m.data.copy())
+    m2.data[5] = np.nextafter(m2.data[5], 2.0)
+    assert S.checksum(m2)[0]["value_hash"] != cs["value_hash"] and S.checksum(m2)[0]["structure_hash"] == cs["structure_hash"]
+
+
+BIN = os.path.join(ROOT, "spada_sim_amd", "bin", "spada-sim")
+CFG = os.path.join(ROOT, "config", "config_1mb_row1.json")
+
+
+def _run_cli(args, cwd):
+    import subprocess
+    return subprocess.run([BIN] + args, cwd=cwd, capture_output=True, text=True, timeout=300)
+
+
+def test_cli_usage_and_exit_codes(matrices_dir):
+    """Exit codes of the drop-in binary: 1 = usage error (clap), 101 = run-time failure (a Rust panic's code; main.rs:119 for the
+    unimplemented simulators, py2rust.rs for NN workloads)."""
+    cwd = os.path.dirname(matrices_dir)
+    os.makedirs(os.path.join(cwd, "matrices"), exist_ok=True)
+    import shutil
+    shutil.copy(os.path.join(matrices_dir, "cari.mtx"), os.path.join(cwd, "matrices", "cari.mtx"))
+    r = _run_cli([], cwd)
+    assert r.returncode == 1 and "USAGE" in r.stderr
+    r = _run_cli(["accuratesimu", "gpu", "ss", "cari", CFG], cwd)
+    assert r.returncode == 1 and "isn't a valid value for '<accelerator>'" in r.stderr
+    r = _run_cli(["accuratesimu", "spada", "ss", "cari", CFG, "--bogus"], cwd)
+    assert r.returncode == 1 and "wasn't expected" in r.stderr
+    r = _run_cli(["accuratesimu", "spada", "ss", "cari", CFG, "--preprocess-by", "width"], cwd)
+    assert r.returncode == 1
+    r = _run_cli(["accuratesimu", "spada", "nn", "alexnet", CFG], cwd)
+    assert r.returncode == 101 and "NN" in r.stderr
+    r = _run_cli(["trafficmodel", "spada", "ss", "cari", CFG], cwd)
+    assert r.returncode == 101 and "Unimplemented simulator" in r.stderr
+    assert r.stdout.startswith(CFG + "\n---- Python Interface ----\n% Load cari from ./matrices\nGet GEMM cari\n---- cari ----\n--A: (400, 1200)\n")   # frontend.rs:79 prints the configuration path first
+    assert "Avg row len of A: 382, Avg row len of B: 127" in r.stdout
+    r = _run_cli(["accuratesimu", "spada", "ss", "missing", CFG], cwd)
+    assert r.returncode == 101 and "missing.mtx" in r.stderr
+    if S.device_count() == 0:      # no GPU: the run itself must fail loudly, not fall back to anything
+        r = _run_cli(["accuratesimu", "spada", "ss", "cari", CFG], cwd)
+        assert r.returncode == 101 and "no HIP device" in r.stderr and "-----Result-----" not in r.stdout

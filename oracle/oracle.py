@@ -39,6 +39,9 @@ def lib():
         L.oracle_spgemm_spa.restype = ctypes.c_uint64
         L.oracle_spgemm_spa.argtypes = [ctypes.c_uint64, ctypes.c_uint64, _u64p, _u64p, _f64p,
                                         _u64p, _u64p, _f64p, _u64p, _u64p, _f64p, ctypes.c_int]
+        L.oracle_spgemm_windowed.restype = ctypes.c_uint64
+        L.oracle_spgemm_windowed.argtypes = [ctypes.c_uint64, ctypes.c_uint64, _u64p, _u64p, _f64p,
+                                             _u64p, _u64p, _f64p, _u64p, _u64p, _f64p]
         L.oracle_transpose_csr.restype = None
         L.oracle_transpose_csr.argtypes = [ctypes.c_uint64, ctypes.c_uint64, _u64p, _u64p, _f64p,
                                            _u64p, _u64p, _f64p]
@@ -104,6 +107,23 @@ def spgemm_sortmerge(a, b):
     c_indices = np.zeros(nnz, dtype=np.uint64)
     c_data = np.zeros(nnz, dtype=np.float64)
     L.oracle_spgemm_sortmerge(*args, _p(c_indptr), _p(c_indices), _p(c_data))
+    return Csr(a.rows, b.cols, c_indptr, c_indices, c_data)
+
+
+def spgemm_windowed(a, b, lane_num=8):
+    """C = A*B with the products added in the reference's order of K-windows of `lane_num` A scalars, then first-in-first-out
+    pairwise merges of the partial fibers (scheduler.rs:482-606, :381-480; see spgemm_ref.c).  Same structure as
+    spgemm_sortmerge; values differ by floating-point re-association only."""
+    assert a.cols == b.rows
+    L = lib()
+    c_indptr = np.zeros(a.rows + 1, dtype=np.uint64)
+    args = (a.rows, lane_num, _p(a.indptr), _p(a.indices), _p(a.data), _p(b.indptr), _p(b.indices), _p(b.data))
+    nnz = L.oracle_spgemm_windowed(*args, _p(c_indptr), None, None)
+    if nnz == 2**64 - 1:
+        raise MemoryError("oracle allocation failed")
+    c_indices = np.zeros(nnz, dtype=np.uint64)
+    c_data = np.zeros(nnz, dtype=np.float64)
+    L.oracle_spgemm_windowed(*args, _p(c_indptr), _p(c_indices), _p(c_data))
     return Csr(a.rows, b.cols, c_indptr, c_indices, c_data)
 
 

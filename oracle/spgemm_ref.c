@@ -39,6 +39,9 @@
  * ascending k (A-nonzero order), which is what a stable sort by column followed by a
  * left-to-right run sum gives when the whole row is one group.  f64 addition order changes
  * results at the 1e-16 level; parity tolerance for values is 1e-9 relative (BASELINE.json).
+ * oracle_spgemm_windowed (end of file) adds in the reference's window / pairwise-merge order instead; the
+ * two differ by at most 3.6e-15 relative on cari and 6.6e-16 of sum|a b| on signed random cases
+ * (tests/test_oracle_golden.py::test_order_faithful_variant_bounds_the_summation_order_effect).
  */
 #include <stdint.h>
 #include <stdlib.h>
@@ -269,4 +272,108 @@ int oracle_num_threads(void)
 #else
     return 1;
 #endif
+}
+
+/*
+ * Order-faithful variant: the SAME products, added in (a timing-independent restatement of) the reference's order instead of
+ * ascending k.  The reference never forms a whole C row at once: with the shipped configuration (block height 1, lane_num 8)
+ * Scheduler::next_window (scheduler.rs:482-606) hands the PE the A scalars of a row `lane_num` at a time; every window is
+ * expanded, stably sorted by column and run-summed left to right (simulator.rs:143-171, :199-230) into a PARTIAL fiber of its
+ * own (one psum address per window, scheduler.rs:548-550); the partial fibers of a row are then merged two at a time --
+ * Scheduler::merge_task drains the two oldest (`psum_addrs.drain(..2)`, scheduler.rs:399-406), the PE multiplies both by 1.0
+ * and merges them with equal columns added left + right (adder_tree.rs:73-83, :173-188: ties -> left), and the result joins
+ * the back of the row's list -- until one fiber is left (simulator.rs:985-1006).  WHEN a merge is issued relative to later
+ * windows depends on the simulated clock; this restatement issues all windows first and then merges first-in-first-out, which
+ * fixes one of the orders the reference can produce.  Structure is identical to oracle_spgemm_sortmerge by construction;
+ * values differ from it only by floating-point re-association (tests/test_oracle_golden.py records by how much).
+ * Same two-phase calling convention.
+ */
+typedef struct {
+    uint64_t *col;
+    double *val;
+    size_t n;
+} fiber_t;
+
+uint64_t oracle_spgemm_windowed(uint64_t a_rows, uint64_t lane_num,
+                                const uint64_t *a_indptr, const uint64_t *a_indices, const double *a_data,
+                                const uint64_t *b_indptr, const uint64_t *b_indices, const double *b_data,
+                                uint64_t *c_indptr, uint64_t *c_indices, double *c_data)
+{
+    if (lane_num == 0) lane_num = 8;
+    const int fill = (c_indices != NULL);
+    uint64_t nnz = 0;
+    if (!fill) c_indptr[0] = 0;
+    for (uint64_t i = 0; i < a_rows; ++i) {
+        const uint64_t a0 = a_indptr[i], a1 = a_indptr[i + 1];
+        const size_t nwin = (size_t)((a1 - a0 + lane_num - 1) / lane_num);
+        /* queue of partial fibers, oldest first; at most 2 * nwin entries are ever appended */
+        fiber_t *q = (fiber_t *)calloc(2 * nwin + 1, sizeof(fiber_t));
+        if (!q) return UINT64_MAX;
+        size_t head = 0, tail = 0;
+        for (size_t w = 0; w < nwin; ++w) {
+            const uint64_t p0 = a0 + w * lane_num, p1 = (p0 + lane_num < a1) ? p0 + lane_num : a1;
+            size_t n = 0;
+            for (uint64_t p = p0; p < p1; ++p) n += (size_t)(b_indptr[a_indices[p] + 1] - b_indptr[a_indices[p]]);
+            if (n == 0) continue;   /* no product, no psum address (simulator.rs:650) */
+            prod_t *buf = (prod_t *)malloc(n * sizeof(prod_t)), *tmp = (prod_t *)malloc(n * sizeof(prod_t));
+            fiber_t f;
+            f.col = (uint64_t *)malloc(n * sizeof(uint64_t));
+            f.val = (double *)malloc(n * sizeof(double));
+            if (!buf || !tmp || !f.col || !f.val) return UINT64_MAX;
+            size_t m = 0;
+            for (uint64_t p = p0; p < p1; ++p) {
+                const uint64_t k = a_indices[p];
+                for (uint64_t t = b_indptr[k]; t < b_indptr[k + 1]; ++t) {
+                    buf[m].col = b_indices[t];
+                    buf[m].val = a_data[p] * b_data[t];
+                    ++m;
+                }
+            }
+            msort(buf, tmp, n);
+            f.n = 0;
+            for (size_t j = 0; j < n;) {
+                const uint64_t col = buf[j].col;
+                double acc = buf[j].val;
+                ++j;
+                while (j < n && buf[j].col == col) { acc += buf[j].val; ++j; }
+                f.col[f.n] = col;
+                f.val[f.n] = acc;
+                ++f.n;
+            }
+            free(buf);
+            free(tmp);
+            q[tail++] = f;
+        }
+        while (tail - head > 1) {   /* merge the two oldest, append the result */
+            fiber_t x = q[head], y = q[head + 1], z;
+            head += 2;
+            z.col = (uint64_t *)malloc((x.n + y.n) * sizeof(uint64_t));
+            z.val = (double *)malloc((x.n + y.n) * sizeof(double));
+            if (!z.col || !z.val) return UINT64_MAX;
+            size_t ix = 0, iy = 0;
+            z.n = 0;
+            while (ix < x.n || iy < y.n) {
+                if (iy >= y.n || (ix < x.n && x.col[ix] < y.col[iy])) { z.col[z.n] = x.col[ix]; z.val[z.n] = x.val[ix] * 1.0; ++ix; }
+                else if (ix >= x.n || y.col[iy] < x.col[ix]) { z.col[z.n] = y.col[iy]; z.val[z.n] = y.val[iy] * 1.0; ++iy; }
+                else { z.col[z.n] = x.col[ix]; z.val[z.n] = x.val[ix] * 1.0 + y.val[iy] * 1.0; ++ix; ++iy; }
+                ++z.n;
+            }
+            free(x.col); free(x.val); free(y.col); free(y.val);
+            q[tail++] = z;
+        }
+        uint64_t cnt = 0;
+        if (tail > head) {
+            cnt = q[head].n;
+            if (fill) {
+                memcpy(c_indices + c_indptr[i], q[head].col, cnt * sizeof(uint64_t));
+                memcpy(c_data + c_indptr[i], q[head].val, cnt * sizeof(double));
+            }
+            free(q[head].col);
+            free(q[head].val);
+        }
+        free(q);
+        nnz += cnt;
+        if (!fill) c_indptr[i + 1] = nnz;
+    }
+    return nnz;
 }

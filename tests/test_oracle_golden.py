@@ -85,3 +85,50 @@ def test_cari_product_pins(matrices_dir):
     assert np.allclose(c.data[g["sample_pos"].astype(np.int64)], g["sample_val"], rtol=1e-12, atol=0)
     assert np.allclose(np.add.reduceat(c.data, c.indptr[:-1].astype(np.int64)), g["row_sums"], rtol=1e-12, atol=0)
     assert abs(c.data.sum() - float(g["total"])) < 1e-9 and c.data.max() == pytest.approx(float(g["vmax"]), rel=1e-12)
+
+
+def test_order_faithful_variant_bounds_the_summation_order_effect(matrices_dir):
+    """The arithmetic half of the oracle cannot be pinned to the reference binary (no Rust toolchain, no golden vectors), so the
+    one thing that could make the reference's values differ from the oracle's -- the order in which the products of an output
+    entry are added -- is bounded instead: oracle.spgemm_windowed adds them the way the reference's dataflow does (K-windows of
+    lane_num = 8 A scalars, partial fibers merged two at a time, oldest first: scheduler.rs:482-606, :381-480,
+    adder_tree.rs:73-83) and must give the same structure and values within a few ulps of the ascending-k sum.
+
+    Recorded maxima (this test prints them with -s):  cari A*A^T (382 products per entry, positive values): 3.6e-15 relative;
+    signed random cases: 6.6e-16 of sum|a_ik b_kj| (the cancellation scale) -- six orders of magnitude inside the 1e-9 tolerance."""
+    import spada_sim_amd as S
+    from fuzz_cases import random_case
+    m = S.load_mm_mat(matrices_dir, "cari")
+    a = oracle.Csr(m.shape[0], m.shape[1], m.indptr, m.indices, m.data)
+    a, b = oracle.from_mat(a)
+    ref = oracle.spgemm_sortmerge(a, b)
+    win = oracle.spgemm_windowed(a, b, 8)
+    assert np.array_equal(win.indptr, ref.indptr) and np.array_equal(win.indices, ref.indices)
+    rel = float(np.max(np.abs(win.data - ref.data) / np.abs(ref.data)))
+    print(f"cari: max relative deviation of the windowed order from ascending k = {rel:.3e}")
+    assert 0 < rel < 5e-15            # different order (not the same sum by accident), far inside 1e-9
+    for lane in (1, 2, 16):           # lane_num = 1: every product its own fiber, pure pairwise tree
+        w2 = oracle.spgemm_windowed(a, b, lane)
+        assert np.array_equal(w2.indices, ref.indices) and np.max(np.abs(w2.data - ref.data) / np.abs(ref.data)) < 5e-15
+    worst = 0.0
+    for seed in range(40):
+        x, y, desc = random_case(seed)
+        if x.nnz() * y.nnz() == 0 or y.shape[1] > 100000:
+            continue
+        xo = oracle.Csr(x.shape[0], x.shape[1], x.indptr, x.indices, x.data)
+        yo = oracle.Csr(y.shape[0], y.shape[1], y.indptr, y.indices, y.data)
+        r = oracle.spgemm_sortmerge(xo, yo)
+        w = oracle.spgemm_windowed(xo, yo, 8)
+        assert np.array_equal(w.indptr, r.indptr) and np.array_equal(w.indices, r.indices), desc
+        xa = oracle.Csr(xo.rows, xo.cols, xo.indptr, xo.indices, np.abs(xo.data))
+        ya = oracle.Csr(yo.rows, yo.cols, yo.indptr, yo.indices, np.abs(yo.data))
+        scale = oracle.spgemm_sortmerge(xa, ya).data
+        if len(scale):
+            worst = max(worst, float(np.max(np.abs(w.data - r.data) / scale)))
+    print(f"random cases: max deviation relative to sum|a b| = {worst:.3e}")
+    assert worst < 5e-15
+    # kept zeros survive the merges too (nothing filters value == 0: simulator.rs:199-230)
+    a, b, _ = load_case("tiny_cancel")
+    w = oracle.spgemm_windowed(a, b, 8)
+    r3 = slice(int(w.indptr[3]), int(w.indptr[4]))
+    assert list(w.indices[r3]) == [0, 1, 2, 4] and w.data[r3][0] == 0.0

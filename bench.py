@@ -399,7 +399,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": (traffic or {}).get("k_task", {}).get("hbm_bytes_per_launch"),
+                "traffic": (traffic or {}).get("k_task<2>" if one_pass else "k_task<1>", {}).get("hbm_bytes_per_launch"),
                 "traffic_source": os.path.relpath(traffic_src, ROOT) if traffic else None,
                 "kernel_ms": k_ms,
                 "kernel_algorithmic_bytes_read": st["bytes_read"],

@@ -89,8 +89,10 @@ struct spada_ctx {
     DevBuf row_nprod, row_bin, row_kmin, row_kmax, cptr, t_rowP, t_rowm, t_rowt, t_rowtmp, t_big, t_tiles;
     DevBuf eb0, elen;
     DevBuf t_tmp, t_tasks, t_status, t_rangeout, t_scrcol, t_scrval, t_scrseq, t_ctr;
+    DevBuf t_parts, t_parthist, t_slots;                      // BIG rows: parts, bucket counts (then cursors) per part, row records
     DevBuf own_idx, own_val, own_ptr, wide_idx;
-    uint64_t t_cap_tmp = 0, t_cap_tasks = 0, t_cap_scr = 0;   // capacities the kernels may rely on
+    uint64_t t_cap_tmp = 0, t_cap_tasks = 0, t_cap_scr = 0, t_cap_parts = 0;   // capacities the kernels may rely on
+    uint32_t direct_factor = 8;   // k_big_plan (measured: 2 .. 32 within 1 % on the web and mesh surrogates, 8 best on R-MAT 16): a BIG row with m ranges and E entries is not spilled if m * E <= factor * products
     TaskCounters *h_tctr = nullptr;   // pinned
     // numeric phase in pieces (spada_dev_spgemm_numeric_plan / _chunk): task boundaries, one event per piece
     std::vector<uint32_t> chunk_task;
@@ -284,6 +286,7 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
     if ((rc = c->t_rowt.ensure(n1 * 4, false, s, &c->ws_bytes))) return rc;
     if ((rc = c->t_rowtmp.ensure(n1 * 4, false, s, &c->ws_bytes))) return rc;
     if ((rc = c->t_big.ensure(n1 * 4, false, s, &c->ws_bytes))) return rc;
+    if ((rc = c->t_slots.ensure(n1 * sizeof(BigSlot), false, s, &c->ws_bytes))) return rc;
     if ((rc = c->cptr.ensure(n1 * 8, false, s, &c->ws_bytes))) return rc;
     if ((rc = c->t_ctr.ensure(sizeof(TaskCounters), false, s, &c->ws_bytes))) return rc;
     if ((rc = c->eb0.ensure(std::max<uint64_t>(a->nnz, 1) * 8, false, s, &c->ws_bytes))) return rc;
@@ -299,11 +302,12 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
     TaskCounters *dc = c->t_ctr.as<TaskCounters>();
     if (!c->t_cap_tasks) {
         c->t_cap_tasks = n / 4 + 4096;
-        c->t_cap_tmp = 4096;
+        c->t_cap_tmp = std::min<uint64_t>(std::max<uint64_t>(a->nnz / 16, 4096), 1u << 20);
         c->t_cap_scr = 1u << 20;
+        c->t_cap_parts = std::min<uint64_t>(std::max<uint64_t>(a->nnz / 128, 2048), 32768);   // (4 KB of bucket counts each)
     }
     c->stats.pipeline_runs = 0;
-    for (int attempt = 0; attempt < 3; ++attempt) {
+    for (int attempt = 0; attempt < 4; ++attempt) {
         c->t_cap_tasks = std::max<uint64_t>(c->t_cap_tasks, (uint64_t)n / 4 + 4096);
         if ((rc = c->t_tasks.ensure(c->t_cap_tasks * sizeof(TaskDesc), false, s, &c->ws_bytes))) return rc;
         if ((rc = c->t_status.ensure(c->t_cap_tasks * 8 * ST_STRIDE, false, s, &c->ws_bytes))) return rc;
@@ -312,9 +316,12 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
         if ((rc = c->t_scrcol.ensure(c->t_cap_scr * 4, false, s, &c->ws_bytes))) return rc;
         if ((rc = c->t_scrval.ensure(c->t_cap_scr * 8, false, s, &c->ws_bytes))) return rc;
         if (c->accumulator == SPADA_ACC_SORT_MERGE && (rc = c->t_scrseq.ensure(c->t_cap_scr * 4, false, s, &c->ws_bytes))) return rc;
+        if ((rc = c->t_parts.ensure(c->t_cap_parts * sizeof(BigPart), false, s, &c->ws_bytes))) return rc;
+        if ((rc = c->t_parthist.ensure(c->t_cap_parts * BX_NB * 4, false, s, &c->ws_bytes))) return rc;
         // capacities the kernels may rely on (DevBuf over-allocates; use what was asked for)
         const uint32_t cap_tasks = (uint32_t)std::min<uint64_t>(c->t_cap_tasks, 0xFFFFFFF0u);
         const uint32_t cap_tmp = (uint32_t)std::min<uint64_t>(c->t_cap_tmp, 0xFFFFFFF0u);
+        const uint32_t cap_parts = (uint32_t)std::min<uint64_t>(c->t_cap_parts, 0xFFFFFFF0u);
         ++c->stats.pipeline_runs;
         HIP_TRY(hipEventRecord(c->tev[0], s));
         HIP_TRY(hipMemsetAsync(dc, 0, sizeof(TaskCounters), s));
@@ -333,12 +340,22 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
         }
         HIP_TRY(hipEventRecord(c->tev[1], s));
         if (n) {
-            hipLaunchKernelGGL(k_big_expand, dim3(c->n_cu * 5), dim3(TK_BLOCK), BX_LDS, s, a->ptr, a->val, b->idx, b->val,
-                               c->eb0.as<uint64_t>(), c->elen.as<uint32_t>(), c->r0, c->t_big.as<uint32_t>(),
-                               c->row_nprod.as<uint32_t>(), c->row_kmin.as<uint32_t>(), c->row_kmax.as<uint32_t>(),
-                               c->t_rowm.as<uint32_t>(), c->t_rowtmp.as<uint32_t>(), c->t_tmp.as<TaskDesc>(), cap_tmp,
-                               c->t_scrcol.as<uint32_t>(), c->t_scrval.as<double>(),
-                               c->accumulator == SPADA_ACC_SORT_MERGE ? c->t_scrseq.as<uint32_t>() : (uint32_t *)nullptr, c->t_cap_scr, dc);
+            uint32_t *seq = c->accumulator == SPADA_ACC_SORT_MERGE ? c->t_scrseq.as<uint32_t>() : (uint32_t *)nullptr;
+            hipLaunchKernelGGL(k_big_parts, dim3(c->n_cu * 2), dim3(256), 0, s, a->ptr, c->elen.as<uint32_t>(), c->r0,
+                               c->t_big.as<uint32_t>(), c->row_nprod.as<uint32_t>(), c->t_parts.as<BigPart>(), cap_parts,
+                               c->t_rowtmp.as<uint32_t>(), cap_tmp, c->t_slots.as<BigSlot>(), dc);
+            hipLaunchKernelGGL(k_big_hist, dim3(c->n_cu * 8), dim3(TK_BLOCK), BX_WALK_LDS, s, b->idx, c->eb0.as<uint64_t>(),
+                               c->elen.as<uint32_t>(), c->t_big.as<uint32_t>(), c->row_kmin.as<uint32_t>(),
+                               c->row_kmax.as<uint32_t>(), c->t_parts.as<BigPart>(), c->t_parthist.as<uint32_t>(), dc);
+            hipLaunchKernelGGL(k_big_plan, dim3(c->n_cu * 8), dim3(TK_BLOCK), BX_PLAN_LDS, s, a->ptr, c->r0,
+                               c->accumulator == SPADA_ACC_SORT_MERGE ? 0u : c->direct_factor, c->t_big.as<uint32_t>(),
+                               c->row_kmin.as<uint32_t>(), c->row_kmax.as<uint32_t>(), c->t_parts.as<BigPart>(),
+                               c->t_parthist.as<uint32_t>(), c->t_rowm.as<uint32_t>(), c->t_rowtmp.as<uint32_t>(),
+                               c->t_tmp.as<TaskDesc>(), c->t_slots.as<BigSlot>(), c->t_cap_scr, dc);
+            hipLaunchKernelGGL(k_big_scatter, dim3(c->n_cu * 8), dim3(TK_BLOCK), BX_WALK_LDS, s, a->val, b->idx, b->val,
+                               c->eb0.as<uint64_t>(), c->elen.as<uint32_t>(), c->t_big.as<uint32_t>(), c->row_kmin.as<uint32_t>(),
+                               c->row_kmax.as<uint32_t>(), c->t_parts.as<BigPart>(), c->t_parthist.as<uint32_t>(),
+                               c->t_slots.as<BigSlot>(), c->t_scrcol.as<uint32_t>(), c->t_scrval.as<double>(), seq, dc);
             HIP_TRY(hipGetLastError());
         }
         HIP_TRY(hipEventRecord(c->tev[2], s));
@@ -369,10 +386,13 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
         for (int k = 0; k < N_CLS; ++k) h.nprod += h.cls_prod[k];
         h.nprod_big = h.cls_prod[CLS_BIG];
         if (!h.abort_flag) break;
-        if (attempt == 2) return fail(SPADA_ERR_HIP, "task pipeline: workspaces still too small after two retries (flag %u)", h.abort_flag);
+        if (attempt == 3) return fail(SPADA_ERR_HIP, "task pipeline: workspaces still too small after three retries (flag %u)", h.abort_flag);
         if (h.abort_flag & 4u) return fail(SPADA_ERR_UNSUPPORTED, "a row of C has 2^32 or more products");
-        c->t_cap_scr = std::max<uint64_t>(c->t_cap_scr, h.nprod_big + h.nprod_big / 16 + 1024);
+        c->t_cap_scr = std::max<uint64_t>(c->t_cap_scr, h.scratch_cursor + h.scratch_cursor / 16 + 1024);
         c->t_cap_tmp = std::max<uint64_t>(c->t_cap_tmp, (uint64_t)h.tmp_cursor + h.tmp_cursor / 16 + 1024);
+        c->t_cap_parts = std::max<uint64_t>(c->t_cap_parts, (uint64_t)h.n_parts + h.n_parts / 16 + 256);
+        if ((h.abort_flag & 16u) && !h.scratch_cursor)   // the plan has not run: a guess, replaced by the exact size if it is too small
+            c->t_cap_scr = std::max<uint64_t>(c->t_cap_scr, std::min<uint64_t>(h.nprod_big, 64ull << 20));
         c->t_cap_tasks = std::max<uint64_t>(c->t_cap_tasks, (uint64_t)h.need_tasks + h.need_tasks / 16 + 1024);
     }
     const TaskCounters &h = *c->h_tctr;
@@ -406,8 +426,8 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
                      (double)h.dbg[12] / h.dbg[15], (double)h.dbg[13] / h.dbg[15], (double)h.dbg[14] / h.dbg[15]);
     st.n_tasks = h.ntasks;
     st.multi_pass_tasks = h.multi_pass_tasks;
-    st.scratch_products = h.nprod_big;
-    st.spill_rows = h.n_big;
+    st.scratch_products = h.scratch_cursor;
+    st.spill_rows = h.n_spilled;
     st.workspace_bytes = c->ws_bytes;
     if (mode == MODE_COUNT) {
         st.ms_symbolic_call = tev_ms(c, 0, 4);
@@ -491,7 +511,7 @@ int spada_create(const spada_options *opts, spada_ctx **out)
     if ((rc = allow_lds(k_task_sm<MODE_COUNT>, task_sm_lds()))) return rc;
     if ((rc = allow_lds(k_task_sm<MODE_NUMERIC>, task_sm_lds()))) return rc;
     if ((rc = allow_lds(k_task_sm<MODE_FUSED>, task_sm_lds()))) return rc;
-    if ((rc = allow_lds(k_big_expand, BX_LDS))) return rc;
+    if ((rc = allow_lds(k_big_hist, BX_WALK_LDS)) || (rc = allow_lds(k_big_scatter, BX_WALK_LDS)) || (rc = allow_lds(k_big_plan, BX_PLAN_LDS))) return rc;
     *out = c.release();
     return SPADA_OK;
 }
@@ -509,7 +529,7 @@ void spada_destroy(spada_ctx *c)
     c->un_val.release();
     for (DevBuf *b : {&c->row_nprod, &c->row_bin, &c->row_kmin, &c->row_kmax, &c->cptr, &c->t_rowP, &c->t_rowm, &c->t_rowt, &c->t_rowtmp,
                       &c->t_big, &c->t_tiles, &c->eb0, &c->elen, &c->t_tmp, &c->t_tasks, &c->t_status, &c->t_rangeout, &c->t_scrcol,
-                      &c->t_scrval, &c->t_scrseq, &c->t_ctr, &c->own_idx, &c->own_val, &c->own_ptr, &c->wide_idx})
+                      &c->t_scrval, &c->t_scrseq, &c->t_ctr, &c->t_parts, &c->t_parthist, &c->t_slots, &c->own_idx, &c->own_val, &c->own_ptr, &c->wide_idx})
         b->release();
     if (c->h_tctr) (void)hipHostFree(c->h_tctr);
     for (auto &e : c->tev)

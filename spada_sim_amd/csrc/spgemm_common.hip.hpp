@@ -228,11 +228,17 @@ __host__ __device__ constexpr size_t flat_walk_bytes()
     return (size_t)BLOCK * EPT * (NUMERIC ? 16 : 8) + (size_t)(FLAT_PWIN / 64) * 12 + 16;
 }
 
-template <int BLOCK, int EPT, int RMAX, bool NUMERIC, int U, class F>
+// `trim(b0, len)` may narrow the (begin, length) descriptors of the EPT entries a thread has just loaded (NoTrim: whole B rows).
+struct NoTrim {
+    template <int EPT>
+    __device__ inline void operator()(uint64_t (&)[EPT], uint32_t (&)[EPT]) const {}
+};
+
+template <int BLOCK, int EPT, int RMAX, bool NUMERIC, int U, class F, class Trim = NoTrim>
 __device__ inline void flat_walk(const uint32_t *s_re, const uint64_t *s_a0, uint32_t R, uint32_t E,
                                  const uint64_t *__restrict__ eb0, const uint32_t *__restrict__ elen,
                                  const double *__restrict__ aval, const uint32_t *__restrict__ bidx,
-                                 const double *__restrict__ bval, unsigned char *scratch, uint32_t *hdr, F &&f)
+                                 const double *__restrict__ bval, unsigned char *scratch, uint32_t *hdr, F &&f, Trim trim = Trim())
 {
     uint32_t pbase = 0;   // products of the chunks already walked
     constexpr int ECH = BLOCK * EPT;
@@ -278,6 +284,7 @@ __device__ inline void flat_walk(const uint32_t *s_re, const uint64_t *s_a0, uin
                     if constexpr (NUMERIC) av[i] = aval[a];
                 }
             }
+            trim(b0, len);
         }
         // packed scan: (entries with products) << 32 | products
         unsigned long long mine = 0;

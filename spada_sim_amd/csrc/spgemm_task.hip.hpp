@@ -50,7 +50,7 @@ struct TaskDesc {
     uint64_t src;       // RANGE: first product of the slice in the scratch arrays
     uint32_t col_lo, col_hi;
 };
-constexpr uint32_t TASK_BATCH = 1, TASK_RANGE = 2;
+constexpr uint32_t TASK_BATCH = 1, TASK_RANGE = 2, TASK_RANGE_DIRECT = 3;   // (DIRECT: the products are taken from B, not from the scratch)
 
 // device counters of one pipeline run (zeroed at its start)
 struct TaskCounters {
@@ -58,10 +58,11 @@ struct TaskCounters {
     unsigned long long scratch_cursor;                // products handed out in the scratch arrays
     unsigned long long nnz_c;                         // written by the last task (COUNT / FUSED)
     unsigned long long cls_rows[N_CLS], cls_prod[N_CLS];
-    uint32_t n_big, tmp_cursor, ntasks, big_cursor;
+    uint32_t n_big, tmp_cursor, ntasks, n_parts;
+    uint32_t n_spilled, pad_spilled;                  // BIG rows whose products go through the scratch arrays
     uint32_t abort_flag;                              // a workspace was too small: results invalid, sizes below say what is needed
     uint32_t cap_overflow;                            // FUSED: nnz(C) exceeded the caller's capacity (C.indptr is complete)
-    uint32_t need_tmp, need_tasks;
+    uint32_t need_tmp, need_tasks;                    // (abort_flag bits: 1 tmp / scratch, 2 tasks, 4 row too long, 8 BIG rows, 16 parts)
     uint32_t multi_pass_tasks, pad;
     uint32_t ticket[TK_NQ * 32];  // TK_NQ ticket counters, one per 128-byte line (a single hot word sustains ~88 atomics / us)
     unsigned long long dbg[16];  // SPADA_TASK_DBG builds: [0] cycles in the chain, [1] look-back windows, [2] spin retries, [3] cycles
@@ -186,79 +187,265 @@ __global__ __launch_bounds__(256) void k_row_class(const uint64_t *__restrict__ 
     if (threadIdx.x == 0 && s_tot) atomicAdd(&ctr->a_nnz, s_tot);
 }
 
-// ---- 2. BIG rows: histogram, column ranges, scatter into HBM scratch -----------------------------------------------------
-// One workgroup per BIG row.  Pass 1 walks the row's products (column indices only) and counts them in BX_NB column
-// buckets of width 2^wshift over [kmin, kmax].  Buckets are then grouped into ranges: a bucket with more than BX_HEAVY
-// products is a range of its own, the others are grouped by floor(prefix / TK_CAP) -- a light range holds fewer than
-// TK_CAP + BX_HEAVY = 1536 products, i.e. it fits one task's table whatever its outputs are; a heavy range holds at most
-// 2^wshift distinct columns and is split further by the task itself if both exceed the table (k_task, multi-pass).  Pass 2
-// walks the products again and stores (column, a * b) at the bucket's cursor: afterwards the scratch slice of every range is
-// contiguous.  Range descriptors go to `tmp` (bump allocated), their number to row_m[row]; k_cut3 copies them into the
-// task list in row order.
-// LDS: 256 B hdr | cnt u32[NB] | pre u32[NB + 1] | aux u32[NB + 1] | rfirst u32[NB + 1] | rows (s_re[2], s_a0[1]) | walk scratch
-constexpr size_t BX_LDS = 256 + (size_t)BX_NB * 4 + (size_t)(BX_NB + 1) * 4 * 3 + 64 + flat_walk_bytes<TK_BLOCK, TK_EPT, true>() + 16;
+// ---- 2. BIG rows: histogram, column ranges, spill of the largest rows into HBM scratch --------------------------------------
+// A BIG row (more products than one task's table takes) becomes column-RANGE tasks.  It is first cut into PARTS of ~BX_PART
+// products (whole A entries), so that a row with a million products is handled by hundreds of workgroups and the largest row
+// does not set the time:
+//   k_big_parts   one wave per BIG row: running sum of its entries' B-row lengths; a new part starts wherever
+//                 floor(prefix / BX_PART) changes.  The row's parts are consecutive records (+ one sentinel)
+//   k_big_hist    one workgroup per part: its products (column indices only) counted in BX_NB column buckets of width
+//                 2^wshift over [kmin, kmax] of the row (LDS), stored per part
+//   k_big_plan    one workgroup per row: bucket counts of the row = sum over its parts; buckets grouped into column RANGES -- a
+//                 bucket with more than BX_HEAVY products is a range of its own, the others are grouped by floor(prefix /
+//                 TK_CAP): a light range holds fewer than TK_CAP + BX_HEAVY = 1536 products, i.e. it fits one task's table
+//                 whatever its outputs are; a heavy range holds at most 2^wshift distinct columns and is split further by the
+//                 task itself if both exceed the table (k_task, multi-pass).  Range descriptors go to `tmp` (bump allocated),
+//                 their number to row_m[row].  Then the row is either left to DIRECT range tasks, which find their products
+//                 in B themselves, or SPILLED: its slice of the scratch arrays is bump allocated and the counts of every part
+//                 are turned into cursors (exclusive prefix over buckets, then over the parts before it)
+//   k_big_scatter one workgroup per part of a spilled row: walks its products again and stores (column, a * b) at the bucket's
+//                 cursor: afterwards the scratch slice of every range is contiguous
+// k_cut3 copies the range descriptors into the task list in row order.
+constexpr uint32_t BX_PART = 8192;
+constexpr uint32_t BX_NOPART = 0xFFFFFFFFu;
+struct BigPart {
+    uint32_t slot;      // position of the row in big_rows; BX_NOPART: sentinel / unused record
+    uint32_t p_begin;   // products of the row before the part (sort-merge: product numbers)
+    uint64_t e_begin;   // first A entry of the part; the part ends where the next record begins
+};
+struct BigSlot {
+    uint64_t scr_base;  // first product of the row in the scratch arrays
+    uint32_t ok;        // 0: a workspace was too small, nothing of the row is written
+    uint32_t direct;    // 1: the row is not spilled, its range tasks walk B themselves (k_big_plan)
+    uint32_t part_begin, part_count;   // records of the row: parts[part_begin .. part_begin + part_count], the last a sentinel
+    uint32_t pad[2];
+};
 
-__global__ __launch_bounds__(TK_BLOCK) void k_big_expand(const uint64_t *__restrict__ aptr, const double *__restrict__ aval,
-                                                         const uint32_t *__restrict__ bidx, const double *__restrict__ bval,
-                                                         const uint64_t *__restrict__ eb0, const uint32_t *__restrict__ elen,
-                                                         uint64_t r0, const uint32_t *__restrict__ big_rows,
-                                                         const uint32_t *__restrict__ row_nprod,
-                                                         const uint32_t *__restrict__ row_kmin, const uint32_t *__restrict__ row_kmax,
-                                                         uint32_t *__restrict__ row_m, uint32_t *__restrict__ row_tmp,
-                                                         TaskDesc *__restrict__ tmp, uint32_t tmp_cap,
-                                                         uint32_t *__restrict__ scr_col, double *__restrict__ scr_val,
-                                                         uint32_t *__restrict__ scr_seq /* may be null */, uint64_t scr_cap,
-                                                         TaskCounters *__restrict__ ctr)
+__device__ inline uint32_t big_wshift(uint32_t kmin, uint32_t kmax)
 {
-    constexpr int NB = BX_NB, BPT = NB / TK_BLOCK, U = SPADA_FLAT_U;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint32_t *hdr = (uint32_t *)smem;
-    uint32_t *cnt = (uint32_t *)(smem + 256);
-    uint32_t *pre = cnt + NB;          // exclusive prefix of cnt, pre[NB] = P
-    uint32_t *aux = pre + NB + 1;      // start flags -> range numbers; later: nonempty flags -> compact numbers
-    uint32_t *rfirst = aux + NB + 1;   // first bucket of range r, rfirst[NR] = NB
-    uint32_t *s_re = rfirst + NB + 1;  // [2]
-    uint64_t *s_a0 = (uint64_t *)(((uintptr_t)(s_re + 2) + 7) & ~(uintptr_t)7);
-    unsigned char *scratch = (unsigned char *)(s_a0 + 1);
-    scratch = (unsigned char *)(((uintptr_t)scratch + 15) & ~(uintptr_t)15);
-    const int tid = threadIdx.x;
+    uint32_t w = 0;
+    while (((kmax - kmin) >> w) >= (uint32_t)BX_NB) ++w;
+    return w;
+}
+
+constexpr int BP_EPL = 8;     // entries per lane and step
+constexpr int BP_ROWS = 16;   // rows per workgroup and round: their records are allocated with ONE device atomic per array (a
+                              // single hot word sustains ~88 atomics / us: one per row would cost more than the kernel's work)
+// ranges of a row with P products: one per TK_CAP products and two more around every heavy bucket (> BX_HEAVY products)
+__host__ __device__ inline uint32_t big_max_ranges(uint32_t P) { return P / TK_CAP + 2u * (P / (BX_HEAVY + 1u)) + 2u; }
+
+__global__ __launch_bounds__(256) void k_big_parts(const uint64_t *__restrict__ aptr, const uint32_t *__restrict__ elen, uint64_t r0,
+                                                   const uint32_t *__restrict__ big_rows, const uint32_t *__restrict__ row_nprod,
+                                                   BigPart *__restrict__ parts, uint32_t part_cap, uint32_t *__restrict__ row_tmp,
+                                                   uint32_t tmp_cap, BigSlot *__restrict__ slots, TaskCounters *__restrict__ ctr)
+{
+    __shared__ uint32_t s_pbase[BP_ROWS], s_tbase[BP_ROWS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t nbig = ctr->n_big;
-    for (;;) {
-        // rows differ in size by orders of magnitude: dequeue dynamically (one device atomic per row)
-        if (tid == 0) hdr[46] = atomicAdd(&ctr->big_cursor, 1u);
+    for (uint32_t s0 = blockIdx.x * BP_ROWS; s0 < nbig; s0 += gridDim.x * BP_ROWS) {
         __syncthreads();
-        const uint32_t slot = hdr[46];
+        if (wave == 0) {   // records of the round's rows: parts (+ sentinel) and range descriptors (upper bound)
+            const uint32_t sl = s0 + lane;
+            const bool have = lane < BP_ROWS && sl < nbig;
+            const uint32_t P = have ? row_nprod[big_rows[sl]] : 0u;
+            const bool good = have && P != 0xFFFFFFFFu;
+            const uint32_t np = good ? P / BX_PART + 2u : 0u, nt = good ? big_max_ranges(P) : 0u;
+            uint32_t ip = np, it = nt;
+#pragma unroll
+            for (int o = 1; o < BP_ROWS; o <<= 1) {
+                const uint32_t a = __shfl_up(ip, o), b = __shfl_up(it, o);
+                if (lane >= o) {
+                    ip += a;
+                    it += b;
+                }
+            }
+            uint32_t bp = 0, bt = 0;
+            if (lane == BP_ROWS - 1) {
+                bp = atomicAdd(&ctr->n_parts, ip);
+                bt = atomicAdd(&ctr->tmp_cursor, it);
+            }
+            bp = __shfl(bp, BP_ROWS - 1);
+            bt = __shfl(bt, BP_ROWS - 1);
+            if (lane < BP_ROWS) {
+                s_pbase[lane] = bp + ip - np;
+                s_tbase[lane] = bt + it - nt;
+            }
+        }
         __syncthreads();
+        for (int rr = wave; rr < BP_ROWS; rr += 4) {
+        const uint32_t slot = s0 + rr;
         if (slot >= nbig) break;
         const uint32_t row = big_rows[slot];
-        if (row_nprod[row] == 0xFFFFFFFFu) {   // 2^32 or more products in one row: the 32-bit bucket counters would wrap
-            if (tid == 0) atomicOr(&ctr->abort_flag, 4u);
+        const uint32_t P = row_nprod[row];
+        if (P == 0xFFFFFFFFu) {   // 2^32 or more products in one row: 32-bit counters would wrap
+            if (lane == 0) atomicOr(&ctr->abort_flag, 4u);
             continue;
         }
         const uint64_t a0 = aptr[r0 + row], a1 = aptr[r0 + row + 1];
-        const uint32_t E = (uint32_t)(a1 - a0);
-        const uint32_t kmin = row_kmin[row], kmax = row_kmax[row];
-        uint32_t wshift = 0;
-        while (((kmax - kmin) >> wshift) >= (uint32_t)NB) ++wshift;
+        // every window [w BX_PART, (w + 1) BX_PART) of the running product count that contains the first product of some entry
+        // starts a part: at most `ub` of them (an entry with an empty B row may sit at prefix P itself)
+        const uint32_t ub = P / BX_PART + 1;
+        const uint32_t base = s_pbase[rr], tbase = s_tbase[rr];
+        const bool fits = (unsigned long long)base + ub + 1 <= part_cap;
+        if (lane == 0) {
+            slots[slot] = BigSlot{0ull, 0u, 0u, base, ub, {0u, 0u}};
+            row_tmp[row] = tbase;
+            if (!fits) atomicOr(&ctr->abort_flag, 16u);
+            if ((unsigned long long)tbase + big_max_ranges(P) > tmp_cap) atomicOr(&ctr->abort_flag, 1u);
+        }
+        if (!fits) continue;
+        uint32_t carry = 0, nstart = 0;   // products / parts before this step
+        uint32_t prev_win = 0xFFFFFFFFu;  // window of the entry before this step (none: the first entry starts a part)
+        for (uint64_t q0 = a0; q0 < a1; q0 += 64 * BP_EPL) {
+            const uint64_t q = q0 + (uint64_t)lane * BP_EPL;
+            uint32_t len[BP_EPL], sum = 0;
+#pragma unroll
+            for (int i = 0; i < BP_EPL; ++i) {
+                len[i] = q + i < a1 ? elen[q + i] : 0u;
+                sum += len[i];
+            }
+            uint32_t inc = sum;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t t = __shfl_up(inc, o);
+                if (lane >= o) inc += t;
+            }
+            uint32_t ex = carry + inc - sum;
+            // window of the last entry of the lane before (lanes past the end repeat the last window: no new start there)
+            const uint32_t my_last = (ex + sum - len[BP_EPL - 1]) / BX_PART;   // (entries past the end have length 0)
+            uint32_t pw = __shfl_up(my_last, 1);
+            if (lane == 0) pw = prev_win;
+            uint32_t w[BP_EPL], exi[BP_EPL], cnt = 0;
+#pragma unroll
+            for (int i = 0; i < BP_EPL; ++i) {
+                exi[i] = ex;
+                w[i] = ex / BX_PART;
+                ex += len[i];
+            }
+            uint32_t startmask = 0, p = pw;
+#pragma unroll
+            for (int i = 0; i < BP_EPL; ++i) {
+                if (q + i < a1 && w[i] != p) {
+                    startmask |= 1u << i;
+                    ++cnt;
+                }
+                if (q + i < a1) p = w[i];
+            }
+            uint32_t cinc = cnt;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t t = __shfl_up(cinc, o);
+                if (lane >= o) cinc += t;
+            }
+            uint32_t k = nstart + cinc - cnt;
+#pragma unroll
+            for (int i = 0; i < BP_EPL; ++i)
+                if (startmask & (1u << i)) parts[base + k++] = BigPart{slot, exi[i], q + i};
+            nstart += __shfl(cinc, 63);
+            carry += __shfl(inc, 63);
+            // window of the last entry of the step
+            const uint64_t last_q = min(q0 + 64 * BP_EPL, a1) - 1;
+            const int ll = (int)((last_q - q0) / BP_EPL), li = (int)((last_q - q0) % BP_EPL);
+            uint32_t wl = 0;
+#pragma unroll
+            for (int i = 0; i < BP_EPL; ++i) wl = li == i ? w[i] : wl;
+            prev_win = __shfl(wl, ll);
+        }
+        for (uint32_t k = nstart + lane; k <= ub; k += 64) parts[base + k] = BigPart{BX_NOPART, P, a1};
+        }
+    }
+}
+
+// LDS of k_big_hist / k_big_scatter: 256 B hdr | cnt u32[NB] | s_re u32[4], s_a0 u64[2] | walk scratch
+constexpr size_t BX_WALK_LDS = 256 + (size_t)BX_NB * 4 + 32 + flat_walk_bytes<TK_BLOCK, TK_EPT, true>() + 16;
+
+__global__ __launch_bounds__(TK_BLOCK) void k_big_hist(const uint32_t *__restrict__ bidx, const uint64_t *__restrict__ eb0,
+                                                       const uint32_t *__restrict__ elen, const uint32_t *__restrict__ big_rows,
+                                                       const uint32_t *__restrict__ row_kmin, const uint32_t *__restrict__ row_kmax,
+                                                       const BigPart *__restrict__ parts, uint32_t *__restrict__ part_hist,
+                                                       const TaskCounters *__restrict__ ctr)
+{
+    constexpr int NB = BX_NB, U = SPADA_FLAT_U;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t *hdr = (uint32_t *)smem;
+    uint32_t *cnt = (uint32_t *)(smem + 256);
+    uint32_t *s_re = cnt + NB;
+    uint64_t *s_a0 = (uint64_t *)(s_re + 4);
+    unsigned char *scratch = (unsigned char *)(s_a0 + 2);
+    const int tid = threadIdx.x;
+    if (ctr->abort_flag) return;
+    const uint32_t nparts = ctr->n_parts;
+    for (uint32_t pi = blockIdx.x; pi < nparts; pi += gridDim.x) {
+        const BigPart pt = parts[pi];
+        if (pt.slot == BX_NOPART) continue;   // (uniform)
+        const uint32_t e_count = (uint32_t)(parts[pi + 1].e_begin - pt.e_begin);
+        const uint32_t row = big_rows[pt.slot];
+        const uint32_t kmin = row_kmin[row], wshift = big_wshift(kmin, row_kmax[row]);
         for (int b = tid; b < NB; b += TK_BLOCK) cnt[b] = 0;
         if (tid == 0) {
             s_re[0] = 0;
-            s_re[1] = E;
-            s_a0[0] = a0;
+            s_re[1] = e_count;
+            s_a0[0] = pt.e_begin;
         }
         __syncthreads();
-        // pass 1: histogram
-#ifdef BX_SKIP_HIST
-        if (false)
-#endif
-        flat_walk<TK_BLOCK, TK_EPT, 1, false, U>(s_re, s_a0, 1u, E, eb0, elen, nullptr, bidx, nullptr, scratch, hdr,
+        flat_walk<TK_BLOCK, TK_EPT, 1, false, U>(s_re, s_a0, 1u, e_count, eb0, elen, nullptr, bidx, nullptr, scratch, hdr,
                                                  [&](uint32_t(&col)[U], uint32_t(&plr)[U], double(&)[U], uint32_t(&)[U]) {
 #pragma unroll
                                                      for (int u = 0; u < U; ++u)
                                                          if (plr[u] != LR_NONE) atomicAdd(&cnt[(col[u] - kmin) >> wshift], 1u);
                                                  });
         __syncthreads();
-        for (int b = tid; b < NB; b += TK_BLOCK) pre[b] = cnt[b];
+        ((uint4 *)(part_hist + (size_t)pi * NB))[tid] = ((const uint4 *)cnt)[tid];
+        __syncthreads();
+    }
+}
+
+// LDS: 256 B hdr | cnt u32[NB] | pre u32[NB + 1] | aux u32[NB + 1] | rfirst u32[NB + 1]
+constexpr size_t BX_PLAN_LDS = 256 + (size_t)BX_NB * 4 + (size_t)(BX_NB + 1) * 4 * 3 + 16;
+static_assert(BX_NB == 4 * TK_BLOCK, "a thread owns four consecutive buckets (one uint4 of a part's counts)");
+
+// A row is spilled only if that is cheaper than letting each of its m range tasks find its products in B: a DIRECT range task
+// loads the row's E entries and narrows every selected B row to its column range with two binary searches (B rows are sorted),
+// so the row costs m * E searches of 1 + log2(P / E) steps instead of a scatter to and a read from HBM -- rows with few ranges
+// (web graphs, meshes) go direct, rows with thousands of entries and hundreds of ranges (R-MAT hubs) are spilled.
+// `direct_factor` = 0 spills every row (the sort-merge accumulator numbers the products of a slice in scratch order).
+__global__ __launch_bounds__(TK_BLOCK) void k_big_plan(const uint64_t *__restrict__ aptr, uint64_t r0, uint32_t direct_factor,
+                                                       const uint32_t *__restrict__ big_rows, const uint32_t *__restrict__ row_kmin,
+                                                       const uint32_t *__restrict__ row_kmax, const BigPart *__restrict__ parts,
+                                                       uint32_t *__restrict__ part_hist, uint32_t *__restrict__ row_m,
+                                                       const uint32_t *__restrict__ row_tmp, TaskDesc *__restrict__ tmp,
+                                                       BigSlot *__restrict__ slots, uint64_t scr_cap, TaskCounters *__restrict__ ctr)
+{
+    constexpr int NB = BX_NB, BPT = NB / TK_BLOCK;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t *hdr = (uint32_t *)smem;
+    uint32_t *cnt = (uint32_t *)(smem + 256);
+    uint32_t *pre = cnt + NB;          // exclusive prefix of cnt, pre[NB] = P
+    uint32_t *aux = pre + NB + 1;      // start flags -> range numbers; later: nonempty flags -> compact numbers
+    uint32_t *rfirst = aux + NB + 1;   // first bucket of range r, rfirst[NR] = NB
+    const int tid = threadIdx.x;
+    const uint32_t nbig = ctr->n_big;
+    if (ctr->abort_flag) return;
+    for (uint32_t slot = blockIdx.x; slot < nbig; slot += gridDim.x) {
+        const uint32_t row = big_rows[slot];
+        const uint32_t kmin = row_kmin[row], kmax = row_kmax[row], wshift = big_wshift(kmin, kmax);
+        const uint32_t pb = slots[slot].part_begin, pc = slots[slot].part_count;
+        {   // bucket counts of the row
+            uint4 acc = make_uint4(0u, 0u, 0u, 0u);
+            for (uint32_t k = 0; k < pc; ++k) {
+                if (parts[pb + k].slot == BX_NOPART) break;   // (uniform; the records of a row are its parts, then sentinels)
+                const uint4 h = ((const uint4 *)(part_hist + (size_t)(pb + k) * NB))[tid];
+                acc.x += h.x;
+                acc.y += h.y;
+                acc.z += h.z;
+                acc.w += h.w;
+            }
+            ((uint4 *)cnt)[tid] = acc;
+            pre[tid * 4 + 0] = acc.x;
+            pre[tid * 4 + 1] = acc.y;
+            pre[tid * 4 + 2] = acc.z;
+            pre[tid * 4 + 3] = acc.w;
+        }
         __syncthreads();
         group_exclusive_scan<TK_BLOCK, NB>(pre, tid, hdr + 2);
         if (tid == TK_BLOCK - 1) pre[NB] = pre[NB - 1] + cnt[NB - 1];
@@ -295,36 +482,50 @@ __global__ __launch_bounds__(TK_BLOCK) void k_big_expand(const uint64_t *__restr
             nef[k] = (r < NR && pre[rfirst[r + 1]] > pre[rfirst[r]]) ? 1u : 0u;
         }
         __syncthreads();
+        if (tid == 0) hdr[47] = 0;
 #pragma unroll
         for (int k = 0; k < BPT; ++k) aux[tid * BPT + k] = nef[k];
         __syncthreads();
+#pragma unroll
+        for (int k = 0; k < BPT; ++k)
+            if (nef[k]) {   // a range that needs several passes (more than TK_SOLO_MAX products AND columns) exists only on scratch
+                const uint32_t r = tid * BPT + k, f0 = rfirst[r], f1 = rfirst[r + 1];
+                if (pre[f1] - pre[f0] > TK_SOLO_MAX && ((uint64_t)(f1 - f0) << wshift) > TK_SOLO_MAX) hdr[47] = 1;
+            }
         group_exclusive_scan<TK_BLOCK, NB>(aux, tid, hdr + 2);
         if (tid == TK_BLOCK - 1) {
             const uint32_t m = aux[NB - 1] + nef[BPT - 1];
             const unsigned long long P = pre[NB];
-            const uint32_t tb = atomicAdd(&ctr->tmp_cursor, m);
-            const unsigned long long sb = atomicAdd(&ctr->scratch_cursor, P);
-            hdr[41] = m;
+            const unsigned long long E = aptr[r0 + row + 1] - aptr[r0 + row];
+            const uint32_t avg_len = (uint32_t)min(P / max(E, 1ull), 0xFFFFFFFFull);
+            const unsigned long long steps = 1ull + (avg_len ? 31u - (uint32_t)__clz((int)avg_len) : 0u);   // of one binary search
+            const bool direct = (unsigned long long)m * E * steps <= (unsigned long long)direct_factor * P && hdr[47] == 0;
+            const uint32_t tb = row_tmp[row];   // big_max_ranges(P) >= m records, allocated by k_big_parts
+            const unsigned long long sb = direct ? 0ull : atomicAdd(&ctr->scratch_cursor, P);
+            hdr[46] = direct ? 1u : 0u;
             hdr[42] = tb;
             hdr[43] = (uint32_t)sb;
             hdr[44] = (uint32_t)(sb >> 32);
-            const bool ok = (unsigned long long)tb + m <= tmp_cap && sb + P <= scr_cap;
+            const bool ok = direct || sb + P <= scr_cap;
             hdr[45] = ok ? 1u : 0u;
             if (!ok) atomicOr(&ctr->abort_flag, 1u);
             row_m[row] = m;
-            row_tmp[row] = tb;
+            slots[slot].scr_base = sb;
+            slots[slot].ok = ok ? 1u : 0u;
+            slots[slot].direct = direct ? 1u : 0u;
+            if (!direct) atomicAdd(&ctr->n_spilled, 1u);
         }
         __syncthreads();
         const uint32_t tb = hdr[42];
         const uint64_t sb = ((uint64_t)hdr[44] << 32) | hdr[43];
-        const bool ok = hdr[45] != 0;
+        const bool ok = hdr[45] != 0, direct = hdr[46] != 0;
         if (ok) {
 #pragma unroll
             for (int k = 0; k < BPT; ++k)
                 if (nef[k]) {
                     const uint32_t r = tid * BPT + k, f0 = rfirst[r], f1 = rfirst[r + 1];
                     TaskDesc d;
-                    d.kind = TASK_RANGE;
+                    d.kind = direct ? TASK_RANGE_DIRECT : TASK_RANGE;
                     d.row = row;
                     d.np = pre[f1] - pre[f0];
                     d.first = aux[r] == 0 ? 1u : 0u;
@@ -335,26 +536,69 @@ __global__ __launch_bounds__(TK_BLOCK) void k_big_expand(const uint64_t *__restr
                     tmp[tb + aux[r]] = d;
                 }
         }
+        if (ok && !direct) {   // spilled: the counts of every part become its cursors (part order = product order)
+            uint4 run = make_uint4(pre[tid * 4 + 0], pre[tid * 4 + 1], pre[tid * 4 + 2], pre[tid * 4 + 3]);
+            for (uint32_t k = 0; k < pc; ++k) {
+                if (parts[pb + k].slot == BX_NOPART) break;
+                uint4 *hp = (uint4 *)(part_hist + (size_t)(pb + k) * NB) + tid;
+                const uint4 h = *hp;
+                *hp = run;
+                run.x += h.x;
+                run.y += h.y;
+                run.z += h.z;
+                run.w += h.w;
+            }
+        }
         __syncthreads();
-        // pass 2: scatter; cnt becomes the cursor of every bucket
-        for (int b = tid; b < NB; b += TK_BLOCK) cnt[b] = pre[b];
+    }
+}
+
+__global__ __launch_bounds__(TK_BLOCK) void k_big_scatter(const double *__restrict__ aval, const uint32_t *__restrict__ bidx,
+                                                          const double *__restrict__ bval, const uint64_t *__restrict__ eb0,
+                                                          const uint32_t *__restrict__ elen, const uint32_t *__restrict__ big_rows,
+                                                          const uint32_t *__restrict__ row_kmin, const uint32_t *__restrict__ row_kmax,
+                                                          const BigPart *__restrict__ parts, const uint32_t *__restrict__ part_hist,
+                                                          const BigSlot *__restrict__ slots, uint32_t *__restrict__ scr_col,
+                                                          double *__restrict__ scr_val, uint32_t *__restrict__ scr_seq /* may be null */,
+                                                          const TaskCounters *__restrict__ ctr)
+{
+    constexpr int NB = BX_NB, U = SPADA_FLAT_U;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t *hdr = (uint32_t *)smem;
+    uint32_t *cur = (uint32_t *)(smem + 256);
+    uint32_t *s_re = cur + NB;
+    uint64_t *s_a0 = (uint64_t *)(s_re + 4);
+    unsigned char *scratch = (unsigned char *)(s_a0 + 2);
+    const int tid = threadIdx.x;
+    if (ctr->abort_flag || ctr->n_spilled == 0) return;
+    const uint32_t nparts = ctr->n_parts;
+    for (uint32_t pi = blockIdx.x; pi < nparts; pi += gridDim.x) {
+        const BigPart pt = parts[pi];
+        if (pt.slot == BX_NOPART) continue;   // (uniform over the workgroup, like the next one)
+        const BigSlot sl = slots[pt.slot];
+        if (!sl.ok || sl.direct) continue;
+        const uint32_t e_count = (uint32_t)(parts[pi + 1].e_begin - pt.e_begin);
+        const uint32_t row = big_rows[pt.slot];
+        const uint32_t kmin = row_kmin[row], wshift = big_wshift(kmin, row_kmax[row]);
+        ((uint4 *)cur)[tid] = ((const uint4 *)(part_hist + (size_t)pi * NB))[tid];
+        if (tid == 0) {
+            s_re[0] = 0;
+            s_re[1] = e_count;
+            s_a0[0] = pt.e_begin;
+        }
         __syncthreads();
-#ifdef BX_SKIP_SCATTER
-        if (false)
-#else
-        if (ok)
-#endif
-            flat_walk<TK_BLOCK, TK_EPT, 1, true, U>(s_re, s_a0, 1u, E, eb0, elen, aval, bidx, bval, scratch, hdr,
-                                                    [&](uint32_t(&col)[U], uint32_t(&plr)[U], double(&v)[U], uint32_t(&pp)[U]) {
+        const uint64_t sb = sl.scr_base;
+        flat_walk<TK_BLOCK, TK_EPT, 1, true, U>(s_re, s_a0, 1u, e_count, eb0, elen, aval, bidx, bval, scratch, hdr,
+                                                [&](uint32_t(&col)[U], uint32_t(&plr)[U], double(&v)[U], uint32_t(&pp)[U]) {
 #pragma unroll
-                                                        for (int u = 0; u < U; ++u)
-                                                            if (plr[u] != LR_NONE) {
-                                                                const uint32_t p = atomicAdd(&cnt[(col[u] - kmin) >> wshift], 1u);
-                                                                scr_col[sb + p] = col[u];
-                                                                scr_val[sb + p] = v[u];
-                                                                if (scr_seq) scr_seq[sb + p] = pp[u];
-                                                            }
-                                                    });
+                                                    for (int u = 0; u < U; ++u)
+                                                        if (plr[u] != LR_NONE) {
+                                                            const uint32_t p = atomicAdd(&cur[(col[u] - kmin) >> wshift], 1u);
+                                                            scr_col[sb + p] = col[u];
+                                                            scr_val[sb + p] = v[u];
+                                                            if (scr_seq) scr_seq[sb + p] = pt.p_begin + pp[u];
+                                                        }
+                                                });
         __syncthreads();
     }
 }
@@ -955,6 +1199,87 @@ __device__ inline uint32_t range_dfs(unsigned char *smem, uint32_t *stack, RowEm
     return total;
 }
 
+// DIRECT range task: the products of BIG row `td.row` whose column lies in [col_lo, col_hi], taken from B itself: every entry's
+// B row is narrowed to the range by two binary searches (B rows are ascending), then the walk is the usual flat one.
+template <bool VALUES>
+__device__ inline uint32_t direct_accumulate(unsigned char *smem, unsigned char *region2, uint32_t *s_re, uint64_t *s_a0,
+                                             const TaskArgs &g, const TaskDesc &td)
+{
+    constexpr int U = SPADA_FLAT_U, EPT = TK_EPT;
+    uint32_t *hdr = (uint32_t *)smem;
+    uint32_t *keys = (uint32_t *)(smem + 256);
+    double *vals = (double *)(keys + TK_T);
+    const uint64_t a0 = g.aptr[g.r0 + td.row];
+    const uint32_t E = (uint32_t)(g.aptr[g.r0 + td.row + 1] - a0);
+    table_clear(smem);
+    if (threadIdx.x == 0) {
+        s_re[0] = 0;
+        s_re[1] = E;
+        s_a0[0] = a0;
+    }
+    __syncthreads();
+    const uint32_t lo = td.col_lo, hi = td.col_hi;
+    const uint32_t *__restrict__ bidx = g.bidx;
+    uint32_t mine = 0;
+    flat_walk<TK_BLOCK, EPT, 1, VALUES, U>(
+        s_re, s_a0, 1u, E, g.eb0, g.elen, g.aval, g.bidx, g.bval, region2, hdr,
+        [&](uint32_t(&col)[U], uint32_t(&plr)[U], double(&v)[U], uint32_t(&)[U]) {
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (plr[u] != LR_NONE) mine += table_insert<VALUES>(keys, vals, col[u], v[u]) ? 1u : 0u;
+        },
+        [&](uint64_t(&b0)[EPT], uint32_t(&len)[EPT]) {
+            // l1 = first position with column >= lo, l2 = first position with column > hi; all searches in lock step
+            uint32_t l1[EPT], n1[EPT], l2[EPT], n2[EPT];
+#pragma unroll
+            for (int i = 0; i < EPT; ++i) {
+                l1[i] = l2[i] = 0;
+                n1[i] = n2[i] = len[i];
+            }
+            for (;;) {
+                uint32_t any = 0;
+#pragma unroll
+                for (int i = 0; i < EPT; ++i) any |= n1[i] | n2[i];
+                if (!any) break;
+                uint32_t c1[EPT], c2[EPT];
+#pragma unroll
+                for (int i = 0; i < EPT; ++i) {
+                    c1[i] = n1[i] ? bidx[b0[i] + l1[i] + (n1[i] >> 1)] : 0u;
+                    c2[i] = n2[i] ? bidx[b0[i] + l2[i] + (n2[i] >> 1)] : 0u;
+                }
+#pragma unroll
+                for (int i = 0; i < EPT; ++i) {
+                    if (n1[i]) {
+                        const uint32_t h = n1[i] >> 1;
+                        if (c1[i] < lo) {
+                            l1[i] += h + 1;
+                            n1[i] -= h + 1;
+                        } else {
+                            n1[i] = h;
+                        }
+                    }
+                    if (n2[i]) {
+                        const uint32_t h = n2[i] >> 1;
+                        if (c2[i] <= hi) {
+                            l2[i] += h + 1;
+                            n2[i] -= h + 1;
+                        } else {
+                            n2[i] = h;
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < EPT; ++i) {
+                b0[i] += l1[i];
+                len[i] = l2[i] - l1[i];
+            }
+        });
+    const uint32_t n = group_sum<TK_BLOCK>(mine, hdr);
+    __syncthreads();
+    return n;
+}
+
 template <int MODE>
 __global__ __launch_bounds__(TK_BLOCK, 4) void k_task(const TaskArgs g)
 {
@@ -979,11 +1304,15 @@ __global__ __launch_bounds__(TK_BLOCK, 4) void k_task(const TaskArgs g)
     // is not finished is either running -- it waits for finished tasks only -- or the next one of its queue, whose workgroups
     // all hold smaller, hence finished, tasks and are free to take it: no cycle of waiting workgroups can form as long as
     // every queue has a resident workgroup, which a grid of at least TK_NQ workgroups dispatched in order guarantees.
+#ifdef SPADA_STATIC_TASKS
+    uint32_t t = g.task_lo + blockIdx.x;
+#else
     uint32_t *my_ticket = &g.ctr->ticket[(blockIdx.x % TK_NQ) * 32];
     if (tid == 0) hdr[50] = g.task_lo + atomicAdd(my_ticket, 1u) * TK_NQ + blockIdx.x % TK_NQ;
     __syncthreads();
     uint32_t t = hdr[50];
     __syncthreads();
+#endif
     unsigned long long dbg_t0 = SPADA_TASK_DBG ? __builtin_amdgcn_s_memtime() : 0, dbg_acc = 0, dbg_chain = 0, dbg_emit = 0;
     unsigned long long dbg_ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     while (t < task_end) {
@@ -1164,9 +1493,12 @@ __global__ __launch_bounds__(TK_BLOCK, 4) void k_task(const TaskArgs g)
         } else {
             // ---- RANGE task: columns [col_lo, col_hi] of a BIG row, products in the scratch slice -----------------------------
             // Single pass when the slice cannot overflow the table (<= TK_SOLO_MAX products or columns), else range_dfs.
-            const bool single = td.np <= TK_SOLO_MAX || td.col_hi - td.col_lo < TK_SOLO_MAX;
+            const bool direct = td.kind == TASK_RANGE_DIRECT;
+            const bool single = direct || td.np <= TK_SOLO_MAX || td.col_hi - td.col_lo < TK_SOLO_MAX;
             uint32_t total;
-            if (single) {
+            if (direct) {
+                total = direct_accumulate<VALUES>(smem, region2, s_re, s_a0, g, td);
+            } else if (single) {
                 total = range_accumulate<VALUES>(smem, g.scr_col, g.scr_val, td.src, td.np, td.col_lo, td.col_hi, false);
             } else {
                 if (tid == 0) atomicAdd(&g.ctr->multi_pass_tasks, 1u);
@@ -1218,10 +1550,14 @@ __global__ __launch_bounds__(TK_BLOCK, 4) void k_task(const TaskArgs g)
             PHASE(5);
             if (SPADA_TASK_DBG && tid == 0) dbg_ph[7] += 1;
         }
+#ifdef SPADA_STATIC_TASKS
+        t += gridDim.x;
+#else
         if (tid == 0) hdr[50] = g.task_lo + atomicAdd(my_ticket, 1u) * TK_NQ + blockIdx.x % TK_NQ;
         __syncthreads();
         t = hdr[50];
         __syncthreads();
+#endif
         if (td.kind == TASK_BATCH) PHASE(6);
 #undef PHASE
         if (SPADA_TASK_DBG) {

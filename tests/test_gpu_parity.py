@@ -83,8 +83,9 @@ def test_generated_workloads_match_oracle(engine, name, kind, p0, p1, seed):
 
 
 def test_spill_path_is_exercised(engine):
-    """R-MAT scale 14, degree 16: hub rows whose accumulator does not fit LDS (SURVEY 7 hard part 3) are BIG rows: their
-    products are spilled to HBM scratch, column range by column range, and the counters say how many."""
+    """R-MAT scale 14, degree 16: hub rows whose accumulator does not fit LDS (SURVEY 7 hard part 3) are BIG rows: they
+    become column-range tasks, and the products of the largest ones are spilled to HBM scratch range by range; the counters say
+    how many."""
     import spada_sim_amd as S
     m = S.generate(S.GEN_RMAT, 14, 16, 3)
     engine.spgemm(m, m)
@@ -93,9 +94,11 @@ def test_spill_path_is_exercised(engine):
     lens = np.diff(m.indptr.astype(np.int64))
     prod = np.array([lens[m.indices[int(m.indptr[r]):int(m.indptr[r + 1])].astype(np.int64)].sum() for r in range(m.shape[0])])
     big = (prod > 1536) & (lens > 1)
-    assert st["spill_rows"] == st["cls_rows"][4] == int(big.sum()) > 0
-    assert st["scratch_products"] == st["cls_prod"][4] == int(prod[big].sum())
-    assert st["n_tasks"] > st["spill_rows"]
+    assert st["cls_rows"][4] == int(big.sum()) > 0 and st["cls_prod"][4] == int(prod[big].sum())
+    # hubs (thousands of entries, hundreds of ranges) are spilled; BIG rows with few ranges are walked from B directly
+    assert 0 < st["spill_rows"] < st["cls_rows"][4]
+    assert 0 < st["scratch_products"] < st["cls_prod"][4]
+    assert st["n_tasks"] > st["cls_rows"][4]
 
 
 def test_empty_and_ragged_inputs(engine):

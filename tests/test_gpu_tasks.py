@@ -50,7 +50,7 @@ def test_fused_generated_workloads(engine, name, kind, p0, p1, seed):
     assert assert_parity(c, ref, a, a, RTOL) == 0
     assert st["nprod"] == oracle.count_products(a, a) and st["c_nnz"] == ref.nnz
     assert sum(st["cls_rows"]) == m.shape[0] and sum(st["cls_prod"]) == st["nprod"]
-    assert st["scratch_products"] == st["cls_prod"][4]
+    assert st["scratch_products"] <= st["cls_prod"][4] and st["spill_rows"] <= st["cls_rows"][4]
 
 
 @pytest.mark.parametrize("seed", range(24))
@@ -138,8 +138,9 @@ def test_multi_pass_range_tasks(engine):
     assert_parity(c2, ref, ao, bo, RTOL)
 
 
-def test_workspace_growth_reruns_once(engine):
-    """A fresh context sizes its task list / scratch from the first run's counters and runs the pipeline again (at most once)."""
+def test_workspace_growth_reruns(engine):
+    """A fresh context sizes its workspaces (part records, range descriptors, scratch, task list) from the counters of the runs
+    that overflowed them and runs the pipeline again: the part records first, then whatever the plan behind them needs."""
     import spada_sim_amd as S
     eng = S.Engine()
     try:
@@ -147,7 +148,7 @@ def test_workspace_growth_reruns_once(engine):
         c, st = fused(eng, m, m)
         a = to_oracle(m)
         assert_parity(c, oracle.spgemm_spa(a, a), a, a, RTOL)
-        assert st["pipeline_runs"] in (1, 2)
+        assert st["pipeline_runs"] in (1, 2, 3)
         c, st = fused(eng, m, m)
         assert st["pipeline_runs"] == 1
     finally:

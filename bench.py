@@ -352,11 +352,12 @@ def main():
         k_ms = ms["ms_task"] if chunk_bounds is None and ms["ms_fused_call"] > 0 else dev_ms
         achieved = st["bytes_read"] / (k_ms * 1e-3) / 1e9
         traffic, traffic_src = load_traffic(args.workload)
-        cls_names = ["empty", "copy (one A entry)", "small", "solo", "big (spilled to HBM scratch)"]
+        cls_names = ["empty", "copy (one A entry)", "small", "solo", "big (column-range tasks)"]
         kernels = [
             {"kernel": "k_entry_stats + k_row_class (B-row descriptors, products per row, row classes)", "ms": ms["ms_row_stats"]},
-            {"kernel": "k_big_expand (big rows: column histogram, ranges, products scattered into HBM scratch)", "ms": ms["ms_big_expand"],
-             "products": st["cls_prod"][4] if "cls_prod" in st else None},
+            {"kernel": "k_big_parts/hist/plan/scatter (big rows: column histograms, ranges; spilled rows scattered into HBM scratch)",
+             "ms": ms["ms_big_expand"], "products": st["cls_prod"][4] if "cls_prod" in st else None,
+             "spilled_products": st.get("scratch_products"), "spilled_rows": st.get("spill_rows")},
             {"kernel": "k_cut1/2/3 (task list)", "ms": ms["ms_cut"]},
             {"kernel": "k_task (expand - scale - accumulate - order, all rows)", "ms": ms["ms_task"], "products": nprod_total if world == 1 else st["nprod"],
              "tasks": st.get("n_tasks")},

@@ -88,16 +88,16 @@ typedef struct spada_stats {
     double ms_numeric_call;   /* whole spada_dev_spgemm_numeric call */
     double ms_fused_call;     /* whole one-pass call (spada_dev_spgemm_fused) */
     double ms_row_stats;      /* B-row descriptors, products per row, row classes */
-    double ms_big_expand;     /* BIG rows: column histogram + scatter of their products into HBM scratch (the spill path) */
+    double ms_big_expand;     /* BIG rows: parts, column histograms, ranges; scatter of the spilled rows' products into HBM scratch */
     double ms_cut;            /* task list (three scan kernels) */
     double ms_task;           /* the task kernel of the last call (count, numeric or one-pass) */
-    uint64_t cls_rows[8];     /* rows per class: 0 EMPTY, 1 COPY (one A entry), 2 SMALL, 3 SOLO, 4 BIG (spilled) */
+    uint64_t cls_rows[8];     /* rows per class: 0 EMPTY, 1 COPY (one A entry), 2 SMALL, 3 SOLO, 4 BIG (column-range tasks) */
     uint64_t cls_prod[8];     /* products per class */
     uint64_t n_tasks;         /* tasks of the last pipeline run */
     uint64_t multi_pass_tasks;/* range tasks that had to halve their column range (more distinct columns than the table takes) */
-    uint64_t scratch_products;/* products spilled to HBM scratch (= products of the BIG rows) */
-    uint64_t spill_rows;      /* rows that took the HBM spill path (= BIG rows) */
-    uint64_t pipeline_runs;   /* 2 when a workspace had to grow and the pipeline was run again */
+    uint64_t scratch_products;/* products spilled to HBM scratch (BIG rows whose range tasks do not read B directly) */
+    uint64_t spill_rows;      /* BIG rows that took the HBM spill path */
+    uint64_t pipeline_runs;   /* > 1 when a workspace had to grow and the pipeline was run again (first call of a context) */
     uint64_t workspace_bytes; /* device scratch owned by the context */
 } spada_stats;
 

@@ -92,7 +92,6 @@ struct spada_ctx {
     DevBuf t_parts, t_parthist, t_slots;                      // BIG rows: parts, bucket counts (then cursors) per part, row records
     DevBuf own_idx, own_val, own_ptr, wide_idx;
     uint64_t t_cap_tmp = 0, t_cap_tasks = 0, t_cap_scr = 0, t_cap_parts = 0;   // capacities the kernels may rely on
-    uint32_t direct_factor = 8;   // k_big_plan (measured: 2 .. 32 within 1 % on the web and mesh surrogates, 8 best on R-MAT 16): a BIG row with m ranges and E entries is not spilled if m * E <= factor * products
     TaskCounters *h_tctr = nullptr;   // pinned
     // numeric phase in pieces (spada_dev_spgemm_numeric_plan / _chunk): task boundaries, one event per piece
     std::vector<uint32_t> chunk_task;
@@ -348,10 +347,10 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
                                c->elen.as<uint32_t>(), c->t_big.as<uint32_t>(), c->row_kmin.as<uint32_t>(),
                                c->row_kmax.as<uint32_t>(), c->t_parts.as<BigPart>(), c->t_parthist.as<uint32_t>(), dc);
             hipLaunchKernelGGL(k_big_plan, dim3(c->n_cu * 8), dim3(TK_BLOCK), BX_PLAN_LDS, s, a->ptr, c->r0,
-                               c->accumulator == SPADA_ACC_SORT_MERGE ? 0u : c->direct_factor, c->t_big.as<uint32_t>(),
+                               c->accumulator == SPADA_ACC_SORT_MERGE ? 0u : 1u, c->t_big.as<uint32_t>(),
                                c->row_kmin.as<uint32_t>(), c->row_kmax.as<uint32_t>(), c->t_parts.as<BigPart>(),
                                c->t_parthist.as<uint32_t>(), c->t_rowm.as<uint32_t>(), c->t_rowtmp.as<uint32_t>(),
-                               c->t_tmp.as<TaskDesc>(), c->t_slots.as<BigSlot>(), c->t_cap_scr, dc);
+                               c->t_tmp.as<TaskDesc>(), cap_tmp, c->t_slots.as<BigSlot>(), c->t_cap_scr, dc);
             hipLaunchKernelGGL(k_big_scatter, dim3(c->n_cu * 8), dim3(TK_BLOCK), BX_WALK_LDS, s, a->val, b->idx, b->val,
                                c->eb0.as<uint64_t>(), c->elen.as<uint32_t>(), c->t_big.as<uint32_t>(), c->row_kmin.as<uint32_t>(),
                                c->row_kmax.as<uint32_t>(), c->t_parts.as<BigPart>(), c->t_parthist.as<uint32_t>(),
@@ -419,6 +418,15 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
                      100.0 * h.dbg[0] / std::max<double>(1, h.dbg[3]), 100.0 * h.dbg[5] / std::max<double>(1, h.dbg[3]),
                      (double)h.dbg[1] / std::max(1u, h.ntasks), (double)h.dbg[2] / std::max(1u, h.ntasks),
                      (double)h.dbg[7] / std::max(1u, h.ntasks), (double)h.dbg[6] / std::max<double>(1, h.dbg[7]));
+#if SPADA_TASK_DBG
+    for (int k = 0; k < 3; ++k) {
+        if (!h.dbgh[k][21]) continue;
+        std::fprintf(stderr, "[publish dbg] kind %d: %llu tasks, cycles to publish mean %.0f max %llu; histogram (4096-cycle bins):", k + 1,
+                     h.dbgh[k][21], (double)h.dbgh[k][20] / h.dbgh[k][21], h.dbgh[k][22]);
+        for (int b = 0; b < 20; ++b) std::fprintf(stderr, " %llu", h.dbgh[k][b]);
+        std::fprintf(stderr, "\n");
+    }
+#endif
     if (SPADA_TASK_DBG && h.dbg[15])
         std::fprintf(stderr, "[batch dbg] %llu batches, cycles each: descriptor %.0f | rows+scan+clear %.0f | walk %.0f | counts+publish %.0f | "
                      "emit (LDS, look-back wait, stores) %.0f | copy rows %.0f | ticket %.0f\n", h.dbg[15], (double)h.dbg[8] / h.dbg[15],

@@ -7,13 +7,18 @@
 //
 //   rows of C            ->  classes by products P_i: EMPTY | COPY (one A entry: C_i = a * B_k) | SMALL (P <= 512, shares a
 //                            batch with its neighbours) | SOLO (P <= 1536: a batch of its own) | BIG (larger)
-//   BIG rows             ->  k_big_expand: histogram of the row's products over <= 1024 column buckets, buckets merged into
-//                            column RANGES of < 1536 products, products scattered into HBM scratch range by range (the
-//                            "spill" of rows whose accumulator does not fit LDS); every range becomes a task of its own
+//   BIG rows             ->  k_big_parts / k_big_hist / k_big_plan: histogram of the row's products over <= 1024 column buckets
+//                            (the row cut into parts of ~8192 products, one workgroup each), buckets merged into column RANGES
+//                            of < 1536 products; every range becomes a task of its own.  A DIRECT range task finds its
+//                            products in B itself (B rows are ascending: two binary searches narrow each selected B row to
+//                            the range); rows for which that costs more than a spill (thousands of entries, hundreds of
+//                            ranges: R-MAT hubs) have their products scattered into HBM scratch range by range
+//                            (k_big_scatter, the "spill" of rows whose accumulator does not fit LDS)
 //   task list            ->  k_cut1/2/3: consecutive non-BIG rows are cut into batches of < 1536 products; tasks are numbered in
 //                            output order (row, then column range)
 //   k_task               ->  persistent workgroups take tasks by ticket.  A task expands its products (flat walk over the A
-//                            entries of its rows, or a stream over its scratch slice), accumulates them in a 2048-slot LDS
+//                            entries of its rows, narrowed to a column range or not, or a stream over its scratch slice),
+//                            accumulates them in a 2048-slot LDS
 //                            hash table (ds_cmpst / ds_add_f64), counts the distinct outputs per row, obtains the position
 //                            of its slice of C from the tasks before it by a decoupled look-back over per-task status words,
 //                            and emits its outputs in (row, column) order (monotone buckets + in-bucket rank).
@@ -25,7 +30,7 @@
 #include "spgemm_common.hip.hpp"
 
 #ifndef SPADA_TASK_DBG
-#define SPADA_TASK_DBG 0   /* 1 (scripts/build_dbg.sh): phase cycle counters of k_big_expand / k_task, printed to stderr */
+#define SPADA_TASK_DBG 0   /* 1 (scripts/build_dbg.sh): phase cycle counters of k_task, printed to stderr */
 #endif
 
 namespace spada {
@@ -65,6 +70,9 @@ struct TaskCounters {
     uint32_t need_tmp, need_tasks;                    // (abort_flag bits: 1 tmp / scratch, 2 tasks, 4 row too long, 8 BIG rows, 16 parts)
     uint32_t multi_pass_tasks, pad;
     uint32_t ticket[TK_NQ * 32];  // TK_NQ ticket counters, one per 128-byte line (a single hot word sustains ~88 atomics / us)
+#if SPADA_TASK_DBG
+    unsigned long long dbgh[3][24];  // per task kind: [0..19] histogram of the cycles from ticket to publish (4096-cycle bins), [20] sum, [21] tasks, [22] max
+#endif
     unsigned long long dbg[16];  // SPADA_TASK_DBG builds: [0] cycles in the chain, [1] look-back windows, [2] spin retries, [3] cycles
                                  // of the task loop, [4] cycles before the chain (expand + accumulate), [5] cycles after it (emit)
 };
@@ -208,6 +216,7 @@ __global__ __launch_bounds__(256) void k_row_class(const uint64_t *__restrict__ 
 // k_cut3 copies the range descriptors into the task list in row order.
 constexpr uint32_t BX_PART = 8192;
 constexpr uint32_t BX_NOPART = 0xFFFFFFFFu;
+constexpr uint32_t BX_RUN = 8;   // consecutive part records per workgroup (k_big_scatter)
 struct BigPart {
     uint32_t slot;      // position of the row in big_rows; BX_NOPART: sentinel / unused record
     uint32_t p_begin;   // products of the row before the part (sort-merge: product numbers)
@@ -406,14 +415,20 @@ static_assert(BX_NB == 4 * TK_BLOCK, "a thread owns four consecutive buckets (on
 
 // A row is spilled only if that is cheaper than letting each of its m range tasks find its products in B: a DIRECT range task
 // loads the row's E entries and narrows every selected B row to its column range with two binary searches (B rows are sorted),
-// so the row costs m * E searches of 1 + log2(P / E) steps instead of a scatter to and a read from HBM -- rows with few ranges
-// (web graphs, meshes) go direct, rows with thousands of entries and hundreds of ranges (R-MAT hubs) are spilled.
-// `direct_factor` = 0 spills every row (the sort-merge accumulator numbers the products of a slice in scratch order).
-__global__ __launch_bounds__(TK_BLOCK) void k_big_plan(const uint64_t *__restrict__ aptr, uint64_t r0, uint32_t direct_factor,
+// so the row costs m * E searches of 1 + log2(P / E) steps instead of a scatter to and a read from HBM.  Direct if
+//   m * E * steps <= BX_DIRECT_FACTOR * P   (the searches of the whole row against its products; measured on MI355X: factors
+//                                            2 .. 32 within 1 % on the web and mesh surrogates, where nearly every BIG row
+//                                            qualifies; 8 best on R-MAT 16) and
+//   E * steps <= BX_DIRECT_MAX_SEARCH       (the searches of ONE task: a task that takes long to count its outputs holds up the
+//                                            offsets of every task behind it; 4096 = the knee on the web surrogate)
+// -- rows with few ranges (web graphs, meshes) go direct, rows with thousands of entries and hundreds of ranges (R-MAT hubs) are
+// spilled.  `allow_direct` = 0 spills every row (the sort-merge accumulator numbers the products of a slice in scratch order).
+constexpr uint32_t BX_DIRECT_FACTOR = 8, BX_DIRECT_MAX_SEARCH = 4096;
+__global__ __launch_bounds__(TK_BLOCK) void k_big_plan(const uint64_t *__restrict__ aptr, uint64_t r0, uint32_t allow_direct,
                                                        const uint32_t *__restrict__ big_rows, const uint32_t *__restrict__ row_kmin,
                                                        const uint32_t *__restrict__ row_kmax, const BigPart *__restrict__ parts,
                                                        uint32_t *__restrict__ part_hist, uint32_t *__restrict__ row_m,
-                                                       const uint32_t *__restrict__ row_tmp, TaskDesc *__restrict__ tmp,
+                                                       const uint32_t *__restrict__ row_tmp, TaskDesc *__restrict__ tmp, uint32_t tmp_cap,
                                                        BigSlot *__restrict__ slots, uint64_t scr_cap, TaskCounters *__restrict__ ctr)
 {
     constexpr int NB = BX_NB, BPT = NB / TK_BLOCK;
@@ -425,7 +440,9 @@ __global__ __launch_bounds__(TK_BLOCK) void k_big_plan(const uint64_t *__restric
     uint32_t *rfirst = aux + NB + 1;   // first bucket of range r, rfirst[NR] = NB
     const int tid = threadIdx.x;
     const uint32_t nbig = ctr->n_big;
-    if (ctr->abort_flag) return;
+    // (an overflow of the scratch or descriptor arrays found HERE must not stop the other rows: the retry sizes the arrays from
+    // the cursors, which have to be complete)
+    if (ctr->abort_flag & ~1u) return;
     for (uint32_t slot = blockIdx.x; slot < nbig; slot += gridDim.x) {
         const uint32_t row = big_rows[slot];
         const uint32_t kmin = row_kmin[row], kmax = row_kmax[row], wshift = big_wshift(kmin, kmax);
@@ -499,14 +516,15 @@ __global__ __launch_bounds__(TK_BLOCK) void k_big_plan(const uint64_t *__restric
             const unsigned long long E = aptr[r0 + row + 1] - aptr[r0 + row];
             const uint32_t avg_len = (uint32_t)min(P / max(E, 1ull), 0xFFFFFFFFull);
             const unsigned long long steps = 1ull + (avg_len ? 31u - (uint32_t)__clz((int)avg_len) : 0u);   // of one binary search
-            const bool direct = (unsigned long long)m * E * steps <= (unsigned long long)direct_factor * P && hdr[47] == 0;
+            const bool direct = allow_direct && hdr[47] == 0 && (unsigned long long)m * E * steps <= (unsigned long long)BX_DIRECT_FACTOR * P &&
+                                E * steps <= BX_DIRECT_MAX_SEARCH;
             const uint32_t tb = row_tmp[row];   // big_max_ranges(P) >= m records, allocated by k_big_parts
             const unsigned long long sb = direct ? 0ull : atomicAdd(&ctr->scratch_cursor, P);
             hdr[46] = direct ? 1u : 0u;
             hdr[42] = tb;
             hdr[43] = (uint32_t)sb;
             hdr[44] = (uint32_t)(sb >> 32);
-            const bool ok = direct || sb + P <= scr_cap;
+            const bool ok = (unsigned long long)tb + m <= tmp_cap && (direct || sb + P <= scr_cap);
             hdr[45] = ok ? 1u : 0u;
             if (!ok) atomicOr(&ctr->abort_flag, 1u);
             row_m[row] = m;
@@ -572,7 +590,10 @@ __global__ __launch_bounds__(TK_BLOCK) void k_big_scatter(const double *__restri
     const int tid = threadIdx.x;
     if (ctr->abort_flag || ctr->n_spilled == 0) return;
     const uint32_t nparts = ctr->n_parts;
-    for (uint32_t pi = blockIdx.x; pi < nparts; pi += gridDim.x) {
+    // a workgroup takes BX_RUN consecutive records: the parts of one row (or of neighbouring rows), whose scattered stores fall into
+    // the same lines of the row's scratch slice, go through one CU and one L2 one after the other
+    for (uint32_t pi0 = blockIdx.x * BX_RUN; pi0 < nparts; pi0 += gridDim.x * BX_RUN)
+    for (uint32_t pi = pi0; pi < min(pi0 + BX_RUN, nparts); ++pi) {
         const BigPart pt = parts[pi];
         if (pt.slot == BX_NOPART) continue;   // (uniform over the workgroup, like the next one)
         const BigSlot sl = slots[pt.slot];
@@ -1406,6 +1427,16 @@ __global__ __launch_bounds__(TK_BLOCK, 4) void k_task(const TaskArgs g)
             // ---- chain: publish the count now, look back as late as possible ------------------------------------------------
             if (SPADA_TASK_DBG) dbg_b = dbg_c = __builtin_amdgcn_s_memtime();
             if constexpr (MODE != MODE_NUMERIC) chain_publish(g.status, t, total);
+#if SPADA_TASK_DBG
+            if (tid == 0) {
+                const unsigned long long w_ = __builtin_amdgcn_s_memtime() - dbg_a;
+                const int kd_ = (int)td.kind - 1;
+                atomicAdd(&g.ctr->dbgh[kd_][w_ / 4096 < 19 ? w_ / 4096 : 19], 1ull);
+                atomicAdd(&g.ctr->dbgh[kd_][20], w_);
+                atomicAdd(&g.ctr->dbgh[kd_][21], 1ull);
+                atomicMax(&g.ctr->dbgh[kd_][22], w_);
+            }
+#endif
             PHASE(3);
             unsigned long long dbg_w = 0;
             auto resolve = [&]() -> unsigned long long {
@@ -1506,6 +1537,16 @@ __global__ __launch_bounds__(TK_BLOCK, 4) void k_task(const TaskArgs g)
             }
             if (SPADA_TASK_DBG) dbg_b = dbg_c = __builtin_amdgcn_s_memtime();
             if constexpr (MODE != MODE_NUMERIC) chain_publish(g.status, t, total);
+#if SPADA_TASK_DBG
+            if (tid == 0) {
+                const unsigned long long w_ = __builtin_amdgcn_s_memtime() - dbg_a;
+                const int kd_ = (int)td.kind - 1;
+                atomicAdd(&g.ctr->dbgh[kd_][w_ / 4096 < 19 ? w_ / 4096 : 19], 1ull);
+                atomicAdd(&g.ctr->dbgh[kd_][20], w_);
+                atomicAdd(&g.ctr->dbgh[kd_][21], 1ull);
+                atomicMax(&g.ctr->dbgh[kd_][22], w_);
+            }
+#endif
             unsigned long long dbg_w = 0;
             auto resolve = [&]() -> unsigned long long {
                 if constexpr (MODE == MODE_NUMERIC) {

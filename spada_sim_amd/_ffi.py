@@ -63,8 +63,28 @@ class Config(ctypes.Structure):
                 ("gpus", ctypes.c_uint32), ("accumulator", ctypes.c_int32), ("repeat", ctypes.c_uint32)]
 
 
-# name -> (restype, argtypes); every symbol include/spada_ffi.h declares
+class CycleConfig(ctypes.Structure):   # include/spada_cycle.h
+    _fields_ = [("struct_size", u64), ("pe_num", u64), ("at_num", u64), ("lane_num", u64), ("cache_size", u64),
+                ("word_byte", u64), ("block_shape", u64 * 2), ("mem_latency", u64), ("cache_latency", u64),
+                ("freq", ctypes.c_float), ("channel", u64), ("bandwidth_per_channel", ctypes.c_float),
+                ("accelerator", ctypes.c_int32), ("pad", ctypes.c_int32)]
+
+
+class CycleCounts(ctypes.Structure):
+    _fields_ = [("struct_size", u64), ("exec_cycles", u64), ("raw_cycles", u64), ("a_read", u64), ("a_write", u64),
+                ("b_read", u64), ("b_write", u64), ("c_read", u64), ("c_write", u64), ("cache_read", u64),
+                ("cache_write", u64), ("cache_miss", u64), ("b_evict", u64), ("psum_evict", u64), ("blocks", u64),
+                ("windows", u64), ("pe_merge_tasks", u64), ("tree_merge_tasks", u64), ("c_nnz", u64)]
+
+
+# name -> (restype, argtypes); every symbol include/spada_ffi.h and include/spada_cycle.h declare
 SIGNATURES = {
+    "spada_cycle_create": (ctypes.c_int, [ctypes.POINTER(CycleConfig), ctypes.POINTER(CsrView), ctypes.POINTER(CsrView), u64p,
+                                          ctypes.POINTER(vp)]),
+    "spada_cycle_execute": (ctypes.c_int, [vp, u64]),
+    "spada_cycle_get_counts": (ctypes.c_int, [vp, ctypes.POINTER(CycleCounts)]),
+    "spada_cycle_get_result": (ctypes.c_int, [vp, u64p, u64p, f64p]),
+    "spada_cycle_destroy": (None, [vp]),
     "spada_last_error": (ctypes.c_char_p, []),
     "spada_abi_version": (ctypes.c_int, []),
     "spada_device_count": (ctypes.c_int, []),

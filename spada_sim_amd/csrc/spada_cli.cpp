@@ -2,13 +2,16 @@
 //
 //   spada-sim <simulator> <accelerator> <category> <workload> <configuration> [-p|--preprocess]
 //             [--preprocess-by length|products] [--output C.mtx|C.bin] [--accumulator lds_hash|sort_merge] [--stats]
+//             [--cycle-model]
 //
 // e.g.  spada-sim accuratesimu spada ss cari config/config_1mb_row1.json
 //
 // Same positional contract, same JSON configuration keys, same stdout skeleton.  What differs, on
 // purpose: the multiply/merge dataflow runs on the GPU instead of being simulated, so no per-task
 // `pe: .. cur_cycle: ..` lines exist and the access/cycle counters are measured quantities (see
-// spada_host.hpp).  Exit codes: 0 ok, 1 usage error, 101 run-time failure (Rust's panic code).
+// spada_host.hpp).  --cycle-model runs the cycle-level Spada model of include/spada_cycle.h on the host instead (no GPU
+// involved): the product in the accelerator's order of operations and the simulated counters under the same labels.
+// Exit codes: 0 ok, 1 usage error, 101 run-time failure (Rust's panic code).
 #include <algorithm>
 #include <cctype>
 #include <cmath>
@@ -17,6 +20,7 @@
 #include <string>
 #include <vector>
 
+#include "spada_cycle.h"
 #include "spada_host.hpp"
 
 using namespace spada;
@@ -97,7 +101,9 @@ static int usage(const char *msg)
                  "        --preprocess-by <length|products>\n"
                  "        --output <C.mtx|C.bin>    write the product as MatrixMarket, or as a binary CSR dump; prints its checksum\n"
                  "        --checksum          print the checksum line of the product\n"
-                 "        --accumulator <lds_hash|sort_merge>\n        --stats             print engine statistics to stderr\n\n"
+                 "        --accumulator <lds_hash|sort_merge>\n        --stats             print engine statistics to stderr\n"
+                 "        --cycle-model       simulate the accelerator cycle by cycle on the host (include/spada_cycle.h) instead of\n"
+                 "                            computing on the GPU: simulated counters, same product\n\n"
                  "ARGS:\n    <simulator>        [possible values: AccurateSimu, TrafficModel, BReuseCounter]\n"
                  "    <accelerator>      [possible values: Ip, Op, MultiRow, Spada]\n"
                  "    <category>         [possible values: SS, NN]\n    <workload>         The workload name\n"
@@ -109,13 +115,14 @@ static int usage(const char *msg)
 int main(int argc, char **argv)
 {
     std::vector<std::string> pos;
-    bool preprocess = false, want_stats = false, want_checksum = false;
+    bool preprocess = false, want_stats = false, want_checksum = false, cycle_model = false;
     std::string output, acc_name, preprocess_by = "length";
     for (int i = 1; i < argc; ++i) {
         std::string s = argv[i];
         if (s == "-p" || s == "--preprocess") preprocess = true;
         else if (s == "--stats") want_stats = true;
         else if (s == "--checksum") want_checksum = true;
+        else if (s == "--cycle-model") cycle_model = true;
         else if (s == "--preprocess-by" && i + 1 < argc) { preprocess = true; preprocess_by = argv[++i]; }
         else if (s == "--output" && i + 1 < argc) output = argv[++i];
         else if (s == "--accumulator" && i + 1 < argc) acc_name = argv[++i];
@@ -165,6 +172,93 @@ int main(int argc, char **argv)
         if (simulator != "accuratesimu") {   // main.rs:119
             std::fprintf(stderr, "Unimplemented simulator %s\n", pos[0].c_str());
             return 101;
+        }
+        if (cycle_model) {
+            // ---- the cycle-level model (host only) ----------------------------------------------------------------------
+            spada_cycle_config cc{};
+            cc.struct_size = sizeof(cc);
+            cc.pe_num = cfg.pe_num;
+            cc.at_num = cfg.at_num;
+            cc.lane_num = cfg.lane_num;
+            cc.cache_size = cfg.cache_size;
+            cc.word_byte = cfg.word_byte;
+            cc.block_shape[0] = cfg.block_shape[0];
+            cc.block_shape[1] = cfg.block_shape[1];
+            cc.mem_latency = cfg.mem_latency;
+            cc.cache_latency = cfg.cache_latency;
+            cc.freq = cfg.freq;
+            cc.channel = cfg.channel;
+            cc.bandwidth_per_channel = cfg.bandwidth_per_channel;
+            cc.accelerator = accelerator == Accelerator::Ip ? SPADA_ACCEL_IP : accelerator == Accelerator::Op ? SPADA_ACCEL_OP
+                             : accelerator == Accelerator::MultiRow ? SPADA_ACCEL_MULTIROW : SPADA_ACCEL_SPADA;
+            const spada_csr_view va = gemm.a->view(), vb = gemm.b->view();
+            std::vector<uint64_t> remap;
+            if (preprocess) {   // preprocessing.rs:76-89: rows by ascending length (or products), stable
+                const uint64_t n = va.rows;
+                std::vector<uint64_t> key(n, 0);
+                for (uint64_t r = 0; r < n; ++r) {
+                    if (preprocess_by == "products") {
+                        for (uint64_t p = va.indptr[r]; p < va.indptr[r + 1]; ++p)
+                            key[r] += vb.indptr[va.indices[p] + 1] - vb.indptr[va.indices[p]];
+                    } else {
+                        key[r] = va.indptr[r + 1] - va.indptr[r];
+                    }
+                }
+                remap.resize(n);
+                for (uint64_t r = 0; r < n; ++r) remap[r] = r;
+                std::stable_sort(remap.begin(), remap.end(), [&](uint64_t x, uint64_t y) { return key[x] < key[y]; });
+            }
+            spada_cycle_model *model = nullptr;
+            check(spada_cycle_create(&cc, &va, &vb, preprocess ? remap.data() : nullptr, &model));
+            const int rc = spada_cycle_execute(model, 0);
+            if (rc != SPADA_OK) {
+                spada_cycle_destroy(model);
+                check(rc);
+            }
+            spada_cycle_counts k{};
+            k.struct_size = sizeof(k);
+            check(spada_cycle_get_counts(model, &k));
+            CsMat c;
+            c.nrows = va.rows;
+            c.ncols = vb.cols;
+            c.indptr.assign(va.rows + 1, 0);
+            c.indices.assign(k.c_nnz, 0);
+            c.data.assign(k.c_nnz, 0.0);
+            check(spada_cycle_get_result(model, c.indptr.data(), c.indices.data(), c.data.data()));
+            spada_cycle_destroy(model);
+            std::printf("-----Result-----\n-----Access count\n");
+            std::printf("Execution count: %llu\n", (unsigned long long)k.exec_cycles);
+            std::printf("A matrix count: read %llu write %llu\n", (unsigned long long)k.a_read, (unsigned long long)k.a_write);
+            std::printf("B matrix count: read %llu write %llu\n", (unsigned long long)k.b_read, (unsigned long long)k.b_write);
+            std::printf("C matrix count: read %llu write %llu\n", (unsigned long long)k.c_read, (unsigned long long)k.c_write);
+            std::printf("Cache count: read %llu write %llu\n", (unsigned long long)k.cache_read, (unsigned long long)k.cache_write);
+            std::printf("-----Output product matrix\n");
+            for (uint64_t r = 0; r < std::min<uint64_t>(c.nrows, 10); ++r) {   // storage.rs:115-126
+                const std::vector<uint64_t> idx(c.indices.begin() + c.indptr[r], c.indices.begin() + c.indptr[r + 1]);
+                const std::vector<double> val(c.data.begin() + c.indptr[r], c.data.begin() + c.indptr[r + 1]);
+                std::printf("rowptr: %llu indptr: %s data: %s\n", (unsigned long long)r, debug_slice(idx, 5, u64s).c_str(),
+                            debug_slice(val, 5, rust_f64).c_str());
+            }
+            if (want_stats)
+                std::fprintf(stderr, "cycle model: %llu cycles (%llu before the drain discount), cache miss %llu words, evicted B %llu / "
+                                     "psum %llu words, %llu blocks, %llu windows, %llu PE merge tasks, %llu tree merge tasks, nnz(C) %llu\n",
+                             (unsigned long long)k.exec_cycles, (unsigned long long)k.raw_cycles, (unsigned long long)k.cache_miss,
+                             (unsigned long long)k.b_evict, (unsigned long long)k.psum_evict, (unsigned long long)k.blocks,
+                             (unsigned long long)k.windows, (unsigned long long)k.pe_merge_tasks,
+                             (unsigned long long)k.tree_merge_tasks, (unsigned long long)k.c_nnz);
+            if (want_checksum || !output.empty()) {
+                spada_csr_view v = c.view();
+                spada_checksum cs;
+                char line[512];
+                check(spada_csr_checksum(&v, &cs));
+                check(spada_checksum_format(&cs, line, sizeof line));
+                std::printf("-----Checksum of the product matrix\n%s\n", line);
+                if (!output.empty()) {
+                    const bool bin = output.size() > 4 && output.compare(output.size() - 4, 4, ".bin") == 0;
+                    check(bin ? spada_csr_write_bin(output.c_str(), &v) : spada_mtx_write(output.c_str(), &v));
+                }
+            }
+            return 0;
         }
         auto drams = CsrMatStorage::init_with_gemm(gemm);
         if (preprocess) {   // main.rs:60-63

@@ -467,6 +467,64 @@ class Simulator:
         return [0, 0]
 
 
+ACCELERATORS = {"ip": 0, "op": 1, "multirow": 2, "spada": 3}   # frontend.rs:26-33, case-insensitive
+
+
+class CycleModel:
+    """The cycle-level Spada model (include/spada_cycle.h): what `accuratesimu` simulates -- the product in
+    the accelerator's order of operations plus the counters main.rs:97-108 prints.  Host code; parity with the Rust tool is
+    unpinned (see the header)."""
+
+    def __init__(self, a, b, config, accelerator="spada", row_remap=None):
+        """a, b: CsMat; config: dict with the keys of the JSON configuration (parse_config)."""
+        cfg = _ffi.CycleConfig()
+        cfg.struct_size = ctypes.sizeof(cfg)
+        for k in ("pe_num", "at_num", "lane_num", "cache_size", "word_byte", "mem_latency", "cache_latency", "channel"):
+            setattr(cfg, k, int(config[k]))
+        cfg.block_shape[0], cfg.block_shape[1] = int(config["block_shape"][0]), int(config["block_shape"][1])
+        cfg.freq = float(config["freq"])
+        cfg.bandwidth_per_channel = float(config["bandwidth_per_channel"])
+        cfg.accelerator = ACCELERATORS[str(accelerator).lower()]
+        self._a, self._b = a, b     # borrowed by the model
+        self._remap = None if row_remap is None else np.ascontiguousarray(row_remap, dtype=np.uint64)
+        self._h = _ffi.vp()
+        self._L = _ffi.lib()
+        va, vb = a.view(), b.view()
+        rp = None if self._remap is None else self._remap.ctypes.data_as(_ffi.u64p)
+        check(self._L.spada_cycle_create(ctypes.byref(cfg), ctypes.byref(va), ctypes.byref(vb), rp, ctypes.byref(self._h)))
+
+    def execute(self, max_cycles=0):
+        check(self._L.spada_cycle_execute(self._h, int(max_cycles)))
+        return self
+
+    def counts(self):
+        c = _ffi.CycleCounts()
+        c.struct_size = ctypes.sizeof(c)
+        check(self._L.spada_cycle_get_counts(self._h, ctypes.byref(c)))
+        return {name: int(getattr(c, name)) for name, _ in c._fields_ if name != "struct_size"}
+
+    def result(self):
+        n = self._a.shape[0]
+        nnz = self.counts()["c_nnz"]
+        indptr = np.zeros(n + 1, np.uint64)
+        indices = np.zeros(max(nnz, 1), np.uint64)
+        data = np.zeros(max(nnz, 1), np.float64)
+        check(self._L.spada_cycle_get_result(self._h, indptr.ctypes.data_as(_ffi.u64p), indices.ctypes.data_as(_ffi.u64p),
+                                             data.ctypes.data_as(_ffi.f64p)))
+        return CsMat((n, self._b.shape[1]), indptr, indices[:nnz], data[:nnz])
+
+    def close(self):
+        if self._h:
+            self._L.spada_cycle_destroy(self._h)
+            self._h = _ffi.vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def partition_rows(a, b, nparts):
     """A-row block boundaries balanced on per-row products (scheduler.rs:296-379 issues disjoint row blocks)."""
     bounds = np.zeros(nparts + 1, np.uint64)

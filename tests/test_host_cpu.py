@@ -19,15 +19,18 @@ MTX = ["general_unsorted_dups", "symmetric", "skew", "pattern_sym", "integer_rec
 
 
 def test_library_exports_every_symbol_of_the_header():
-    """Every function include/spada_ffi.h declares is exported, and nothing is missing from the binding."""
-    hdr = open(os.path.join(ROOT, "include", "spada_ffi.h")).read()
-    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    declared = set(re.findall(r"\b(spada_[a-z0-9_]+)\s*\(", hdr))
+    """Every function include/spada_ffi.h and include/spada_cycle.h declare is exported, and nothing is missing from the binding."""
+    declared = set()
+    for name in ("spada_ffi.h", "spada_cycle.h"):
+        hdr = open(os.path.join(ROOT, "include", name)).read()
+        hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+        declared |= set(re.findall(r"\b(spada_[a-z0-9_]+)\s*\(", hdr))
     declared -= {"spada_options", "spada_stats", "spada_config"}
-    assert len(declared) >= 25
+    assert len(declared) >= 30 and {"spada_cycle_create", "spada_cycle_execute", "spada_cycle_get_counts", "spada_cycle_get_result",
+                                    "spada_cycle_destroy"} <= declared
     L = ctypes.CDLL(_ffi.LIB_PATH)
     for name in sorted(declared):
-        assert hasattr(L, name), f"{name} declared in spada_ffi.h but not exported"
+        assert hasattr(L, name), f"{name} declared in include/*.h but not exported"
     assert declared == set(_ffi.SIGNATURES), declared ^ set(_ffi.SIGNATURES)
     assert _ffi.lib().spada_abi_version() == 3
 
@@ -53,13 +56,14 @@ def test_struct_layouts_match_the_header():
     with tempfile.TemporaryDirectory() as d:
         src = os.path.join(d, "sz.c")
         with open(src, "w") as f:
-            f.write('#include <stdio.h>\n#include "spada_ffi.h"\nint main(void){printf("%zu %zu %zu %zu\\n", '
-                    'sizeof(spada_csr_view), sizeof(spada_options), sizeof(spada_stats), sizeof(spada_config));return 0;}\n')
+            f.write('#include <stdio.h>\n#include "spada_ffi.h"\n#include "spada_cycle.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu\\n", '
+                    'sizeof(spada_csr_view), sizeof(spada_options), sizeof(spada_stats), sizeof(spada_config), '
+                    'sizeof(spada_cycle_config), sizeof(spada_cycle_counts));return 0;}\n')
         exe = os.path.join(d, "sz")
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), src, "-o", exe])
         sizes = [int(x) for x in subprocess.check_output([exe]).split()]
     assert sizes == [ctypes.sizeof(_ffi.CsrView), ctypes.sizeof(_ffi.Options), ctypes.sizeof(_ffi.Stats),
-                     ctypes.sizeof(_ffi.Config)]
+                     ctypes.sizeof(_ffi.Config), ctypes.sizeof(_ffi.CycleConfig), ctypes.sizeof(_ffi.CycleCounts)]
 
 
 def test_cari_loader_pins(matrices_dir):

@@ -19,7 +19,7 @@
 //   * the progress lines the reference prints for every finished window (simulator.rs:563-573) are not printed;
 //   * containers the reference iterates in hash order are visited in ascending key order (see spada_cycle.h);
 //   * a window never reaches past its block (Planner::next_window: the reference's Op accelerator multiplies the elements of
-//     a partial last row group several times).
+//     a partial last row group several times), and the first block is fitted to the matrix for every accelerator.
 // Where the reference would panic (an unwrap on a missing entry) this model throws and the C entry point reports an error.
 #include "spada_cycle.h"
 
@@ -652,7 +652,8 @@ struct Planner {
             if (row_s == NONE && col_s == NONE) {
                 row_s = col_s = 0;
                 if (n_rows == 0) return NONE;
-                if (accel == SPADA_ACCEL_SPADA) fit_height();
+                fit_height();   // (the reference adjusts only Spada's first block, :304: an Op run on fewer rows than lanes indexes
+                                // past the end of A and panics; the other accelerators' first block is fitted here as well)
                 return open_block();
             }
             if (row_s >= n_rows) return NONE;

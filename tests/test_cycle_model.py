@@ -84,6 +84,31 @@ def test_exact_cancellation_keeps_the_zero():
     assert list(c.indptr) == [0, 1, 1]
 
 
+@pytest.mark.parametrize("accelerator", ["spada", "ip", "op", "multirow"])
+def test_fewer_rows_than_lanes(accelerator):
+    """One to three rows of A (the reference's Op run would index past the end of A here: the model fits the first block)."""
+    import spada_sim_amd as S
+    for rows in (1, 3):
+        rng = np.random.default_rng(rows)
+        lens = rng.integers(0, 6, rows)
+        indptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+        idx = np.concatenate([np.sort(rng.choice(5, int(l), replace=False)) for l in lens]).astype(np.uint64) if lens.sum() else np.zeros(0, np.uint64)
+        a = S.CsMat((rows, 5), indptr, idx, rng.uniform(0.1, 1.0, int(lens.sum())))
+        b = S.generate(S.GEN_UNIFORM, 5, 3, 7)
+        c, k = simulate(a, b, accelerator)
+        ao, bo = to_oracle(a), to_oracle(b)
+        assert_parity(c, oracle.spgemm_sortmerge(ao, bo), ao, bo, RTOL)
+
+
+def test_a_fiber_larger_than_the_cache_is_an_error_not_a_crash():
+    """The reference panics when a single B row or partial fiber does not fit the fiber cache (storage.rs:604-609, :643-648); the
+    model reports it."""
+    import spada_sim_amd as S
+    a = S.generate(S.GEN_UNIFORM, 40, 12, 3)
+    with pytest.raises(S.SpadaError):
+        simulate(a, a, cache_size=64)
+
+
 def test_power_law_rows_merge_tasks_and_policy():
     """R-MAT rows: long rows are cut into many windows whose partial fibers are merged by the adder trees (and by PE pairs once
     A is exhausted); the Spada policy samples block heights 1, 2, 4, 8."""

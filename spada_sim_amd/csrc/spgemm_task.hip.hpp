@@ -204,10 +204,10 @@ __global__ __launch_bounds__(256) void k_row_class(const uint64_t *__restrict__ 
 //   k_big_hist    one workgroup per part: its products (column indices only) counted in BX_NB column buckets of width
 //                 2^wshift over [kmin, kmax] of the row (LDS), stored per part
 //   k_big_plan    one workgroup per row: bucket counts of the row = sum over its parts; buckets grouped into column RANGES -- a
-//                 bucket with more than BX_HEAVY products is a range of its own, the others are grouped by floor(prefix /
-//                 TK_CAP): a light range holds fewer than TK_CAP + BX_HEAVY = 1536 products, i.e. it fits one task's table
-//                 whatever its outputs are; a heavy range holds at most 2^wshift distinct columns and is split further by the
-//                 task itself if both exceed the table (k_task, multi-pass).  Range descriptors go to `tmp` (bump allocated),
+//                 bucket with more than BX_HEAVY products is a range of its own, the others are packed greedily into ranges
+//                 of at most TK_SOLO_MAX = 1536 products, i.e. a light range fits one task's table whatever its outputs
+//                 are; a heavy range holds at most 2^wshift distinct columns and is split further by the task itself if
+//                 both exceed the table (k_task, multi-pass).  Range descriptors go to `tmp` (bump allocated),
 //                 their number to row_m[row].  Then the row is either left to DIRECT range tasks, which find their products
 //                 in B themselves, or SPILLED: its slice of the scratch arrays is bump allocated and the counts of every part
 //                 are turned into cursors (exclusive prefix over buckets, then over the parts before it)
@@ -467,15 +467,59 @@ __global__ __launch_bounds__(TK_BLOCK) void k_big_plan(const uint64_t *__restric
         group_exclusive_scan<TK_BLOCK, NB>(pre, tid, hdr + 2);
         if (tid == TK_BLOCK - 1) pre[NB] = pre[NB - 1] + cnt[NB - 1];
         __syncthreads();
-        // range starts
+        // range starts: a heavy bucket is a range of its own; the light buckets between heavy ones are packed greedily, as many
+        // as fit one task's table (<= TK_SOLO_MAX products: the next bucket, itself <= BX_HEAVY, did not fit, so a range that was
+        // closed for capacity holds more than TK_SOLO_MAX - BX_HEAVY = TK_CAP products).  Fuller ranges = fewer range tasks,
+        // fewer searches of the direct tasks, fewer hops of the chain.  Greedy packing is sequential, so it is done with jump
+        // pointers: nxt[b] = where the range that starts at b ends (capacity by binary search over the prefix sums, or the next
+        // forced start -- a heavy bucket or the bucket after one), all b in parallel; then one thread follows the pointers.
+        {
+            uint32_t forced[BPT], fex[BPT];
 #pragma unroll
-        for (int k = 0; k < BPT; ++k) {
-            const int b = tid * BPT + k;
-            bool st = b == 0 || cnt[b] > BX_HEAVY;
-            if (b > 0) st = st || cnt[b - 1] > BX_HEAVY || (pre[b] / TK_CAP) != (pre[b - 1] / TK_CAP);
-            aux[b] = st ? 1u : 0u;
+            for (int k = 0; k < BPT; ++k) {
+                const int bk = tid * BPT + k;
+                forced[k] = (bk == 0 || cnt[bk] > BX_HEAVY || cnt[bk - (bk > 0)] > BX_HEAVY) ? 1u : 0u;
+            }
+            __syncthreads();   // (cnt is read above and reused for the pointers below)
+#pragma unroll
+            for (int k = 0; k < BPT; ++k) aux[tid * BPT + k] = forced[k];
+            __syncthreads();
+            group_exclusive_scan<TK_BLOCK, NB>(aux, tid, hdr + 2);
+#pragma unroll
+            for (int k = 0; k < BPT; ++k) {
+                fex[k] = aux[tid * BPT + k];
+                if (forced[k]) rfirst[fex[k]] = tid * BPT + k;   // positions of the forced starts, ascending
+            }
+            if (tid == TK_BLOCK - 1) rfirst[fex[BPT - 1] + forced[BPT - 1]] = NB;
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < BPT; ++k) {
+                const uint32_t bk = tid * BPT + k;
+                const uint32_t nf = rfirst[fex[k] + forced[k]];   // next forced start behind bk
+                // largest e with pre[e] - pre[bk] <= TK_SOLO_MAX (pre[NB] = P)
+                const uint32_t lim = pre[bk] + TK_SOLO_MAX;
+                uint32_t lo = bk + 1, n = NB - bk;   // e in [bk + 1, NB]: first e with pre[e] > lim, minus one ... searched as upper bound
+                while (n) {
+                    const uint32_t h = n >> 1;
+                    if (pre[lo + h] <= lim) {
+                        lo += h + 1;
+                        n -= h + 1;
+                    } else {
+                        n = h;
+                    }
+                }
+                // lo = first index in [bk + 1, NB + 1] whose prefix exceeds lim; the range [bk, lo - 1) fits
+                const uint32_t cap_end = max(lo - 1, bk + 1);
+                cnt[bk] = min(cap_end, nf);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < BPT; ++k) aux[tid * BPT + k] = 0u;
+            __syncthreads();
+            if (tid == 0)
+                for (uint32_t bk = 0; bk < (uint32_t)NB; bk = cnt[bk]) aux[bk] = 1u;
+            __syncthreads();
         }
-        __syncthreads();
         uint32_t stf[BPT];
 #pragma unroll
         for (int k = 0; k < BPT; ++k) stf[k] = aux[tid * BPT + k];

@@ -5,4 +5,4 @@ set -e
 cd "$(dirname "$0")/../spada_sim_amd/csrc"
 mkdir -p build/dbg
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-parameter -I../../include -I. -DSPADA_TASK_DBG=1 "$@" -c spada_engine.hip -o build/dbg/spada_engine.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o ../lib/libspada_dbg.so build/spada_host.o build/dbg/spada_engine.o -lgomp
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o ../lib/libspada_dbg.so build/spada_host.o build/spada_cycle.o build/dbg/spada_engine.o -lgomp

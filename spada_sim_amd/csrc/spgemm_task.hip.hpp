@@ -38,14 +38,13 @@ namespace spada {
 constexpr uint8_t CLS_EMPTY = 0, CLS_COPY = 1, CLS_SMALL = 2, CLS_SOLO = 3, CLS_BIG = 4;
 constexpr int N_CLS = 5;
 constexpr int TK_BLOCK = 256, TK_EPT = 2, TK_LOG_T = 11, TK_T = 1 << TK_LOG_T, TK_NOUT = 1536, TK_RMAX = 128;
-constexpr uint32_t TK_CAP = 1024;        // BIG rows: light column ranges are cut every TK_CAP products
 constexpr uint32_t TK_SMALL_MAX = 512;   // class boundary SMALL | SOLO (statistics only: both are packed into batches)
 constexpr uint32_t TK_SOLO_MAX = 1536;   // 0.75 of the table: products one task hashes at most; rows above are BIG
-constexpr uint32_t BX_HEAVY_C = 512;
 constexpr int TK_NQ = 16;                // ticket queues: task t belongs to queue t % TK_NQ, workgroup b serves queue b % TK_NQ
 constexpr int BX_NB = 1024;              // column buckets of the big-row histogram
-constexpr uint32_t BX_HEAVY = BX_HEAVY_C; // a bucket with more products is a range of its own
-static_assert(TK_CAP + BX_HEAVY_C <= TK_SOLO_MAX && TK_SOLO_MAX <= TK_NOUT && TK_NOUT * 4 <= TK_T * 3, "table load <= 0.75");
+constexpr uint32_t BX_HEAVY = TK_SOLO_MAX;   // a bucket with more products than a table takes is a range of its own (measured:
+                                             // thresholds 1024 .. 1536 equal, 512 slower -- 9 % on R-MAT 16 / 18, 2 % on the web surrogate)
+static_assert(BX_HEAVY <= TK_SOLO_MAX && TK_SOLO_MAX <= TK_NOUT && TK_NOUT * 4 <= TK_T * 3, "table load <= 0.75");
 
 struct TaskDesc {
     uint32_t kind;      // TASK_BATCH: rows [row, row of the next task) | TASK_RANGE: columns [col_lo, col_hi] of BIG row `row`
@@ -240,8 +239,9 @@ __device__ inline uint32_t big_wshift(uint32_t kmin, uint32_t kmax)
 constexpr int BP_EPL = 8;     // entries per lane and step
 constexpr int BP_ROWS = 16;   // rows per workgroup and round: their records are allocated with ONE device atomic per array (a
                               // single hot word sustains ~88 atomics / us: one per row would cost more than the kernel's work)
-// ranges of a row with P products: one per TK_CAP products and two more around every heavy bucket (> BX_HEAVY products)
-__host__ __device__ inline uint32_t big_max_ranges(uint32_t P) { return P / TK_CAP + 2u * (P / (BX_HEAVY + 1u)) + 2u; }
+// ranges of a row with P products, upper bound: a light range is closed when the next bucket does not fit, so two consecutive
+// ones hold more than TK_SOLO_MAX products together; a heavy bucket (> BX_HEAVY products) ends the range before it and is one itself
+__host__ __device__ inline uint32_t big_max_ranges(uint32_t P) { return 2u * (P / TK_SOLO_MAX) + 2u * (P / (BX_HEAVY + 1u)) + 3u; }
 
 __global__ __launch_bounds__(256) void k_big_parts(const uint64_t *__restrict__ aptr, const uint32_t *__restrict__ elen, uint64_t r0,
                                                    const uint32_t *__restrict__ big_rows, const uint32_t *__restrict__ row_nprod,
@@ -468,8 +468,8 @@ __global__ __launch_bounds__(TK_BLOCK) void k_big_plan(const uint64_t *__restric
         if (tid == TK_BLOCK - 1) pre[NB] = pre[NB - 1] + cnt[NB - 1];
         __syncthreads();
         // range starts: a heavy bucket is a range of its own; the light buckets between heavy ones are packed greedily, as many
-        // as fit one task's table (<= TK_SOLO_MAX products: the next bucket, itself <= BX_HEAVY, did not fit, so a range that was
-        // closed for capacity holds more than TK_SOLO_MAX - BX_HEAVY = TK_CAP products).  Fuller ranges = fewer range tasks,
+        // as fit one task's table (<= TK_SOLO_MAX products: a range is closed when the next bucket does not fit, so two consecutive
+        // ranges hold more than TK_SOLO_MAX products together).  Fuller ranges = fewer range tasks,
         // fewer searches of the direct tasks, fewer hops of the chain.  Greedy packing is sequential, so it is done with jump
         // pointers: nxt[b] = where the range that starts at b ends (capacity by binary search over the prefix sums, or the next
         // forced start -- a heavy bucket or the bucket after one), all b in parallel; then one thread follows the pointers.

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define SPADA_ABI_VERSION 3
+#define SPADA_ABI_VERSION 4
 
 enum spada_status {
     SPADA_OK = 0,
@@ -99,6 +99,8 @@ typedef struct spada_stats {
     uint64_t spill_rows;      /* BIG rows that took the HBM spill path */
     uint64_t pipeline_runs;   /* > 1 when a workspace had to grow and the pipeline was run again (first call of a context) */
     uint64_t workspace_bytes; /* device scratch owned by the context */
+    uint64_t task_product_limit; /* products one task hashes at most: 1536, or 1792 where the sampled products / outputs ratio of the
+                                    input is high (fuller tables, fewer tasks); rows with more products are BIG */
 } spada_stats;
 
 typedef struct spada_ctx spada_ctx;          /* engine context: one GPU, one stream, scratch */

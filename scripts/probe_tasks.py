@@ -24,7 +24,7 @@ for name in names:
             best = (st, wall)
     st, wall = best
     dev = st["ms_fused_call"]
-    print(f"== {name}: rows {m.shape[0]} nnzA {m.nnz()} nprod {st['nprod']} nnzC {st['c_nnz']}  tasks {st['n_tasks']} multi-pass {st['multi_pass_tasks']} runs {st['pipeline_runs']}")
+    print(f"== {name}: rows {m.shape[0]} nnzA {m.nnz()} nprod {st['nprod']} nnzC {st['c_nnz']}  tasks {st['n_tasks']} limit {st['task_product_limit']} multi-pass {st['multi_pass_tasks']} runs {st['pipeline_runs']}")
     print(f"   one pass: device {dev:.3f} ms (wall {wall:.3f})  stats {st['ms_row_stats']:.3f} big {st['ms_big_expand']:.3f} cut {st['ms_cut']:.3f} task {st['ms_task']:.3f}")
     print(f"   {st['c_nnz'] / dev / 1e6:.2f} G nnzC/s   read {st['bytes_read'] / dev / 1e6:.1f} GB/s ({st['bytes_read'] / dev / 1e6 / 8000 * 100:.2f}% of 8 TB/s)")
     print(f"   class rows {st['cls_rows'][:5]}  class products {st['cls_prod'][:5]}")

@@ -91,7 +91,8 @@ struct spada_ctx {
     DevBuf t_tmp, t_tasks, t_status, t_rangeout, t_scrcol, t_scrval, t_scrseq, t_ctr;
     DevBuf t_parts, t_parthist, t_slots;                      // BIG rows: parts, bucket counts (then cursors) per part, row records
     DevBuf own_idx, own_val, own_ptr, wide_idx;
-    uint64_t t_cap_tmp = 0, t_cap_tasks = 0, t_cap_scr = 0, t_cap_parts = 0;   // capacities the kernels may rely on
+    uint64_t t_cap_tmp = 0, t_cap_tasks = 0, t_cap_scr = 0, t_cap_parts = 0;
+    uint32_t prod_limit = TK_SOLO_MAX;   // capacities the kernels may rely on
     TaskCounters *h_tctr = nullptr;   // pinned
     // numeric phase in pieces (spada_dev_spgemm_numeric_plan / _chunk): task boundaries, one event per piece
     std::vector<uint32_t> chunk_task;
@@ -230,7 +231,10 @@ void launch_task(spada_ctx *c, const TaskArgs &g)
     if (c->accumulator == SPADA_ACC_SORT_MERGE)
         hipLaunchKernelGGL(k_task_sm<MODE>, dim3(c->n_cu * 3), dim3(TK_BLOCK), task_sm_lds(), c->stream, g);
     else
-        hipLaunchKernelGGL(k_task<MODE>, dim3(c->n_cu * 4), dim3(TK_BLOCK), task_lds(), c->stream, g);
+    {
+        hipLaunchKernelGGL((k_task<MODE, TK_NOUT_LO>), dim3(c->n_cu * 4), dim3(TK_BLOCK), task_lds(), c->stream, g);
+        hipLaunchKernelGGL((k_task<MODE, TK_NOUT_HI>), dim3(c->n_cu * 4), dim3(TK_BLOCK), task_lds(), c->stream, g);
+    }
 }
 
 TaskArgs task_args(spada_ctx *c, uint64_t *cptr, uint32_t *d_idx, double *d_val, uint64_t capacity)
@@ -329,9 +333,10 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
             HIP_TRY(hipMemsetAsync(c->row_kmin.p, 0xFF, (size_t)n * 4, s));
             HIP_TRY(hipMemsetAsync(c->row_kmax.p, 0, (size_t)n * 4, s));
             const uint32_t gent = (uint32_t)std::min<uint64_t>((a->nnz + 255) / 256 + 1, (uint64_t)c->n_cu * 8 * 4);
-            hipLaunchKernelGGL(k_entry_stats, dim3(gent), dim3(256), 0, s, a->ptr, a->idx, a->rowid, b->ptr, b->idx, c->r0, n,
+            hipLaunchKernelGGL(k_entry_stats, dim3(gent + EST_ROWS), dim3(256), 0, s, a->ptr, a->idx, a->rowid, b->ptr, b->idx, c->r0, n,
                                c->eb0.as<uint64_t>(), c->elen.as<uint32_t>(), c->t_rowP.as<unsigned long long>(),
-                               c->row_kmin.as<uint32_t>(), c->row_kmax.as<uint32_t>());
+                               c->row_kmin.as<uint32_t>(), c->row_kmax.as<uint32_t>(), gent,
+                               c->accumulator == SPADA_ACC_SORT_MERGE ? (uint32_t)TK_SOLO_MAX : 0u, dc);
             hipLaunchKernelGGL(k_row_class, dim3(std::min<uint32_t>((n + 255) / 256, c->n_cu)), dim3(256), 0, s, a->ptr, c->r0,
                                n, rmax, c->t_rowP.as<unsigned long long>(), c->row_nprod.as<uint32_t>(), c->row_bin.as<uint8_t>(),
                                c->t_rowm.as<uint32_t>(), c->t_big.as<uint32_t>(), dc);
@@ -360,7 +365,7 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
         HIP_TRY(hipEventRecord(c->tev[2], s));
         if (n) {
             hipLaunchKernelGGL(k_cut1, dim3(ntiles), dim3(256), 0, s, c->row_bin.as<uint8_t>(), c->row_nprod.as<uint32_t>(),
-                               c->t_rowm.as<uint32_t>(), n, rmax, c->t_tiles.as<uint32_t>(), c->t_rowt.as<uint32_t>());
+                               c->t_rowm.as<uint32_t>(), n, rmax, dc, c->t_tiles.as<uint32_t>(), c->t_rowt.as<uint32_t>());
             hipLaunchKernelGGL(k_cut2, dim3(1), dim3(256), 0, s, c->t_tiles.as<uint32_t>(), ntiles, cap_tasks, dc);
             hipLaunchKernelGGL(k_cut3, dim3(ntiles), dim3(256), 0, s, c->row_bin.as<uint8_t>(), c->t_rowt.as<uint32_t>(),
                                c->t_rowtmp.as<uint32_t>(), n, c->t_tiles.as<uint32_t>(),
@@ -437,6 +442,7 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
     st.scratch_products = h.scratch_cursor;
     st.spill_rows = h.n_spilled;
     st.workspace_bytes = c->ws_bytes;
+    st.task_product_limit = h.prod_limit;
     if (mode == MODE_COUNT) {
         st.ms_symbolic_call = tev_ms(c, 0, 4);
     } else {
@@ -513,9 +519,9 @@ int spada_create(const spada_options *opts, spada_ctx **out)
     for (auto &e : c->tev) HIP_TRY(hipEventCreate(&e));
     c->n_cu = (uint32_t)std::max(1, prop.multiProcessorCount);
     int rc;
-    if ((rc = allow_lds(k_task<MODE_COUNT>, task_lds()))) return rc;
-    if ((rc = allow_lds(k_task<MODE_NUMERIC>, task_lds()))) return rc;
-    if ((rc = allow_lds(k_task<MODE_FUSED>, task_lds()))) return rc;
+    if ((rc = allow_lds(k_task<MODE_COUNT, TK_NOUT_LO>, task_lds())) || (rc = allow_lds(k_task<MODE_COUNT, TK_NOUT_HI>, task_lds()))) return rc;
+    if ((rc = allow_lds(k_task<MODE_NUMERIC, TK_NOUT_LO>, task_lds())) || (rc = allow_lds(k_task<MODE_NUMERIC, TK_NOUT_HI>, task_lds()))) return rc;
+    if ((rc = allow_lds(k_task<MODE_FUSED, TK_NOUT_LO>, task_lds())) || (rc = allow_lds(k_task<MODE_FUSED, TK_NOUT_HI>, task_lds()))) return rc;
     if ((rc = allow_lds(k_task_sm<MODE_COUNT>, task_sm_lds()))) return rc;
     if ((rc = allow_lds(k_task_sm<MODE_NUMERIC>, task_sm_lds()))) return rc;
     if ((rc = allow_lds(k_task_sm<MODE_FUSED>, task_sm_lds()))) return rc;

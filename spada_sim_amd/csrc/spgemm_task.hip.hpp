@@ -37,14 +37,18 @@ namespace spada {
 
 constexpr uint8_t CLS_EMPTY = 0, CLS_COPY = 1, CLS_SMALL = 2, CLS_SOLO = 3, CLS_BIG = 4;
 constexpr int N_CLS = 5;
-constexpr int TK_BLOCK = 256, TK_EPT = 2, TK_LOG_T = 11, TK_T = 1 << TK_LOG_T, TK_NOUT = 1536, TK_RMAX = 128;
+constexpr int TK_BLOCK = 256, TK_EPT = 2, TK_LOG_T = 11, TK_T = 1 << TK_LOG_T, TK_RMAX = 128;
+// Products a task hashes at most = its table capacity in outputs.  Two builds of the task kernel: 1536 (0.75 of the table) and
+// 1792 (0.875).  Fuller tables mean fewer tasks, but the probe sequences of a table that really fills up get long: 1792 wins where
+// products collapse onto few outputs (measured: -10 % on the cop20k_A surrogate, compression 4.3; -9 % on cage12, 2.2) and loses
+// where they do not (+17 % on the web surrogate, 1.4).  k_estimate samples the compression of the input and picks the limit
+// (TaskCounters::prod_limit); classification, ranges and batches follow it, and only the matching build of k_task does the work.
+constexpr int TK_NOUT_LO = 1536, TK_NOUT_HI = 1792, TK_NOUT = TK_NOUT_HI;   // TK_NOUT: what the LDS layout is sized for
 constexpr uint32_t TK_SMALL_MAX = 512;   // class boundary SMALL | SOLO (statistics only: both are packed into batches)
-constexpr uint32_t TK_SOLO_MAX = 1536;   // 0.75 of the table: products one task hashes at most; rows above are BIG
+constexpr uint32_t TK_SOLO_MAX = TK_NOUT_LO;   // the default limit (and the sort-merge accumulator's); rows above the limit are BIG
 constexpr int TK_NQ = 16;                // ticket queues: task t belongs to queue t % TK_NQ, workgroup b serves queue b % TK_NQ
 constexpr int BX_NB = 1024;              // column buckets of the big-row histogram
-constexpr uint32_t BX_HEAVY = TK_SOLO_MAX;   // a bucket with more products than a table takes is a range of its own (measured:
-                                             // thresholds 1024 .. 1536 equal, 512 slower -- 9 % on R-MAT 16 / 18, 2 % on the web surrogate)
-static_assert(BX_HEAVY <= TK_SOLO_MAX && TK_SOLO_MAX <= TK_NOUT && TK_NOUT * 4 <= TK_T * 3, "table load <= 0.75");
+static_assert(TK_SOLO_MAX <= TK_NOUT && TK_NOUT < TK_T && TK_NOUT_LO % TK_BLOCK == 0 && TK_NOUT_HI % TK_BLOCK == 0, "the table must keep an empty slot");
 
 struct TaskDesc {
     uint32_t kind;      // TASK_BATCH: rows [row, row of the next task) | TASK_RANGE: columns [col_lo, col_hi] of BIG row `row`
@@ -64,6 +68,8 @@ struct TaskCounters {
     unsigned long long cls_rows[N_CLS], cls_prod[N_CLS];
     uint32_t n_big, tmp_cursor, ntasks, n_parts;
     uint32_t n_spilled, pad_spilled;                  // BIG rows whose products go through the scratch arrays
+    unsigned long long est_products, est_outputs;     // k_estimate: products and distinct outputs of the sampled rows
+    uint32_t est_done, prod_limit;                    // workgroups of k_estimate that have finished | products a task hashes at most
     uint32_t abort_flag;                              // a workspace was too small: results invalid, sizes below say what is needed
     uint32_t cap_overflow;                            // FUSED: nnz(C) exceeded the caller's capacity (C.indptr is complete)
     uint32_t need_tmp, need_tasks;                    // (abort_flag bits: 1 tmp / scratch, 2 tasks, 4 row too long, 8 BIG rows, 16 parts)
@@ -76,12 +82,12 @@ struct TaskCounters {
                                  // of the task loop, [4] cycles before the chain (expand + accumulate), [5] cycles after it (emit)
 };
 
-__device__ inline uint8_t row_class(uint64_t P, uint32_t L, uint32_t rmax)
+__device__ inline uint8_t row_class(uint64_t P, uint32_t L, uint32_t rmax, uint32_t lim)
 {
     if (P == 0) return CLS_EMPTY;
     if (L == 1) return CLS_COPY;
     if (P <= TK_SMALL_MAX && rmax > 1) return CLS_SMALL;
-    if (P <= TK_SOLO_MAX) return CLS_SOLO;
+    if (P <= lim) return CLS_SOLO;
     return CLS_BIG;
 }
 // ---- 1. entry descriptors + row statistics ---------------------------------------------------------------------------------
@@ -91,16 +97,108 @@ __device__ inline uint8_t row_class(uint64_t P, uint32_t L, uint32_t rmax)
 // segmented wave scan adds them up, and the last lane of every run adds the run to the row's totals (row_P, row_kmin,
 // row_kmax, preset to 0 / max / 0) with one device atomic each -- ~1 atomic triple per row, none of them contended.
 // k_row_class: one lane per row: class, statistics, the list of BIG rows.
+// How strongly do the products of this input collapse onto outputs?  EST_ROWS extra workgroups of k_entry_stats (they run next to
+// the statistics and need nothing from them); workgroup w looks at the first row at or behind row w * n / EST_ROWS (within EST_SCAN
+// rows) that has 2 .. 64 entries, and -- if it has 8 .. TK_NOUT_LO products -- counts its distinct output columns in an LDS hash
+// set.  The last one to finish sets TaskCounters::prod_limit: the larger table fill where the sampled products / outputs ratio is
+// at least EST_RATIO (cop20k_A 4.3, cage12 2.2 against mc2depi 1.6, web 1.4, and the short rows of R-MAT around 1), the default
+// otherwise, or when nothing could be sampled.  `fixed_limit` != 0 (sort-merge accumulator) skips the sampling.
+constexpr int EST_ROWS = 96, EST_SCAN = 64;
+constexpr unsigned long long EST_RATIO_NUM = 9, EST_RATIO_DEN = 5;   // 1.8
+__device__ inline void estimate_block(uint32_t w, uint32_t nw, const uint64_t *__restrict__ aptr, const uint32_t *__restrict__ aidx,
+                                      const uint64_t *__restrict__ bptr, const uint32_t *__restrict__ bidx, uint64_t r0,
+                                      uint32_t nrows, uint32_t fixed_limit, TaskCounters *__restrict__ ctr)
+{
+    __shared__ uint32_t s_keys[TK_T];
+    __shared__ uint32_t s_row, s_new, s_prod;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (fixed_limit) {
+        if (w == 0 && tid == 0) ctr->prod_limit = fixed_limit;
+        return;
+    }
+    if (wave == 0) {
+        // EST_SCAN candidate rows at once; then the products of the chosen one (one entry per lane)
+        const uint32_t start = (uint32_t)((uint64_t)w * nrows / nw), r = start + lane;
+        bool ok = false;
+        if (r < nrows) {
+            const uint64_t L = aptr[r0 + r + 1] - aptr[r0 + r];
+            ok = L >= 2 && L <= 64;
+        }
+        const unsigned long long m = __ballot(ok);
+        uint32_t row = 0xFFFFFFFFu, P = 0;
+        if (m) {
+            row = start + (uint32_t)(__ffsll((long long)m) - 1);
+            const uint64_t a0 = aptr[r0 + row], a1 = aptr[r0 + row + 1];
+            unsigned long long len = 0;
+            if (a0 + lane < a1) {
+                const uint32_t k = aidx[a0 + lane];
+                len = bptr[k + 1] - bptr[k];
+            }
+            len = wave_sum_u64(len);
+            P = len > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)len;
+            if (P < 8 || P > (uint32_t)TK_NOUT_LO) row = 0xFFFFFFFFu;
+        }
+        if (lane == 0) {
+            s_row = row;
+            s_prod = P;
+            s_new = 0;
+        }
+    }
+    for (int k = tid; k < TK_T; k += 256) s_keys[k] = EMPTY_KEY;
+    __syncthreads();
+    const uint32_t row = s_row;
+    if (row != 0xFFFFFFFFu) {
+        uint32_t fresh = 0;
+        for (uint64_t e = aptr[r0 + row] + wave; e < aptr[r0 + row + 1]; e += 4) {   // one wave per entry, lanes over its B row
+            const uint32_t k = aidx[e];
+            const uint64_t b0 = bptr[k];
+            const uint32_t len = (uint32_t)(bptr[k + 1] - b0);
+            for (uint32_t p = lane; p < len; p += 64) {
+                const uint32_t key = bidx[b0 + p];
+                uint32_t h = hash_slot<TK_LOG_T>(key);
+                for (;;) {
+                    const uint32_t o = atomicCAS(&s_keys[h], EMPTY_KEY, key);
+                    if (o == EMPTY_KEY) {
+                        ++fresh;
+                        break;
+                    }
+                    if (o == key) break;
+                    h = (h + 1) & (TK_T - 1);
+                }
+            }
+        }
+        if (fresh) atomicAdd(&s_new, fresh);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        if (row != 0xFFFFFFFFu) {
+            atomicAdd(&ctr->est_products, (unsigned long long)s_prod);
+            atomicAdd(&ctr->est_outputs, (unsigned long long)s_new);
+        }
+        __threadfence();
+        if (atomicAdd(&ctr->est_done, 1u) == nw - 1) {   // the last workgroup decides
+            const unsigned long long prods = atomicAdd(&ctr->est_products, 0ull), outs = atomicAdd(&ctr->est_outputs, 0ull);
+            ctr->prod_limit = (outs && prods * EST_RATIO_DEN >= outs * EST_RATIO_NUM) ? (uint32_t)TK_NOUT_HI : (uint32_t)TK_NOUT_LO;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_entry_stats(const uint64_t *__restrict__ aptr, const uint32_t *__restrict__ aidx,
                                                      const uint32_t *__restrict__ arow, const uint64_t *__restrict__ bptr,
                                                      const uint32_t *__restrict__ bidx, uint64_t r0, uint32_t nrows,
                                                      uint64_t *__restrict__ eb0, uint32_t *__restrict__ elen,
                                                      unsigned long long *__restrict__ row_P, uint32_t *__restrict__ row_kmin,
-                                                     uint32_t *__restrict__ row_kmax)
+                                                     uint32_t *__restrict__ row_kmax, uint32_t stat_blocks, uint32_t fixed_limit,
+                                                     TaskCounters *__restrict__ ctr)
 {
+    const uint32_t est_blocks = gridDim.x - stat_blocks;
+    if (blockIdx.x < est_blocks) {   // the sampling workgroups (above) come first: their chain of dependent loads overlaps the rest
+        estimate_block(blockIdx.x, est_blocks, aptr, aidx, bptr, bidx, r0, nrows, fixed_limit, ctr);
+        return;
+    }
     const uint64_t e0 = aptr[r0], e1 = aptr[r0 + nrows];
     const int lane = threadIdx.x & 63;
-    for (uint64_t q0 = e0 + (uint64_t)blockIdx.x * 256 + (threadIdx.x & ~63); q0 < e1; q0 += (uint64_t)gridDim.x * 256) {
+    for (uint64_t q0 = e0 + (uint64_t)(blockIdx.x - est_blocks) * 256 + (threadIdx.x & ~63); q0 < e1; q0 += (uint64_t)stat_blocks * 256) {
         const uint64_t q = q0 + lane;
         uint32_t row = 0xFFFFFFFFu, mn = 0xFFFFFFFFu, mx = 0;
         unsigned long long len = 0;
@@ -143,6 +241,7 @@ __global__ __launch_bounds__(256) void k_row_class(const uint64_t *__restrict__ 
                                                    uint8_t *__restrict__ row_cls, uint32_t *__restrict__ row_m,
                                                    uint32_t *__restrict__ big_rows, TaskCounters *__restrict__ ctr)
 {
+    const uint32_t lim = ctr->prod_limit;
     __shared__ unsigned long long s_rows[N_CLS], s_prod[N_CLS], s_tot;
     if (threadIdx.x < N_CLS) s_rows[threadIdx.x] = s_prod[threadIdx.x] = 0;
     if (threadIdx.x == 0) s_tot = 0;
@@ -155,7 +254,7 @@ __global__ __launch_bounds__(256) void k_row_class(const uint64_t *__restrict__ 
         if (i < nrows) {
             const unsigned long long P = row_P[i];
             const uint32_t L = (uint32_t)(aptr[r0 + i + 1] - aptr[r0 + i]);
-            cls = row_class(P, L, rmax);
+            cls = row_class(P, L, rmax, lim);
             row_nprod[i] = P > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)P;
             row_cls[i] = cls;
             row_m[i] = 0;
@@ -203,8 +302,8 @@ __global__ __launch_bounds__(256) void k_row_class(const uint64_t *__restrict__ 
 //   k_big_hist    one workgroup per part: its products (column indices only) counted in BX_NB column buckets of width
 //                 2^wshift over [kmin, kmax] of the row (LDS), stored per part
 //   k_big_plan    one workgroup per row: bucket counts of the row = sum over its parts; buckets grouped into column RANGES -- a
-//                 bucket with more than BX_HEAVY products is a range of its own, the others are packed greedily into ranges
-//                 of at most TK_SOLO_MAX = 1536 products, i.e. a light range fits one task's table whatever its outputs
+//                 bucket with more products than the limit is a range of its own, the others are packed greedily into ranges
+//                 of at most `limit` (1536 or 1792) products, i.e. a light range fits one task's table whatever its outputs
 //                 are; a heavy range holds at most 2^wshift distinct columns and is split further by the task itself if
 //                 both exceed the table (k_task, multi-pass).  Range descriptors go to `tmp` (bump allocated),
 //                 their number to row_m[row].  Then the row is either left to DIRECT range tasks, which find their products
@@ -240,14 +339,15 @@ constexpr int BP_EPL = 8;     // entries per lane and step
 constexpr int BP_ROWS = 16;   // rows per workgroup and round: their records are allocated with ONE device atomic per array (a
                               // single hot word sustains ~88 atomics / us: one per row would cost more than the kernel's work)
 // ranges of a row with P products, upper bound: a light range is closed when the next bucket does not fit, so two consecutive
-// ones hold more than TK_SOLO_MAX products together; a heavy bucket (> BX_HEAVY products) ends the range before it and is one itself
-__host__ __device__ inline uint32_t big_max_ranges(uint32_t P) { return 2u * (P / TK_SOLO_MAX) + 2u * (P / (BX_HEAVY + 1u)) + 3u; }
+// ones hold more than `lim` products together; a heavy bucket (more than `lim` products) ends the range before it and is one itself
+__host__ __device__ inline uint32_t big_max_ranges(uint32_t P, uint32_t lim) { return 2u * (P / lim) + 2u * (P / (lim + 1u)) + 3u; }
 
 __global__ __launch_bounds__(256) void k_big_parts(const uint64_t *__restrict__ aptr, const uint32_t *__restrict__ elen, uint64_t r0,
                                                    const uint32_t *__restrict__ big_rows, const uint32_t *__restrict__ row_nprod,
                                                    BigPart *__restrict__ parts, uint32_t part_cap, uint32_t *__restrict__ row_tmp,
                                                    uint32_t tmp_cap, BigSlot *__restrict__ slots, TaskCounters *__restrict__ ctr)
 {
+    const uint32_t lim = ctr->prod_limit;
     __shared__ uint32_t s_pbase[BP_ROWS], s_tbase[BP_ROWS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t nbig = ctr->n_big;
@@ -258,7 +358,7 @@ __global__ __launch_bounds__(256) void k_big_parts(const uint64_t *__restrict__ 
             const bool have = lane < BP_ROWS && sl < nbig;
             const uint32_t P = have ? row_nprod[big_rows[sl]] : 0u;
             const bool good = have && P != 0xFFFFFFFFu;
-            const uint32_t np = good ? P / BX_PART + 2u : 0u, nt = good ? big_max_ranges(P) : 0u;
+            const uint32_t np = good ? P / BX_PART + 2u : 0u, nt = good ? big_max_ranges(P, lim) : 0u;
             uint32_t ip = np, it = nt;
 #pragma unroll
             for (int o = 1; o < BP_ROWS; o <<= 1) {
@@ -300,7 +400,7 @@ __global__ __launch_bounds__(256) void k_big_parts(const uint64_t *__restrict__ 
             slots[slot] = BigSlot{0ull, 0u, 0u, base, ub, {0u, 0u}};
             row_tmp[row] = tbase;
             if (!fits) atomicOr(&ctr->abort_flag, 16u);
-            if ((unsigned long long)tbase + big_max_ranges(P) > tmp_cap) atomicOr(&ctr->abort_flag, 1u);
+            if ((unsigned long long)tbase + big_max_ranges(P, lim) > tmp_cap) atomicOr(&ctr->abort_flag, 1u);
         }
         if (!fits) continue;
         uint32_t carry = 0, nstart = 0;   // products / parts before this step
@@ -431,6 +531,7 @@ __global__ __launch_bounds__(TK_BLOCK) void k_big_plan(const uint64_t *__restric
                                                        const uint32_t *__restrict__ row_tmp, TaskDesc *__restrict__ tmp, uint32_t tmp_cap,
                                                        BigSlot *__restrict__ slots, uint64_t scr_cap, TaskCounters *__restrict__ ctr)
 {
+    const uint32_t lim = ctr->prod_limit;
     constexpr int NB = BX_NB, BPT = NB / TK_BLOCK;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *hdr = (uint32_t *)smem;
@@ -478,7 +579,7 @@ __global__ __launch_bounds__(TK_BLOCK) void k_big_plan(const uint64_t *__restric
 #pragma unroll
             for (int k = 0; k < BPT; ++k) {
                 const int bk = tid * BPT + k;
-                forced[k] = (bk == 0 || cnt[bk] > BX_HEAVY || cnt[bk - (bk > 0)] > BX_HEAVY) ? 1u : 0u;
+                forced[k] = (bk == 0 || cnt[bk] > lim || cnt[bk - (bk > 0)] > lim) ? 1u : 0u;
             }
             __syncthreads();   // (cnt is read above and reused for the pointers below)
 #pragma unroll
@@ -496,12 +597,12 @@ __global__ __launch_bounds__(TK_BLOCK) void k_big_plan(const uint64_t *__restric
             for (int k = 0; k < BPT; ++k) {
                 const uint32_t bk = tid * BPT + k;
                 const uint32_t nf = rfirst[fex[k] + forced[k]];   // next forced start behind bk
-                // largest e with pre[e] - pre[bk] <= TK_SOLO_MAX (pre[NB] = P)
-                const uint32_t lim = pre[bk] + TK_SOLO_MAX;
+                // largest e with pre[e] - pre[bk] <= lim (pre[NB] = P)
+                const uint32_t plim = pre[bk] + lim;
                 uint32_t lo = bk + 1, n = NB - bk;   // e in [bk + 1, NB]: first e with pre[e] > lim, minus one ... searched as upper bound
                 while (n) {
                     const uint32_t h = n >> 1;
-                    if (pre[lo + h] <= lim) {
+                    if (pre[lo + h] <= plim) {
                         lo += h + 1;
                         n -= h + 1;
                     } else {
@@ -551,7 +652,7 @@ __global__ __launch_bounds__(TK_BLOCK) void k_big_plan(const uint64_t *__restric
         for (int k = 0; k < BPT; ++k)
             if (nef[k]) {   // a range that needs several passes (more than TK_SOLO_MAX products AND columns) exists only on scratch
                 const uint32_t r = tid * BPT + k, f0 = rfirst[r], f1 = rfirst[r + 1];
-                if (pre[f1] - pre[f0] > TK_SOLO_MAX && ((uint64_t)(f1 - f0) << wshift) > TK_SOLO_MAX) hdr[47] = 1;
+                if (pre[f1] - pre[f0] > lim && ((uint64_t)(f1 - f0) << wshift) > lim) hdr[47] = 1;
             }
         group_exclusive_scan<TK_BLOCK, NB>(aux, tid, hdr + 2);
         if (tid == TK_BLOCK - 1) {
@@ -713,8 +814,8 @@ struct CutLds {
 
 // tasks started by every row of the tile; returns the exclusive prefix of this thread's first row and the tile total
 __device__ inline uint32_t cut_tile(const uint8_t *__restrict__ row_cls, const uint32_t *__restrict__ row_nprod,
-                                    const uint32_t *__restrict__ row_m, uint32_t n, uint32_t rmax, CutLds &L, CutRow &cr,
-                                    uint32_t *tile_total)
+                                    const uint32_t *__restrict__ row_m, uint32_t n, uint32_t rmax, uint32_t lim, CutLds &L,
+                                    CutRow &cr, uint32_t *tile_total)
 {
     const uint32_t tile_base = blockIdx.x * CUT_TILE, base = tile_base + threadIdx.x * CUT_ITEMS;
     const uint32_t cnt = min((uint32_t)CUT_TILE, n - tile_base);
@@ -725,7 +826,7 @@ __device__ inline uint32_t cut_tile(const uint8_t *__restrict__ row_cls, const u
         const uint32_t i = base + j;
         cls[j] = i < n ? row_cls[i] : CLS_EMPTY;
         const uint32_t P = i < n ? row_nprod[i] : 0u;
-        c[j] = cls[j] == CLS_BIG ? TK_SOLO_MAX + 1 : ((cls[j] == CLS_SMALL || cls[j] == CLS_SOLO) ? P : 0u);
+        c[j] = cls[j] == CLS_BIG ? lim + 1 : ((cls[j] == CLS_SMALL || cls[j] == CLS_SOLO) ? P : 0u);
         w[j] = cls[j] == CLS_COPY ? min(P, CUT_COPY_MAX) : 0u;
         L.mark[threadIdx.x * CUT_ITEMS + j] = 0;
         sc += c[j];
@@ -753,7 +854,7 @@ __device__ inline uint32_t cut_tile(const uint8_t *__restrict__ row_cls, const u
         const uint32_t li = threadIdx.x * CUT_ITEMS + j;
         uint32_t nx = li + 1;
         if (li < cnt && cls[j] != CLS_BIG) {
-            const uint32_t limc = L.pc[li] + TK_SOLO_MAX, limw = L.pw[li] + CUT_COPY_MAX;
+            const uint32_t limc = L.pc[li] + lim, limw = L.pw[li] + CUT_COPY_MAX;
             uint32_t lo = li + 1, hi = min(cnt, li + rmax);   // invariant: lo is feasible
             while (lo < hi) {
                 const uint32_t mid = (lo + hi + 1) >> 1;
@@ -773,8 +874,8 @@ __device__ inline uint32_t cut_tile(const uint8_t *__restrict__ row_cls, const u
         if (li >= cnt) continue;
         if (cls[j] == CLS_BIG) {
             L.mark[li] = 1;
-        } else if (li == 0 || L.pc[li] - L.pc[li - 1] > TK_SOLO_MAX) {   // the row before is BIG
-            for (uint32_t i = li; i < cnt && L.pc[i + 1] - L.pc[i] <= TK_SOLO_MAX; i = L.nxt[i]) L.mark[i] = 1;
+        } else if (li == 0 || L.pc[li] - L.pc[li - 1] > lim) {   // the row before is BIG
+            for (uint32_t i = li; i < cnt && L.pc[i + 1] - L.pc[i] <= lim; i = L.nxt[i]) L.mark[i] = 1;
         }
     }
     __syncthreads();
@@ -797,12 +898,14 @@ __device__ inline uint32_t cut_tile(const uint8_t *__restrict__ row_cls, const u
 // k_cut1: tasks started by every row -> row_t (0: none; BIG rows: their range tasks; else 1) and the tile totals
 __global__ __launch_bounds__(256) void k_cut1(const uint8_t *__restrict__ row_cls, const uint32_t *__restrict__ row_nprod,
                                               const uint32_t *__restrict__ row_m, uint32_t n, uint32_t rmax,
-                                              uint32_t *__restrict__ tile_tasks, uint32_t *__restrict__ row_t)
+                                              const TaskCounters *__restrict__ ctr, uint32_t *__restrict__ tile_tasks,
+                                              uint32_t *__restrict__ row_t)
 {
+    const uint32_t lim = ctr->prod_limit;
     __shared__ CutLds L;
     CutRow cr;
     uint32_t tot;
-    (void)cut_tile(row_cls, row_nprod, row_m, n, rmax, L, cr, &tot);
+    (void)cut_tile(row_cls, row_nprod, row_m, n, rmax, lim, L, cr, &tot);
     if (threadIdx.x == 0) tile_tasks[blockIdx.x] = tot;
     const uint32_t base = blockIdx.x * CUT_TILE + threadIdx.x * CUT_ITEMS;
 #pragma unroll
@@ -1054,11 +1157,11 @@ __device__ inline unsigned long long chain_lookback(unsigned long long *status, 
 // caller's buffers are too small) and the outputs are stored.  Returns what resolve() returned.
 // s_row[lr] = {boff, n, kmin, scale}, s_out[lr] = first output of the row relative to that position.  NO = outputs in the table.
 constexpr unsigned long long NO_STORE = ~0ull;
-template <bool SINGLE_ROW, class Resolve>
+template <bool SINGLE_ROW, int NOUT, class Resolve>
 __device__ inline unsigned long long emit_table(unsigned char *smem, uint32_t NO, uint32_t colbits, uint32_t *__restrict__ c_idx,
                                                 double *__restrict__ c_val, Resolve &&resolve)
 {
-    constexpr int BLOCK = TK_BLOCK, T = TK_T, NOUT = TK_NOUT, SPT = T / BLOCK, OPT = NOUT / BLOCK;
+    constexpr int BLOCK = TK_BLOCK, T = TK_T, SPT = T / BLOCK, OPT = NOUT / BLOCK;
     uint32_t *hdr = (uint32_t *)smem;
     uint32_t *keys = (uint32_t *)(smem + 256);
     double *vals = (double *)(keys + T);
@@ -1218,7 +1321,7 @@ __device__ inline uint32_t range_count_products(unsigned char *smem, const uint3
 // range, ascending; a leaf holds <= TK_SOLO_MAX products or <= TK_SOLO_MAX columns, so it fits.  The walk is deterministic: it is
 // run once to count (the chain needs the task's total before anything is stored) and once more to emit.
 // `stack` = 2 * 40 words of LDS that nothing else uses during a RANGE task.
-template <bool EMIT>
+template <bool EMIT, int NOUT>
 __device__ inline uint32_t range_dfs(unsigned char *smem, uint32_t *stack, RowEmit *s_row, uint64_t *s_out, const TaskDesc &td,
                                      const uint32_t *__restrict__ scr_col, const double *__restrict__ scr_val,
                                      unsigned long long base, uint32_t *__restrict__ c_idx, double *__restrict__ c_val)
@@ -1236,7 +1339,7 @@ __device__ inline uint32_t range_dfs(unsigned char *smem, uint32_t *stack, RowEm
         __syncthreads();
         const uint32_t cntp = range_count_products(smem, scr_col, td.src, td.np, lo, hi);
         if (cntp == 0) continue;
-        if (cntp > TK_SOLO_MAX && hi - lo >= TK_SOLO_MAX) {
+        if (cntp > (uint32_t)NOUT && hi - lo >= (uint32_t)NOUT) {
             const uint32_t mid = lo + (hi - lo) / 2;
             if (tid == 0) {   // upper half below the lower half: the lower half is popped first
                 stack[2 * sp] = mid + 1;
@@ -1256,7 +1359,7 @@ __device__ inline uint32_t range_dfs(unsigned char *smem, uint32_t *stack, RowEm
                     s_out[0] = base + total;
                 }
                 __syncthreads();
-                (void)emit_table<true>(smem, nl, 32u, c_idx, c_val, []() -> unsigned long long { return 0ull; });
+                (void)emit_table<true, NOUT>(smem, nl, 32u, c_idx, c_val, []() -> unsigned long long { return 0ull; });
             }
         }
         total += nl;
@@ -1345,9 +1448,11 @@ __device__ inline uint32_t direct_accumulate(unsigned char *smem, unsigned char 
     return n;
 }
 
-template <int MODE>
+template <int MODE, int NOUT>
 __global__ __launch_bounds__(TK_BLOCK, 4) void k_task(const TaskArgs g)
 {
+    // (both builds are launched: the one whose capacity is not the input's limit leaves at once)
+    if ((g.ctr->prod_limit > (uint32_t)TK_NOUT_LO) != (NOUT == TK_NOUT_HI)) return;
     constexpr int BLOCK = TK_BLOCK, EPT = TK_EPT, T = TK_T, RMAX = TK_RMAX, U = SPADA_FLAT_U;
     constexpr bool VALUES = MODE != MODE_COUNT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1512,7 +1617,7 @@ __global__ __launch_bounds__(TK_BLOCK, 4) void k_task(const TaskArgs g)
                     s_out[tid] = MODE == MODE_NUMERIC ? c0 : (uint64_t)ooff;
                 }
                 __syncthreads();
-                base = emit_table<false>(smem, NO, g.colbits, g.c_idx, g.c_val, resolve);
+                base = emit_table<false, NOUT>(smem, NO, g.colbits, g.c_idx, g.c_val, resolve);
             } else {
                 base = resolve();
             }
@@ -1569,7 +1674,7 @@ __global__ __launch_bounds__(TK_BLOCK, 4) void k_task(const TaskArgs g)
             // ---- RANGE task: columns [col_lo, col_hi] of a BIG row, products in the scratch slice -----------------------------
             // Single pass when the slice cannot overflow the table (<= TK_SOLO_MAX products or columns), else range_dfs.
             const bool direct = td.kind == TASK_RANGE_DIRECT;
-            const bool single = direct || td.np <= TK_SOLO_MAX || td.col_hi - td.col_lo < TK_SOLO_MAX;
+            const bool single = direct || td.np <= (uint32_t)NOUT || td.col_hi - td.col_lo < (uint32_t)NOUT;
             uint32_t total;
             if (direct) {
                 total = direct_accumulate<VALUES>(smem, region2, s_re, s_a0, g, td);
@@ -1577,7 +1682,7 @@ __global__ __launch_bounds__(TK_BLOCK, 4) void k_task(const TaskArgs g)
                 total = range_accumulate<VALUES>(smem, g.scr_col, g.scr_val, td.src, td.np, td.col_lo, td.col_hi, false);
             } else {
                 if (tid == 0) atomicAdd(&g.ctr->multi_pass_tasks, 1u);
-                total = range_dfs<false>(smem, s_re, s_row, s_out, td, g.scr_col, g.scr_val, 0ull, nullptr, nullptr);
+                total = range_dfs<false, NOUT>(smem, s_re, s_row, s_out, td, g.scr_col, g.scr_val, 0ull, nullptr, nullptr);
             }
             if (SPADA_TASK_DBG) dbg_b = dbg_c = __builtin_amdgcn_s_memtime();
             if constexpr (MODE != MODE_NUMERIC) chain_publish(g.status, t, total);
@@ -1622,11 +1727,11 @@ __global__ __launch_bounds__(TK_BLOCK, 4) void k_task(const TaskArgs g)
                     s_out[0] = 0;
                 }
                 __syncthreads();
-                (void)emit_table<true>(smem, total, 32u, g.c_idx, g.c_val, resolve);
+                (void)emit_table<true, NOUT>(smem, total, 32u, g.c_idx, g.c_val, resolve);
             } else {
                 const unsigned long long base = resolve();
                 if (MODE != MODE_COUNT && !single && base != NO_STORE)
-                    (void)range_dfs<true>(smem, s_re, s_row, s_out, td, g.scr_col, g.scr_val, base, g.c_idx, g.c_val);
+                    (void)range_dfs<true, NOUT>(smem, s_re, s_row, s_out, td, g.scr_col, g.scr_val, base, g.c_idx, g.c_val);
             }
             if (SPADA_TASK_DBG) dbg_c = dbg_b + dbg_w;
         }

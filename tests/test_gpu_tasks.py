@@ -53,6 +53,23 @@ def test_fused_generated_workloads(engine, name, kind, p0, p1, seed):
     assert st["scratch_products"] <= st["cls_prod"][4] and st["spill_rows"] <= st["cls_rows"][4]
 
 
+def test_task_capacity_follows_the_sampled_compression(engine):
+    """The sampling workgroups of the statistics launch pick 1792 products per task where products collapse onto few outputs
+    (mesh-like inputs: compression 4.3 / 2.2) and 1536 where they do not (web-like 1.4, stencil 1.6); both builds of the task
+    kernel give the oracle's product."""
+    import spada_sim_amd as S
+    seen = {}
+    for name, kind, p0, p1, seed in (("cop20k", S.GEN_COP20K_LIKE, 20000, 0, 5), ("cage12", S.GEN_CAGE12_LIKE, 20000, 0, 6),
+                                     ("web", S.GEN_WEBBASE_LIKE, 50000, 155000, 4), ("mc2depi", S.GEN_MC2DEPI_LIKE, 779 * 40, 0, 7)):
+        m = S.generate(kind, p0, p1, seed)
+        c, st = fused(engine, m, m)
+        a = to_oracle(m)
+        assert_parity(c, oracle.spgemm_spa(a, a), a, a, RTOL)
+        seen[name] = st["task_product_limit"]
+    assert seen["cop20k"] == 1792 and seen["cage12"] == 1792, seen
+    assert seen["web"] == 1536 and seen["mc2depi"] == 1536, seen
+
+
 @pytest.mark.parametrize("seed", range(24))
 def test_fused_random_sweep(engine, seed):
     a, b, desc = random_case(seed)

@@ -400,7 +400,9 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": (traffic or {}).get("k_task<2>" if one_pass else "k_task<1>", {}).get("hbm_bytes_per_launch"),
+                # (two builds of the task kernel are launched, k_task<mode, 1536> and k_task<mode, 1792>: the one that does the work)
+                "traffic": max([v.get("hbm_bytes_per_launch") or 0 for k, v in (traffic or {}).items()
+                                if isinstance(v, dict) and k.startswith("k_task<2" if one_pass else "k_task<1")] or [None]) or None,
                 "traffic_source": os.path.relpath(traffic_src, ROOT) if traffic else None,
                 "kernel_ms": k_ms,
                 "kernel_algorithmic_bytes_read": st["bytes_read"],

@@ -5,21 +5,22 @@
 // (simulator.rs:86-230) and the partial-fiber merging (scheduler.rs:381-480, adder_tree.rs:145-188) become one LDS
 // accumulator per task; psum write-back and result assembly (simulator.rs:955-1062) become the chained output offsets.
 //
-//   rows of C            ->  classes by products P_i: EMPTY | COPY (one A entry: C_i = a * B_k) | SMALL (P <= 512, shares a
-//                            batch with its neighbours) | SOLO (P <= 1536: a batch of its own) | BIG (larger)
+//   table fill           ->  `limit` = products a task hashes at most: 1536 or 1792 of the 2048 slots, chosen on the device from a
+//                            sampled products / outputs ratio of the input (estimate_block, inside the statistics launch)
+//   rows of C            ->  classes by products P_i: EMPTY | COPY (one A entry: C_i = a * B_k) | SMALL (P <= 512) | SOLO
+//                            (P <= limit), both packed into batches with their neighbours | BIG (larger)
 //   BIG rows             ->  k_big_parts / k_big_hist / k_big_plan: histogram of the row's products over <= 1024 column buckets
-//                            (the row cut into parts of ~8192 products, one workgroup each), buckets merged into column RANGES
-//                            of < 1536 products; every range becomes a task of its own.  A DIRECT range task finds its
+//                            (the row cut into parts of ~8192 products, one workgroup each), buckets packed greedily into column
+//                            RANGES of <= limit products; every range becomes a task of its own.  A DIRECT range task finds its
 //                            products in B itself (B rows are ascending: two binary searches narrow each selected B row to
 //                            the range); rows for which that costs more than a spill (thousands of entries, hundreds of
 //                            ranges: R-MAT hubs) have their products scattered into HBM scratch range by range
 //                            (k_big_scatter, the "spill" of rows whose accumulator does not fit LDS)
-//   task list            ->  k_cut1/2/3: consecutive non-BIG rows are cut into batches of < 1536 products; tasks are numbered in
+//   task list            ->  k_cut1/2/3: consecutive non-BIG rows are cut into batches of <= limit products; tasks are numbered in
 //                            output order (row, then column range)
 //   k_task               ->  persistent workgroups take tasks by ticket.  A task expands its products (flat walk over the A
 //                            entries of its rows, narrowed to a column range or not, or a stream over its scratch slice),
-//                            accumulates them in a 2048-slot LDS
-//                            hash table (ds_cmpst / ds_add_f64), counts the distinct outputs per row, obtains the position
+//                            accumulates them in a 2048-slot LDS hash table (ds_cmpst / ds_add_f64), counts the distinct outputs per row, obtains the position
 //                            of its slice of C from the tasks before it by a decoupled look-back over per-task status words,
 //                            and emits its outputs in (row, column) order (monotone buckets + in-bucket rank).
 //                            MODE COUNT   : symbolic phase of the two-phase ABI -- counts only, writes C.indptr

@@ -231,10 +231,7 @@ void launch_task(spada_ctx *c, const TaskArgs &g)
     if (c->accumulator == SPADA_ACC_SORT_MERGE)
         hipLaunchKernelGGL(k_task_sm<MODE>, dim3(c->n_cu * 3), dim3(TK_BLOCK), task_sm_lds(), c->stream, g);
     else
-    {
-        hipLaunchKernelGGL((k_task<MODE, TK_NOUT_LO>), dim3(c->n_cu * 4), dim3(TK_BLOCK), task_lds(), c->stream, g);
-        hipLaunchKernelGGL((k_task<MODE, TK_NOUT_HI>), dim3(c->n_cu * 4), dim3(TK_BLOCK), task_lds(), c->stream, g);
-    }
+        hipLaunchKernelGGL((k_task<MODE, TK_NOUT>), dim3(c->n_cu * 4), dim3(TK_BLOCK), task_lds(), c->stream, g);
 }
 
 TaskArgs task_args(spada_ctx *c, uint64_t *cptr, uint32_t *d_idx, double *d_val, uint64_t capacity)
@@ -519,9 +516,9 @@ int spada_create(const spada_options *opts, spada_ctx **out)
     for (auto &e : c->tev) HIP_TRY(hipEventCreate(&e));
     c->n_cu = (uint32_t)std::max(1, prop.multiProcessorCount);
     int rc;
-    if ((rc = allow_lds(k_task<MODE_COUNT, TK_NOUT_LO>, task_lds())) || (rc = allow_lds(k_task<MODE_COUNT, TK_NOUT_HI>, task_lds()))) return rc;
-    if ((rc = allow_lds(k_task<MODE_NUMERIC, TK_NOUT_LO>, task_lds())) || (rc = allow_lds(k_task<MODE_NUMERIC, TK_NOUT_HI>, task_lds()))) return rc;
-    if ((rc = allow_lds(k_task<MODE_FUSED, TK_NOUT_LO>, task_lds())) || (rc = allow_lds(k_task<MODE_FUSED, TK_NOUT_HI>, task_lds()))) return rc;
+    if ((rc = allow_lds(k_task<MODE_COUNT, TK_NOUT>, task_lds()))) return rc;
+    if ((rc = allow_lds(k_task<MODE_NUMERIC, TK_NOUT>, task_lds()))) return rc;
+    if ((rc = allow_lds(k_task<MODE_FUSED, TK_NOUT>, task_lds()))) return rc;
     if ((rc = allow_lds(k_task_sm<MODE_COUNT>, task_sm_lds()))) return rc;
     if ((rc = allow_lds(k_task_sm<MODE_NUMERIC>, task_sm_lds()))) return rc;
     if ((rc = allow_lds(k_task_sm<MODE_FUSED>, task_sm_lds()))) return rc;

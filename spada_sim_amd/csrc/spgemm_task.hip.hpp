@@ -39,17 +39,19 @@ namespace spada {
 constexpr uint8_t CLS_EMPTY = 0, CLS_COPY = 1, CLS_SMALL = 2, CLS_SOLO = 3, CLS_BIG = 4;
 constexpr int N_CLS = 5;
 constexpr int TK_BLOCK = 256, TK_EPT = 2, TK_LOG_T = 11, TK_T = 1 << TK_LOG_T, TK_RMAX = 128;
-// Products a task hashes at most = its table capacity in outputs.  Two builds of the task kernel: 1536 (0.75 of the table) and
-// 1792 (0.875).  Fuller tables mean fewer tasks, but the probe sequences of a table that really fills up get long: 1792 wins where
-// products collapse onto few outputs (measured: -10 % on the cop20k_A surrogate, compression 4.3; -9 % on cage12, 2.2) and loses
-// where they do not (+17 % on the web surrogate, 1.4).  k_estimate samples the compression of the input and picks the limit
-// (TaskCounters::prod_limit); classification, ranges and batches follow it, and only the matching build of k_task does the work.
-constexpr int TK_NOUT_LO = 1536, TK_NOUT_HI = 1792, TK_NOUT = TK_NOUT_HI;   // TK_NOUT: what the LDS layout is sized for
+// Products a task hashes at most (`limit`): the table has TK_T = 2048 slots and is probed by double hashing, which stays cheap up to
+// high fills, so fuller tables win -- fewer tasks, fewer chain hops -- until the probe sequences of a table that REALLY fills up
+// get long: inputs whose products collapse onto few outputs (cop20k_A 4.3-fold, cage12 2.2) are fastest at 2040 products per
+// task, inputs whose products mostly stay distinct (web 1.4, R-MAT) at 1920 (measured sweep in DESIGN.md).  estimate_block samples
+// the products / outputs ratio of the input and picks the limit on the device (TaskCounters::prod_limit); classification, ranges
+// and batches follow it.  At most TK_T - 8 products per task: the table keeps empty slots, so every probe sequence ends.
+constexpr int TK_NOUT = TK_T;                          // outputs the emission's LDS arrays are sized for
+constexpr uint32_t TK_LIMIT_LO = 1920, TK_LIMIT_HI = 2040;
 constexpr uint32_t TK_SMALL_MAX = 512;   // class boundary SMALL | SOLO (statistics only: both are packed into batches)
-constexpr uint32_t TK_SOLO_MAX = TK_NOUT_LO;   // the default limit (and the sort-merge accumulator's); rows above the limit are BIG
+constexpr uint32_t TK_SOLO_MAX = 1536;   // the sort-merge accumulator's limit (its network holds 2048 pairs)
 constexpr int TK_NQ = 16;                // ticket queues: task t belongs to queue t % TK_NQ, workgroup b serves queue b % TK_NQ
 constexpr int BX_NB = 1024;              // column buckets of the big-row histogram
-static_assert(TK_SOLO_MAX <= TK_NOUT && TK_NOUT < TK_T && TK_NOUT_LO % TK_BLOCK == 0 && TK_NOUT_HI % TK_BLOCK == 0, "the table must keep an empty slot");
+static_assert(TK_LIMIT_LO <= TK_LIMIT_HI && TK_LIMIT_HI + 8 <= (uint32_t)TK_T && TK_NOUT % TK_BLOCK == 0, "the table must keep empty slots");
 
 struct TaskDesc {
     uint32_t kind;      // TASK_BATCH: rows [row, row of the next task) | TASK_RANGE: columns [col_lo, col_hi] of BIG row `row`
@@ -100,7 +102,7 @@ __device__ inline uint8_t row_class(uint64_t P, uint32_t L, uint32_t rmax, uint3
 // k_row_class: one lane per row: class, statistics, the list of BIG rows.
 // How strongly do the products of this input collapse onto outputs?  EST_ROWS extra workgroups of k_entry_stats (they run next to
 // the statistics and need nothing from them); workgroup w looks at the first row at or behind row w * n / EST_ROWS (within EST_SCAN
-// rows) that has 2 .. 64 entries, and -- if it has 8 .. TK_NOUT_LO products -- counts its distinct output columns in an LDS hash
+// rows) that has 2 .. 64 entries, and -- if it has 8 .. TK_LIMIT_LO products -- counts its distinct output columns in an LDS hash
 // set.  The last one to finish sets TaskCounters::prod_limit: the larger table fill where the sampled products / outputs ratio is
 // at least EST_RATIO (cop20k_A 4.3, cage12 2.2 against mc2depi 1.6, web 1.4, and the short rows of R-MAT around 1), the default
 // otherwise, or when nothing could be sampled.  `fixed_limit` != 0 (sort-merge accumulator) skips the sampling.
@@ -137,7 +139,7 @@ __device__ inline void estimate_block(uint32_t w, uint32_t nw, const uint64_t *_
             }
             len = wave_sum_u64(len);
             P = len > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)len;
-            if (P < 8 || P > (uint32_t)TK_NOUT_LO) row = 0xFFFFFFFFu;
+            if (P < 8 || P > TK_LIMIT_LO) row = 0xFFFFFFFFu;
         }
         if (lane == 0) {
             s_row = row;
@@ -179,7 +181,7 @@ __device__ inline void estimate_block(uint32_t w, uint32_t nw, const uint64_t *_
         __threadfence();
         if (atomicAdd(&ctr->est_done, 1u) == nw - 1) {   // the last workgroup decides
             const unsigned long long prods = atomicAdd(&ctr->est_products, 0ull), outs = atomicAdd(&ctr->est_outputs, 0ull);
-            ctr->prod_limit = (outs && prods * EST_RATIO_DEN >= outs * EST_RATIO_NUM) ? (uint32_t)TK_NOUT_HI : (uint32_t)TK_NOUT_LO;
+            ctr->prod_limit = (outs && prods * EST_RATIO_DEN >= outs * EST_RATIO_NUM) ? TK_LIMIT_HI : TK_LIMIT_LO;
         }
     }
 }
@@ -1243,6 +1245,14 @@ __device__ inline unsigned long long emit_table(unsigned char *smem, uint32_t NO
     return base;
 }
 
+// Double hashing: the probe sequence of a key advances by an odd step of its own (odd: it visits every slot of the power-of-two
+// table).  A wave waits for the longest probe sequence among its 64 lanes, and linear probing's clusters make that tail long.
+#ifndef SPADA_X_LINEAR
+__device__ inline uint32_t probe_step(uint32_t key) { return ((key * 0x85EBCA6Bu) >> (32 - TK_LOG_T)) | 1u; }
+#else
+__device__ inline uint32_t probe_step(uint32_t) { return 1u; }
+#endif
+
 __device__ inline void table_clear(unsigned char *smem)
 {
     uint4 *k4 = (uint4 *)(smem + 256);
@@ -1256,12 +1266,13 @@ template <bool VALUES>
 __device__ inline bool table_insert(uint32_t *keys, double *vals, uint32_t key, double v)
 {
     uint32_t h = hash_slot<TK_LOG_T>(key);
+    const uint32_t step = probe_step(key);
     bool isnew = false;
     for (;;) {
         const uint32_t o = atomicCAS(&keys[h], EMPTY_KEY, key);
         if (o == EMPTY_KEY) { isnew = true; break; }
         if (o == key) break;
-        h = (h + 1) & (TK_T - 1);
+        h = (h + step) & (TK_T - 1);
     }
     if constexpr (VALUES) atomicAdd(&vals[h], v);   // simulator.rs:213-218 (order differs)
     return isnew;
@@ -1452,8 +1463,6 @@ __device__ inline uint32_t direct_accumulate(unsigned char *smem, unsigned char 
 template <int MODE, int NOUT>
 __global__ __launch_bounds__(TK_BLOCK, 4) void k_task(const TaskArgs g)
 {
-    // (both builds are launched: the one whose capacity is not the input's limit leaves at once)
-    if ((g.ctr->prod_limit > (uint32_t)TK_NOUT_LO) != (NOUT == TK_NOUT_HI)) return;
     constexpr int BLOCK = TK_BLOCK, EPT = TK_EPT, T = TK_T, RMAX = TK_RMAX, U = SPADA_FLAT_U;
     constexpr bool VALUES = MODE != MODE_COUNT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1548,8 +1557,9 @@ __global__ __launch_bounds__(TK_BLOCK, 4) void k_task(const TaskArgs g)
                         for (int u = 0; u < U; ++u) {
                             bool isnew = old[u] == EMPTY_KEY;
                             if (!isnew && old[u] != key[u]) {
+                                const uint32_t step = probe_step(key[u]);
                                 for (;;) {
-                                    h[u] = (h[u] + 1) & (T - 1);
+                                    h[u] = (h[u] + step) & (T - 1);
                                     const uint32_t o = atomicCAS(&keys[h[u]], EMPTY_KEY, key[u]);
                                     if (o == EMPTY_KEY) { isnew = true; break; }
                                     if (o == key[u]) break;

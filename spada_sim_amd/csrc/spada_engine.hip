@@ -248,6 +248,7 @@ TaskArgs task_args(spada_ctx *c, uint64_t *cptr, uint32_t *d_idx, double *d_val,
     g.colbits = c->colbits;
     g.row_cls = c->row_bin.as<uint8_t>();
     g.row_kmin = c->row_kmin.as<uint32_t>();
+    g.row_nprod = c->row_nprod.as<uint32_t>();
     g.row_kmax = c->row_kmax.as<uint32_t>();
     g.tasks = c->t_tasks.as<TaskDesc>();
     g.scr_col = c->t_scrcol.as<uint32_t>();

@@ -1036,7 +1036,7 @@ struct TaskArgs {
     uint32_t nrows;
     uint32_t colbits;
     const uint8_t *row_cls;
-    const uint32_t *row_kmin, *row_kmax;
+    const uint32_t *row_kmin, *row_kmax, *row_nprod;
     const TaskDesc *tasks;
     const uint32_t *scr_col;
     const double *scr_val;
@@ -1524,9 +1524,10 @@ __global__ __launch_bounds__(TK_BLOCK, 4) void k_task(const TaskArgs g)
                     kmin = g.row_kmin[rid];
                     kmax = g.row_kmax[rid];
                 } else if (cls == CLS_COPY) {
-                    cb0 = g.eb0[a0];
-                    clen = g.elen[a0];
-                    if constexpr (VALUES) cav = g.aval[a0];
+                    // the length of the one selected B row = the row's products: an independent load.  Where that B row starts
+                    // and the A value are only needed for the copy itself: they are fetched after the count has been published
+                    // (everything before the publication is waited for by the tasks behind this one)
+                    clen = g.row_nprod[rid];
                 }
                 if constexpr (MODE == MODE_NUMERIC) {
                     c0 = g.cptr[rid];
@@ -1643,6 +1644,11 @@ __global__ __launch_bounds__(TK_BLOCK, 4) void k_task(const TaskArgs g)
                 double *s_cav = (double *)(s_cb0 + RMAX);
                 uint64_t *s_cc0 = (uint64_t *)(s_cav + RMAX);
                 const bool copy = (uint32_t)tid < R && cls == CLS_COPY;
+                if (copy) {
+                    const uint64_t a0 = s_a0[tid];
+                    cb0 = g.eb0[a0];
+                    if constexpr (VALUES) cav = g.aval[a0];
+                }
                 uint32_t Cp;
                 const uint32_t cex = group_scan_excl<BLOCK>(copy ? clen : 0u, tid, hdr + 2, &Cp);
                 if (Cp) {   // uniform

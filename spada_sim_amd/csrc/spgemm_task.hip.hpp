@@ -1513,32 +1513,37 @@ __global__ __launch_bounds__(TK_BLOCK, 4) void k_task(const TaskArgs g)
             uint64_t cb0 = 0, c0 = 0;
             double cav = 0.0;
             uint8_t cls = CLS_EMPTY;
+            // one round trip for everything a row needs before the walk: the loads are independent of each other (class, column
+            // bounds and product count are fetched for every row of the batch, whatever its class turns out to be), and the table
+            // is cleared while they are in flight -- all of this sits before the publication of the count
+            uint64_t a0 = 0, a1 = 0;
+            uint32_t np_row = 0;
             if ((uint32_t)tid < R) {
                 rid = rb + tid;
-                const uint64_t a0 = g.aptr[g.r0 + rid], a1 = g.aptr[g.r0 + rid + 1];
+                a0 = g.aptr[g.r0 + rid];
+                a1 = g.aptr[g.r0 + rid + 1];
                 cls = g.row_cls[rid];
-                s_a0[tid] = a0;
-                s_cnt[tid] = 0;
-                if (cls == CLS_SMALL || cls == CLS_SOLO) {
-                    L = (uint32_t)(a1 - a0);
-                    kmin = g.row_kmin[rid];
-                    kmax = g.row_kmax[rid];
-                } else if (cls == CLS_COPY) {
-                    // the length of the one selected B row = the row's products: an independent load.  Where that B row starts
-                    // and the A value are only needed for the copy itself: they are fetched after the count has been published
-                    // (everything before the publication is waited for by the tasks behind this one)
-                    clen = g.row_nprod[rid];
-                }
+                kmin = g.row_kmin[rid];
+                kmax = g.row_kmax[rid];
+                np_row = g.row_nprod[rid];
                 if constexpr (MODE == MODE_NUMERIC) {
                     c0 = g.cptr[rid];
                     n = (uint32_t)(g.cptr[rid + 1] - c0);
                 }
             }
+            table_clear(smem);
+            if ((uint32_t)tid < R) {
+                s_a0[tid] = a0;
+                s_cnt[tid] = 0;
+                if (cls == CLS_SMALL || cls == CLS_SOLO) L = (uint32_t)(a1 - a0);
+                // COPY row: the length of the one selected B row = the row's products.  Where that B row starts and the A value
+                // are only needed for the copy itself: they are fetched after the count has been published
+                else if (cls == CLS_COPY) clen = np_row;
+            }
             uint32_t E;
             const uint32_t exl = group_scan_excl<BLOCK>(L, tid, hdr + 2, &E);
             if ((uint32_t)tid < R) s_re[tid] = exl;
             if (tid == 0) s_re[R] = E;
-            if (E) table_clear(smem);
             __syncthreads();
             PHASE(1);
             // ---- expand - scale - accumulate (simulator.rs:86-111, :199-230) ---------------------------------------------

@@ -57,7 +57,7 @@ struct TaskDesc {
     uint32_t kind;      // TASK_BATCH: rows [row, row of the next task) | TASK_RANGE: columns [col_lo, col_hi] of BIG row `row`
     uint32_t row;
     uint32_t np;        // RANGE: products of the slice
-    uint32_t first;     // RANGE: 1 = first range of its row (writes C.indptr[row])
+    uint32_t first;     // RANGE: bit 0 = first range of its row (writes C.indptr[row]); DIRECT: the row's A entries above it
     uint64_t src;       // RANGE: first product of the slice in the scratch arrays
     uint32_t col_lo, col_hi;
 };
@@ -661,7 +661,10 @@ __global__ __launch_bounds__(TK_BLOCK) void k_big_plan(const uint64_t *__restric
         if (tid == TK_BLOCK - 1) {
             const uint32_t m = aux[NB - 1] + nef[BPT - 1];
             const unsigned long long P = pre[NB];
-            const unsigned long long E = aptr[r0 + row + 1] - aptr[r0 + row];
+            const unsigned long long a0 = aptr[r0 + row], E = aptr[r0 + row + 1] - a0;
+            hdr[48] = (uint32_t)min(E, 0x7FFFFFFFull);
+            hdr[49] = (uint32_t)a0;
+            hdr[50] = (uint32_t)(a0 >> 32);
             const uint32_t avg_len = (uint32_t)min(P / max(E, 1ull), 0xFFFFFFFFull);
             const unsigned long long steps = 1ull + (avg_len ? 31u - (uint32_t)__clz((int)avg_len) : 0u);   // of one binary search
             const bool direct = allow_direct && hdr[47] == 0 && (unsigned long long)m * E * steps <= (unsigned long long)BX_DIRECT_FACTOR * P &&
@@ -694,8 +697,9 @@ __global__ __launch_bounds__(TK_BLOCK) void k_big_plan(const uint64_t *__restric
                     d.kind = direct ? TASK_RANGE_DIRECT : TASK_RANGE;
                     d.row = row;
                     d.np = pre[f1] - pre[f0];
-                    d.first = aux[r] == 0 ? 1u : 0u;
-                    d.src = sb + pre[f0];
+                    // bit 0: first range of its row | direct tasks: entries of the row above it, first entry in `src`
+                    d.first = (aux[r] == 0 ? 1u : 0u) | (direct ? (uint32_t)hdr[48] << 1 : 0u);
+                    d.src = direct ? ((uint64_t)hdr[50] << 32 | hdr[49]) : sb + pre[f0];
                     d.col_lo = kmin + (f0 << wshift);
                     const uint64_t hi = (uint64_t)kmin + ((uint64_t)f1 << wshift) - 1ull;
                     d.col_hi = hi > kmax ? kmax : (uint32_t)hi;
@@ -1389,8 +1393,8 @@ __device__ inline uint32_t direct_accumulate(unsigned char *smem, unsigned char 
     uint32_t *hdr = (uint32_t *)smem;
     uint32_t *keys = (uint32_t *)(smem + 256);
     double *vals = (double *)(keys + TK_T);
-    const uint64_t a0 = g.aptr[g.r0 + td.row];
-    const uint32_t E = (uint32_t)(g.aptr[g.r0 + td.row + 1] - a0);
+    const uint64_t a0 = td.src;          // (first entry and entry count travel in the descriptor: no look-up of A's row pointers)
+    const uint32_t E = td.first >> 1;
     table_clear(smem);
     if (threadIdx.x == 0) {
         s_re[0] = 0;
@@ -1501,12 +1505,12 @@ __global__ __launch_bounds__(TK_BLOCK, 4) void k_task(const TaskArgs g)
         // round trip -- sits unstarted in the chain, every later task waits for it, and the pipeline loses more than the
         // round trip it saved: measured +6 % on the web surrogate, +30 % on R-MAT 16)
         const TaskDesc td = g.tasks[t];
+        const uint32_t next_row = t + 1 < ntasks ? g.tasks[t + 1].row : g.nrows;   // (with the descriptor: not a round trip of its own)
         unsigned long long ph_prev = dbg_a;
 #define PHASE(i) do { if (SPADA_TASK_DBG && tid == 0) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); dbg_ph[i] += n_ - ph_prev; ph_prev = n_; } } while (0)
         if (td.kind == TASK_BATCH) {
             const uint32_t rb = td.row;
-            const uint32_t re = t + 1 < ntasks ? g.tasks[t + 1].row : g.nrows;
-            const uint32_t R = re - rb;   // 1 .. RMAX
+            const uint32_t R = next_row - rb;   // 1 .. RMAX
             PHASE(0);
             // ---- rows of the batch ------------------------------------------------------------------------------------
             uint32_t L = 0, n = 0, kmin = 0, kmax = 0, rid = 0, clen = 0;
@@ -1727,7 +1731,7 @@ __global__ __launch_bounds__(TK_BLOCK, 4) void k_task(const TaskArgs g)
                     const unsigned long long b0 = chain_lookback(g.status, t, total, hdr, g.ctr);
                     if (SPADA_TASK_DBG) dbg_w = __builtin_amdgcn_s_memtime() - w0;
                     if (tid == 0) {
-                        if (td.first) g.cptr[td.row] = b0;
+                        if (td.first & 1u) g.cptr[td.row] = b0;
                         g.range_out[t] = b0;
                         if (t == ntasks - 1) {
                             g.cptr[g.nrows] = b0 + total;
@@ -2169,7 +2173,7 @@ __global__ __launch_bounds__(TK_BLOCK, 3) void k_task_sm(const TaskArgs g)
                 chain_publish(g.status, t, total);
                 base = chain_lookback(g.status, t, total, hdr, g.ctr);
                 if (tid == 0) {
-                    if (td.first) g.cptr[td.row] = base;
+                    if (td.first & 1u) g.cptr[td.row] = base;
                     g.range_out[t] = base;
                     if (t == ntasks - 1) {
                         g.cptr[g.nrows] = base + total;

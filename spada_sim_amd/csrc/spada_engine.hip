@@ -325,11 +325,10 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
         const uint32_t cap_parts = (uint32_t)std::min<uint64_t>(c->t_cap_parts, 0xFFFFFFF0u);
         ++c->stats.pipeline_runs;
         HIP_TRY(hipEventRecord(c->tev[0], s));
-        HIP_TRY(hipMemsetAsync(dc, 0, sizeof(TaskCounters), s));
+        static_assert(sizeof(TaskCounters) % 8 == 0, "k_init clears the counters in 8-byte words");
+        hipLaunchKernelGGL(k_init, dim3(c->n_cu * 4), dim3(256), 0, s, dc, c->t_rowP.as<unsigned long long>(), c->row_kmin.as<uint32_t>(),
+                           c->row_kmax.as<uint32_t>(), n, c->t_status.as<unsigned long long>(), (uint64_t)cap_tasks * ST_STRIDE);
         if (n) {
-            HIP_TRY(hipMemsetAsync(c->t_rowP.p, 0, (size_t)n * 8, s));
-            HIP_TRY(hipMemsetAsync(c->row_kmin.p, 0xFF, (size_t)n * 4, s));
-            HIP_TRY(hipMemsetAsync(c->row_kmax.p, 0, (size_t)n * 4, s));
             const uint32_t gent = (uint32_t)std::min<uint64_t>((a->nnz + 255) / 256 + 1, (uint64_t)c->n_cu * 8 * 4);
             hipLaunchKernelGGL(k_entry_stats, dim3(gent + EST_ROWS), dim3(256), 0, s, a->ptr, a->idx, a->rowid, b->ptr, b->idx, c->r0, n,
                                c->eb0.as<uint64_t>(), c->elen.as<uint32_t>(), c->t_rowP.as<unsigned long long>(),
@@ -370,7 +369,6 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
                                c->t_tmp.as<TaskDesc>(), c->t_tasks.as<TaskDesc>(), cap_tasks, dc);
             HIP_TRY(hipGetLastError());
         }
-        HIP_TRY(hipMemsetAsync(c->t_status.p, 0, (size_t)cap_tasks * 8 * ST_STRIDE, s));
         HIP_TRY(hipEventRecord(c->tev[3], s));
         if (n) {
             const TaskArgs g = task_args(c, cptr, d_idx, d_val, capacity);

@@ -64,7 +64,7 @@ struct TaskDesc {
 constexpr uint32_t TASK_BATCH = 1, TASK_RANGE = 2, TASK_RANGE_DIRECT = 3;   // (DIRECT: the products are taken from B, not from the scratch)
 
 // device counters of one pipeline run (zeroed at its start)
-struct TaskCounters {
+struct TaskCounters {   // (a multiple of 8 bytes: k_init clears it in 8-byte words)
     unsigned long long nprod, a_nnz, nprod_big;       // of the row range
     unsigned long long scratch_cursor;                // products handed out in the scratch arrays
     unsigned long long nnz_c;                         // written by the last task (COUNT / FUSED)
@@ -100,6 +100,22 @@ __device__ inline uint8_t row_class(uint64_t P, uint32_t L, uint32_t rmax, uint3
 // segmented wave scan adds them up, and the last lane of every run adds the run to the row's totals (row_P, row_kmin,
 // row_kmax, preset to 0 / max / 0) with one device atomic each -- ~1 atomic triple per row, none of them contended.
 // k_row_class: one lane per row: class, statistics, the list of BIG rows.
+// k_init: everything the pipeline wants cleared before it starts, in one launch instead of five fills: the counters, the per-row
+// accumulators of k_entry_stats (products 0, first column 0xFFFFFFFF, last column 0) and the chain's status words.
+__global__ __launch_bounds__(256) void k_init(TaskCounters *__restrict__ ctr, unsigned long long *__restrict__ row_P,
+                                              uint32_t *__restrict__ row_kmin, uint32_t *__restrict__ row_kmax, uint32_t nrows,
+                                              unsigned long long *__restrict__ status, uint64_t status_words)
+{
+    const uint64_t i0 = (uint64_t)blockIdx.x * 256 + threadIdx.x, stride = (uint64_t)gridDim.x * 256;
+    for (uint64_t i = i0; i < sizeof(TaskCounters) / 8; i += stride) ((unsigned long long *)ctr)[i] = 0ull;
+    for (uint64_t i = i0; i < nrows; i += stride) {
+        row_P[i] = 0ull;
+        row_kmin[i] = 0xFFFFFFFFu;
+        row_kmax[i] = 0u;
+    }
+    for (uint64_t i = i0; i < status_words; i += stride) status[i] = 0ull;
+}
+
 // How strongly do the products of this input collapse onto outputs?  EST_ROWS extra workgroups of k_entry_stats (they run next to
 // the statistics and need nothing from them); workgroup w looks at the first row at or behind row w * n / EST_ROWS (within EST_SCAN
 // rows) that has 2 .. 64 entries, and -- if it has 8 .. TK_LIMIT_LO products -- counts its distinct output columns in an LDS hash

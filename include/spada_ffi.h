@@ -99,7 +99,7 @@ typedef struct spada_stats {
     uint64_t spill_rows;      /* BIG rows that took the HBM spill path */
     uint64_t pipeline_runs;   /* > 1 when a workspace had to grow and the pipeline was run again (first call of a context) */
     uint64_t workspace_bytes; /* device scratch owned by the context */
-    uint64_t task_product_limit; /* products one task hashes at most: 1536, or 1792 where the sampled products / outputs ratio of the
+    uint64_t task_product_limit; /* products one task hashes at most: 1920, or 2040 where the sampled products / outputs ratio of the
                                     input is high (fuller tables, fewer tasks); rows with more products are BIG */
 } spada_stats;
 

@@ -5,7 +5,7 @@
 // (simulator.rs:86-230) and the partial-fiber merging (scheduler.rs:381-480, adder_tree.rs:145-188) become one LDS
 // accumulator per task; psum write-back and result assembly (simulator.rs:955-1062) become the chained output offsets.
 //
-//   table fill           ->  `limit` = products a task hashes at most: 1536 or 1792 of the 2048 slots, chosen on the device from a
+//   table fill           ->  `limit` = products a task hashes at most: 1920 or 2040 of the 2048 slots, chosen on the device from a
 //                            sampled products / outputs ratio of the input (estimate_block, inside the statistics launch)
 //   rows of C            ->  classes by products P_i: EMPTY | COPY (one A entry: C_i = a * B_k) | SMALL (P <= 512) | SOLO
 //                            (P <= limit), both packed into batches with their neighbours | BIG (larger)
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(256) void k_row_class(const uint64_t *__restrict__ 
 //                 2^wshift over [kmin, kmax] of the row (LDS), stored per part
 //   k_big_plan    one workgroup per row: bucket counts of the row = sum over its parts; buckets grouped into column RANGES -- a
 //                 bucket with more products than the limit is a range of its own, the others are packed greedily into ranges
-//                 of at most `limit` (1536 or 1792) products, i.e. a light range fits one task's table whatever its outputs
+//                 of at most `limit` (1920 or 2040) products, i.e. a light range fits one task's table whatever its outputs
 //                 are; a heavy range holds at most 2^wshift distinct columns and is split further by the task itself if
 //                 both exceed the table (k_task, multi-pass).  Range descriptors go to `tmp` (bump allocated),
 //                 their number to row_m[row].  Then the row is either left to DIRECT range tasks, which find their products

@@ -799,7 +799,8 @@ __global__ __launch_bounds__(TK_BLOCK) void k_big_scatter(const double *__restri
 // products.  Full batches mean fewer tasks and -- what matters to the chain -- tasks of equal length.  nxt[i] (first row
 // after a batch that starts at row i) is found for all rows in parallel by binary search over the tile's prefix sums; one
 // thread then follows the chain from the tile's first row (batches do not cross tiles).
-constexpr int CUT_ITEMS = 8, CUT_TILE = 256 * CUT_ITEMS;
+constexpr int CUT_ITEMS = 4, CUT_TILE = 256 * CUT_ITEMS;   // (tiles of 1024 rows: 2048 leaves too few workgroups on the smaller inputs,
+                                                           // 512 cuts too many batches at tile borders -- +11 % tasks on the stencil input)
 constexpr uint32_t CUT_COPY_MAX = 8192;
 
 __device__ inline uint32_t block_scan_excl_u32(uint32_t v, uint32_t *s_w /*[4]*/, uint32_t *total)
@@ -828,6 +829,7 @@ struct CutRow {
     uint32_t t[CUT_ITEMS];      // tasks started by the row
     uint32_t kind[CUT_ITEMS];   // 0 none, 1 batch start, 2 BIG
 };
+constexpr uint32_t CUT_END = 0xFFFFFFFFu;
 struct CutLds {
     uint32_t pc[CUT_TILE + 1], pw[CUT_TILE + 1];   // prefix sums: products to hash, products to copy
     uint32_t nxt[CUT_TILE];
@@ -886,22 +888,33 @@ __device__ inline uint32_t cut_tile(const uint8_t *__restrict__ row_cls, const u
             }
             nx = lo;
         }
-        L.nxt[li] = nx;
+        // (BIG rows and the end of the tile stop a walk: they point nowhere)
+        L.nxt[li] = (li < cnt && cls[j] != CLS_BIG && nx < cnt) ? nx : CUT_END;
+        // batch starts, to begin with: BIG rows (tasks of their own), and the first row of every run of non-BIG rows -- the tile's
+        // first row, or the row after a BIG row
+        if (li < cnt) L.mark[li] = (cls[j] == CLS_BIG || li == 0 || L.pc[li] - L.pc[li - 1] > lim) ? 1 : 0;
     }
     __syncthreads();
-    // batch starts: every run of non-BIG rows is walked from its first row (the tile's first row, or the row after a BIG
-    // row) by the thread that owns that row; BIG rows mark themselves
+    // ... then every row that a walk along nxt reaches from such a start.  Walked by pointer doubling (round k marks what lies
+    // 2^k hops behind a marked row, then squares the pointers): log2(tile) rounds for all runs at once, where one thread per run
+    // following the pointers took up to a tile's worth of dependent LDS reads (the cut of cop20k_A: 71 -> 30 us)
+    for (uint32_t span = 1; span < cnt; span <<= 1) {
+        uint32_t j1[CUT_ITEMS], j2[CUT_ITEMS];
 #pragma unroll
-    for (int j = 0; j < CUT_ITEMS; ++j) {
-        const uint32_t li = threadIdx.x * CUT_ITEMS + j;
-        if (li >= cnt) continue;
-        if (cls[j] == CLS_BIG) {
-            L.mark[li] = 1;
-        } else if (li == 0 || L.pc[li] - L.pc[li - 1] > lim) {   // the row before is BIG
-            for (uint32_t i = li; i < cnt && L.pc[i + 1] - L.pc[i] <= lim; i = L.nxt[i]) L.mark[i] = 1;
+        for (int j = 0; j < CUT_ITEMS; ++j) {
+            const uint32_t li = threadIdx.x * CUT_ITEMS + j;
+            j1[j] = li < cnt ? L.nxt[li] : CUT_END;
+            j2[j] = j1[j] != CUT_END ? L.nxt[j1[j]] : CUT_END;
+            if (j1[j] != CUT_END && L.mark[li]) L.mark[j1[j]] = 1;
         }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < CUT_ITEMS; ++j) {
+            const uint32_t li = threadIdx.x * CUT_ITEMS + j;
+            if (li < cnt) L.nxt[li] = j2[j];
+        }
+        __syncthreads();
     }
-    __syncthreads();
     uint32_t local = 0;
 #pragma unroll
     for (int j = 0; j < CUT_ITEMS; ++j) {

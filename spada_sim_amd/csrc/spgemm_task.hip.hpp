@@ -1280,11 +1280,7 @@ __device__ inline unsigned long long emit_table(unsigned char *smem, uint32_t NO
 
 // Double hashing: the probe sequence of a key advances by an odd step of its own (odd: it visits every slot of the power-of-two
 // table).  A wave waits for the longest probe sequence among its 64 lanes, and linear probing's clusters make that tail long.
-#ifndef SPADA_X_LINEAR
 __device__ inline uint32_t probe_step(uint32_t key) { return ((key * 0x85EBCA6Bu) >> (32 - TK_LOG_T)) | 1u; }
-#else
-__device__ inline uint32_t probe_step(uint32_t) { return 1u; }
-#endif
 
 __device__ inline void table_clear(unsigned char *smem)
 {

@@ -1513,15 +1513,11 @@ __global__ __launch_bounds__(TK_BLOCK, 4) void k_task(const TaskArgs g)
     // is not finished is either running -- it waits for finished tasks only -- or the next one of its queue, whose workgroups
     // all hold smaller, hence finished, tasks and are free to take it: no cycle of waiting workgroups can form as long as
     // every queue has a resident workgroup, which a grid of at least TK_NQ workgroups dispatched in order guarantees.
-#ifdef SPADA_STATIC_TASKS
-    uint32_t t = g.task_lo + blockIdx.x;
-#else
     uint32_t *my_ticket = &g.ctr->ticket[(blockIdx.x % TK_NQ) * 32];
     if (tid == 0) hdr[50] = g.task_lo + atomicAdd(my_ticket, 1u) * TK_NQ + blockIdx.x % TK_NQ;
     __syncthreads();
     uint32_t t = hdr[50];
     __syncthreads();
-#endif
     unsigned long long dbg_t0 = SPADA_TASK_DBG ? __builtin_amdgcn_s_memtime() : 0, dbg_acc = 0, dbg_chain = 0, dbg_emit = 0;
     unsigned long long dbg_ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     while (t < task_end) {
@@ -1791,14 +1787,10 @@ __global__ __launch_bounds__(TK_BLOCK, 4) void k_task(const TaskArgs g)
             PHASE(5);
             if (SPADA_TASK_DBG && tid == 0) dbg_ph[7] += 1;
         }
-#ifdef SPADA_STATIC_TASKS
-        t += gridDim.x;
-#else
         if (tid == 0) hdr[50] = g.task_lo + atomicAdd(my_ticket, 1u) * TK_NQ + blockIdx.x % TK_NQ;
         __syncthreads();
         t = hdr[50];
         __syncthreads();
-#endif
         if (td.kind == TASK_BATCH) PHASE(6);
 #undef PHASE
         if (SPADA_TASK_DBG) {

@@ -182,23 +182,6 @@ __device__ inline unsigned long long group_scan_excl_u64(unsigned long long v, i
 
 constexpr uint32_t LR_NONE = 0xFFFFFFFFu;
 
-// Within one wave the products handled by adjacent lanes belong to non-decreasing local rows; every run of
-// equal `lr` adds its number of new keys to s_cnt[lr] with ONE LDS atomic (a per-lane atomic would serialise
-// 64-fold on the same address).  Must be called by all lanes of the wave.
-__device__ inline void segmented_count_add(uint32_t lr, bool isnew, uint32_t *s_cnt, int lane)
-{
-    const uint32_t prev = __shfl_up(lr, 1);
-    const bool head = lane == 0 || prev != lr;
-    const unsigned long long hm = __ballot(head), nm = __ballot(isnew);
-    if (head && lr != LR_NONE) {
-        const unsigned long long from = ~0ull << lane;                              // lanes >= this one
-        const unsigned long long above = lane == 63 ? 0ull : (hm & (~0ull << (lane + 1)));
-        const unsigned long long upto = above ? ((1ull << (__ffsll((long long)above) - 1)) - 1ull) : ~0ull;
-        const uint32_t c = (uint32_t)__popcll(nm & from & upto);
-        if (c) atomicAdd(&s_cnt[lr], c);
-    }
-}
-
 // ---- the flat product walk -----------------------------------------------------------------------------------------
 // The A entries of the batch's flat rows are taken ECH = BLOCK * EPT at a time (each thread EPT consecutive
 // entries: descriptor (begin, length) of the selected B row, the A value, the local row).  Entries that select an
@@ -357,33 +340,51 @@ __device__ inline void flat_walk(const uint32_t *s_re, const uint64_t *s_a0, uin
                 // lane l of a segment holds product seg + l, i.e. bit l of one bitmap word (lo, base and the segments are
                 // multiples of 64): the word and its prefix are wave-uniform reads, the rank is a v_mbcnt pair.  Lanes past
                 // the end fall back to product 0 of entry 0 (a valid address; their result is discarded).
+                // (the 2 U bitmap reads are issued together, then the U entry records, then the gathers: asm pins keep the
+                // compiler from sinking each read into the branch of its own `act` and waiting for them one by one)
+                unsigned long long bits[U];
+                uint32_t bp[U];
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const uint32_t seg = base + (u * NW + wave_u) * 64;      // wave-uniform
-                    const uint32_t p = seg + lane;
-                    act[u] = p < hi;
                     const uint32_t w = min((seg - lo) >> 6, (uint32_t)PWORDS - 1u);
-                    const unsigned long long bits = bm[w];
-                    const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(bits >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bits, 0u));
-                    const uint32_t self = (bits & lane_bit) ? 1u : 0u;
-                    j[u] = act[u] ? bpre[w] + below + self - 1u : 0u;
+                    bits[u] = bm[w];
+                    bp[u] = bpre[w];
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) asm volatile("" : "+v"(bits[u]), "+v"(bp[u]));
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const uint32_t p = base + (u * NW + wave_u) * 64 + lane;
+                    act[u] = p < hi;
+                    const uint32_t below =
+                        __builtin_amdgcn_mbcnt_hi((uint32_t)(bits[u] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bits[u], 0u));
+                    const uint32_t self = (bits[u] & lane_bit) ? 1u : 0u;
+                    j[u] = act[u] ? bp[u] + below + self - 1u : 0u;
                     pp[u] = act[u] ? p : 0u;
                 }
-                uint64_t q[U];
+                uint64_t q[U], pack[U];
                 double a_[U];
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    uint64_t pack;
                     a_[u] = 0.0;
                     if constexpr (NUMERIC) {
                         const EntryRecNum er = w_ent[j[u]];
-                        pack = er.pack;
+                        pack[u] = er.pack;
                         a_[u] = er.av;
                     } else {
-                        pack = w_pack[j[u]];
+                        pack[u] = w_pack[j[u]];
                     }
-                    q[u] = ((pack & M48) + pp[u]) & M48;
-                    plr[u] = act[u] ? (uint32_t)(pack >> 48) : LR_NONE;
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    asm volatile("" : "+v"(pack[u]));
+                    if constexpr (NUMERIC) asm volatile("" : "+v"(a_[u]));
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    q[u] = ((pack[u] & M48) + pp[u]) & M48;
+                    plr[u] = act[u] ? (uint32_t)(pack[u] >> 48) : LR_NONE;
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u) col[u] = bidx[q[u]];

@@ -1572,6 +1572,7 @@ __global__ __launch_bounds__(TK_BLOCK, 4) void k_task(const TaskArgs g)
             __syncthreads();
             PHASE(1);
             // ---- expand - scale - accumulate (simulator.rs:86-111, :199-230) ---------------------------------------------
+            uint32_t mynew = 0;   // keys this lane has put into the table
             if (E)
                 flat_walk<BLOCK, EPT, RMAX, VALUES, U>(
                     s_re, s_a0, R, E, g.eb0, g.elen, g.aval, g.bidx, g.bval, region2, hdr,
@@ -1596,7 +1597,7 @@ __global__ __launch_bounds__(TK_BLOCK, 4) void k_task(const TaskArgs g)
                                     if (o == key[u]) break;
                                 }
                             }
-                            if constexpr (MODE != MODE_NUMERIC) segmented_count_add(plr[u], isnew, s_cnt, lane);
+                            if constexpr (MODE != MODE_NUMERIC) mynew += isnew && plr[u] != LR_NONE ? 1u : 0u;
                         }
                         if constexpr (VALUES) {
 #pragma unroll
@@ -1608,12 +1609,21 @@ __global__ __launch_bounds__(TK_BLOCK, 4) void k_task(const TaskArgs g)
             PHASE(2);
             // ---- outputs per row, offsets inside the batch ------------------------------------------------------------------
             const bool hashed = cls == CLS_SMALL || cls == CLS_SOLO;
-            if constexpr (MODE != MODE_NUMERIC) n = hashed ? s_cnt[tid < RMAX ? tid : 0] : (cls == CLS_COPY ? clen : 0u);
-            unsigned long long tot64;
-            const unsigned long long ex64 = group_scan_excl_u64<BLOCK>(((unsigned long long)n << 32) | (hashed ? n : 0u), tid,
-                                                                       (unsigned long long *)(hdr + 4), &tot64);
-            const uint32_t boff = (uint32_t)ex64, ooff = (uint32_t)(ex64 >> 32);
-            const uint32_t NO = (uint32_t)tot64, total = (uint32_t)(tot64 >> 32);
+            // The count of the task -- all the chain needs -- is the number of keys the lanes have inserted plus the lengths of the
+            // COPY rows; how the keys spread over the rows is only needed for the emission and is counted after the publication.
+            uint32_t boff = 0, ooff = 0, NO, total;
+            if constexpr (MODE != MODE_NUMERIC) {
+                unsigned long long tot64;
+                group_scan_excl_u64<BLOCK>(((unsigned long long)clen << 32) | mynew, tid, (unsigned long long *)(hdr + 4), &tot64);
+                NO = (uint32_t)tot64;
+                total = NO + (uint32_t)(tot64 >> 32);
+            } else {
+                unsigned long long tot64;
+                const unsigned long long ex64 = group_scan_excl_u64<BLOCK>(((unsigned long long)n << 32) | (hashed ? n : 0u), tid,
+                                                                           (unsigned long long *)(hdr + 4), &tot64);
+                boff = (uint32_t)ex64, ooff = (uint32_t)(ex64 >> 32);
+                NO = (uint32_t)tot64, total = (uint32_t)(tot64 >> 32);
+            }
             __syncthreads();
             // ---- chain: publish the count now, look back as late as possible ------------------------------------------------
             if (SPADA_TASK_DBG) dbg_b = dbg_c = __builtin_amdgcn_s_memtime();
@@ -1629,6 +1639,26 @@ __global__ __launch_bounds__(TK_BLOCK, 4) void k_task(const TaskArgs g)
             }
 #endif
             PHASE(3);
+            if constexpr (MODE != MODE_NUMERIC) {
+                // ---- outputs per row (one LDS atomic per occupied slot), offsets inside the batch ---------------------------
+                if (R > 1) {
+                    if (NO) {
+                        for (uint32_t sl = tid; sl < (uint32_t)T; sl += BLOCK) {
+                            const uint32_t k = keys[sl];
+                            if (k != EMPTY_KEY) atomicAdd(&s_cnt[k >> g.colbits], 1u);
+                        }
+                        __syncthreads();
+                    }
+                    n = hashed ? s_cnt[tid < RMAX ? tid : 0] : clen;
+                } else {
+                    n = hashed ? NO : clen;
+                }
+                unsigned long long tot64;
+                const unsigned long long ex64 = group_scan_excl_u64<BLOCK>(((unsigned long long)n << 32) | (hashed ? n : 0u), tid,
+                                                                           (unsigned long long *)(hdr + 4), &tot64);
+                boff = (uint32_t)ex64, ooff = (uint32_t)(ex64 >> 32);
+                __syncthreads();
+            }
             unsigned long long dbg_w = 0;
             auto resolve = [&]() -> unsigned long long {
                 if constexpr (MODE == MODE_NUMERIC) {

@@ -89,6 +89,7 @@ struct spada_ctx {
     DevBuf row_nprod, row_bin, row_kmin, row_kmax, cptr, t_rowP, t_rowm, t_rowt, t_rowtmp, t_big, t_tiles;
     DevBuf eb0, elen;
     DevBuf t_tmp, t_tasks, t_status, t_rangeout, t_scrcol, t_scrval, t_scrseq, t_ctr;
+    DevBuf t_possum;                                          // COUNT mode: sums of the tasks' counts per tile
     DevBuf t_parts, t_parthist, t_slots;                      // BIG rows: parts, bucket counts (then cursors) per part, row records
     DevBuf own_idx, own_val, own_ptr, wide_idx;
     uint64_t t_cap_tmp = 0, t_cap_tasks = 0, t_cap_scr = 0, t_cap_parts = 0;
@@ -313,6 +314,7 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
         if ((rc = c->t_tasks.ensure(c->t_cap_tasks * sizeof(TaskDesc), false, s, &c->ws_bytes))) return rc;
         if ((rc = c->t_status.ensure(c->t_cap_tasks * 8 * ST_STRIDE, false, s, &c->ws_bytes))) return rc;
         if ((rc = c->t_rangeout.ensure(c->t_cap_tasks * 8, false, s, &c->ws_bytes))) return rc;
+        if ((rc = c->t_possum.ensure((c->t_cap_tasks / POS_TILE + 2) * 8, false, s, &c->ws_bytes))) return rc;
         if ((rc = c->t_tmp.ensure(c->t_cap_tmp * sizeof(TaskDesc), false, s, &c->ws_bytes))) return rc;
         if ((rc = c->t_scrcol.ensure(c->t_cap_scr * 4, false, s, &c->ws_bytes))) return rc;
         if ((rc = c->t_scrval.ensure(c->t_cap_scr * 8, false, s, &c->ws_bytes))) return rc;
@@ -372,8 +374,17 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
         HIP_TRY(hipEventRecord(c->tev[3], s));
         if (n) {
             const TaskArgs g = task_args(c, cptr, d_idx, d_val, capacity);
-            if (mode == MODE_COUNT) launch_task<MODE_COUNT>(c, g);
-            else launch_task<MODE_FUSED>(c, g);
+            if (mode == MODE_COUNT) {
+                // no chain in the counting mode: the tasks leave their counts, three small kernels turn them into positions
+                launch_task<MODE_COUNT>(c, g);
+                unsigned long long *tsum = c->t_possum.as<unsigned long long>();
+                const uint32_t ptiles = std::max<uint32_t>(1, std::min<uint32_t>((cap_tasks + POS_TILE - 1) / POS_TILE, c->n_cu * 8));
+                hipLaunchKernelGGL(k_pos1, dim3(ptiles), dim3(256), 0, s, g.range_out, dc, tsum);
+                hipLaunchKernelGGL(k_pos2, dim3(1), dim3(256), 0, s, tsum, cptr, n, dc);
+                hipLaunchKernelGGL(k_pos3, dim3(ptiles), dim3(256), POS_LDS, s, g.tasks, tsum, dc, n, g.range_out, cptr);
+            } else {
+                launch_task<MODE_FUSED>(c, g);
+            }
             HIP_TRY(hipGetLastError());
         } else {
             HIP_TRY(hipMemsetAsync(cptr, 0, 8, s));
@@ -538,7 +549,7 @@ void spada_destroy(spada_ctx *c)
     c->un_idx.release();
     c->un_val.release();
     for (DevBuf *b : {&c->row_nprod, &c->row_bin, &c->row_kmin, &c->row_kmax, &c->cptr, &c->t_rowP, &c->t_rowm, &c->t_rowt, &c->t_rowtmp,
-                      &c->t_big, &c->t_tiles, &c->eb0, &c->elen, &c->t_tmp, &c->t_tasks, &c->t_status, &c->t_rangeout, &c->t_scrcol,
+                      &c->t_big, &c->t_tiles, &c->eb0, &c->elen, &c->t_tmp, &c->t_tasks, &c->t_status, &c->t_rangeout, &c->t_possum, &c->t_scrcol,
                       &c->t_scrval, &c->t_scrseq, &c->t_ctr, &c->t_parts, &c->t_parthist, &c->t_slots, &c->own_idx, &c->own_val, &c->own_ptr, &c->wide_idx})
         b->release();
     if (c->h_tctr) (void)hipHostFree(c->h_tctr);

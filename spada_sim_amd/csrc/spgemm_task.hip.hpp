@@ -1084,6 +1084,109 @@ struct TaskArgs {
     uint32_t task_lo, task_hi;      // tasks [task_lo, min(task_hi, all)) are run (NUMERIC in chunks; otherwise 0, 0xFFFFFFFF)
 };
 
+// ---- positions after a COUNT run: exclusive scan of the tasks' counts (left in range_out by the task kernel) ---------------------
+// k_pos1: sums per tile of POS_TILE tasks; k_pos2 (one workgroup): exclusive scan of the tile sums, nnz(C); k_pos3: positions of the
+// tile's tasks -> range_out of the RANGE tasks, C.indptr of the first range of a BIG row, and C.indptr of the rows of a batch
+// (their offsets inside the batch are there already: the position of the batch is added).
+constexpr int POS_TILE = 2048, POS_PER = POS_TILE / 256;
+constexpr size_t POS_LDS = 32 + (size_t)POS_TILE * 8 + (size_t)(POS_TILE + 4) * 4 + POS_TILE;   // wave totals | positions | first rows | kinds
+
+__global__ __launch_bounds__(256) void k_pos1(const uint64_t *__restrict__ range_out, const TaskCounters *__restrict__ ctr,
+                                              unsigned long long *__restrict__ tile_sum)
+{
+    __shared__ unsigned long long wtot[4];
+    if (ctr->abort_flag) return;
+    const uint32_t nt = ctr->ntasks, tiles = (nt + POS_TILE - 1) / POS_TILE;
+    for (uint32_t b = blockIdx.x; b < tiles; b += gridDim.x) {
+        unsigned long long v = 0;
+#pragma unroll
+        for (int i = 0; i < POS_PER; ++i) {
+            const uint32_t t = b * POS_TILE + i * 256 + threadIdx.x;
+            if (t < nt) v += range_out[t];
+        }
+        unsigned long long tot;
+        (void)group_scan_excl_u64<256>(v, threadIdx.x, wtot, &tot);
+        if (threadIdx.x == 0) tile_sum[b] = tot;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void k_pos2(unsigned long long *__restrict__ tile_sum, uint64_t *__restrict__ cptr, uint32_t nrows,
+                                              TaskCounters *__restrict__ ctr)
+{
+    __shared__ unsigned long long wtot[4];
+    if (ctr->abort_flag) return;
+    const uint32_t nt = ctr->ntasks, tiles = (nt + POS_TILE - 1) / POS_TILE;
+    unsigned long long carry = 0;
+    for (uint32_t b0 = 0; b0 < tiles; b0 += 256) {
+        const uint32_t b = b0 + threadIdx.x;
+        const unsigned long long v = b < tiles ? tile_sum[b] : 0ull;
+        unsigned long long tot;
+        const unsigned long long ex = group_scan_excl_u64<256>(v, threadIdx.x, wtot, &tot);
+        if (b < tiles) tile_sum[b] = carry + ex;
+        carry += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        cptr[nrows] = carry;
+        ctr->nnz_c = carry;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_pos3(const TaskDesc *__restrict__ tasks, const unsigned long long *__restrict__ tile_sum,
+                                              const TaskCounters *__restrict__ ctr, uint32_t nrows, uint64_t *__restrict__ range_out,
+                                              uint64_t *__restrict__ cptr)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned long long *wtot = (unsigned long long *)smem;
+    unsigned long long *s_pos = wtot + 4;
+    uint32_t *s_trow = (uint32_t *)(s_pos + POS_TILE);
+    uint8_t *s_batch = (uint8_t *)(s_trow + POS_TILE + 4);
+    if (ctr->abort_flag) return;
+    const uint32_t nt = ctr->ntasks, tiles = (nt + POS_TILE - 1) / POS_TILE;
+    const int tid = threadIdx.x;
+    for (uint32_t b = blockIdx.x; b < tiles; b += gridDim.x) {
+        const uint32_t t0 = b * POS_TILE, cnt = min((uint32_t)POS_TILE, nt - t0);
+        unsigned long long v[POS_PER], mine = 0;   // thread `tid` owns tasks t0 + tid * POS_PER + i
+#pragma unroll
+        for (int i = 0; i < POS_PER; ++i) {
+            const uint32_t k = tid * POS_PER + i;
+            v[i] = k < cnt ? range_out[t0 + k] : 0ull;
+            mine += v[i];
+        }
+        unsigned long long tot;
+        unsigned long long pos = tile_sum[b] + group_scan_excl_u64<256>(mine, tid, wtot, &tot);
+#pragma unroll
+        for (int i = 0; i < POS_PER; ++i) {
+            const uint32_t k = tid * POS_PER + i;
+            if (k < cnt) {
+                const TaskDesc td = tasks[t0 + k];
+                s_pos[k] = pos;
+                s_trow[k] = td.row;
+                s_batch[k] = td.kind == TASK_BATCH ? 1 : 0;
+                if (td.kind != TASK_BATCH) {
+                    range_out[t0 + k] = pos;
+                    if (td.first & 1u) cptr[td.row] = pos;
+                }
+            }
+            pos += v[i];
+        }
+        __syncthreads();
+        // rows of the tile's batches: [row of its first task, row of the first task of the next tile)
+        const uint32_t r_begin = s_trow[0], r_end = t0 + cnt < nt ? tasks[t0 + cnt].row : nrows;
+        for (uint32_t r = r_begin + tid; r < r_end; r += 256) {
+            uint32_t lo = 0, hi = cnt - 1;   // last task of the tile whose first row is <= r
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi + 1) >> 1;
+                if (s_trow[mid] <= r) lo = mid;
+                else hi = mid - 1;
+            }
+            if (s_batch[lo]) cptr[r] += s_pos[lo];
+        }
+        __syncthreads();
+    }
+}
+
 // first output position of tasks t[0 .. n) (t[k] == number of tasks: nnz(C)) after a COUNT run: the chunk boundaries of a
 // numeric phase that is run in pieces (spada_dev_spgemm_numeric_plan)
 __global__ void k_task_positions(const TaskDesc *__restrict__ tasks, const uint64_t *__restrict__ cptr,
@@ -1184,6 +1287,26 @@ __device__ inline unsigned long long chain_lookback(unsigned long long *status, 
     const unsigned long long base = ((unsigned long long)hdr[49] << 32) | hdr[48];
     __syncthreads();
     return base;
+}
+
+// The counting mode needs no chain: nothing is stored at the positions, so a task leaves its count in range_out[t] (and the
+// offsets of its rows inside the batch in C.indptr) and k_pos1/2/3 turn the counts into positions afterwards.  With the chain,
+// one task that takes long to count -- a multi-pass range of an R-MAT hub -- holds up every task behind it while they occupy
+// the workgroup slots: measured 7x on the hub chunks of R-MAT 22 (277 ms against 38 ms for the numeric phase over the same tasks).
+template <int MODE>
+__device__ inline void task_publish(const TaskArgs &g, uint32_t t, unsigned long long count)
+{
+    if constexpr (MODE == MODE_COUNT) {
+        if (threadIdx.x == 0) g.range_out[t] = count;
+    } else {
+        chain_publish(g.status, t, count);
+    }
+}
+template <int MODE>
+__device__ inline unsigned long long task_position(const TaskArgs &g, uint32_t t, unsigned long long count, uint32_t *hdr)
+{
+    if constexpr (MODE == MODE_COUNT) return 0ull;
+    else return chain_lookback(g.status, t, count, hdr, g.ctr);
 }
 
 // Ordered emission of the table (all waves): every occupied slot -> bucket = boff[lr] + floor((col - kmin) * n / span), monotone
@@ -1627,7 +1750,7 @@ __global__ __launch_bounds__(TK_BLOCK, 4) void k_task(const TaskArgs g)
             __syncthreads();
             // ---- chain: publish the count now, look back as late as possible ------------------------------------------------
             if (SPADA_TASK_DBG) dbg_b = dbg_c = __builtin_amdgcn_s_memtime();
-            if constexpr (MODE != MODE_NUMERIC) chain_publish(g.status, t, total);
+            if constexpr (MODE != MODE_NUMERIC) task_publish<MODE>(g, t, total);
 #if SPADA_TASK_DBG
             if (tid == 0) {
                 const unsigned long long w_ = __builtin_amdgcn_s_memtime() - dbg_a;
@@ -1665,10 +1788,10 @@ __global__ __launch_bounds__(TK_BLOCK, 4) void k_task(const TaskArgs g)
                     return 0ull;
                 } else {
                     const unsigned long long w0 = SPADA_TASK_DBG ? __builtin_amdgcn_s_memtime() : 0;
-                    const unsigned long long b0 = chain_lookback(g.status, t, total, hdr, g.ctr);
+                    const unsigned long long b0 = task_position<MODE>(g, t, total, hdr);
                     if (SPADA_TASK_DBG) dbg_w = __builtin_amdgcn_s_memtime() - w0;
                     if ((uint32_t)tid < R) g.cptr[rid] = b0 + ooff;
-                    if (t == ntasks - 1 && tid == 0) {
+                    if (MODE != MODE_COUNT && t == ntasks - 1 && tid == 0) {
                         g.cptr[g.nrows] = b0 + total;
                         g.ctr->nnz_c = b0 + total;
                     }
@@ -1762,7 +1885,7 @@ __global__ __launch_bounds__(TK_BLOCK, 4) void k_task(const TaskArgs g)
                 total = range_dfs<false, NOUT>(smem, s_re, s_row, s_out, td, g.scr_col, g.scr_val, 0ull, nullptr, nullptr);
             }
             if (SPADA_TASK_DBG) dbg_b = dbg_c = __builtin_amdgcn_s_memtime();
-            if constexpr (MODE != MODE_NUMERIC) chain_publish(g.status, t, total);
+            if constexpr (MODE != MODE_NUMERIC) task_publish<MODE>(g, t, total);
 #if SPADA_TASK_DBG
             if (tid == 0) {
                 const unsigned long long w_ = __builtin_amdgcn_s_memtime() - dbg_a;
@@ -1779,9 +1902,9 @@ __global__ __launch_bounds__(TK_BLOCK, 4) void k_task(const TaskArgs g)
                     return g.range_out[t];
                 } else {
                     const unsigned long long w0 = SPADA_TASK_DBG ? __builtin_amdgcn_s_memtime() : 0;
-                    const unsigned long long b0 = chain_lookback(g.status, t, total, hdr, g.ctr);
+                    const unsigned long long b0 = task_position<MODE>(g, t, total, hdr);
                     if (SPADA_TASK_DBG) dbg_w = __builtin_amdgcn_s_memtime() - w0;
-                    if (tid == 0) {
+                    if (MODE != MODE_COUNT && tid == 0) {
                         if (td.first & 1u) g.cptr[td.row] = b0;
                         g.range_out[t] = b0;
                         if (t == ntasks - 1) {
@@ -2026,10 +2149,10 @@ __global__ __launch_bounds__(TK_BLOCK, 3) void k_task_sm(const TaskArgs g)
             __syncthreads();
             unsigned long long base = 0;
             if constexpr (MODE != MODE_NUMERIC) {
-                chain_publish(g.status, t, total);
-                base = chain_lookback(g.status, t, total, hdr, g.ctr);
+                task_publish<MODE>(g, t, total);
+                base = task_position<MODE>(g, t, total, hdr);
                 if ((uint32_t)tid < R) g.cptr[rid] = base + ooff;
-                if (t == ntasks - 1 && tid == 0) {
+                if (MODE != MODE_COUNT && t == ntasks - 1 && tid == 0) {
                     g.cptr[g.nrows] = base + total;
                     g.ctr->nnz_c = base + total;
                 }
@@ -2217,9 +2340,9 @@ __global__ __launch_bounds__(TK_BLOCK, 3) void k_task_sm(const TaskArgs g)
             }
             unsigned long long base;
             if constexpr (MODE != MODE_NUMERIC) {
-                chain_publish(g.status, t, total);
-                base = chain_lookback(g.status, t, total, hdr, g.ctr);
-                if (tid == 0) {
+                task_publish<MODE>(g, t, total);
+                base = task_position<MODE>(g, t, total, hdr);
+                if (MODE != MODE_COUNT && tid == 0) {
                     if (td.first & 1u) g.cptr[td.row] = base;
                     g.range_out[t] = base;
                     if (t == ntasks - 1) {

@@ -29,6 +29,14 @@ def fused(engine, a, b, capacity=None, r0=0, r1=None):
             engine.free(db)
 
 
+@pytest.fixture(scope="module")
+def engine_sm():
+    import spada_sim_amd as S
+    e = S.Engine(accumulator=S.ACC_SORT_MERGE)
+    yield e
+    e.close()
+
+
 GEN = [
     ("uniform_small", 5, 2000, 6, 1),
     ("rmat_s12", 0, 12, 8, 2),
@@ -153,6 +161,38 @@ def test_multi_pass_range_tasks(engine):
     # and through the two-phase contract
     c2 = engine.spgemm(a, b)
     assert_parity(c2, ref, ao, bo, RTOL)
+
+
+def test_counting_mode_positions_across_tiles(engine, engine_sm):
+    """The counting mode has no chain: tasks leave their counts and k_pos1/2/3 scan them into C.indptr and the range positions,
+    2048 tasks per tile.  R-MAT 16 has 232 k tasks (114 tiles) and BIG rows whose range tasks straddle tile boundaries: the
+    two-phase product must equal the one-pass product (chain) entry for entry, and its row pointers the oracle's counts."""
+    import spada_sim_amd as S
+    m = S.generate(S.GEN_RMAT, 16, 16, 22)
+    c1, st1 = fused(engine, m, m)
+    assert st1["n_tasks"] > 50 * 2048 and st1["cls_rows"][4] > 0
+    d = engine.upload(m)
+    nnz = engine.symbolic(d, d, 0, m.shape[0])
+    p, i, v = engine.numeric_owned()
+    c2 = engine.download(p, i, v, m.shape[0], nnz, m.shape[1])
+    engine.free(d)
+    assert nnz == c1.nnz()
+    assert np.array_equal(c1.indptr, c2.indptr) and np.array_equal(c1.indices, c2.indices)
+    assert np.all(np.abs(c1.data - c2.data) <= RTOL * np.abs(c1.data))
+    ao = to_oracle(m)
+    assert np.array_equal(c2.indptr, oracle.spgemm_spa(ao, ao, symbolic_only=True))
+    # the sort-merge kernel shares the position kernels; a row range that starts inside the matrix
+    r0, r1 = 1000, 30000
+    d = engine_sm.upload(m)
+    nnz = engine_sm.symbolic(d, d, r0, r1)
+    p, i, v = engine_sm.numeric_owned()
+    c3 = engine_sm.download(p, i, v, r1 - r0, nnz, m.shape[1])
+    engine_sm.free(d)
+    lo, hi = int(c1.indptr[r0]), int(c1.indptr[r1])
+    assert nnz == hi - lo
+    assert np.array_equal(c3.indptr.astype(np.int64), c1.indptr[r0:r1 + 1].astype(np.int64) - lo)
+    assert np.array_equal(c3.indices, c1.indices[lo:hi])
+    assert np.all(np.abs(c3.data - c1.data[lo:hi]) <= RTOL * np.abs(c1.data[lo:hi]))
 
 
 def test_workspace_growth_reruns(engine):

@@ -345,7 +345,8 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
         if (n) {
             uint32_t *seq = c->accumulator == SPADA_ACC_SORT_MERGE ? c->t_scrseq.as<uint32_t>() : (uint32_t *)nullptr;
             hipLaunchKernelGGL(k_big_parts, dim3(c->n_cu * 2), dim3(256), 0, s, a->ptr, c->elen.as<uint32_t>(), c->r0,
-                               c->t_big.as<uint32_t>(), c->row_nprod.as<uint32_t>(), c->t_parts.as<BigPart>(), cap_parts,
+                               c->t_big.as<uint32_t>(), c->row_nprod.as<uint32_t>(), c->row_kmin.as<uint32_t>(),
+                               c->row_kmax.as<uint32_t>(), c->accumulator == SPADA_ACC_SORT_MERGE ? 0u : 1u, c->t_parts.as<BigPart>(), cap_parts,
                                c->t_rowtmp.as<uint32_t>(), cap_tmp, c->t_slots.as<BigSlot>(), dc);
             hipLaunchKernelGGL(k_big_hist, dim3(c->n_cu * 8), dim3(TK_BLOCK), BX_WALK_LDS, s, b->idx, c->eb0.as<uint64_t>(),
                                c->elen.as<uint32_t>(), c->t_big.as<uint32_t>(), c->row_kmin.as<uint32_t>(),

@@ -359,15 +359,25 @@ constexpr int BP_ROWS = 16;   // rows per workgroup and round: their records are
                               // single hot word sustains ~88 atomics / us: one per row would cost more than the kernel's work)
 // ranges of a row with P products, upper bound: a light range is closed when the next bucket does not fit, so two consecutive
 // ones hold more than `lim` products together; a heavy bucket (more than `lim` products) ends the range before it and is one itself
-__host__ __device__ inline uint32_t big_max_ranges(uint32_t P, uint32_t lim) { return 2u * (P / lim) + 2u * (P / (lim + 1u)) + 3u; }
+// -- plus, for a row whose buckets are wider than the table (`wide`), up to BX_SUB_MAX descriptors for each of its at most
+// P / lim heavy buckets (below: column sub-ranges)
+constexpr uint32_t BX_SUB_MAX = 8;
+__host__ __device__ inline uint32_t big_max_ranges(uint32_t P, uint32_t lim, bool wide)
+{
+    return 2u * (P / lim) + 2u * (P / (lim + 1u)) + 3u + (wide ? (BX_SUB_MAX - 1u) * (P / lim) : 0u);
+}
 
 __global__ __launch_bounds__(256) void k_big_parts(const uint64_t *__restrict__ aptr, const uint32_t *__restrict__ elen, uint64_t r0,
                                                    const uint32_t *__restrict__ big_rows, const uint32_t *__restrict__ row_nprod,
-                                                   BigPart *__restrict__ parts, uint32_t part_cap, uint32_t *__restrict__ row_tmp,
-                                                   uint32_t tmp_cap, BigSlot *__restrict__ slots, TaskCounters *__restrict__ ctr)
+                                                   const uint32_t *__restrict__ row_kmin, const uint32_t *__restrict__ row_kmax,
+                                                   uint32_t allow_sub, BigPart *__restrict__ parts, uint32_t part_cap,
+                                                   uint32_t *__restrict__ row_tmp, uint32_t tmp_cap, BigSlot *__restrict__ slots,
+                                                   TaskCounters *__restrict__ ctr)
 {
     const uint32_t lim = ctr->prod_limit;
     __shared__ uint32_t s_pbase[BP_ROWS], s_tbase[BP_ROWS];
+    // (a row whose histogram buckets are wider than the table may get several descriptors per heavy bucket: k_big_plan)
+    auto wide_row = [&](uint32_t row) { return allow_sub && (1ull << big_wshift(row_kmin[row], row_kmax[row])) > (unsigned long long)TK_NOUT; };
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t nbig = ctr->n_big;
     for (uint32_t s0 = blockIdx.x * BP_ROWS; s0 < nbig; s0 += gridDim.x * BP_ROWS) {
@@ -377,7 +387,7 @@ __global__ __launch_bounds__(256) void k_big_parts(const uint64_t *__restrict__ 
             const bool have = lane < BP_ROWS && sl < nbig;
             const uint32_t P = have ? row_nprod[big_rows[sl]] : 0u;
             const bool good = have && P != 0xFFFFFFFFu;
-            const uint32_t np = good ? P / BX_PART + 2u : 0u, nt = good ? big_max_ranges(P, lim) : 0u;
+            const uint32_t np = good ? P / BX_PART + 2u : 0u, nt = good ? big_max_ranges(P, lim, wide_row(big_rows[sl])) : 0u;
             uint32_t ip = np, it = nt;
 #pragma unroll
             for (int o = 1; o < BP_ROWS; o <<= 1) {
@@ -419,7 +429,7 @@ __global__ __launch_bounds__(256) void k_big_parts(const uint64_t *__restrict__ 
             slots[slot] = BigSlot{0ull, 0u, 0u, base, ub, {0u, 0u}};
             row_tmp[row] = tbase;
             if (!fits) atomicOr(&ctr->abort_flag, 16u);
-            if ((unsigned long long)tbase + big_max_ranges(P, lim) > tmp_cap) atomicOr(&ctr->abort_flag, 1u);
+            if ((unsigned long long)tbase + big_max_ranges(P, lim, wide_row(row)) > tmp_cap) atomicOr(&ctr->abort_flag, 1u);
         }
         if (!fits) continue;
         uint32_t carry = 0, nstart = 0;   // products / parts before this step
@@ -664,8 +674,25 @@ __global__ __launch_bounds__(TK_BLOCK) void k_big_plan(const uint64_t *__restric
         }
         __syncthreads();
         if (tid == 0) hdr[47] = 0;
+        // descriptors per range: one -- or, for a range that would need several passes over its slice (more distinct columns
+        // than the table may take: more than TK_NOUT products AND columns; only a heavy bucket of a row that spans more than
+        // BX_NB * TK_NOUT columns can be one), one per TK_NOUT columns: every such task reads the whole slice ONCE and keeps the
+        // products of its own columns (bit 1 of `first`), instead of one task halving the range depth first with a counting and
+        // an accumulating pass over the slice per node -- R-MAT 22's hubs: 24 instead of 36 bytes per product, in independent tasks
+        uint32_t wgt[BPT];
 #pragma unroll
-        for (int k = 0; k < BPT; ++k) aux[tid * BPT + k] = nef[k];
+        for (int k = 0; k < BPT; ++k) {
+            wgt[k] = nef[k];
+            if (nef[k]) {
+                const uint32_t r = tid * BPT + k, f0 = rfirst[r], f1 = rfirst[r + 1];
+                const uint64_t lo = (uint64_t)kmin + ((uint64_t)f0 << wshift);
+                const uint64_t hi = min((uint64_t)kmin + ((uint64_t)f1 << wshift) - 1ull, (uint64_t)kmax);
+                const uint64_t nsub = (hi - lo + (uint64_t)TK_NOUT) / (uint64_t)TK_NOUT;
+                if (allow_direct && pre[f1] - pre[f0] > (uint32_t)TK_NOUT && hi - lo >= (uint64_t)TK_NOUT && nsub <= BX_SUB_MAX)
+                    wgt[k] = (uint32_t)nsub;
+            }
+            aux[tid * BPT + k] = wgt[k];
+        }
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < BPT; ++k)
@@ -675,7 +702,7 @@ __global__ __launch_bounds__(TK_BLOCK) void k_big_plan(const uint64_t *__restric
             }
         group_exclusive_scan<TK_BLOCK, NB>(aux, tid, hdr + 2);
         if (tid == TK_BLOCK - 1) {
-            const uint32_t m = aux[NB - 1] + nef[BPT - 1];
+            const uint32_t m = aux[NB - 1] + wgt[BPT - 1];
             const unsigned long long P = pre[NB];
             const unsigned long long a0 = aptr[r0 + row], E = aptr[r0 + row + 1] - a0;
             hdr[48] = (uint32_t)min(E, 0x7FFFFFFFull);
@@ -713,13 +740,18 @@ __global__ __launch_bounds__(TK_BLOCK) void k_big_plan(const uint64_t *__restric
                     d.kind = direct ? TASK_RANGE_DIRECT : TASK_RANGE;
                     d.row = row;
                     d.np = pre[f1] - pre[f0];
-                    // bit 0: first range of its row | direct tasks: entries of the row above it, first entry in `src`
-                    d.first = (aux[r] == 0 ? 1u : 0u) | (direct ? (uint32_t)hdr[48] << 1 : 0u);
                     d.src = direct ? ((uint64_t)hdr[50] << 32 | hdr[49]) : sb + pre[f0];
-                    d.col_lo = kmin + (f0 << wshift);
-                    const uint64_t hi = (uint64_t)kmin + ((uint64_t)f1 << wshift) - 1ull;
-                    d.col_hi = hi > kmax ? kmax : (uint32_t)hi;
-                    tmp[tb + aux[r]] = d;
+                    const uint32_t lo = kmin + (f0 << wshift);
+                    const uint64_t hi64 = (uint64_t)kmin + ((uint64_t)f1 << wshift) - 1ull;
+                    const uint32_t hi = hi64 > kmax ? kmax : (uint32_t)hi64;
+                    for (uint32_t j = 0; j < wgt[k]; ++j) {
+                        // bit 0: first range of its row | bit 1: column sub-range, the slice holds other columns too | direct
+                        // tasks: entries of the row above bit 0, first entry in `src`
+                        d.first = (aux[r] + j == 0 ? 1u : 0u) | (wgt[k] > 1 ? 2u : 0u) | (direct ? (uint32_t)hdr[48] << 1 : 0u);
+                        d.col_lo = lo + j * (uint32_t)TK_NOUT;
+                        d.col_hi = j + 1 == wgt[k] ? hi : d.col_lo + (uint32_t)TK_NOUT - 1u;
+                        tmp[tb + aux[r] + j] = d;
+                    }
                 }
         }
         if (ok && !direct) {   // spilled: the counts of every part become its cursors (part order = product order)
@@ -1879,7 +1911,7 @@ __global__ __launch_bounds__(TK_BLOCK, 4) void k_task(const TaskArgs g)
             if (direct) {
                 total = direct_accumulate<VALUES>(smem, region2, s_re, s_a0, g, td);
             } else if (single) {
-                total = range_accumulate<VALUES>(smem, g.scr_col, g.scr_val, td.src, td.np, td.col_lo, td.col_hi, false);
+                total = range_accumulate<VALUES>(smem, g.scr_col, g.scr_val, td.src, td.np, td.col_lo, td.col_hi, (td.first & 2u) != 0);
             } else {
                 if (tid == 0) atomicAdd(&g.ctr->multi_pass_tasks, 1u);
                 total = range_dfs<false, NOUT>(smem, s_re, s_row, s_out, td, g.scr_col, g.scr_val, 0ull, nullptr, nullptr);

@@ -130,12 +130,14 @@ def test_fused_row_blocks(engine):
     assert pos == ref.nnz
 
 
-def test_multi_pass_range_tasks(engine):
-    """More than 1.5 M columns and a BIG row whose products crowd into one histogram bucket wider than the table: the range
-    task has to halve its column range (stats.multi_pass_tasks > 0); also rows with many entries and short B rows."""
+@pytest.mark.parametrize("cols,multi_pass", [(6_000_000, False), (40_000_000, True)])
+def test_heavy_buckets_wider_than_the_table(engine, cols, multi_pass):
+    """A BIG row whose products crowd into histogram buckets wider than the table (more than 2 M columns).  6 M columns: buckets of
+    8192 columns, every heavy one becomes four column sub-range tasks over the same scratch slice (no multi-pass task); 40 M
+    columns: buckets of 65536 columns, more than eight sub-ranges, so the range task halves its column range depth first
+    (stats.multi_pass_tasks > 0).  Also rows with many entries and short B rows."""
     import spada_sim_amd as S
     rng = np.random.default_rng(3)
-    cols = 6_000_000
     k = 4000
     # B: row j has 6 entries inside a 40 000-column window + 2 far outliers
     bi, bv, bptr = [], [], [0]
@@ -157,7 +159,7 @@ def test_multi_pass_range_tasks(engine):
     ref = oracle.spgemm_sortmerge(ao, bo)
     c, st = fused(engine, a, b)
     assert_parity(c, ref, ao, bo, RTOL)
-    assert st["multi_pass_tasks"] > 0 and st["cls_rows"][4] > 0
+    assert (st["multi_pass_tasks"] > 0) == multi_pass and st["cls_rows"][4] > 0 and st["spill_rows"] > 0
     # and through the two-phase contract
     c2 = engine.spgemm(a, b)
     assert_parity(c2, ref, ao, bo, RTOL)

@@ -382,7 +382,9 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
                 const uint32_t ptiles = std::max<uint32_t>(1, std::min<uint32_t>((cap_tasks + POS_TILE - 1) / POS_TILE, c->n_cu * 8));
                 hipLaunchKernelGGL(k_pos1, dim3(ptiles), dim3(256), 0, s, g.range_out, dc, tsum);
                 hipLaunchKernelGGL(k_pos2, dim3(1), dim3(256), 0, s, tsum, cptr, n, dc);
-                hipLaunchKernelGGL(k_pos3, dim3(ptiles), dim3(256), POS_LDS, s, g.tasks, tsum, dc, n, g.range_out, cptr);
+                hipLaunchKernelGGL(k_pos3, dim3(ptiles), dim3(256), 0, s, g.tasks, tsum, dc, g.range_out, cptr);
+                hipLaunchKernelGGL(k_pos4, dim3(ntiles), dim3(256), 0, s, c->row_bin.as<uint8_t>(), c->t_rowt.as<uint32_t>(),
+                                   c->t_tiles.as<uint32_t>(), n, g.range_out, dc, cptr);
             } else {
                 launch_task<MODE_FUSED>(c, g);
             }

@@ -1118,10 +1118,9 @@ struct TaskArgs {
 
 // ---- positions after a COUNT run: exclusive scan of the tasks' counts (left in range_out by the task kernel) ---------------------
 // k_pos1: sums per tile of POS_TILE tasks; k_pos2 (one workgroup): exclusive scan of the tile sums, nnz(C); k_pos3: positions of the
-// tile's tasks -> range_out of the RANGE tasks, C.indptr of the first range of a BIG row, and C.indptr of the rows of a batch
-// (their offsets inside the batch are there already: the position of the batch is added).
+// tile's tasks -> range_out (every task) and C.indptr of the first range of a BIG row; k_pos4 (one thread per row, the cut's
+// tiles): C.indptr of the rows of the batches -- their offsets inside the batch are there already, the position of the batch is added.
 constexpr int POS_TILE = 2048, POS_PER = POS_TILE / 256;
-constexpr size_t POS_LDS = 32 + (size_t)POS_TILE * 8 + (size_t)(POS_TILE + 4) * 4 + POS_TILE;   // wave totals | positions | first rows | kinds
 
 __global__ __launch_bounds__(256) void k_pos1(const uint64_t *__restrict__ range_out, const TaskCounters *__restrict__ ctr,
                                               unsigned long long *__restrict__ tile_sum)
@@ -1166,14 +1165,10 @@ __global__ __launch_bounds__(256) void k_pos2(unsigned long long *__restrict__ t
 }
 
 __global__ __launch_bounds__(256) void k_pos3(const TaskDesc *__restrict__ tasks, const unsigned long long *__restrict__ tile_sum,
-                                              const TaskCounters *__restrict__ ctr, uint32_t nrows, uint64_t *__restrict__ range_out,
+                                              const TaskCounters *__restrict__ ctr, uint64_t *__restrict__ range_out,
                                               uint64_t *__restrict__ cptr)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned long long *wtot = (unsigned long long *)smem;
-    unsigned long long *s_pos = wtot + 4;
-    uint32_t *s_trow = (uint32_t *)(s_pos + POS_TILE);
-    uint8_t *s_batch = (uint8_t *)(s_trow + POS_TILE + 4);
+    __shared__ unsigned long long wtot[4];
     if (ctr->abort_flag) return;
     const uint32_t nt = ctr->ntasks, tiles = (nt + POS_TILE - 1) / POS_TILE;
     const int tid = threadIdx.x;
@@ -1193,29 +1188,36 @@ __global__ __launch_bounds__(256) void k_pos3(const TaskDesc *__restrict__ tasks
             const uint32_t k = tid * POS_PER + i;
             if (k < cnt) {
                 const TaskDesc td = tasks[t0 + k];
-                s_pos[k] = pos;
-                s_trow[k] = td.row;
-                s_batch[k] = td.kind == TASK_BATCH ? 1 : 0;
-                if (td.kind != TASK_BATCH) {
-                    range_out[t0 + k] = pos;
-                    if (td.first & 1u) cptr[td.row] = pos;
-                }
+                range_out[t0 + k] = pos;
+                if (td.kind != TASK_BATCH && (td.first & 1u)) cptr[td.row] = pos;
             }
             pos += v[i];
         }
         __syncthreads();
-        // rows of the tile's batches: [row of its first task, row of the first task of the next tile)
-        const uint32_t r_begin = s_trow[0], r_end = t0 + cnt < nt ? tasks[t0 + cnt].row : nrows;
-        for (uint32_t r = r_begin + tid; r < r_end; r += 256) {
-            uint32_t lo = 0, hi = cnt - 1;   // last task of the tile whose first row is <= r
-            while (lo < hi) {
-                const uint32_t mid = (lo + hi + 1) >> 1;
-                if (s_trow[mid] <= r) lo = mid;
-                else hi = mid - 1;
-            }
-            if (s_batch[lo]) cptr[r] += s_pos[lo];
-        }
-        __syncthreads();
+    }
+}
+
+// The batch of row r is task  tile_tasks[tile of r] + (tasks started by the tile's rows up to and including r) - 1  (batches do
+// not cross the cut's tiles; row_t and tile_tasks are what k_cut1 / k_cut2 left).
+__global__ __launch_bounds__(256) void k_pos4(const uint8_t *__restrict__ row_cls, const uint32_t *__restrict__ row_t,
+                                              const uint32_t *__restrict__ tile_tasks, uint32_t n, const uint64_t *__restrict__ range_out,
+                                              const TaskCounters *__restrict__ ctr, uint64_t *__restrict__ cptr)
+{
+    __shared__ uint32_t s_w[4];
+    if (ctr->abort_flag) return;
+    const uint32_t base = blockIdx.x * CUT_TILE + threadIdx.x * CUT_ITEMS;
+    uint32_t t[CUT_ITEMS], local = 0;
+#pragma unroll
+    for (int j = 0; j < CUT_ITEMS; ++j) {
+        t[j] = base + j < n ? row_t[base + j] : 0u;
+        local += t[j];
+    }
+    uint32_t tot;
+    uint32_t idx = block_scan_excl_u32(local, s_w, &tot) + tile_tasks[blockIdx.x];
+#pragma unroll
+    for (int j = 0; j < CUT_ITEMS; ++j) {
+        idx += t[j];
+        if (base + j < n && idx && row_cls[base + j] != CLS_BIG) cptr[base + j] += range_out[idx - 1];
     }
 }
 

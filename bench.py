@@ -359,9 +359,19 @@ def main():
              "ms": ms["ms_big_expand"], "products": st["cls_prod"][4] if "cls_prod" in st else None,
              "spilled_products": st.get("scratch_products"), "spilled_rows": st.get("spill_rows")},
             {"kernel": "k_cut1/2/3 (task list)", "ms": ms["ms_cut"]},
-            {"kernel": "k_task (expand - scale - accumulate - order, all rows)", "ms": ms["ms_task"], "products": nprod_total if world == 1 else st["nprod"],
-             "tasks": st.get("n_tasks")},
         ]
+        two_phase = not (ms["ms_fused_call"] > 0)
+        if two_phase:
+            # (the phase times of a two-phase step: the counters of the symbolic call survive the numeric call except ms_task)
+            kernels += [
+                {"kernel": "k_task<COUNT> + k_pos1-4 (expand - accumulate keys, counts scanned into C.indptr; no chain)",
+                 "ms": ms["ms_symbolic_call"] - ms["ms_row_stats"] - ms["ms_big_expand"] - ms["ms_cut"],
+                 "products": nprod_total if world == 1 else st["nprod"], "tasks": st.get("n_tasks")},
+                {"kernel": "k_task<NUMERIC> (expand - scale - accumulate - order at the known positions)", "ms": ms["ms_numeric_call"],
+                 "products": nprod_total if world == 1 else st["nprod"], "tasks": st.get("n_tasks")}]
+        else:
+            kernels += [{"kernel": "k_task (expand - scale - accumulate - order, all rows)", "ms": ms["ms_task"],
+                         "products": nprod_total if world == 1 else st["nprod"], "tasks": st.get("n_tasks")}]
         out = {
             "metric": "nnz(C)/sec on A*A SpGEMM",
             "value": nnz_total / (elapsed / K),
@@ -387,20 +397,22 @@ def main():
                         "(N-1)/N of 12 B x nnz(C) over xGMI, which bounds strong scaling once that exceeds the compute time"},
             "config": {"workload": f"{args.workload} A*A", "rows": rows, "nnz_a": a.nnz(), "products": nprod_total,
                        "nnz_c": nnz_total, "accumulator": args.accumulator,
-                       "entry_point": "spada_dev_spgemm_fused (one pass, C buffers sized by the product count)" if one_pass
+                       "entry_point": "spada_dev_spgemm_fused (one pass, C buffers sized by the product count)"
+                                      if one_pass and chunk_bounds is None
                                       else "spada_dev_spgemm_symbolic + spada_dev_spgemm_numeric",
                        "parallelism": f"row-block x{world}, B replicated" +
                                       (f", C streamed in {len(chunk_bounds) - 1} row chunks per rank and not gathered"
                                        if chunk_bounds is not None else (", allgatherv of C" if world > 1 else ""))},
             "roofline": {
                 "bound": "hbm",
-                "kernel": "k_task (persistent task kernel: expand - scale - LDS-hash accumulate - ordered emission of every row of C); "
-                          "average duration per step by HIP events on its stream, rank 0",
+                "kernel": ("k_task (persistent task kernel: expand - scale - LDS-hash accumulate - ordered emission of every row of C); "
+                           "average duration per step by HIP events on its stream, rank 0") if not two_phase else
+                          ("whole device time of the symbolic + numeric calls (k_task<COUNT>, k_task<NUMERIC> and the kernels around "
+                           "them) against the algorithmic bytes of ONE pass over the products; HIP events on the engine stream, rank 0"),
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                # (two builds of the task kernel are launched, k_task<mode, 1536> and k_task<mode, 1792>: the one that does the work)
                 "traffic": max([v.get("hbm_bytes_per_launch") or 0 for k, v in (traffic or {}).items()
                                 if isinstance(v, dict) and k.startswith("k_task<2" if one_pass else "k_task<1")] or [None]) or None,
                 "traffic_source": os.path.relpath(traffic_src, ROOT) if traffic else None,

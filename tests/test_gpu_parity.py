@@ -155,6 +155,17 @@ def test_repeatability(engine):
     c2 = engine.spgemm(m, m)
     assert np.array_equal(c1.indptr, c2.indptr) and np.array_equal(c1.indices, c2.indices)
     assert np.all(np.abs(c1.data - c2.data) <= 1e-12 * np.abs(c1.data))
+    # one symbolic call, two numeric calls (the ABI does not forbid it): the second fills its buffers like the first
+    m = S.generate(S.GEN_RMAT, 13, 12, 23)          # BIG rows, spilled and direct ranges
+    d = engine.upload(m)
+    nnz = engine.symbolic(d, d, 0, m.shape[0])
+    first = engine.download(*engine.numeric_owned(), m.shape[0], nnz, m.shape[1])
+    second = engine.download(*engine.numeric_owned(), m.shape[0], nnz, m.shape[1])
+    engine.free(d)
+    assert np.array_equal(first.indptr, second.indptr) and np.array_equal(first.indices, second.indices)
+    assert np.all(np.abs(first.data - second.data) <= 1e-12 * np.abs(first.data))
+    ao = to_oracle(m)
+    assert_parity(second, oracle.spgemm_spa(ao, ao), ao, ao, RTOL)
 
 
 def test_error_paths(engine):

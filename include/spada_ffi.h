@@ -186,6 +186,10 @@ int spada_dev_download_c(spada_ctx *ctx, const void *d_c_indptr, const void *d_c
                          uint64_t rows, uint64_t nnz_c, uint64_t *c_indptr, uint64_t *c_indices, double *c_data);
 
 int spada_get_stats(const spada_ctx *ctx, spada_stats *out);
+/* Phase times inside a call (ms_row_stats, ms_big_expand, ms_cut) need an event record between the kernels, and each record idles
+ * the stream for about 5 us.  enabled = 0: those three fields stay 0 and the records are left out (ms_task and the call times
+ * are still measured); default 1. */
+int spada_set_phase_timing(spada_ctx *ctx, int enabled);
 
 /* ---- host-side ingest (CPU only, usable without a GPU) -------------------------------------- */
 /* load_mm_mat (py2rust.rs:62-97): <dir>/<name>.mtx -> canonical CSR as scipy mmread(...).tocsr() */

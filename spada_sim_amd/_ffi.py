@@ -111,6 +111,7 @@ SIGNATURES = {
     "spada_dev_spgemm_numeric_owned": (ctypes.c_int, [vp, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(vp)]),
     "spada_dev_download_c": (ctypes.c_int, [vp, vp, vp, vp, u64, u64, u64p, u64p, f64p]),
     "spada_get_stats": (ctypes.c_int, [vp, ctypes.POINTER(Stats)]),
+    "spada_set_phase_timing": (ctypes.c_int, [vp, ctypes.c_int]),
     "spada_mtx_read": (ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(vp)]),
     "spada_mtx_write": (ctypes.c_int, [ctypes.c_char_p, ctypes.POINTER(CsrView)]),
     "spada_csr_checksum": (ctypes.c_int, [ctypes.POINTER(CsrView), ctypes.POINTER(Checksum)]),

@@ -77,6 +77,7 @@ struct spada_ctx {
     int accumulator = SPADA_ACC_LDS_HASH;
     uint32_t n_cu = 256;
     hipEvent_t tev[6] = {};           // phase boundaries of the last pipeline run
+    bool phase_timing = true;         // record tev[1], tev[2] (spada_set_phase_timing)
     // state carried from the symbolic to the numeric call
     bool have_symbolic = false;
     const spada_dev_csr *A = nullptr, *B = nullptr;
@@ -341,7 +342,7 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
                                c->t_rowm.as<uint32_t>(), c->t_big.as<uint32_t>(), dc);
             HIP_TRY(hipGetLastError());
         }
-        HIP_TRY(hipEventRecord(c->tev[1], s));
+        if (c->phase_timing) HIP_TRY(hipEventRecord(c->tev[1], s));
         if (n) {
             uint32_t *seq = c->accumulator == SPADA_ACC_SORT_MERGE ? c->t_scrseq.as<uint32_t>() : (uint32_t *)nullptr;
             hipLaunchKernelGGL(k_big_parts, dim3(c->n_cu * 2), dim3(256), 0, s, a->ptr, c->elen.as<uint32_t>(), c->r0,
@@ -362,7 +363,7 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
                                c->t_slots.as<BigSlot>(), c->t_scrcol.as<uint32_t>(), c->t_scrval.as<double>(), seq, dc);
             HIP_TRY(hipGetLastError());
         }
-        HIP_TRY(hipEventRecord(c->tev[2], s));
+        if (c->phase_timing) HIP_TRY(hipEventRecord(c->tev[2], s));
         if (n) {
             hipLaunchKernelGGL(k_cut1, dim3(ntiles), dim3(256), 0, s, c->row_bin.as<uint8_t>(), c->row_nprod.as<uint32_t>(),
                                c->t_rowm.as<uint32_t>(), n, rmax, dc, c->t_tiles.as<uint32_t>(), c->t_rowt.as<uint32_t>());
@@ -419,9 +420,9 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
     st.c_nnz = c->nnz_c;
     st.bytes_read = ((uint64_t)n + 1) * 8 + h.a_nnz * 12 + h.a_nnz * 16 + h.nprod * 12;
     st.bytes_write = ((uint64_t)n + 1) * 8 + c->nnz_c * 12;
-    st.ms_row_stats = tev_ms(c, 0, 1);
-    st.ms_big_expand = tev_ms(c, 1, 2);
-    st.ms_cut = tev_ms(c, 2, 3);
+    st.ms_row_stats = c->phase_timing ? tev_ms(c, 0, 1) : 0.f;
+    st.ms_big_expand = c->phase_timing ? tev_ms(c, 1, 2) : 0.f;
+    st.ms_cut = c->phase_timing ? tev_ms(c, 2, 3) : 0.f;
     st.ms_task = tev_ms(c, 3, 4);
     for (int k = 0; k < N_CLS; ++k) {
         st.cls_rows[k] = h.cls_rows[k];
@@ -971,6 +972,13 @@ int spada_spgemm_numeric(spada_ctx *c, uint64_t *c_indptr, uint64_t *c_indices, 
         dv = c->un_val.p;
     }
     return spada_dev_download_c(c, dp, di, dv, c->nrows, c->nnz_c, c_indptr, c_indices, c_data);
+}
+
+int spada_set_phase_timing(spada_ctx *c, int enabled)
+{
+    if (!c) return fail(SPADA_ERR_INVALID, "spada_set_phase_timing: null context");
+    c->phase_timing = enabled != 0;
+    return SPADA_OK;
 }
 
 int spada_get_stats(const spada_ctx *c, spada_stats *out)

@@ -358,6 +358,11 @@ class Engine:
             total += nnz
         return total
 
+    def set_phase_timing(self, enabled):
+        """Event records between the small kernels of a call (ms_row_stats / ms_big_expand / ms_cut) on or off: each idles the
+        stream for about 5 us (spada_set_phase_timing)."""
+        check(self._L.spada_set_phase_timing(self._ctx, 1 if enabled else 0))
+
     def stats(self):
         st = _ffi.Stats()
         check(self._L.spada_get_stats(self._ctx, ctypes.byref(st)))

@@ -197,6 +197,23 @@ def test_counting_mode_positions_across_tiles(engine, engine_sm):
     assert np.all(np.abs(c3.data - c1.data[lo:hi]) <= RTOL * np.abs(c1.data[lo:hi]))
 
 
+def test_phase_timing_switch(engine):
+    """spada_set_phase_timing(0): the event records between the small kernels are left out (their three times read 0), the call
+    and the task kernel are still timed and the product is the same."""
+    import spada_sim_amd as S
+    m = S.generate(S.GEN_RMAT, 12, 8, 31)
+    try:
+        c1, st1 = fused(engine, m, m)
+        assert st1["ms_row_stats"] > 0 and st1["ms_cut"] > 0 and st1["ms_task"] > 0
+        engine.set_phase_timing(False)
+        c2, st2 = fused(engine, m, m)
+        assert st2["ms_row_stats"] == 0 and st2["ms_big_expand"] == 0 and st2["ms_cut"] == 0
+        assert st2["ms_task"] > 0 and st2["ms_fused_call"] >= st2["ms_task"]
+        assert np.array_equal(c1.indptr, c2.indptr) and np.array_equal(c1.indices, c2.indices)
+    finally:
+        engine.set_phase_timing(True)
+
+
 def test_workspace_growth_reruns(engine):
     """A fresh context sizes its workspaces (part records, range descriptors, scratch, task list) from the counters of the runs
     that overflowed them and runs the pipeline again: the part records first, then whatever the plan behind them needs."""

@@ -171,11 +171,15 @@ def main():
     if exchange in ("overlap", "after") and (backend != "nccl" or args.accumulator != "lds_hash" and exchange == "after"):
         exchange = "torch"     # several ranks per GPU (gloo validation runs): RCCL refuses that
     comm = None
+    exchange_fallback = None      # why the native exchange was given up for the torch.distributed one, if it was
     if exchange in ("overlap", "after"):
         # the 128-byte RCCL id travels from rank 0 through the process group that launched us
         uid = [S.Comm.unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
-        comm = S.Comm(uid[0], rank, world, local_rank)
+        try:
+            comm = S.Comm(uid[0], rank, world, local_rank)
+        except Exception as e:     # (every rank votes below: the exchange must be the same one everywhere)
+            exchange_fallback = f"spada_comm_create failed on rank {rank}: {e}"
 
     def exchange_native(mode):
         """One step at N > 1 through libspada_comm.so; returns (stats, local nnz, (indptr, indices, data) of the whole C)."""
@@ -284,6 +288,32 @@ def main():
         eng.free(da)
         eng.close()
         return
+    if exchange in ("overlap", "after"):
+        # the native exchange against the torch.distributed one, once, before anything is timed: structure identical, values
+        # within 1e-9; if a rank could not create its communicator, or the two disagree anywhere, EVERY rank falls back to the
+        # torch.distributed exchange (and the JSON line says so)
+        if comm is not None and exchange_fallback is None:
+            try:
+                _, _, (fp, fi, fv) = exchange_native(exchange)
+                c_ptr = torch.empty(r1 - r0 + 1, dtype=torch.int64, device=dev)
+                nnz = eng.symbolic(da, da, r0, r1)
+                c_idx = torch.empty(max(nnz, 1), dtype=torch.int32, device=dev)
+                c_val = torch.empty(max(nnz, 1), dtype=torch.float64, device=dev)
+                eng.numeric(c_ptr.data_ptr(), c_idx.data_ptr(), c_val.data_ptr())
+                tp, ti, tv = parallel.allgatherv_c(c_ptr, c_idx[:nnz], c_val[:nnz])
+                if not (fi.numel() == ti.numel() and bool(torch.equal(fp, tp)) and bool(torch.equal(fi, ti)) and
+                        bool(torch.allclose(fv, tv, rtol=1e-9, atol=0))):
+                    exchange_fallback = f"libspada_comm.so ({exchange}) and torch.distributed disagree on the gathered C (rank {rank})"
+                del fp, fi, fv, tp, ti, tv
+            except Exception as e:
+                exchange_fallback = f"native exchange failed on rank {rank}: {e}"
+        vote = torch.tensor([0 if exchange_fallback is None else 1], dtype=torch.int32, device=dev)
+        dist.all_reduce(vote, op=dist.ReduceOp.MAX)
+        if int(vote.item()):
+            exchange_fallback = exchange_fallback or "another rank gave up the native exchange"
+            if comm is not None:
+                comm.close()
+            comm, exchange = None, "torch"
     # The split of a call into its small kernels (row statistics / BIG-row stage / cut) needs an event record between them, and
     # each record idles the stream for about 5 us: the split is taken in the warm-up steps (one extra step if there are none)
     # and the records are switched off for the timed steps, where only the call and k_task are bracketed by events.
@@ -298,21 +328,7 @@ def main():
     sync()
     compute_only_s = None
     if world > 1 and chunk_bounds is None:
-        # (a) the native exchange against the torch.distributed one, once, on the device: nnz, column and value checksums
-        if comm is not None:
-            _, _, (fp, fi, fv) = exchange_native(exchange)
-            c_ptr = torch.empty(r1 - r0 + 1, dtype=torch.int64, device=dev)
-            nnz = eng.symbolic(da, da, r0, r1)
-            c_idx = torch.empty(max(nnz, 1), dtype=torch.int32, device=dev)
-            c_val = torch.empty(max(nnz, 1), dtype=torch.float64, device=dev)
-            eng.numeric(c_ptr.data_ptr(), c_idx.data_ptr(), c_val.data_ptr())
-            tp, ti, tv = parallel.allgatherv_c(c_ptr, c_idx[:nnz], c_val[:nnz])
-            ok = (fi.numel() == ti.numel() and bool(torch.equal(fp, tp)) and bool(torch.equal(fi, ti)) and
-                  bool(torch.allclose(fv, tv, rtol=1e-9, atol=0)))
-            if not ok:
-                raise SystemExit(f"rank {rank}: libspada_comm.so ({exchange}) and torch.distributed disagree on the gathered C")
-            del fp, fi, fv, tp, ti, tv
-        # (b) the block computation alone (C left sharded), same number of steps: what the exchange is compared with
+        # the block computation alone (C left sharded), same number of steps: what the exchange is compared with
         sync()
         tc = time.perf_counter()
         for _ in range(args.steps):
@@ -401,6 +417,7 @@ def main():
                                         f"is computed, {args.exchange_chunks} pieces", "after": "libspada_comm.so: RCCL allgatherv after the "
                                         "one-pass SpGEMM of the block", "torch": "torch.distributed allgatherv after the SpGEMM of the block",
                              None: "none (C streamed in row chunks, not gathered)"}[exchange],
+                "exchange_fallback": exchange_fallback,
                 "allgatherv_ms_per_step": gather_max_s / K * 1e3 if exchange != "overlap" else None,   # max over ranks
                 "compute_ms_per_step": compute_max_s / K * 1e3,            # max over ranks: the block SpGEMM alone, timed separately
                 "value_compute_only": nnz_total / (compute_max_s / K),     # nnz(C)/s with C left sharded by row block

@@ -19,6 +19,12 @@
 
 using namespace spada;
 
+#ifndef SPADA_BH_GRID
+#define SPADA_BH_GRID 32   /* workgroups per CU in the grid of k_big_hist (8 -> 32: BIG-row stage -11 % web, -12 % R-MAT 16 / 18; 64, 128 the same) */
+#endif
+#ifndef SPADA_BP_GRID
+#define SPADA_BP_GRID 32   /* ... of k_big_plan */
+#endif
 #define HIP_TRY(expr)                                                                                      \
     do {                                                                                                   \
         hipError_t e_ = (expr);                                                                            \
@@ -349,10 +355,10 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
                                c->t_big.as<uint32_t>(), c->row_nprod.as<uint32_t>(), c->row_kmin.as<uint32_t>(),
                                c->row_kmax.as<uint32_t>(), c->accumulator == SPADA_ACC_SORT_MERGE ? 0u : 1u, c->t_parts.as<BigPart>(), cap_parts,
                                c->t_rowtmp.as<uint32_t>(), cap_tmp, c->t_slots.as<BigSlot>(), dc);
-            hipLaunchKernelGGL(k_big_hist, dim3(c->n_cu * 8), dim3(TK_BLOCK), BX_WALK_LDS, s, b->idx, c->eb0.as<uint64_t>(),
+            hipLaunchKernelGGL(k_big_hist, dim3(c->n_cu * SPADA_BH_GRID), dim3(TK_BLOCK), BX_WALK_LDS, s, b->idx, c->eb0.as<uint64_t>(),
                                c->elen.as<uint32_t>(), c->t_big.as<uint32_t>(), c->row_kmin.as<uint32_t>(),
                                c->row_kmax.as<uint32_t>(), c->t_parts.as<BigPart>(), c->t_parthist.as<uint32_t>(), dc);
-            hipLaunchKernelGGL(k_big_plan, dim3(c->n_cu * 8), dim3(TK_BLOCK), BX_PLAN_LDS, s, a->ptr, c->r0,
+            hipLaunchKernelGGL(k_big_plan, dim3(c->n_cu * SPADA_BP_GRID), dim3(TK_BLOCK), BX_PLAN_LDS, s, a->ptr, c->r0,
                                c->accumulator == SPADA_ACC_SORT_MERGE ? 0u : 1u, c->t_big.as<uint32_t>(),
                                c->row_kmin.as<uint32_t>(), c->row_kmax.as<uint32_t>(), c->t_parts.as<BigPart>(),
                                c->t_parthist.as<uint32_t>(), c->t_rowm.as<uint32_t>(), c->t_rowtmp.as<uint32_t>(),

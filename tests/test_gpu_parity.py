@@ -355,3 +355,34 @@ def test_bench_workloads_at_full_size(engine, kind, name):
     assert np.array_equal(c.indptr, ref.indptr)
     assert np.array_equal(c.indices, ref.indices)
     assert np.all(np.abs(c.data - ref.data) <= RTOL * np.abs(ref.data))
+
+
+def test_rmat22_row_ranges_against_oracle(engine):
+    """BASELINE.json configs[4] at its full size: R-MAT scale 22, degree 16 (4.19 M rows and columns, 65 M entries, 146 G products
+    -- bench.py streams C in 69 row chunks).  Three row ranges of about 0.2 G products each -- the hubs at the top, the middle, the
+    tail -- through the same two-phase calls the chunks use, against the oracle: structure bit-exact, values within 1e-9.  The hub
+    rows are spilled to HBM scratch and their histogram buckets (4096 columns) are wider than the table: column sub-range tasks."""
+    import spada_sim_amd as S
+    m = S.generate(S.GEN_RMAT, 22, 16, 22)
+    assert m.shape[0] == 1 << 22 and m.nnz() > 60_000_000
+    fine = S.partition_rows(m, m, 690)
+    d = engine.upload(m)
+    ao = to_oracle(m)
+    try:
+        for piece in (0, 345, 689):
+            r0, r1 = int(fine[piece]), int(fine[piece + 1])
+            nnz = engine.symbolic(d, d, r0, r1)
+            st = engine.stats()
+            c = engine.download(*engine.numeric_owned(), r1 - r0, nnz, m.shape[1])
+            lo, hi = int(ao.indptr[r0]), int(ao.indptr[r1])
+            sub = oracle.Csr(r1 - r0, ao.cols, (ao.indptr[r0:r1 + 1] - ao.indptr[r0]).astype(np.uint64), ao.indices[lo:hi], ao.data[lo:hi])
+            ref = oracle.spgemm_spa(sub, ao)
+            assert nnz == ref.nnz and st["nprod"] == oracle.count_products(sub, ao)
+            assert np.array_equal(c.indptr, ref.indptr)
+            assert np.array_equal(c.indices, ref.indices)
+            assert np.all(np.abs(c.data - ref.data) <= RTOL * np.abs(ref.data))
+            if piece == 0:
+                assert st["spill_rows"] > 0 and st["multi_pass_tasks"] == 0 and st["cls_prod"][4] > 0.99 * st["nprod"]
+            del c, ref, sub
+    finally:
+        engine.free(d)

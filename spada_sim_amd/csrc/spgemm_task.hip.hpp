@@ -30,6 +30,10 @@
 #pragma once
 #include "spgemm_common.hip.hpp"
 
+#ifndef SPADA_PRIO
+#define SPADA_PRIO 3   /* wave priority from a task's start until its count is published (one-pass mode): what the tasks behind it wait
+                         for wins the arbitration against emissions and stores; measured -1.4 % (web), -1.1 % (R-MAT 16), 0 elsewhere */
+#endif
 #ifndef SPADA_TASK_DBG
 #define SPADA_TASK_DBG 0   /* 1 (scripts/build_dbg.sh): phase cycle counters of k_task, printed to stderr */
 #endif
@@ -1682,6 +1686,9 @@ __global__ __launch_bounds__(TK_BLOCK, 4) void k_task(const TaskArgs g)
         // (tickets are taken when the work starts: one taken earlier -- even only across this task's stores, to hide its
         // round trip -- sits unstarted in the chain, every later task waits for it, and the pipeline loses more than the
         // round trip it saved: measured +6 % on the web surrogate, +30 % on R-MAT 16)
+#if SPADA_PRIO
+        if constexpr (MODE == MODE_FUSED) __builtin_amdgcn_s_setprio(SPADA_PRIO);
+#endif
         const TaskDesc td = g.tasks[t];
         const uint32_t next_row = t + 1 < ntasks ? g.tasks[t + 1].row : g.nrows;   // (with the descriptor: not a round trip of its own)
         unsigned long long ph_prev = dbg_a;
@@ -1785,6 +1792,9 @@ __global__ __launch_bounds__(TK_BLOCK, 4) void k_task(const TaskArgs g)
             // ---- chain: publish the count now, look back as late as possible ------------------------------------------------
             if (SPADA_TASK_DBG) dbg_b = dbg_c = __builtin_amdgcn_s_memtime();
             if constexpr (MODE != MODE_NUMERIC) task_publish<MODE>(g, t, total);
+#if SPADA_PRIO
+            if constexpr (MODE == MODE_FUSED) __builtin_amdgcn_s_setprio(0);
+#endif
 #if SPADA_TASK_DBG
             if (tid == 0) {
                 const unsigned long long w_ = __builtin_amdgcn_s_memtime() - dbg_a;
@@ -1920,6 +1930,9 @@ __global__ __launch_bounds__(TK_BLOCK, 4) void k_task(const TaskArgs g)
             }
             if (SPADA_TASK_DBG) dbg_b = dbg_c = __builtin_amdgcn_s_memtime();
             if constexpr (MODE != MODE_NUMERIC) task_publish<MODE>(g, t, total);
+#if SPADA_PRIO
+            if constexpr (MODE == MODE_FUSED) __builtin_amdgcn_s_setprio(0);
+#endif
 #if SPADA_TASK_DBG
             if (tid == 0) {
                 const unsigned long long w_ = __builtin_amdgcn_s_memtime() - dbg_a;

@@ -23,7 +23,8 @@
 //                            accumulates them in a 2048-slot LDS hash table (ds_cmpst / ds_add_f64), counts the distinct outputs per row, obtains the position
 //                            of its slice of C from the tasks before it by a decoupled look-back over per-task status words,
 //                            and emits its outputs in (row, column) order (monotone buckets + in-bucket rank).
-//                            MODE COUNT   : symbolic phase of the two-phase ABI -- counts only, writes C.indptr
+//                            MODE COUNT   : symbolic phase of the two-phase ABI -- counts only, no chain: the tasks leave their
+//                                           counts and k_pos1-4 scan them into C.indptr and the positions of the range tasks
 //                            MODE NUMERIC : numeric phase after COUNT -- C.indptr known, no chain
 //                            MODE FUSED   : one pass, C written into an upper-bound buffer, C.indptr produced by the chain
 // Every workgroup uses the same 39 KiB of LDS (4 per CU): nothing needs a CU of its own.
@@ -1916,7 +1917,8 @@ __global__ __launch_bounds__(TK_BLOCK, 4) void k_task(const TaskArgs g)
             }
         } else {
             // ---- RANGE task: columns [col_lo, col_hi] of a BIG row, products in the scratch slice -----------------------------
-            // Single pass when the slice cannot overflow the table (<= TK_SOLO_MAX products or columns), else range_dfs.
+            // Single pass when the slice cannot overflow the table (at most NOUT products or columns; a column sub-range of a heavy
+            // bucket keeps the products of its own columns), else range_dfs.
             const bool direct = td.kind == TASK_RANGE_DIRECT;
             const bool single = direct || td.np <= (uint32_t)NOUT || td.col_hi - td.col_lo < (uint32_t)NOUT;
             uint32_t total;
@@ -2013,7 +2015,7 @@ __global__ __launch_bounds__(TK_BLOCK, 4) void k_task(const TaskArgs g)
 // ---- 5. the task kernel with the SORT-MERGE accumulator (SPADA_ACC_SORT_MERGE) --------------------------------------------
 // The closest GPU analogue of what the reference's PE does to one group: collect the products (simulator.rs:86-111), sort them
 // by column (SortingNetwork, simulator.rs:143-171), add runs of equal column left to right (MergeTree, simulator.rs:199-230).
-// Same task list, same chain, same three modes as k_task -- only the accumulator differs, over exactly the same rows, so the
+// Same task list, same chain (none in the counting mode), same three modes as k_task -- only the accumulator differs, over exactly the same rows, so the
 // two variants of BASELINE.json configs[2] are like for like.  A task writes its products to LDS as (key, value) pairs with
 // key = (local row, column, product number) in 64 bits (the product number -- ascending k -- breaks ties, so a run is added in
 // the order of the CPU restatement and the values are bit-identical to a sequential sort-merge), sorts them with a bitonic

@@ -31,6 +31,10 @@
 #pragma once
 #include "spgemm_common.hip.hpp"
 
+#ifndef SPADA_NT_STORE
+#define SPADA_NT_STORE 1   /* C is written once and not read again by the pipeline: non-temporal stores keep A, B and the descriptors
+                            in the caches (web -3 %, cop20k_A -1.3 %, R-MAT 16 -1 % per step) */
+#endif
 #ifndef SPADA_PRIO
 #define SPADA_PRIO 3   /* wave priority from a task's start until its count is published (one-pass mode): what the tasks behind it wait
                          for wins the arbitration against emissions and stores; measured -1.4 % (web), -1.1 % (R-MAT 16), 0 elsewhere */
@@ -820,6 +824,8 @@ __global__ __launch_bounds__(TK_BLOCK) void k_big_scatter(const double *__restri
                                                     for (int u = 0; u < U; ++u)
                                                         if (plr[u] != LR_NONE) {
                                                             const uint32_t p = atomicAdd(&cur[(col[u] - kmin) >> wshift], 1u);
+                                                            // (plain stores: the runs of a range are completed in the caches;
+                                                            // non-temporal ones made the stage 1.4 - 2 x slower)
                                                             scr_col[sb + p] = col[u];
                                                             scr_val[sb + p] = v[u];
                                                             if (scr_seq) scr_seq[sb + p] = pt.p_begin + pp[u];
@@ -1432,8 +1438,13 @@ __device__ inline unsigned long long emit_table(unsigned char *smem, uint32_t NO
 #pragma unroll
         for (int w = 0; w < OPT; ++w)
             if (tid + w * BLOCK < NO) {
+#if SPADA_NT_STORE
+                __builtin_nontemporal_store(ecol[w], &c_idx[base + epos[w]]);
+                __builtin_nontemporal_store(evl[w], &c_val[base + epos[w]]);
+#else
                 c_idx[base + epos[w]] = ecol[w];
                 c_val[base + epos[w]] = evl[w];
+#endif
             }
     }
     __syncthreads();
@@ -1909,8 +1920,13 @@ __global__ __launch_bounds__(TK_BLOCK, 4) void k_task(const TaskArgs g)
 #pragma unroll
                         for (int u = 0; u < 4; ++u)
                             if (p0 + u * BLOCK < Cp) {
+#if SPADA_NT_STORE
+                                __builtin_nontemporal_store(k4[u], &g.c_idx[s_cc0[lr4[u]] + off4[u]]);
+                                __builtin_nontemporal_store(s_cav[lr4[u]] * v4[u], &g.c_val[s_cc0[lr4[u]] + off4[u]]);
+#else
                                 g.c_idx[s_cc0[lr4[u]] + off4[u]] = k4[u];
                                 g.c_val[s_cc0[lr4[u]] + off4[u]] = s_cav[lr4[u]] * v4[u];
+#endif
                             }
                     }
                 }

@@ -2135,8 +2135,8 @@ __global__ __launch_bounds__(TK_BLOCK, 3) void k_task_sm(const TaskArgs g)
             for (uint32_t q = p + 1; q < N && (uint32_t)(sk[q] >> 32) == key; ++q) acc += sv[q];
             const uint32_t lr = (!batch || g.colbits >= 32) ? 0u : (key >> g.colbits);
             const uint64_t pos = base + s_out[lr] + (rank - s_row[lr].boff);
-            g.c_idx[pos] = batch ? (key & colmask) : key;
-            g.c_val[pos] = acc;
+            __builtin_nontemporal_store(batch ? (key & colmask) : key, &g.c_idx[pos]);   // (as in k_task: C is not read again)
+            __builtin_nontemporal_store(acc, &g.c_val[pos]);
         }
     };
 
@@ -2260,8 +2260,8 @@ __global__ __launch_bounds__(TK_BLOCK, 3) void k_task_sm(const TaskArgs g)
                         for (int step = RMAX / 2; step >= 1; step >>= 1)
                             if (lo + step < R && s_cpre[lo + step] <= p) lo += step;
                         const uint32_t off = p - s_cpre[lo];
-                        g.c_idx[s_cc0[lo] + off] = g.bidx[s_cb0[lo] + off];
-                        g.c_val[s_cc0[lo] + off] = s_cav[lo] * g.bval[s_cb0[lo] + off];
+                        __builtin_nontemporal_store(g.bidx[s_cb0[lo] + off], &g.c_idx[s_cc0[lo] + off]);
+                        __builtin_nontemporal_store(s_cav[lo] * g.bval[s_cb0[lo] + off], &g.c_val[s_cc0[lo] + off]);
                     }
                 }
             }

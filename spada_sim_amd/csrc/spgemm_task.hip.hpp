@@ -1678,7 +1678,7 @@ __global__ __launch_bounds__(TK_BLOCK, 4) void k_task(const TaskArgs g)
     uint64_t *s_out = s_a0 + RMAX;
     uint32_t *s_re = (uint32_t *)(s_out + RMAX);
     uint32_t *s_cnt = s_re + RMAX + 1;
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = threadIdx.x;
     const uint32_t ntasks = g.ctr->ntasks, task_end = min(ntasks, g.task_hi);
     if (g.ctr->abort_flag) return;
 

@@ -1,11 +1,15 @@
 #!/usr/bin/env python3
 """bench.py -- nnz(C)/s of A*A SpGEMM on MI355X, with roofline and CPU baseline (contract: see DESIGN.md).
 
-One "step" = one complete SpGEMM of the workload: allocation of C, the one-pass task pipeline (row statistics, spill
-of the big rows, task list, task kernel; `--two-phase` times the symbolic + numeric contract instead) and
-(for N > 1) the allgatherv of the C row blocks.  Inputs (A, B = A) are resident in HBM before the
-timed region starts; the timed region is bracketed by a barrier + torch.cuda.synchronize() on both sides
-and the max over ranks is taken.
+One "step" = one complete SpGEMM of the workload: the one-pass task pipeline (row statistics, BIG-row stage, task list,
+task kernel) into CALLER-OWNED C buffers that are allocated once, sized by the product count of the row block, and
+reused from step to step (`"c_alloc": "reused"` in the JSON line; `--two-phase` times the symbolic + numeric contract
+instead, whose buffers can only be sized after the symbolic call and are allocated in every step: `"c_alloc": "per_step"`),
+and (for N > 1) the allgatherv of the C row blocks.  Inputs (A, B = A) are resident in HBM before the timed region
+starts; the timed region is bracketed by a barrier + torch.cuda.synchronize() on both sides and the max over ranks is
+taken.  `value` and `ms_per_step` are the mean over the K steps (the contract); `ms_per_step_median` is printed beside it.
+Once, outside the timed region, the C of the timed entry point is checked (`"verified"`): against the other entry point
+(structure identical, values within 1e-9) and, unless --no-cpu-baseline, against the CPU oracle's product of the same matrix.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--accumulator lds_hash|sort_merge]
 
@@ -231,6 +235,9 @@ def main():
 
             def consume(b0, b1, nnz, st):
                 checksum.add_(bufs["v"][:nnz].sum())
+                # the sum runs on torch's stream, the next chunk is written by the engine's own (non-blocking) stream: it must
+                # have read the buffer before the buffer is dropped and its memory handed to the next chunk
+                torch.cuda.current_stream().synchronize()
                 for k in ("c_nnz", "nprod", "bytes_read", "bytes_write"):
                     agg[k] += st[k]
                 for k, v in st.items():
@@ -340,7 +347,7 @@ def main():
         for _ in range(args.steps):
             c_ptr = torch.empty(r1 - r0 + 1, dtype=torch.int64, device=dev)
             buf = torch.empty(max(cap, 1) * 12, dtype=torch.uint8, device=dev)
-            if one_pass:
+            if one_pass and exchange != "overlap":      # (the overlapped exchange times the two-phase contract: compare like with like)
                 eng.fused(da, da, r0, r1, c_ptr.data_ptr(), buf[max(cap, 1) * 8:].data_ptr(), buf.data_ptr(), cap)
             else:
                 nnz = eng.symbolic(da, da, r0, r1)
@@ -351,8 +358,11 @@ def main():
     t0 = time.perf_counter()
     acc = {}
     TIMES = ("ms_fused_call", "ms_symbolic_call", "ms_numeric_call", "ms_row_stats", "ms_big_expand", "ms_cut", "ms_task")
+    step_wall = []
     for _ in range(args.steps):
+        ts = time.perf_counter()
         st, nnz_local, _ = step()
+        step_wall.append(time.perf_counter() - ts)     # (every step returns after its stream has drained)
         for k in TIMES:
             acc[k] = acc.get(k, 0.0) + st.get(k, 0.0)
     sync()
@@ -368,6 +378,54 @@ def main():
         nnz_total, nprod_total = int(tot[0]), int(tot[1])
     else:
         nnz_total, nprod_total = st["c_nnz"], st["nprod"]
+
+    # ---- verification, outside the timed region: the C of the entry point that was timed -----------------------------------
+    verified = None
+    if world == 1 and chunk_bounds is None:
+        verified = {}
+        try:
+            _, nnz_t, (t_ptr, t_idx, t_val) = step()
+            t_ptr, t_idx, t_val = t_ptr.clone(), t_idx[:nnz_t].clone(), t_val[:nnz_t].clone()
+            if one_pass or args.accumulator != "lds_hash":
+                # the other entry point: the symbolic + numeric contract (sort-merge runs: the one-pass call)
+                if one_pass:
+                    o_nnz = eng.symbolic(da, da, r0, r1)
+                    o_ptr = torch.empty(r1 - r0 + 1, dtype=torch.int64, device=dev)
+                    o_idx = torch.empty(max(o_nnz, 1), dtype=torch.int32, device=dev)
+                    o_val = torch.empty(max(o_nnz, 1), dtype=torch.float64, device=dev)
+                    eng.numeric(o_ptr.data_ptr(), o_idx.data_ptr(), o_val.data_ptr())
+                    other = "spada_dev_spgemm_symbolic + _numeric"
+                else:
+                    o_ptr = torch.empty(r1 - r0 + 1, dtype=torch.int64, device=dev)
+                    o_idx = torch.empty(max(cap, 1), dtype=torch.int32, device=dev)
+                    o_val = torch.empty(max(cap, 1), dtype=torch.float64, device=dev)
+                    o_nnz = eng.fused(da, da, r0, r1, o_ptr.data_ptr(), o_idx.data_ptr(), o_val.data_ptr(), cap)
+                    other = "spada_dev_spgemm_fused"
+                torch.cuda.synchronize()
+                verified["other_entry_point"] = other
+                verified["entry_points_agree"] = bool(
+                    o_nnz == nnz_t and torch.equal(o_ptr, t_ptr) and torch.equal(o_idx[:o_nnz], t_idx) and
+                    torch.all((o_val[:o_nnz] - t_val).abs() <= 1e-9 * t_val.abs()).item())
+                del o_ptr, o_idx, o_val
+            if not args.no_cpu_baseline and st["nprod"] <= 1.0e9:
+                # the CPU oracle on the whole matrix (the checker, never the thing measured): structure bit-exact, values 1e-9
+                from oracle import oracle
+                ao = oracle.Csr(a.shape[0], a.shape[1], a.indptr, a.indices, a.data)
+                ref = oracle.spgemm_spa(ao, ao)
+                h_ptr = t_ptr.cpu().numpy().astype(np.uint64)
+                h_idx = t_idx.cpu().numpy().astype(np.uint32).astype(np.uint64)
+                h_val = t_val.cpu().numpy()
+                verified["oracle_agrees"] = bool(
+                    nnz_t == ref.nnz and np.array_equal(h_ptr, ref.indptr) and np.array_equal(h_idx, ref.indices) and
+                    np.all(np.abs(h_val - ref.data) <= 1e-9 * np.abs(ref.data)))
+                del ref, h_ptr, h_idx, h_val
+            else:
+                verified["oracle_agrees"] = None
+            verified["nnz_c"] = int(nnz_t)
+            verified["ok"] = all(v is not False for k, v in verified.items() if k.endswith("agree") or k.endswith("agrees"))
+            del t_ptr, t_idx, t_val
+        except Exception as e:      # a failed check must not lose the measurement: the line says what happened
+            verified = {"ok": False, "error": f"{type(e).__name__}: {e}"}
 
     if rank == 0:
         K = args.steps
@@ -394,6 +452,9 @@ def main():
             {"kernel": "k_cut1/2/3 (task list)", "ms": ms["ms_cut"]},
         ]
         two_phase = not (ms["ms_fused_call"] > 0)
+        # a two-phase step whose numeric phase was not timed (0 ms) would price the whole step at the symbolic time alone: no
+        # roofline is printed from such a record
+        roofline_valid = not two_phase or ms["ms_numeric_call"] > 0
         if two_phase:
             # (the phase times of a two-phase step: the counters of the symbolic call survive the numeric call except ms_task)
             kernels += [
@@ -413,6 +474,10 @@ def main():
             "steps": K,
             "warmup": args.warmup,
             "ms_per_step": ms_step,
+            "ms_per_step_median": float(np.median(step_wall)) * 1e3,   # per-step wall times on rank 0 (every step drains its stream)
+            "verified": None if verified is None else bool(verified.get("ok")),
+            "verification": verified,
+            "c_alloc": "reused" if one_pass and chunk_bounds is None and comm is None and world == 1 else "per_step",
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
@@ -431,7 +496,9 @@ def main():
                         "(N-1)/N of 12 B x nnz(C) over xGMI, which bounds strong scaling once that exceeds the compute time"},
             "config": {"workload": f"{args.workload} A*A", "rows": rows, "nnz_a": a.nnz(), "products": nprod_total,
                        "nnz_c": nnz_total, "accumulator": args.accumulator,
-                       "entry_point": "spada_dev_spgemm_fused (one pass, C buffers sized by the product count)"
+                       "entry_point": ("spada_dist_spgemm_symbolic + spada_dist_spgemm_numeric (libspada_comm.so: two-phase, numeric phase in "
+                                       f"{args.exchange_chunks} pieces overlapped with their broadcast)") if exchange == "overlap" else
+                                      "spada_dev_spgemm_fused (one pass, C buffers sized by the product count)"
                                       if one_pass and chunk_bounds is None
                                       else "spada_dev_spgemm_symbolic + spada_dev_spgemm_numeric",
                        "parallelism": f"row-block x{world}, B replicated" +
@@ -443,10 +510,11 @@ def main():
                            "average duration per step by HIP events on its stream, rank 0") if not two_phase else
                           ("whole device time of the symbolic + numeric calls (k_task<COUNT>, k_task<NUMERIC> and the kernels around "
                            "them) against the algorithmic bytes of ONE pass over the products; HIP events on the engine stream, rank 0"),
-                "achieved": achieved,
+                "achieved": achieved if roofline_valid else None,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
+                "frac": achieved / HBM_PEAK_GBS if roofline_valid else None,
+                "error": None if roofline_valid else "the numeric phase of the two-phase step reported 0 ms: not priced",
                 "traffic": max([v.get("hbm_bytes_per_launch") or 0 for k, v in (traffic or {}).items()
                                 if isinstance(v, dict) and k.startswith("k_task<2" if one_pass else "k_task<1")] or [None]) or None,
                 "traffic_source": os.path.relpath(traffic_src, ROOT) if traffic else None,

@@ -39,6 +39,18 @@ int spada_comm_size(const spada_comm *comm);
 /* rows and nnz(C) of every rank's block (host arrays of nranks entries) */
 int spada_comm_allgather_counts(spada_comm *comm, uint64_t my_rows, uint64_t my_nnz, uint64_t *rows_of_rank,
                                 uint64_t *nnz_of_rank);
+/* The offset arithmetic of the exchange, as a pure function of the gathered counts (host only: no GPU, no RCCL call; both
+ * exchange forms below place every segment with it, and tests/test_host_cpu.py checks it for N = 2, 3, 8 with empty blocks and
+ * empty pieces against the offsets of the torch.distributed path).  Inputs: rows / nnz of every rank's block (nranks entries
+ * each) and, when chunks > 0, the piece positions of every rank inside its own block, chunk_pos[r * (chunks + 1) + k], k = 0 ..
+ * chunks (first 0, last nnz[r], ascending -- what spada_dev_spgemm_numeric_plan returned on rank r).  Outputs: row_off / nnz_off
+ * [nranks + 1] = first row / first entry of every block in the whole C (last = totals); piece_begin / piece_count [nranks * chunks]
+ * = where piece k of rank r starts in the whole C and how many entries it holds (null when chunks == 0).
+ * Replaces nothing in the reference (it has no exchange); the row blocks are those of scheduler.rs:296-379. */
+int spada_comm_plan(int nranks, const uint64_t *rows_of_rank, const uint64_t *nnz_of_rank, uint32_t chunks,
+                    const uint64_t *chunk_pos, uint64_t *row_off, uint64_t *nnz_off, uint64_t *piece_begin,
+                    uint64_t *piece_count);
+
 /* Concatenation of the finished blocks on every rank.  Inputs: this rank's block (device; indptr u64[my_rows + 1] starting
  * at 0, indices u32, data f64).  Outputs (device, caller-allocated from the counts): indptr u64[sum rows + 1],
  * indices u32[sum nnz], data f64[sum nnz] of the whole C.  Returns when the result is complete. */

@@ -26,6 +26,16 @@
  *     SPADA_ERR_NO_DEVICE and every compute entry point fails with SPADA_ERR_STATE.
  *   - column indices are narrowed to 32 bit on the device (cols < 2^32 is checked); the host ABI
  *     stays 64 bit to match `usize`.
+ *   - STREAM ORDER (spada_dev_* entry points): the engine queues its kernels on a stream of its own (non-blocking, i.e. not
+ *     ordered against the caller's default or torch stream).  Every spada_dev_* compute call returns only after that stream has
+ *     drained -- EXCEPT spada_dev_spgemm_numeric_chunk and spada_dev_spgemm_indptr, which return as soon as their work is
+ *     queued (wait for the event the former returns, or call spada_dev_synchronize).  So results may be read on any stream once a
+ *     call has returned; but work the CALLER has queued on its own streams is not waited for: a caller that reads, fills or
+ *     frees a buffer on its own stream must have that stream finished with the buffer before it hands it (or memory reused
+ *     from it) to the next spada_dev_* call (hipStreamSynchronize / an event wait of its own).
+ *   - SPADA_TRACE=0/1/2 in the environment (replaces the trace_exec cargo feature, util.rs:1-24, Cargo.toml:19-21): 1 = one line per
+ *     call on stderr (what was loaded, products / nnz(C) / tasks / device time of a pipeline run), 2 = also row classes, phase
+ *     times and workspace growth.  0 / unset: silent.
  */
 #ifndef SPADA_FFI_H
 #define SPADA_FFI_H

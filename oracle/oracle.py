@@ -12,6 +12,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "liboracle_spgemm.so")
+_SO_OVERRIDE = os.environ.get("SPADA_ORACLE_LIB_PATH")     # scripts/run_asan_tests.sh: the sanitizer build of this same source
 _lib = None
 
 _u64p = ctypes.POINTER(ctypes.c_uint64)
@@ -29,8 +30,9 @@ def build(force=False):
 def lib():
     global _lib
     if _lib is None:
-        build()
-        L = ctypes.CDLL(_SO)
+        if not _SO_OVERRIDE:
+            build()
+        L = ctypes.CDLL(_SO_OVERRIDE or _SO)
         L.oracle_count_products.restype = ctypes.c_uint64
         L.oracle_count_products.argtypes = [ctypes.c_uint64, _u64p, _u64p, _u64p]
         L.oracle_spgemm_sortmerge.restype = ctypes.c_uint64

@@ -131,7 +131,7 @@ SIGNATURES = {
 }
 
 # libspada_comm.so (include/spada_comm.h): the RCCL exchange; loaded on demand, it pulls in librccl
-COMM_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libspada_comm.so")
+COMM_LIB_PATH = os.environ.get("SPADA_COMM_LIB_PATH") or os.path.join(os.path.dirname(LIB_PATH), "libspada_comm.so")
 COMM_ID_BYTES = 128
 COMM_SIGNATURES = {
     "spada_comm_get_unique_id": (ctypes.c_int, [vp]),
@@ -140,6 +140,7 @@ COMM_SIGNATURES = {
     "spada_comm_rank": (ctypes.c_int, [vp]),
     "spada_comm_size": (ctypes.c_int, [vp]),
     "spada_comm_allgather_counts": (ctypes.c_int, [vp, u64, u64, u64p, u64p]),
+    "spada_comm_plan": (ctypes.c_int, [ctypes.c_int, u64p, u64p, ctypes.c_uint32, u64p, u64p, u64p, u64p, u64p]),
     "spada_comm_allgatherv_c": (ctypes.c_int, [vp, vp, vp, vp, u64p, u64p, vp, vp, vp]),
     "spada_dist_spgemm_symbolic": (ctypes.c_int, [vp, vp, vp, vp, u64, u64, ctypes.c_uint32, u64p, u64p]),
     "spada_dist_spgemm_numeric": (ctypes.c_int, [vp, vp, vp, vp, vp]),

@@ -73,31 +73,24 @@ int allgather_words(spada_comm *m, const uint64_t *mine, size_t per, uint64_t *o
 }
 
 // indptr of the whole C from the blocks' local ones: broadcast entries 1 .. rows_r of every block behind one another, then
-// shift every segment by the nnz before it.  d_local = this rank's local indptr (rows + 1 entries, first = 0).
-int gather_indptr(spada_comm *m, const uint64_t *d_local, const uint64_t *rows, const uint64_t *nnz, uint64_t *d_full)
+// shift every segment by the nnz before it.  d_local = this rank's local indptr (rows + 1 entries, first = 0); row_off / nnz_off =
+// what spada_comm_plan computed from the gathered counts.
+int gather_indptr(spada_comm *m, const uint64_t *d_local, const uint64_t *rows, const uint64_t *row_off, const uint64_t *nnz_off,
+                  uint64_t *d_full)
 {
-    uint64_t roff = 0;
-    for (int r = 0; r < m->rank; ++r) roff += rows[r];
     HIP_TRY(hipMemsetAsync(d_full, 0, 8, m->stream));
     if (rows[m->rank])
-        HIP_TRY(hipMemcpyAsync(d_full + roff + 1, d_local + 1, rows[m->rank] * 8, hipMemcpyDeviceToDevice, m->stream));
+        HIP_TRY(hipMemcpyAsync(d_full + row_off[m->rank] + 1, d_local + 1, rows[m->rank] * 8, hipMemcpyDeviceToDevice, m->stream));
     NCCL_TRY(ncclGroupStart());
-    uint64_t ro = 0;
-    for (int r = 0; r < m->nranks; ++r) {
-        if (rows[r]) NCCL_TRY(ncclBroadcast(d_full + ro + 1, d_full + ro + 1, rows[r], ncclUint64, r, m->comm, m->stream));
-        ro += rows[r];
-    }
+    for (int r = 0; r < m->nranks; ++r)
+        if (rows[r])
+            NCCL_TRY(ncclBroadcast(d_full + row_off[r] + 1, d_full + row_off[r] + 1, rows[r], ncclUint64, r, m->comm, m->stream));
     NCCL_TRY(ncclGroupEnd());
-    uint64_t no = 0;
-    ro = 0;
-    for (int r = 0; r < m->nranks; ++r) {
-        if (rows[r] && no) {
+    for (int r = 0; r < m->nranks; ++r)
+        if (rows[r] && nnz_off[r]) {
             const uint32_t grid = (uint32_t)std::min<uint64_t>((rows[r] + 255) / 256, 2048);
-            hipLaunchKernelGGL(k_shift_indptr, dim3(grid), dim3(256), 0, m->stream, d_full + ro + 1, rows[r], no);
+            hipLaunchKernelGGL(k_shift_indptr, dim3(grid), dim3(256), 0, m->stream, d_full + row_off[r] + 1, rows[r], nnz_off[r]);
         }
-        ro += rows[r];
-        no += nnz[r];
-    }
     HIP_TRY(hipGetLastError());
     return SPADA_OK;
 }
@@ -171,16 +164,43 @@ int spada_comm_allgather_counts(spada_comm *m, uint64_t my_rows, uint64_t my_nnz
     return SPADA_OK;
 }
 
+int spada_comm_plan(int nranks, const uint64_t *rows, const uint64_t *nnz, uint32_t chunks, const uint64_t *chunk_pos,
+                    uint64_t *row_off, uint64_t *nnz_off, uint64_t *piece_begin, uint64_t *piece_count)
+{
+    if (nranks < 1 || !rows || !nnz || !row_off || !nnz_off) return fail(SPADA_ERR_INVALID, "spada_comm_plan: bad argument");
+    if (chunks && (!chunk_pos || !piece_begin || !piece_count)) return fail(SPADA_ERR_INVALID, "spada_comm_plan: chunks without positions");
+    uint64_t ro = 0, no = 0;
+    for (int r = 0; r < nranks; ++r) {
+        row_off[r] = ro;
+        nnz_off[r] = no;
+        if (ro + rows[r] < ro || no + nnz[r] < no) return fail(SPADA_ERR_INVALID, "spada_comm_plan: counts overflow 64 bits");
+        if (chunks) {
+            const uint64_t *p = chunk_pos + (size_t)r * (chunks + 1);
+            if (p[0] != 0 || p[chunks] != nnz[r])
+                return fail(SPADA_ERR_INVALID, "spada_comm_plan: pieces of rank %d do not cover its %llu entries", r, (unsigned long long)nnz[r]);
+            for (uint32_t k = 0; k < chunks; ++k) {
+                if (p[k + 1] < p[k]) return fail(SPADA_ERR_INVALID, "spada_comm_plan: piece positions of rank %d descend", r);
+                piece_begin[(size_t)r * chunks + k] = no + p[k];
+                piece_count[(size_t)r * chunks + k] = p[k + 1] - p[k];
+            }
+        }
+        ro += rows[r];
+        no += nnz[r];
+    }
+    row_off[nranks] = ro;
+    nnz_off[nranks] = no;
+    return SPADA_OK;
+}
+
 int spada_comm_allgatherv_c(spada_comm *m, const void *d_my_indptr, const void *d_my_indices, const void *d_my_data,
                             const uint64_t *rows, const uint64_t *nnz, void *d_c_indptr, void *d_c_indices, void *d_c_data)
 {
     if (!m || !d_my_indptr || !rows || !nnz || !d_c_indptr) return fail(SPADA_ERR_INVALID, "spada_comm_allgatherv_c: null argument");
     HIP_TRY(hipSetDevice(m->device));
-    uint64_t total = 0, off = 0;
-    for (int r = 0; r < m->nranks; ++r) {
-        if (r < m->rank) off += nnz[r];
-        total += nnz[r];
-    }
+    std::vector<uint64_t> row_off(m->nranks + 1), nnz_off(m->nranks + 1);
+    int rc = spada_comm_plan(m->nranks, rows, nnz, 0, nullptr, row_off.data(), nnz_off.data(), nullptr, nullptr);
+    if (rc) return rc;
+    const uint64_t total = nnz_off[m->nranks], off = nnz_off[m->rank];
     if (total && (!d_c_indices || !d_c_data || (nnz[m->rank] && (!d_my_indices || !d_my_data))))
         return fail(SPADA_ERR_INVALID, "spada_comm_allgatherv_c: null data pointer");
     uint32_t *ci = (uint32_t *)d_c_indices;
@@ -190,17 +210,13 @@ int spada_comm_allgatherv_c(spada_comm *m, const void *d_my_indptr, const void *
         HIP_TRY(hipMemcpyAsync(cv + off, d_my_data, nnz[m->rank] * 8, hipMemcpyDeviceToDevice, m->stream));
     }
     NCCL_TRY(ncclGroupStart());
-    uint64_t o = 0;
-    for (int r = 0; r < m->nranks; ++r) {
+    for (int r = 0; r < m->nranks; ++r)
         if (nnz[r]) {
-            NCCL_TRY(ncclBroadcast(ci + o, ci + o, nnz[r], ncclUint32, r, m->comm, m->stream));
-            NCCL_TRY(ncclBroadcast(cv + o, cv + o, nnz[r], ncclFloat64, r, m->comm, m->stream));
+            NCCL_TRY(ncclBroadcast(ci + nnz_off[r], ci + nnz_off[r], nnz[r], ncclUint32, r, m->comm, m->stream));
+            NCCL_TRY(ncclBroadcast(cv + nnz_off[r], cv + nnz_off[r], nnz[r], ncclFloat64, r, m->comm, m->stream));
         }
-        o += nnz[r];
-    }
     NCCL_TRY(ncclGroupEnd());
-    int rc = gather_indptr(m, (const uint64_t *)d_my_indptr, rows, nnz, (uint64_t *)d_c_indptr);
-    if (rc) return rc;
+    if ((rc = gather_indptr(m, (const uint64_t *)d_my_indptr, rows, row_off.data(), nnz_off.data(), (uint64_t *)d_c_indptr))) return rc;
     HIP_TRY(hipStreamSynchronize(m->stream));
     return SPADA_OK;
 }
@@ -240,17 +256,14 @@ int spada_dist_spgemm_numeric(spada_ctx *ctx, spada_comm *m, void *d_c_indptr, v
         return fail(SPADA_ERR_STATE, "spada_dist_spgemm_numeric called without spada_dist_spgemm_symbolic");
     HIP_TRY(hipSetDevice(m->device));
     const uint32_t K = m->chunks;
-    uint64_t total = 0, off_me = 0;
-    std::vector<uint64_t> off(m->nranks);
-    for (int r = 0; r < m->nranks; ++r) {
-        off[r] = total;
-        if (r == m->rank) off_me = total;
-        total += m->nnz[r];
-    }
+    std::vector<uint64_t> row_off(m->nranks + 1), nnz_off(m->nranks + 1), pbeg((size_t)m->nranks * K), pcnt((size_t)m->nranks * K);
+    int rc = spada_comm_plan(m->nranks, m->rows.data(), m->nnz.data(), K, m->pos.data(), row_off.data(), nnz_off.data(), pbeg.data(),
+                             pcnt.data());
+    if (rc) return rc;
+    const uint64_t total = nnz_off[m->nranks], off_me = nnz_off[m->rank];
     if (total && (!d_c_indices || !d_c_data)) return fail(SPADA_ERR_INVALID, "spada_dist_spgemm_numeric: null data pointer");
     uint32_t *ci = (uint32_t *)d_c_indices;
     double *cv = (double *)d_c_data;
-    int rc;
     // every piece of the own block is computed at its final place in the whole C and broadcast from there as soon as it is
     // complete, on the communication stream, while the engine stream computes the next piece
     for (uint32_t k = 0; k < K; ++k) {
@@ -259,10 +272,10 @@ int spada_dist_spgemm_numeric(spada_ctx *ctx, spada_comm *m, void *d_c_indptr, v
         HIP_TRY(hipStreamWaitEvent(m->stream, (hipEvent_t)ev, 0));
         NCCL_TRY(ncclGroupStart());
         for (int r = 0; r < m->nranks; ++r) {
-            const uint64_t p0 = m->pos[(size_t)r * (K + 1) + k], p1 = m->pos[(size_t)r * (K + 1) + k + 1];
-            if (p1 > p0) {
-                NCCL_TRY(ncclBroadcast(ci + off[r] + p0, ci + off[r] + p0, p1 - p0, ncclUint32, r, m->comm, m->stream));
-                NCCL_TRY(ncclBroadcast(cv + off[r] + p0, cv + off[r] + p0, p1 - p0, ncclFloat64, r, m->comm, m->stream));
+            const uint64_t p0 = pbeg[(size_t)r * K + k], n = pcnt[(size_t)r * K + k];
+            if (n) {
+                NCCL_TRY(ncclBroadcast(ci + p0, ci + p0, n, ncclUint32, r, m->comm, m->stream));
+                NCCL_TRY(ncclBroadcast(cv + p0, cv + p0, n, ncclFloat64, r, m->comm, m->stream));
             }
         }
         NCCL_TRY(ncclGroupEnd());
@@ -278,7 +291,8 @@ int spada_dist_spgemm_numeric(spada_ctx *ctx, spada_comm *m, void *d_c_indptr, v
     }
     if ((rc = spada_dev_spgemm_indptr(ctx, m->d_tmp_ptr))) return rc;
     if ((rc = spada_dev_synchronize(ctx))) return rc;   // the copy above ran on the engine stream
-    if ((rc = gather_indptr(m, (const uint64_t *)m->d_tmp_ptr, m->rows.data(), m->nnz.data(), (uint64_t *)d_c_indptr))) return rc;
+    if ((rc = gather_indptr(m, (const uint64_t *)m->d_tmp_ptr, m->rows.data(), row_off.data(), nnz_off.data(), (uint64_t *)d_c_indptr)))
+        return rc;
     HIP_TRY(hipStreamSynchronize(m->stream));
     return SPADA_OK;
 }

@@ -105,6 +105,7 @@ struct spada_ctx {
     // numeric phase in pieces (spada_dev_spgemm_numeric_plan / _chunk): task boundaries, one event per piece
     std::vector<uint32_t> chunk_task;
     std::vector<hipEvent_t> chunk_ev;
+    bool chunk_timing_open = false;   // pieces have been queued since the plan: tev[0] .. tev[4] bracket them (closed by spada_dev_synchronize)
     DevBuf t_chunk;
     // matrices uploaded by the host-pointer API; hAr = A reordered by spada_spgemm_symbolic_reordered (-p)
     spada_dev_csr *hA = nullptr, *hB = nullptr, *hAr = nullptr;
@@ -415,6 +416,9 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
         if ((h.abort_flag & 16u) && !h.scratch_cursor)   // the plan has not run: a guess, replaced by the exact size if it is too small
             c->t_cap_scr = std::max<uint64_t>(c->t_cap_scr, std::min<uint64_t>(h.nprod_big, 64ull << 20));
         c->t_cap_tasks = std::max<uint64_t>(c->t_cap_tasks, (uint64_t)h.need_tasks + h.need_tasks / 16 + 1024);
+        trace(2, "  workspace too small (flag %u): tasks %llu, range descriptors %llu, parts %llu, scratch %llu products -- running again",
+              h.abort_flag, (unsigned long long)c->t_cap_tasks, (unsigned long long)c->t_cap_tmp, (unsigned long long)c->t_cap_parts,
+              (unsigned long long)c->t_cap_scr);
     }
     const TaskCounters &h = *c->h_tctr;
     c->nnz_c = n ? h.nnz_c : 0;
@@ -465,6 +469,15 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
     } else {
         st.ms_fused_call = tev_ms(c, 0, 4);
     }
+    trace(1, "%s rows [%llu, %llu): %llu products -> %llu nnz(C), %u tasks, %.3f ms on the device (%llu pipeline run%s)",
+          mode == MODE_COUNT ? "symbolic" : "one-pass", (unsigned long long)c->r0, (unsigned long long)(c->r0 + n),
+          (unsigned long long)h.nprod, (unsigned long long)c->nnz_c, h.ntasks, tev_ms(c, 0, 4), (unsigned long long)st.pipeline_runs,
+          st.pipeline_runs == 1 ? "" : "s");
+    trace(2, "  rows empty / copy / small / solo / big: %llu / %llu / %llu / %llu / %llu; products per task <= %u; spilled rows %u (%llu "
+          "products); statistics %.3f, BIG-row stage %.3f, cut %.3f, task kernel %.3f ms; workspaces %.1f MB",
+          (unsigned long long)h.cls_rows[0], (unsigned long long)h.cls_rows[1], (unsigned long long)h.cls_rows[2],
+          (unsigned long long)h.cls_rows[3], (unsigned long long)h.cls_rows[4], h.prod_limit, h.n_spilled,
+          (unsigned long long)h.scratch_cursor, st.ms_row_stats, st.ms_big_expand, st.ms_cut, st.ms_task, c->ws_bytes / 1e6);
     return SPADA_OK;
 }
 
@@ -483,6 +496,8 @@ int task_numeric(spada_ctx *c, uint64_t *d_ptr, uint32_t *d_idx, double *d_val)
     HIP_TRY(hipStreamSynchronize(s));
     c->stats.ms_numeric_call = c->stats.ms_task = tev_ms(c, 0, 4);
     c->stats.workspace_bytes = c->ws_bytes;
+    trace(1, "numeric rows [%llu, %llu): %llu nnz(C), %.3f ms on the device", (unsigned long long)c->r0,
+          (unsigned long long)(c->r0 + c->nrows), (unsigned long long)c->nnz_c, c->stats.ms_numeric_call);
     return SPADA_OK;
 }
 
@@ -601,6 +616,8 @@ int spada_dev_csr_reorder(spada_ctx *c, const spada_dev_csr *a, const spada_dev_
     if (key == SPADA_REORDER_BY_PRODUCTS && (!b || a->cols != b->rows))
         return fail(SPADA_ERR_INVALID, "reordering by products needs B with rows(B) == cols(A)");
     *out = nullptr;
+    if (a->rows > 0x7FFFFFFEull)   // (the hipcub sort / scan below take int counts of rows + 1)
+        return fail(SPADA_ERR_UNSUPPORTED, "spada_dev_csr_reorder: %llu rows exceed the 2^31 - 2 the device sort takes", (unsigned long long)a->rows);
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t s = c->stream;
     const uint32_t rows = (uint32_t)a->rows;
@@ -662,6 +679,8 @@ int spada_dev_unpermute_c(spada_ctx *c, const spada_dev_csr *a_reordered, const 
     if (!c) return fail(SPADA_ERR_STATE, "spada_dev_unpermute_c: no engine context (no GPU?)");
     if (!a_reordered || !a_reordered->rowmap) return fail(SPADA_ERR_INVALID, "spada_dev_unpermute_c: the matrix was not produced by spada_dev_csr_reorder");
     if (!d_p_indptr || !d_c_indptr) return fail(SPADA_ERR_INVALID, "spada_dev_unpermute_c: null argument");
+    if (a_reordered->rows > 0x7FFFFFFEull)
+        return fail(SPADA_ERR_UNSUPPORTED, "spada_dev_unpermute_c: %llu rows exceed the 2^31 - 2 the device scan takes", (unsigned long long)a_reordered->rows);
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t s = c->stream;
     const uint32_t rows = (uint32_t)a_reordered->rows;
@@ -743,6 +762,7 @@ int spada_dev_spgemm_numeric_plan(spada_ctx *c, uint32_t chunks, uint64_t *chunk
     if (!chunks || chunks > 4096 || !chunk_pos) return fail(SPADA_ERR_INVALID, "spada_dev_spgemm_numeric_plan: 1 .. 4096 chunks");
     HIP_TRY(hipSetDevice(c->device));
     const uint32_t nt = c->nrows ? c->h_tctr->ntasks : 0;
+    c->chunk_timing_open = false;
     c->chunk_task.assign(chunks + 1, 0);
     for (uint32_t k = 0; k <= chunks; ++k) c->chunk_task[k] = (uint32_t)((uint64_t)nt * k / chunks);
     while (c->chunk_ev.size() < chunks) {
@@ -776,6 +796,10 @@ int spada_dev_spgemm_numeric_chunk(spada_ctx *c, uint32_t k, void *d_c_indices, 
     if (c->nnz_c && (!d_c_indices || !d_c_data)) return fail(SPADA_ERR_INVALID, "null output pointer");
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t s = c->stream;
+    if (!c->chunk_timing_open) {   // the numeric phase in pieces is timed as a whole: first piece queued .. last piece finished
+        HIP_TRY(hipEventRecord(c->tev[0], s));
+        c->chunk_timing_open = true;
+    }
     if (c->nrows && c->chunk_task[k + 1] > c->chunk_task[k]) {
         HIP_TRY(hipMemsetAsync(c->t_ctr.as<TaskCounters>()->ticket, 0, sizeof(TaskCounters::ticket), s));
         TaskArgs g = task_args(c, c->cptr.as<uint64_t>(), (uint32_t *)d_c_indices, (double *)d_c_data, c->nnz_c);
@@ -785,6 +809,7 @@ int spada_dev_spgemm_numeric_chunk(spada_ctx *c, uint32_t k, void *d_c_indices, 
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(c->chunk_ev[k], s));
+    HIP_TRY(hipEventRecord(c->tev[4], s));
     if (done_event) *done_event = (void *)c->chunk_ev[k];
     return SPADA_OK;
 }
@@ -803,6 +828,10 @@ int spada_dev_synchronize(spada_ctx *c)
     if (!c) return fail(SPADA_ERR_STATE, "spada_dev_synchronize: no engine context (no GPU?)");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->chunk_timing_open) {   // the pieces queued by spada_dev_spgemm_numeric_chunk since the plan, as one numeric phase
+        c->chunk_timing_open = false;
+        c->stats.ms_numeric_call = c->stats.ms_task = tev_ms(c, 0, 4);
+    }
     return SPADA_OK;
 }
 
@@ -938,17 +967,8 @@ int spada_spgemm_fused(spada_ctx *c, const spada_csr_view *a, const spada_csr_vi
 {
     if (!c) return fail(SPADA_ERR_STATE, "spada_spgemm_fused: no engine context (no GPU?)");
     if (!a || !b || !nnz_c || !c_indptr) return fail(SPADA_ERR_INVALID, "spada_spgemm_fused: null argument");
-    HIP_TRY(hipSetDevice(c->device));
-    c->have_symbolic = false;
-    dev_free(c->hA);
-    if (c->hB != c->hA) dev_free(c->hB);
-    c->hA = c->hB = nullptr;
-    int rc = spada_dev_csr_upload(c, a, &c->hA);
+    int rc = upload_pair(c, a, b);   // (also releases a reordered copy of A left by spada_spgemm_symbolic_reordered)
     if (rc) return rc;
-    const bool same = a->indptr == b->indptr && a->indices == b->indices && a->data == b->data && a->rows == b->rows &&
-                      a->cols == b->cols;
-    if (same) c->hB = c->hA;
-    else if ((rc = spada_dev_csr_upload(c, b, &c->hB))) return rc;
     void *dp, *di, *dv;
     rc = spada_dev_spgemm_fused_owned(c, c->hA, c->hB, 0, a->rows, capacity, &dp, &di, &dv, nnz_c);
     if (rc == SPADA_ERR_CAPACITY) {

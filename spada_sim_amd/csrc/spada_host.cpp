@@ -7,6 +7,8 @@
 //   CsrMatStorage      storage.rs:150-160, :214-239
 //   parse_config       frontend.rs:8-23, :77-85
 //   row blocks         scheduler.rs:296-379 (disjoint A-row blocks)
+#include <sys/stat.h>
+
 #include <algorithm>
 #include <cctype>
 #include <cerrno>
@@ -19,6 +21,7 @@
 #include <memory>
 #include <numeric>
 #include <sstream>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -40,6 +43,30 @@ int fail(int code, const char *fmt, ...)
 }
 
 void clear_error() { g_last_error.clear(); }
+
+// SPADA_TRACE=0/1/2: replaces the reference's trace_println! / trace_print! macros, which a cargo feature compiles in
+// or out (util.rs:1-24); here the level is read once from the environment and the lines go to stderr.  1: one line per call
+// (what was loaded, what a pipeline run did); 2: the details behind it (row classes, workspace growth, phase times).
+int trace_level()
+{
+    static const int level = [] {
+        const char *e = std::getenv("SPADA_TRACE");
+        const int v = e ? std::atoi(e) : 0;
+        return v < 0 ? 0 : (v > 2 ? 2 : v);
+    }();
+    return level;
+}
+
+void trace(int level, const char *fmt, ...)
+{
+    if (trace_level() < level) return;
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    std::fprintf(stderr, "[spada trace %d] %s\n", level, buf);
+}
 
 // COO triplets -> canonical CSR exactly as coo_matrix.tocsr() leaves it: entries bucketed by row in
 // file order, columns sorted inside a row, duplicates summed.
@@ -442,6 +469,11 @@ static int mtx_read(const char *path, spada_host_csr &out)
     }
     std::vector<uint64_t> ri, ci;
     std::vector<double> vv;
+    // (an entry takes at least four bytes of text: a size line that announces more than the file can hold is refused before
+    // anything is reserved for it)
+    if (nent > (uint64_t)text.size() / 4 + 1)
+        return fail(SPADA_ERR_PARSE, "%s: size line announces %llu entries, the file has %llu bytes", path, (unsigned long long)nent,
+                    (unsigned long long)text.size());
     const size_t cap = (size_t)nent * (sym ? 2 : 1);
     ri.reserve(cap);
     ci.reserve(cap);
@@ -626,6 +658,22 @@ struct JParser {
 
 using namespace spada;
 
+// No C++ exception crosses the C ABI (the reference's panic! => process exit is not copied): sizes that come from
+// files or callers may make an allocation throw; the entry points that allocate run their body through this.
+template <class F>
+static int guarded(const char *what, F &&body)
+{
+    try {
+        return body();
+    } catch (const std::bad_alloc &) {
+        return fail(SPADA_ERR_OOM, "%s: out of host memory", what);
+    } catch (const std::length_error &) {
+        return fail(SPADA_ERR_OOM, "%s: size exceeds what the host can allocate", what);
+    } catch (const std::exception &e) {
+        return fail(SPADA_ERR_INVALID, "%s: %s", what, e.what());
+    }
+}
+
 extern "C" {
 
 const char *spada_last_error(void) { return g_last_error.c_str(); }
@@ -633,13 +681,17 @@ int spada_abi_version(void) { return SPADA_ABI_VERSION; }
 
 int spada_mtx_read(const char *path, spada_host_csr **out)
 {
-    if (!path || !out) return fail(SPADA_ERR_INVALID, "spada_mtx_read: null argument");
-    *out = nullptr;
-    auto m = std::make_unique<spada_host_csr>();
-    int rc = mtx_read(path, *m);
-    if (rc) return rc;
-    *out = m.release();
-    return SPADA_OK;
+    return guarded("spada_mtx_read", [&]() -> int {
+        if (!path || !out) return fail(SPADA_ERR_INVALID, "spada_mtx_read: null argument");
+        *out = nullptr;
+        auto m = std::make_unique<spada_host_csr>();
+        int rc = mtx_read(path, *m);
+        if (rc) return rc;
+        trace(1, "load_mm_mat %s: %llu x %llu, %llu entries", path, (unsigned long long)m->rows, (unsigned long long)m->cols,
+              (unsigned long long)m->nnz());
+        *out = m.release();
+        return SPADA_OK;
+    });
 }
 
 // FNV-1a, 64 bit, over a byte range
@@ -691,91 +743,103 @@ static const char BIN_MAGIC[8] = {'S', 'P', 'A', 'D', 'A', 'C', 'S', 'R'};
 
 int spada_csr_write_bin(const char *path, const spada_csr_view *m)
 {
-    if (!path) return fail(SPADA_ERR_INVALID, "spada_csr_write_bin: null path");
-    spada_checksum cs;
-    int rc = spada_csr_checksum(m, &cs);
-    if (rc) return rc;
-    FILE *f = std::fopen(path, "wb");
-    if (!f) return fail(SPADA_ERR_IO, "cannot create %s: %s", path, std::strerror(errno));
-    const uint64_t hdr[4] = {1, m->rows, m->cols, m->nnz}, tail[2] = {cs.structure_hash, cs.value_hash};
-    bool ok = std::fwrite(BIN_MAGIC, 1, 8, f) == 8 && std::fwrite(hdr, 8, 4, f) == 4 &&
-              std::fwrite(m->indptr, 8, m->rows + 1, f) == m->rows + 1 && std::fwrite(m->indices, 8, m->nnz, f) == m->nnz &&
-              std::fwrite(m->data, 8, m->nnz, f) == m->nnz && std::fwrite(tail, 8, 2, f) == 2;
-    if (std::fclose(f) != 0) ok = false;
-    if (!ok) return fail(SPADA_ERR_IO, "write to %s failed", path);
-    return SPADA_OK;
+    return guarded("spada_csr_write_bin", [&]() -> int {
+        if (!path) return fail(SPADA_ERR_INVALID, "spada_csr_write_bin: null path");
+        spada_checksum cs;
+        int rc = spada_csr_checksum(m, &cs);
+        if (rc) return rc;
+        FILE *f = std::fopen(path, "wb");
+        if (!f) return fail(SPADA_ERR_IO, "cannot create %s: %s", path, std::strerror(errno));
+        const uint64_t hdr[4] = {1, m->rows, m->cols, m->nnz}, tail[2] = {cs.structure_hash, cs.value_hash};
+        bool ok = std::fwrite(BIN_MAGIC, 1, 8, f) == 8 && std::fwrite(hdr, 8, 4, f) == 4 &&
+                  std::fwrite(m->indptr, 8, m->rows + 1, f) == m->rows + 1 && std::fwrite(m->indices, 8, m->nnz, f) == m->nnz &&
+                  std::fwrite(m->data, 8, m->nnz, f) == m->nnz && std::fwrite(tail, 8, 2, f) == 2;
+        if (std::fclose(f) != 0) ok = false;
+        if (!ok) return fail(SPADA_ERR_IO, "write to %s failed", path);
+        return SPADA_OK;
+    });
 }
 
 int spada_csr_read_bin(const char *path, spada_host_csr **out)
 {
-    if (!path || !out) return fail(SPADA_ERR_INVALID, "spada_csr_read_bin: null argument");
-    *out = nullptr;
-    FILE *f = std::fopen(path, "rb");
-    if (!f) return fail(SPADA_ERR_IO, "cannot open %s: %s", path, std::strerror(errno));
-    char magic[8];
-    uint64_t hdr[4], tail[2];
-    auto m = std::make_unique<spada_host_csr>();
-    bool ok = std::fread(magic, 1, 8, f) == 8 && std::memcmp(magic, BIN_MAGIC, 8) == 0 && std::fread(hdr, 8, 4, f) == 4 && hdr[0] == 1;
-    if (ok) {
-        m->rows = hdr[1];
-        m->cols = hdr[2];
-        if (hdr[1] > (1ull << 40) || hdr[3] > (1ull << 44)) ok = false;
-    }
-    if (ok) {
-        m->indptr.resize(hdr[1] + 1);
-        m->indices.resize(hdr[3]);
-        m->data.resize(hdr[3]);
-        ok = std::fread(m->indptr.data(), 8, hdr[1] + 1, f) == hdr[1] + 1 && std::fread(m->indices.data(), 8, hdr[3], f) == hdr[3] &&
-             std::fread(m->data.data(), 8, hdr[3], f) == hdr[3] && std::fread(tail, 8, 2, f) == 2;
-    }
-    std::fclose(f);
-    if (!ok) return fail(SPADA_ERR_PARSE, "%s is not a complete SPADACSR version 1 file", path);
-    const spada_csr_view v = view_of(*m);
-    spada_checksum cs;
-    if (spada_csr_checksum(&v, &cs)) {
-        const std::string why = spada_last_error();
-        return fail(SPADA_ERR_PARSE, "%s: corrupt CSR (%s)", path, why.c_str());
-    }
-    if (cs.structure_hash != tail[0] || cs.value_hash != tail[1]) return fail(SPADA_ERR_PARSE, "%s: checksum mismatch", path);
-    *out = m.release();
-    return SPADA_OK;
+    return guarded("spada_csr_read_bin", [&]() -> int {
+        if (!path || !out) return fail(SPADA_ERR_INVALID, "spada_csr_read_bin: null argument");
+        *out = nullptr;
+        FILE *f = std::fopen(path, "rb");
+        if (!f) return fail(SPADA_ERR_IO, "cannot open %s: %s", path, std::strerror(errno));
+        char magic[8];
+        uint64_t hdr[4], tail[2];
+        auto m = std::make_unique<spada_host_csr>();
+        bool ok = std::fread(magic, 1, 8, f) == 8 && std::memcmp(magic, BIN_MAGIC, 8) == 0 && std::fread(hdr, 8, 4, f) == 4 && hdr[0] == 1;
+        if (ok) {
+            m->rows = hdr[1];
+            m->cols = hdr[2];
+            // the header is not trusted: the file must have exactly the size it announces before anything is allocated from it
+        struct stat fst;
+        if (hdr[1] > (1ull << 40) || hdr[3] > (1ull << 44) || fstat(fileno(f), &fst) != 0 ||
+            (unsigned long long)fst.st_size != 8ull + 32ull + (hdr[1] + 1) * 8ull + hdr[3] * 16ull + 16ull)
+            ok = false;
+        }
+        if (ok) {
+            m->indptr.resize(hdr[1] + 1);
+            m->indices.resize(hdr[3]);
+            m->data.resize(hdr[3]);
+            ok = std::fread(m->indptr.data(), 8, hdr[1] + 1, f) == hdr[1] + 1 && std::fread(m->indices.data(), 8, hdr[3], f) == hdr[3] &&
+                 std::fread(m->data.data(), 8, hdr[3], f) == hdr[3] && std::fread(tail, 8, 2, f) == 2;
+        }
+        std::fclose(f);
+        if (!ok) return fail(SPADA_ERR_PARSE, "%s is not a complete SPADACSR version 1 file", path);
+        const spada_csr_view v = view_of(*m);
+        spada_checksum cs;
+        if (spada_csr_checksum(&v, &cs)) {
+            const std::string why = spada_last_error();
+            return fail(SPADA_ERR_PARSE, "%s: corrupt CSR (%s)", path, why.c_str());
+        }
+        if (cs.structure_hash != tail[0] || cs.value_hash != tail[1]) return fail(SPADA_ERR_PARSE, "%s: checksum mismatch", path);
+        *out = m.release();
+        return SPADA_OK;
+    });
 }
 
 int spada_mtx_write(const char *path, const spada_csr_view *m)
 {
-    if (!path) return fail(SPADA_ERR_INVALID, "spada_mtx_write: null path");
-    int rc = validate(m, "spada_mtx_write");
-    if (rc) return rc;
-    spada_checksum cs;
-    if ((rc = spada_csr_checksum(m, &cs))) return rc;
-    char line[512];
-    (void)spada_checksum_format(&cs, line, sizeof line);
-    FILE *f = std::fopen(path, "wb");
-    if (!f) return fail(SPADA_ERR_IO, "cannot create %s: %s", path, std::strerror(errno));
-    // the checksum travels as a MatrixMarket comment: any reader skips it, `spada-sim --checksum` prints the same line
-    std::fprintf(f, "%%%%MatrixMarket matrix coordinate real general\n%% spada-sim checksum: %s\n%llu %llu %llu\n", line,
-                 (unsigned long long)m->rows, (unsigned long long)m->cols, (unsigned long long)m->nnz);
-    for (uint64_t r = 0; r < m->rows; ++r)
-        for (uint64_t q = m->indptr[r]; q < m->indptr[r + 1]; ++q)
-            std::fprintf(f, "%llu %llu %.17g\n", (unsigned long long)r + 1, (unsigned long long)m->indices[q] + 1, m->data[q]);
-    if (std::fclose(f) != 0) return fail(SPADA_ERR_IO, "write to %s failed", path);
-    return SPADA_OK;
+    return guarded("spada_mtx_write", [&]() -> int {
+        if (!path) return fail(SPADA_ERR_INVALID, "spada_mtx_write: null path");
+        int rc = validate(m, "spada_mtx_write");
+        if (rc) return rc;
+        spada_checksum cs;
+        if ((rc = spada_csr_checksum(m, &cs))) return rc;
+        char line[512];
+        (void)spada_checksum_format(&cs, line, sizeof line);
+        FILE *f = std::fopen(path, "wb");
+        if (!f) return fail(SPADA_ERR_IO, "cannot create %s: %s", path, std::strerror(errno));
+        // the checksum travels as a MatrixMarket comment: any reader skips it, `spada-sim --checksum` prints the same line
+        std::fprintf(f, "%%%%MatrixMarket matrix coordinate real general\n%% spada-sim checksum: %s\n%llu %llu %llu\n", line,
+                     (unsigned long long)m->rows, (unsigned long long)m->cols, (unsigned long long)m->nnz);
+        for (uint64_t r = 0; r < m->rows; ++r)
+            for (uint64_t q = m->indptr[r]; q < m->indptr[r + 1]; ++q)
+                std::fprintf(f, "%llu %llu %.17g\n", (unsigned long long)r + 1, (unsigned long long)m->indices[q] + 1, m->data[q]);
+        if (std::fclose(f) != 0) return fail(SPADA_ERR_IO, "write to %s failed", path);
+        return SPADA_OK;
+    });
 }
 
 int spada_host_csr_from_view(const spada_csr_view *v, spada_host_csr **out)
 {
-    if (!out) return fail(SPADA_ERR_INVALID, "spada_host_csr_from_view: null out");
-    *out = nullptr;
-    int rc = validate(v, "spada_host_csr_from_view");
-    if (rc) return rc;
-    auto m = std::make_unique<spada_host_csr>();
-    m->rows = v->rows;
-    m->cols = v->cols;
-    m->indptr.assign(v->indptr, v->indptr + v->rows + 1);
-    m->indices.assign(v->indices, v->indices + v->nnz);
-    m->data.assign(v->data, v->data + v->nnz);
-    *out = m.release();
-    return SPADA_OK;
+    return guarded("spada_host_csr_from_view", [&]() -> int {
+        if (!out) return fail(SPADA_ERR_INVALID, "spada_host_csr_from_view: null out");
+        *out = nullptr;
+        int rc = validate(v, "spada_host_csr_from_view");
+        if (rc) return rc;
+        auto m = std::make_unique<spada_host_csr>();
+        m->rows = v->rows;
+        m->cols = v->cols;
+        m->indptr.assign(v->indptr, v->indptr + v->rows + 1);
+        m->indices.assign(v->indices, v->indices + v->nnz);
+        m->data.assign(v->data, v->data + v->nnz);
+        *out = m.release();
+        return SPADA_OK;
+    });
 }
 
 int spada_host_csr_view(const spada_host_csr *m, spada_csr_view *out)
@@ -791,14 +855,16 @@ int spada_csr_validate(const spada_csr_view *m) { return validate(m, "csr"); }
 
 int spada_transpose(const spada_csr_view *a, spada_host_csr **out)
 {
-    if (!out) return fail(SPADA_ERR_INVALID, "spada_transpose: null out");
-    *out = nullptr;
-    int rc = validate(a, "spada_transpose");
-    if (rc) return rc;
-    auto t = std::make_unique<spada_host_csr>();
-    transpose(*a, *t);
-    *out = t.release();
-    return SPADA_OK;
+    return guarded("spada_transpose", [&]() -> int {
+        if (!out) return fail(SPADA_ERR_INVALID, "spada_transpose: null out");
+        *out = nullptr;
+        int rc = validate(a, "spada_transpose");
+        if (rc) return rc;
+        auto t = std::make_unique<spada_host_csr>();
+        transpose(*a, *t);
+        *out = t.release();
+        return SPADA_OK;
+    });
 }
 
 int spada_from_mat(const spada_csr_view *a, spada_host_csr **b_out, int *b_is_a)
@@ -833,129 +899,135 @@ int spada_count_products(const spada_csr_view *a, const spada_csr_view *b, uint6
 
 int spada_partition_rows(const spada_csr_view *a, const spada_csr_view *b, uint32_t nparts, uint64_t *bounds)
 {
-    if (!a || !b || !bounds || nparts == 0) return fail(SPADA_ERR_INVALID, "spada_partition_rows: bad argument");
-    if (a->cols != b->rows) return fail(SPADA_ERR_INVALID, "inner dimensions differ");
-    // per-row cost = products + row length + 1 (so that empty rows still spread out)
-    std::vector<uint64_t> pre(a->rows + 1, 0);
-    for (uint64_t r = 0; r < a->rows; ++r) {
-        uint64_t w = 1 + (a->indptr[r + 1] - a->indptr[r]);
-        for (uint64_t q = a->indptr[r]; q < a->indptr[r + 1]; ++q) {
-            uint64_t k = a->indices[q];
-            if (k >= b->rows) return fail(SPADA_ERR_INVALID, "A column %llu >= B.rows", (unsigned long long)k);
-            w += b->indptr[k + 1] - b->indptr[k];
+    return guarded("spada_partition_rows", [&]() -> int {
+        if (!a || !b || !bounds || nparts == 0) return fail(SPADA_ERR_INVALID, "spada_partition_rows: bad argument");
+        if (a->cols != b->rows) return fail(SPADA_ERR_INVALID, "inner dimensions differ");
+        // per-row cost = products + row length + 1 (so that empty rows still spread out)
+        std::vector<uint64_t> pre(a->rows + 1, 0);
+        for (uint64_t r = 0; r < a->rows; ++r) {
+            uint64_t w = 1 + (a->indptr[r + 1] - a->indptr[r]);
+            for (uint64_t q = a->indptr[r]; q < a->indptr[r + 1]; ++q) {
+                uint64_t k = a->indices[q];
+                if (k >= b->rows) return fail(SPADA_ERR_INVALID, "A column %llu >= B.rows", (unsigned long long)k);
+                w += b->indptr[k + 1] - b->indptr[k];
+            }
+            pre[r + 1] = pre[r] + w;
         }
-        pre[r + 1] = pre[r] + w;
-    }
-    const uint64_t total = pre[a->rows];
-    bounds[0] = 0;
-    for (uint32_t p = 1; p < nparts; ++p) {
-        // smallest r with pre[r] >= total * p / nparts
-        long double target = (long double)total * p / nparts;
-        uint64_t r = (uint64_t)(std::lower_bound(pre.begin(), pre.end(), (uint64_t)std::ceil((double)target)) - pre.begin());
-        r = std::min<uint64_t>(r, a->rows);
-        bounds[p] = std::max(r, bounds[p - 1]);
-    }
-    bounds[nparts] = a->rows;
-    return SPADA_OK;
+        const uint64_t total = pre[a->rows];
+        bounds[0] = 0;
+        for (uint32_t p = 1; p < nparts; ++p) {
+            // smallest r with pre[r] >= total * p / nparts
+            long double target = (long double)total * p / nparts;
+            uint64_t r = (uint64_t)(std::lower_bound(pre.begin(), pre.end(), (uint64_t)std::ceil((double)target)) - pre.begin());
+            r = std::min<uint64_t>(r, a->rows);
+            bounds[p] = std::max(r, bounds[p - 1]);
+        }
+        bounds[nparts] = a->rows;
+        return SPADA_OK;
+    });
 }
 
 int spada_generate(int kind, uint64_t p0, uint64_t p1, uint64_t seed, spada_host_csr **out)
 {
-    if (!out) return fail(SPADA_ERR_INVALID, "spada_generate: null out");
-    *out = nullptr;
-    auto m = std::make_unique<spada_host_csr>();
-    switch (kind) {
-        case SPADA_GEN_RMAT:
-            if (p0 < 1 || p0 > 30) return fail(SPADA_ERR_INVALID, "rmat scale %llu out of range", (unsigned long long)p0);
-            gen_rmat(p0, p1 ? p1 : 16, seed, *m);
-            break;
-        case SPADA_GEN_WEBBASE_LIKE: gen_webbase_like(p0, p1, seed, *m); break;
-        case SPADA_GEN_COP20K_LIKE: gen_cop20k_like(p0, seed, *m); break;
-        case SPADA_GEN_CAGE12_LIKE: gen_cage12_like(p0, seed, *m); break;
-        case SPADA_GEN_MC2DEPI_LIKE: gen_mc2depi_like(p0, seed, *m); break;
-        case SPADA_GEN_UNIFORM:
-            if (p0 == 0) return fail(SPADA_ERR_INVALID, "uniform generator needs rows > 0");
-            gen_uniform(p0, p1 ? p1 : 8, seed, *m);
-            break;
-        default: return fail(SPADA_ERR_INVALID, "unknown generator kind %d", kind);
-    }
-    *out = m.release();
-    return SPADA_OK;
+    return guarded("spada_generate", [&]() -> int {
+        if (!out) return fail(SPADA_ERR_INVALID, "spada_generate: null out");
+        *out = nullptr;
+        auto m = std::make_unique<spada_host_csr>();
+        switch (kind) {
+            case SPADA_GEN_RMAT:
+                if (p0 < 1 || p0 > 30) return fail(SPADA_ERR_INVALID, "rmat scale %llu out of range", (unsigned long long)p0);
+                gen_rmat(p0, p1 ? p1 : 16, seed, *m);
+                break;
+            case SPADA_GEN_WEBBASE_LIKE: gen_webbase_like(p0, p1, seed, *m); break;
+            case SPADA_GEN_COP20K_LIKE: gen_cop20k_like(p0, seed, *m); break;
+            case SPADA_GEN_CAGE12_LIKE: gen_cage12_like(p0, seed, *m); break;
+            case SPADA_GEN_MC2DEPI_LIKE: gen_mc2depi_like(p0, seed, *m); break;
+            case SPADA_GEN_UNIFORM:
+                if (p0 == 0) return fail(SPADA_ERR_INVALID, "uniform generator needs rows > 0");
+                gen_uniform(p0, p1 ? p1 : 8, seed, *m);
+                break;
+            default: return fail(SPADA_ERR_INVALID, "unknown generator kind %d", kind);
+        }
+        *out = m.release();
+        return SPADA_OK;
+    });
 }
 
 int spada_config_parse(const char *path, spada_config *out)
 {
-    if (!path || !out) return fail(SPADA_ERR_INVALID, "spada_config_parse: null argument");
-    std::ifstream in(path, std::ios::binary);
-    if (!in) return fail(SPADA_ERR_IO, "cannot open %s: %s", path, std::strerror(errno));
-    std::stringstream ss;
-    ss << in.rdbuf();
-    std::string text = ss.str();
-    JParser jp{text.c_str(), text.c_str() + text.size(), {}};
-    JVal root;
-    if (!jp.parse(root)) return fail(SPADA_ERR_PARSE, "%s: JSON error: %s", path, jp.err.c_str());
-    jp.ws();
-    if (jp.p != jp.e) return fail(SPADA_ERR_PARSE, "%s: trailing characters after JSON value", path);
-    if (root.t != JVal::OBJ) return fail(SPADA_ERR_PARSE, "%s: top-level JSON value must be an object", path);
-    std::memset(out, 0, sizeof *out);
-    auto need = [&](const char *k, int type) -> const JVal * {
-        auto it = root.obj.find(k);
-        if (it == root.obj.end()) { fail(SPADA_ERR_PARSE, "%s: missing field `%s`", path, k); return nullptr; }
-        if ((int)it->second.t != type) { fail(SPADA_ERR_PARSE, "%s: field `%s` has the wrong type", path, k); return nullptr; }
-        return &it->second;
-    };
-    auto get_usize = [&](const char *k, uint64_t &dst) -> bool {
-        const JVal *v = need(k, JVal::NUM);
-        if (!v) return false;
-        if (!v->integral || v->num < 0) { fail(SPADA_ERR_PARSE, "%s: field `%s` must be a non-negative integer", path, k); return false; }
-        dst = (uint64_t)v->num;
-        return true;
-    };
-    auto get_f32 = [&](const char *k, float &dst) -> bool {
-        const JVal *v = need(k, JVal::NUM);
-        if (!v) return false;
-        dst = (float)v->num;
-        return true;
-    };
-    auto get_str = [&](const char *k, char *dst, size_t cap) -> bool {
-        const JVal *v = need(k, JVal::STR);
-        if (!v) return false;
-        if (v->str.size() >= cap) { fail(SPADA_ERR_PARSE, "%s: field `%s` too long", path, k); return false; }
-        std::memcpy(dst, v->str.c_str(), v->str.size() + 1);
-        return true;
-    };
-    if (!get_str("ss_filepath", out->ss_filepath, sizeof out->ss_filepath)) return SPADA_ERR_PARSE;
-    if (!get_str("nn_filepath", out->nn_filepath, sizeof out->nn_filepath)) return SPADA_ERR_PARSE;
-    if (!get_usize("pe_num", out->pe_num) || !get_usize("at_num", out->at_num) || !get_usize("lane_num", out->lane_num) ||
-        !get_usize("cache_size", out->cache_size) || !get_usize("word_byte", out->word_byte) ||
-        !get_usize("mem_latency", out->mem_latency) || !get_usize("cache_latency", out->cache_latency) ||
-        !get_usize("channel", out->channel))
-        return SPADA_ERR_PARSE;
-    if (!get_f32("freq", out->freq) || !get_f32("bandwidth_per_channel", out->bandwidth_per_channel)) return SPADA_ERR_PARSE;
-    {
-        const JVal *v = need("block_shape", JVal::ARR);
-        if (!v) return SPADA_ERR_PARSE;
-        if (v->arr.size() != 2 || v->arr[0].t != JVal::NUM || v->arr[1].t != JVal::NUM || !v->arr[0].integral ||
-            !v->arr[1].integral || v->arr[0].num < 0 || v->arr[1].num < 0)
-            return fail(SPADA_ERR_PARSE, "%s: field `block_shape` must be an array of 2 non-negative integers", path);
-        out->block_shape[0] = (uint64_t)v->arr[0].num;
-        out->block_shape[1] = (uint64_t)v->arr[1].num;
-    }
-    // optional engine keys
-    out->gpus = 1;
-    out->accumulator = SPADA_ACC_LDS_HASH;
-    out->repeat = 1;
-    auto it = root.obj.find("gpus");
-    if (it != root.obj.end() && it->second.t == JVal::NUM && it->second.num >= 1) out->gpus = (uint32_t)it->second.num;
-    it = root.obj.find("repeat");
-    if (it != root.obj.end() && it->second.t == JVal::NUM && it->second.num >= 1) out->repeat = (uint32_t)it->second.num;
-    it = root.obj.find("accumulator");
-    if (it != root.obj.end()) {
-        if (it->second.t != JVal::STR || (it->second.str != "lds_hash" && it->second.str != "sort_merge"))
-            return fail(SPADA_ERR_PARSE, "%s: field `accumulator` must be \"lds_hash\" or \"sort_merge\"", path);
-        out->accumulator = it->second.str == "sort_merge" ? SPADA_ACC_SORT_MERGE : SPADA_ACC_LDS_HASH;
-    }
-    return SPADA_OK;
+    return guarded("spada_config_parse", [&]() -> int {
+        if (!path || !out) return fail(SPADA_ERR_INVALID, "spada_config_parse: null argument");
+        std::ifstream in(path, std::ios::binary);
+        if (!in) return fail(SPADA_ERR_IO, "cannot open %s: %s", path, std::strerror(errno));
+        std::stringstream ss;
+        ss << in.rdbuf();
+        std::string text = ss.str();
+        JParser jp{text.c_str(), text.c_str() + text.size(), {}};
+        JVal root;
+        if (!jp.parse(root)) return fail(SPADA_ERR_PARSE, "%s: JSON error: %s", path, jp.err.c_str());
+        jp.ws();
+        if (jp.p != jp.e) return fail(SPADA_ERR_PARSE, "%s: trailing characters after JSON value", path);
+        if (root.t != JVal::OBJ) return fail(SPADA_ERR_PARSE, "%s: top-level JSON value must be an object", path);
+        std::memset(out, 0, sizeof *out);
+        auto need = [&](const char *k, int type) -> const JVal * {
+            auto it = root.obj.find(k);
+            if (it == root.obj.end()) { fail(SPADA_ERR_PARSE, "%s: missing field `%s`", path, k); return nullptr; }
+            if ((int)it->second.t != type) { fail(SPADA_ERR_PARSE, "%s: field `%s` has the wrong type", path, k); return nullptr; }
+            return &it->second;
+        };
+        auto get_usize = [&](const char *k, uint64_t &dst) -> bool {
+            const JVal *v = need(k, JVal::NUM);
+            if (!v) return false;
+            if (!v->integral || v->num < 0) { fail(SPADA_ERR_PARSE, "%s: field `%s` must be a non-negative integer", path, k); return false; }
+            dst = (uint64_t)v->num;
+            return true;
+        };
+        auto get_f32 = [&](const char *k, float &dst) -> bool {
+            const JVal *v = need(k, JVal::NUM);
+            if (!v) return false;
+            dst = (float)v->num;
+            return true;
+        };
+        auto get_str = [&](const char *k, char *dst, size_t cap) -> bool {
+            const JVal *v = need(k, JVal::STR);
+            if (!v) return false;
+            if (v->str.size() >= cap) { fail(SPADA_ERR_PARSE, "%s: field `%s` too long", path, k); return false; }
+            std::memcpy(dst, v->str.c_str(), v->str.size() + 1);
+            return true;
+        };
+        if (!get_str("ss_filepath", out->ss_filepath, sizeof out->ss_filepath)) return SPADA_ERR_PARSE;
+        if (!get_str("nn_filepath", out->nn_filepath, sizeof out->nn_filepath)) return SPADA_ERR_PARSE;
+        if (!get_usize("pe_num", out->pe_num) || !get_usize("at_num", out->at_num) || !get_usize("lane_num", out->lane_num) ||
+            !get_usize("cache_size", out->cache_size) || !get_usize("word_byte", out->word_byte) ||
+            !get_usize("mem_latency", out->mem_latency) || !get_usize("cache_latency", out->cache_latency) ||
+            !get_usize("channel", out->channel))
+            return SPADA_ERR_PARSE;
+        if (!get_f32("freq", out->freq) || !get_f32("bandwidth_per_channel", out->bandwidth_per_channel)) return SPADA_ERR_PARSE;
+        {
+            const JVal *v = need("block_shape", JVal::ARR);
+            if (!v) return SPADA_ERR_PARSE;
+            if (v->arr.size() != 2 || v->arr[0].t != JVal::NUM || v->arr[1].t != JVal::NUM || !v->arr[0].integral ||
+                !v->arr[1].integral || v->arr[0].num < 0 || v->arr[1].num < 0)
+                return fail(SPADA_ERR_PARSE, "%s: field `block_shape` must be an array of 2 non-negative integers", path);
+            out->block_shape[0] = (uint64_t)v->arr[0].num;
+            out->block_shape[1] = (uint64_t)v->arr[1].num;
+        }
+        // optional engine keys
+        out->gpus = 1;
+        out->accumulator = SPADA_ACC_LDS_HASH;
+        out->repeat = 1;
+        auto it = root.obj.find("gpus");
+        if (it != root.obj.end() && it->second.t == JVal::NUM && it->second.num >= 1) out->gpus = (uint32_t)it->second.num;
+        it = root.obj.find("repeat");
+        if (it != root.obj.end() && it->second.t == JVal::NUM && it->second.num >= 1) out->repeat = (uint32_t)it->second.num;
+        it = root.obj.find("accumulator");
+        if (it != root.obj.end()) {
+            if (it->second.t != JVal::STR || (it->second.str != "lds_hash" && it->second.str != "sort_merge"))
+                return fail(SPADA_ERR_PARSE, "%s: field `accumulator` must be \"lds_hash\" or \"sort_merge\"", path);
+            out->accumulator = it->second.str == "sort_merge" ? SPADA_ACC_SORT_MERGE : SPADA_ACC_LDS_HASH;
+        }
+        return SPADA_OK;
+    });
 }
 
 }  // extern "C"

@@ -20,6 +20,9 @@ namespace spada {
 // Records the message returned by spada_last_error() and returns `code`.
 int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 void clear_error();
+// SPADA_TRACE=0/1/2: lines on stderr at or below the level set in the environment (replaces util.rs:1-24)
+int trace_level();
+void trace(int level, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 inline spada_csr_view view_of(const spada_host_csr &m)
 {
     return spada_csr_view{m.rows, m.cols, m.nnz(), m.indptr.data(), m.indices.data(), m.data.data()};

@@ -414,6 +414,26 @@ class Comm:
                                                 _ffi.vp(d_full_data)))
 
 
+def comm_plan(rows, nnz, chunk_pos=None):
+    """spada_comm_plan: (row_off, nnz_off, piece_begin, piece_count) of the exchange from the gathered counts; chunk_pos =
+    array [nranks, chunks + 1] of piece positions inside every block, or None.  Host arithmetic only."""
+    rows = np.ascontiguousarray(rows, dtype=np.uint64)
+    nnz = np.ascontiguousarray(nnz, dtype=np.uint64)
+    n = len(rows)
+    row_off, nnz_off = np.zeros(n + 1, np.uint64), np.zeros(n + 1, np.uint64)
+    if chunk_pos is None:
+        check(_ffi.comm_lib().spada_comm_plan(n, rows.ctypes.data_as(_ffi.u64p), nnz.ctypes.data_as(_ffi.u64p), 0, None,
+                                              row_off.ctypes.data_as(_ffi.u64p), nnz_off.ctypes.data_as(_ffi.u64p), None, None))
+        return row_off, nnz_off, None, None
+    pos = np.ascontiguousarray(chunk_pos, dtype=np.uint64)
+    k = pos.shape[1] - 1
+    pb, pc = np.zeros((n, k), np.uint64), np.zeros((n, k), np.uint64)
+    check(_ffi.comm_lib().spada_comm_plan(n, rows.ctypes.data_as(_ffi.u64p), nnz.ctypes.data_as(_ffi.u64p), k,
+                                          pos.ctypes.data_as(_ffi.u64p), row_off.ctypes.data_as(_ffi.u64p),
+                                          nnz_off.ctypes.data_as(_ffi.u64p), pb.ctypes.data_as(_ffi.u64p), pc.ctypes.data_as(_ffi.u64p)))
+    return row_off, nnz_off, pb, pc
+
+
 class Simulator:
     """Drop-in for the reference's Simulator: same constructor arguments (simulator.rs:431-448); the
     accelerator-model parameters are accepted and kept but do not steer the GPU kernels."""

@@ -188,7 +188,7 @@ CARI_PINS = {"exec_cycles": 4267108, "raw_cycles": 4361281, "a_read": 305600, "a
 def test_cli_cycle_model_on_cari(cari_dir):
     """The shipped workload through the command line (no GPU involved): stdout skeleton of main.rs:44-116 with the simulated
     counters, the first ten rows of the product against the committed product pin, the checksum against the oracle."""
-    exe = os.path.join(ROOT, "spada_sim_amd", "bin", "spada-sim")
+    exe = os.environ.get("SPADA_BIN_PATH") or os.path.join(ROOT, "spada_sim_amd", "bin", "spada-sim")
     out = subprocess.run([exe, "accuratesimu", "spada", "ss", "cari", "config/config_1mb_row1.json", "--cycle-model",
                           "--output", "C.bin"], cwd=cari_dir, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr
@@ -228,7 +228,7 @@ def test_cli_cycle_model_preprocess_and_accelerators(tmp_path):
     os.makedirs(tmp_path / "matrices")
     a = S.generate(S.GEN_RMAT, 7, 6, 2)
     S.write_mm_mat(str(tmp_path / "matrices" / "small.mtx"), a)
-    exe = os.path.join(ROOT, "spada_sim_amd", "bin", "spada-sim")
+    exe = os.environ.get("SPADA_BIN_PATH") or os.path.join(ROOT, "spada_sim_amd", "bin", "spada-sim")
     sums, cycles = [], []
     for extra in ([], ["-p"], ["--preprocess-by", "products"]):
         for acc in ("Spada", "IP", "op", "MultiRow"):

@@ -337,24 +337,60 @@ def test_random_parity_sweep(engine, engine_sm, seed):
         assert_parity(e.spgemm(a, b), ref, ao, bo, RTOL)
 
 
-@pytest.mark.parametrize("kind,name", [(1, "webbase-1M surrogate"), (2, "cop20k_A surrogate"), (4, "mc2depi surrogate")])
-def test_bench_workloads_at_full_size(engine, kind, name):
-    """The workloads bench.py times, at BASELINE.json's full sizes, against the oracle (structure bit-exact, values within
-    1e-9): 51.7 M / 18.5 M / 5.2 M nnz(C).  The oracle's OpenMP SPA variant finishes them in seconds."""
+@pytest.fixture(scope="module")
+def full_size_refs():
+    """oracle products of the full-size bench workloads, computed once per (kind) and shared by the entry-point cases"""
+    return {}
+
+
+@pytest.mark.parametrize("entry", ["fused", "two_phase"])
+@pytest.mark.parametrize("kind,name", [(1, "webbase-1M surrogate"), (2, "cop20k_A surrogate"), (3, "cage12 surrogate"),
+                                       (4, "mc2depi surrogate")])
+def test_bench_workloads_at_full_size(engine, full_size_refs, kind, name, entry):
+    """Every workload bench.py times, at BASELINE.json's full sizes, through BOTH entry points -- `fused` is
+    spada_dev_spgemm_fused, the one-pass call bench.py times by default; `two_phase` the symbolic + numeric contract
+    (`--two-phase`) -- against the oracle (structure bit-exact, values within 1e-9): 51.7 M / 18.5 M / 15.5 M / 5.2 M nnz(C).
+    The oracle's OpenMP SPA variant finishes them in seconds."""
     import spada_sim_amd as S
-    seeds = {1: 12347, 2: 12346, 4: 12349}
+    seeds = {1: 12347, 2: 12346, 3: 12348, 4: 12349}
     m = S.generate(kind, 0, 0, seeds[kind])
+    if kind not in full_size_refs:
+        full_size_refs.clear()          # one reference product in memory at a time
+        ao = to_oracle(m)
+        full_size_refs[kind] = oracle.spgemm_spa(ao, ao)
+    ref = full_size_refs[kind]
     d = engine.upload(m)
-    nnz = engine.symbolic(d, d, 0, m.shape[0])
-    p, i, v = engine.numeric_owned()
-    c = engine.download(p, i, v, m.shape[0], nnz, m.shape[1])
-    engine.free(d)
-    ao = to_oracle(m)
-    ref = oracle.spgemm_spa(ao, ao)
+    try:
+        if entry == "fused":
+            cap = S.count_products(m, m, 0, m.shape[0])
+            p, i, v, nnz = engine.fused_owned(d, d, 0, m.shape[0], cap)
+        else:
+            nnz = engine.symbolic(d, d, 0, m.shape[0])
+            p, i, v = engine.numeric_owned()
+        c = engine.download(p, i, v, m.shape[0], nnz, m.shape[1])
+    finally:
+        engine.free(d)
     assert nnz == ref.nnz
     assert np.array_equal(c.indptr, ref.indptr)
     assert np.array_equal(c.indices, ref.indices)
     assert np.all(np.abs(c.data - ref.data) <= RTOL * np.abs(ref.data))
+
+
+@pytest.mark.parametrize("name", ["cop20k_A", "webbase-1M", "cage12", "mc2depi"])
+def test_suitesparse_file_when_present(engine, name):
+    """Real SuiteSparse inputs: the image ships none and there is no network, so this runs only where $SPADA_MTX_DIR/<name>.mtx
+    exists (as bench.py does); both entry points against the oracle."""
+    import spada_sim_amd as S
+    d = os.environ.get("SPADA_MTX_DIR")
+    if not d or not os.path.exists(os.path.join(d, name + ".mtx")):
+        pytest.skip(f"$SPADA_MTX_DIR/{name}.mtx not present (no SuiteSparse file in the image)")
+    m = S.load_mm_mat(d, name)
+    gemm = S.GEMM.from_mat(name, m)
+    a, b = gemm.a, gemm.b
+    ao, bo = to_oracle(a), (to_oracle(a) if b is a else to_oracle(b))
+    ref = oracle.spgemm_spa(ao, bo)
+    assert_parity(engine.spgemm(a, b), ref, ao, bo, RTOL)
+    assert_parity(engine.spgemm_fused(a, b), ref, ao, bo, RTOL)
 
 
 def test_rmat22_row_ranges_against_oracle(engine):

@@ -5,6 +5,7 @@ import hashlib
 import json
 import os
 import re
+import subprocess
 
 import numpy as np
 import pytest
@@ -40,11 +41,76 @@ def test_comm_library_exports_every_symbol_of_its_header():
     hdr = open(os.path.join(ROOT, "include", "spada_comm.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
     declared = set(re.findall(r"\b(spada_[a-z0-9_]+)\s*\(", hdr))
-    assert len(declared) == 9
+    assert len(declared) == 10 and "spada_comm_plan" in declared
     L = ctypes.CDLL(_ffi.COMM_LIB_PATH)
     for name in sorted(declared):
         assert hasattr(L, name), f"{name} declared in spada_comm.h but not exported"
     assert declared == set(_ffi.COMM_SIGNATURES), declared ^ set(_ffi.COMM_SIGNATURES)
+
+
+@pytest.mark.parametrize("nranks", [2, 3, 8])
+@pytest.mark.parametrize("chunks", [0, 1, 4])
+def test_comm_plan_places_every_segment(nranks, chunks):
+    """spada_comm_plan -- the offset arithmetic both native exchange forms (spada_comm_allgatherv_c, spada_dist_spgemm_numeric) use,
+    as a pure host function: for N = 2, 3, 8 with empty row blocks, blocks without entries and empty pieces, an exchange simulated with
+    its offsets (every rank copies the root's segment at the planned position: what the in-place ncclBroadcast does) leaves the same
+    whole C on every rank as the torch.distributed path builds (spada_sim_amd/parallel.py: concatenation + cumulative row lengths).
+    No N > 1 RCCL run exists yet; this is the part of it that needs no GPU."""
+    rng = np.random.default_rng(100 * nranks + chunks)
+    for trial in range(20):
+        rows = rng.integers(0, 40, nranks).astype(np.uint64)
+        rows[rng.integers(0, nranks)] = 0                       # an empty row block
+        lens = [rng.integers(0, 9, int(r)) for r in rows]
+        if trial % 3 == 0:
+            lens[int(rng.integers(0, nranks))][:] = 0            # a block whose rows are all empty
+        nnz = np.array([int(l.sum()) for l in lens], np.uint64)
+        blocks = []
+        for r in range(nranks):
+            ptr = np.concatenate([[0], np.cumsum(lens[r])]).astype(np.uint64)
+            blocks.append((ptr, rng.integers(0, 1000, int(nnz[r])).astype(np.uint32), rng.uniform(0, 1, int(nnz[r]))))
+        pos = None
+        if chunks:
+            pos = np.zeros((nranks, chunks + 1), np.uint64)
+            for r in range(nranks):
+                cuts = np.sort(rng.integers(0, int(nnz[r]) + 1, chunks - 1)) if chunks > 1 else np.zeros(0, np.int64)
+                if trial % 2 == 0 and chunks > 1:
+                    cuts[0] = 0                                  # an empty first piece
+                pos[r] = np.concatenate([[0], np.sort(cuts), [int(nnz[r])]])
+        row_off, nnz_off, pb, pc = S.comm_plan(rows, nnz, pos)
+        # the torch.distributed path's layout (parallel.allgatherv_c): concatenation, indptr = cumulative sum of the row lengths
+        exp_idx = np.concatenate([b[1] for b in blocks])
+        exp_val = np.concatenate([b[2] for b in blocks])
+        exp_ptr = np.concatenate([[0], np.cumsum(np.concatenate(lens))]).astype(np.uint64)
+        assert row_off[-1] == rows.sum() and nnz_off[-1] == nnz.sum()
+        assert np.array_equal(nnz_off[:-1], np.concatenate([[0], np.cumsum(nnz)[:-1]]).astype(np.uint64))
+        # simulated exchange on every rank
+        for me in range(nranks):
+            fi = np.full(int(nnz_off[-1]), 0xFFFFFFFF, np.uint32)
+            fv = np.full(int(nnz_off[-1]), np.nan)
+            fp = np.full(int(row_off[-1]) + 1, 0xFFFFFFFFFFFFFFFF, np.uint64)
+            if chunks:
+                for k in range(chunks):
+                    for r in range(nranks):
+                        b, n = int(pb[r, k]), int(pc[r, k])
+                        lo = int(pos[r, k])
+                        fi[b:b + n] = blocks[r][1][lo:lo + n]
+                        fv[b:b + n] = blocks[r][2][lo:lo + n]
+            else:
+                for r in range(nranks):
+                    o, n = int(nnz_off[r]), int(nnz[r])
+                    fi[o:o + n] = blocks[r][1]
+                    fv[o:o + n] = blocks[r][2]
+            fp[0] = 0                                            # gather_indptr: entries 1 .. rows_r of every block, shifted
+            for r in range(nranks):
+                o, n = int(row_off[r]), int(rows[r])
+                fp[o + 1:o + 1 + n] = blocks[r][0][1:] + nnz_off[r]
+            assert np.array_equal(fi, exp_idx) and np.array_equal(fv, exp_val) and np.array_equal(fp, exp_ptr), (me, trial)
+    # malformed piece positions are refused, not trusted
+    bad = np.array([[0, 5, 3, 7]], np.uint64)
+    with pytest.raises(S.SpadaError):
+        S.comm_plan(np.array([4], np.uint64), np.array([7], np.uint64), bad)
+    with pytest.raises(S.SpadaError):
+        S.comm_plan(np.array([4], np.uint64), np.array([9], np.uint64), np.array([[0, 2, 7]], np.uint64))
 
 
 def test_struct_layouts_match_the_header():
@@ -193,7 +259,8 @@ def test_parse_config(tmp_path):
     assert cfg["cache_size"] == 1572864 and cfg["word_byte"] == 8 and cfg["block_shape"] == [1, 10000000]
     assert cfg["mem_latency"] == 30 and cfg["channel"] == 16 and cfg["bandwidth_per_channel"] == 8.0 and cfg["freq"] == 1.0
     base = json.load(open(os.path.join(ROOT, "config", "config_1mb_row1.json")))
-    for k in ("accumulator", "gpus", "repeat"):
+    assert "gpus" not in base          # the binary drives one GPU: the shipped configuration does not pretend otherwise
+    for k in ("accumulator", "repeat"):
         base.pop(k)
     p = tmp_path / "min.json"
     p.write_text(json.dumps(base))
@@ -271,7 +338,27 @@ def test_checksum_and_binary_dump_round_trip(tmp_path):
     assert S.checksum(m2)[0]["value_hash"] != cs["value_hash"] and S.checksum(m2)[0]["structure_hash"] == cs["structure_hash"]
 
 
-BIN = os.path.join(ROOT, "spada_sim_amd", "bin", "spada-sim")
+def test_hostile_sizes_are_refused_not_allocated(tmp_path):
+    """Sizes read from files are not trusted: a 40-byte binary dump that announces 2^40 rows and 2^44 entries, and a MatrixMarket size
+    line that announces 2^60 entries, come back as error codes -- no allocation is attempted from them and no C++ exception leaves
+    the C ABI (the process would abort)."""
+    import struct
+    p = tmp_path / "huge.bin"
+    p.write_bytes(b"SPADACSR" + struct.pack("<4Q", 1, 1 << 40, 10, 1 << 44))
+    with pytest.raises(S.SpadaError) as e:
+        S.read_bin(p)
+    assert e.value.code == 6
+    p.write_bytes(b"SPADACSR" + struct.pack("<4Q", 1, 3, 10, 1 << 43) + b"\0" * 64)     # inside the bounds, still not the file's size
+    with pytest.raises(S.SpadaError) as e:
+        S.read_bin(p)
+    assert e.value.code == 6
+    (tmp_path / "big.mtx").write_text("%%MatrixMarket matrix coordinate real general\n10 10 1152921504606846976\n1 1 1.0\n")
+    with pytest.raises(S.SpadaError) as e:
+        S.load_mm_mat(str(tmp_path), "big")
+    assert e.value.code == 6 and "announces" in str(e.value)
+
+
+BIN = os.environ.get("SPADA_BIN_PATH") or os.path.join(ROOT, "spada_sim_amd", "bin", "spada-sim")   # (env: the sanitizer build)
 CFG = os.path.join(ROOT, "config", "config_1mb_row1.json")
 
 
@@ -301,6 +388,17 @@ def test_cli_usage_and_exit_codes(matrices_dir):
     assert r.returncode == 101 and "Unimplemented simulator" in r.stderr
     assert r.stdout.startswith(CFG + "\n---- Python Interface ----\n% Load cari from ./matrices\nGet GEMM cari\n---- cari ----\n--A: (400, 1200)\n")   # frontend.rs:79 prints the configuration path first
     assert "Avg row len of A: 382, Avg row len of B: 127" in r.stdout
+    # `gpus` > 1 in a configuration is refused (the sharded path is libspada_comm.so's, one process per GPU), not ignored
+    cfg2 = os.path.join(cwd, "two_gpus.json")
+    d = json.load(open(CFG))
+    d["gpus"] = 2
+    json.dump(d, open(cfg2, "w"))
+    r = _run_cli(["accuratesimu", "spada", "ss", "cari", cfg2], cwd)
+    assert r.returncode == 101 and "`gpus` = 2" in r.stderr and "-----Result-----" not in r.stdout
+    # SPADA_TRACE=1: the trace lines that replace the reference's trace_exec feature go to stderr, stdout keeps the skeleton
+    r = subprocess.run([BIN, "trafficmodel", "spada", "ss", "cari", CFG], cwd=cwd, capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, SPADA_TRACE="1"))
+    assert "[spada trace 1] load_mm_mat" in r.stderr and "400 x 1200, 152800 entries" in r.stderr and "spada trace" not in r.stdout
     r = _run_cli(["accuratesimu", "spada", "ss", "missing", CFG], cwd)
     assert r.returncode == 101 and "missing.mtx" in r.stderr
     if S.device_count() == 0:      # no GPU: the run itself must fail loudly, not fall back to anything

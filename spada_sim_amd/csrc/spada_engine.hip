@@ -94,6 +94,7 @@ struct spada_ctx {
     // workspace (grow only): per row | per A entry | task pipeline | buffers handed out by the *_owned entry points
     size_t ws_bytes = 0;
     DevBuf row_nprod, row_bin, row_kmin, row_kmax, cptr, t_rowP, t_rowm, t_rowt, t_rowtmp, t_big, t_tiles;
+    DevBuf row_cl, row_rec, row_binfo;   // per row: class | length; RowRec; batch_info of the batch that starts at the row
     DevBuf eb0, elen;
     DevBuf t_tmp, t_tasks, t_status, t_rangeout, t_scrcol, t_scrval, t_scrseq, t_ctr;
     DevBuf t_possum;                                          // COUNT mode: sums of the tasks' counts per tile
@@ -240,7 +241,7 @@ void launch_task(spada_ctx *c, const TaskArgs &g)
     if (c->accumulator == SPADA_ACC_SORT_MERGE)
         hipLaunchKernelGGL(k_task_sm<MODE>, dim3(c->n_cu * 3), dim3(TK_BLOCK), task_sm_lds(), c->stream, g);
     else
-        hipLaunchKernelGGL((k_task<MODE, TK_NOUT>), dim3(c->n_cu * 4), dim3(TK_BLOCK), task_lds(), c->stream, g);
+        hipLaunchKernelGGL((k_task<MODE, TK_NOUT>), dim3(c->n_cu * 4), dim3(TK_BLOCK), task_kernel_lds(), c->stream, g);
 }
 
 TaskArgs task_args(spada_ctx *c, uint64_t *cptr, uint32_t *d_idx, double *d_val, uint64_t capacity)
@@ -259,6 +260,8 @@ TaskArgs task_args(spada_ctx *c, uint64_t *cptr, uint32_t *d_idx, double *d_val,
     g.row_kmin = c->row_kmin.as<uint32_t>();
     g.row_nprod = c->row_nprod.as<uint32_t>();
     g.row_kmax = c->row_kmax.as<uint32_t>();
+    g.arow = c->A->rowid;
+    g.row_rec = c->row_rec.as<RowRec>();
     g.tasks = c->t_tasks.as<TaskDesc>();
     g.scr_col = c->t_scrcol.as<uint32_t>();
     g.scr_val = c->t_scrval.as<double>();
@@ -291,6 +294,9 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
     if ((rc = c->row_bin.ensure(n1, false, s, &c->ws_bytes))) return rc;
     if ((rc = c->row_kmin.ensure(n1 * 4, false, s, &c->ws_bytes))) return rc;
     if ((rc = c->row_kmax.ensure(n1 * 4, false, s, &c->ws_bytes))) return rc;
+    if ((rc = c->row_cl.ensure(n1 * 4, false, s, &c->ws_bytes))) return rc;
+    if ((rc = c->row_rec.ensure(n1 * sizeof(RowRec), false, s, &c->ws_bytes))) return rc;
+    if ((rc = c->row_binfo.ensure(n1 * 4, false, s, &c->ws_bytes))) return rc;
     if ((rc = c->t_rowP.ensure(n1 * 8, false, s, &c->ws_bytes))) return rc;
     if ((rc = c->t_rowm.ensure(n1 * 4, false, s, &c->ws_bytes))) return rc;
     if ((rc = c->t_rowt.ensure(n1 * 4, false, s, &c->ws_bytes))) return rc;
@@ -304,7 +310,7 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
     const uint32_t ntiles = std::max<uint32_t>((n + CUT_TILE - 1) / CUT_TILE, 1);
     if ((rc = c->t_tiles.ensure(((size_t)ntiles + 2) * 4, false, s, &c->ws_bytes))) return rc;
     // composite hash keys of a batch: (local row << colbits) | column
-    uint32_t cb = 0;
+    uint32_t cb = BT_BSHIFT;   // (at least the bits of a block of columns: the batch tasks key their table by column >> BT_BSHIFT)
     while (cb < 32 && (1ull << cb) < b->cols) ++cb;
     c->colbits = cb;
     const uint32_t rmax = cb >= 32 ? 1u : (uint32_t)std::min<uint64_t>((1ull << (32 - cb)) - 1, TK_RMAX);
@@ -345,8 +351,9 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
                                c->row_kmin.as<uint32_t>(), c->row_kmax.as<uint32_t>(), gent,
                                c->accumulator == SPADA_ACC_SORT_MERGE ? (uint32_t)TK_SOLO_MAX : 0u, dc);
             hipLaunchKernelGGL(k_row_class, dim3(std::min<uint32_t>((n + 255) / 256, c->n_cu)), dim3(256), 0, s, a->ptr, c->r0,
-                               n, rmax, c->t_rowP.as<unsigned long long>(), c->row_nprod.as<uint32_t>(), c->row_bin.as<uint8_t>(),
-                               c->t_rowm.as<uint32_t>(), c->t_big.as<uint32_t>(), dc);
+                               n, rmax, c->t_rowP.as<unsigned long long>(), c->row_kmin.as<uint32_t>(), c->row_kmax.as<uint32_t>(),
+                               c->row_nprod.as<uint32_t>(), c->row_bin.as<uint8_t>(), c->row_cl.as<uint32_t>(),
+                               c->row_rec.as<RowRec>(), c->t_rowm.as<uint32_t>(), c->t_big.as<uint32_t>(), dc);
             HIP_TRY(hipGetLastError());
         }
         if (c->phase_timing) HIP_TRY(hipEventRecord(c->tev[1], s));
@@ -372,11 +379,12 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
         }
         if (c->phase_timing) HIP_TRY(hipEventRecord(c->tev[2], s));
         if (n) {
-            hipLaunchKernelGGL(k_cut1, dim3(ntiles), dim3(256), 0, s, c->row_bin.as<uint8_t>(), c->row_nprod.as<uint32_t>(),
-                               c->t_rowm.as<uint32_t>(), n, rmax, dc, c->t_tiles.as<uint32_t>(), c->t_rowt.as<uint32_t>());
+            hipLaunchKernelGGL(k_cut1, dim3(ntiles), dim3(256), 0, s, c->row_cl.as<uint32_t>(), c->row_nprod.as<uint32_t>(),
+                               c->t_rowm.as<uint32_t>(), n, rmax, dc, c->t_tiles.as<uint32_t>(), c->t_rowt.as<uint32_t>(),
+                               c->row_binfo.as<uint32_t>());
             hipLaunchKernelGGL(k_cut2, dim3(1), dim3(256), 0, s, c->t_tiles.as<uint32_t>(), ntiles, cap_tasks, dc);
             hipLaunchKernelGGL(k_cut3, dim3(ntiles), dim3(256), 0, s, c->row_bin.as<uint8_t>(), c->t_rowt.as<uint32_t>(),
-                               c->t_rowtmp.as<uint32_t>(), n, c->t_tiles.as<uint32_t>(),
+                               c->row_binfo.as<uint32_t>(), a->ptr, c->r0, c->t_rowtmp.as<uint32_t>(), n, c->t_tiles.as<uint32_t>(),
                                c->t_tmp.as<TaskDesc>(), c->t_tasks.as<TaskDesc>(), cap_tasks, dc);
             HIP_TRY(hipGetLastError());
         }
@@ -453,11 +461,11 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
         std::fprintf(stderr, "\n");
     }
 #endif
-    if (SPADA_TASK_DBG && h.dbg[15])
-        std::fprintf(stderr, "[batch dbg] %llu batches, cycles each: descriptor %.0f | rows+scan+clear %.0f | walk %.0f | counts+publish %.0f | "
-                     "emit (LDS, look-back wait, stores) %.0f | copy rows %.0f | ticket %.0f\n", h.dbg[15], (double)h.dbg[8] / h.dbg[15],
-                     (double)h.dbg[9] / h.dbg[15], (double)h.dbg[10] / h.dbg[15], (double)h.dbg[11] / h.dbg[15],
-                     (double)h.dbg[12] / h.dbg[15], (double)h.dbg[13] / h.dbg[15], (double)h.dbg[14] / h.dbg[15]);
+    if (SPADA_TASK_DBG && h.dbg[6])
+        std::fprintf(stderr, "[batch dbg] %llu batches, cycles each: prologue %.0f | records + head bits %.0f | rounds (gather, keys, masks) %.0f | "
+                     "counts, publish, rows %.0f | block sort %.0f | scale-add %.0f | look-back %.0f | stores %.0f\n", h.dbg[6],
+                     (double)h.dbg[8] / h.dbg[6], (double)h.dbg[9] / h.dbg[6], (double)h.dbg[10] / h.dbg[6], (double)h.dbg[11] / h.dbg[6],
+                     (double)h.dbg[12] / h.dbg[6], (double)h.dbg[13] / h.dbg[6], (double)h.dbg[14] / h.dbg[6], (double)h.dbg[15] / h.dbg[6]);
     st.n_tasks = h.ntasks;
     st.multi_pass_tasks = h.multi_pass_tasks;
     st.scratch_products = h.scratch_cursor;
@@ -551,9 +559,9 @@ int spada_create(const spada_options *opts, spada_ctx **out)
     for (auto &e : c->tev) HIP_TRY(hipEventCreate(&e));
     c->n_cu = (uint32_t)std::max(1, prop.multiProcessorCount);
     int rc;
-    if ((rc = allow_lds(k_task<MODE_COUNT, TK_NOUT>, task_lds()))) return rc;
-    if ((rc = allow_lds(k_task<MODE_NUMERIC, TK_NOUT>, task_lds()))) return rc;
-    if ((rc = allow_lds(k_task<MODE_FUSED, TK_NOUT>, task_lds()))) return rc;
+    if ((rc = allow_lds(k_task<MODE_COUNT, TK_NOUT>, task_kernel_lds()))) return rc;
+    if ((rc = allow_lds(k_task<MODE_NUMERIC, TK_NOUT>, task_kernel_lds()))) return rc;
+    if ((rc = allow_lds(k_task<MODE_FUSED, TK_NOUT>, task_kernel_lds()))) return rc;
     if ((rc = allow_lds(k_task_sm<MODE_COUNT>, task_sm_lds()))) return rc;
     if ((rc = allow_lds(k_task_sm<MODE_NUMERIC>, task_sm_lds()))) return rc;
     if ((rc = allow_lds(k_task_sm<MODE_FUSED>, task_sm_lds()))) return rc;
@@ -573,7 +581,7 @@ void spada_destroy(spada_ctx *c)
     c->un_ptr.release();
     c->un_idx.release();
     c->un_val.release();
-    for (DevBuf *b : {&c->row_nprod, &c->row_bin, &c->row_kmin, &c->row_kmax, &c->cptr, &c->t_rowP, &c->t_rowm, &c->t_rowt, &c->t_rowtmp,
+    for (DevBuf *b : {&c->row_cl, &c->row_rec, &c->row_binfo, &c->row_nprod, &c->row_bin, &c->row_kmin, &c->row_kmax, &c->cptr, &c->t_rowP, &c->t_rowm, &c->t_rowt, &c->t_rowtmp,
                       &c->t_big, &c->t_tiles, &c->eb0, &c->elen, &c->t_tmp, &c->t_tasks, &c->t_status, &c->t_rangeout, &c->t_possum, &c->t_scrcol,
                       &c->t_scrval, &c->t_scrseq, &c->t_ctr, &c->t_parts, &c->t_parthist, &c->t_slots, &c->own_idx, &c->own_val, &c->own_ptr, &c->wide_idx})
         b->release();

@@ -1,0 +1,545 @@
+// gfx950 kernels, part 4: the BATCH task of the task kernel (included by spgemm_task.hip.hpp) -- consecutive non-BIG rows of C
+// computed by one workgroup with one round trip per stage and the ordered emission done on BLOCKS of columns.
+//
+// What it replaces in the reference (citations into /root/reference/src): for the rows of one batch, the window fetch of A
+// scalars (scheduler.rs:482-606, storage.rs:279-323), the B-fiber streaming (simulator.rs:892-953), the multiplier
+// (simulator.rs:86-111), the sort by column (simulator.rs:143-171), the sum of equal columns (simulator.rs:199-230) and the
+// result assembly (simulator.rs:1034-1062: columns ascending and unique, explicit zeros kept).
+//
+// Shape of a batch (k_cut1, batch_info): R <= 128 consecutive rows, E <= 512 A entries (contiguous: the entries of consecutive
+// rows are), P <= 2048 products of which at most `limit` are hashed; the rest belong to COPY rows (one A entry: C_i = a * B_k is
+// already ascending and needs no accumulator).  That shape is what makes the stages short:
+//   prologue   the descriptor carries R, E, P and the first A entry: the entry loads (B-row begin / length, A value, row of the
+//              entry) and the row records (one 16-byte RowRec per row) are issued together, the table is cleared under them
+//   expand     ONE chunk: two entries per thread, one packed scan, head bits of the products (2048 bits), then two rounds of
+//              four products per thread -- 64 consecutive products per wave and step (coalesced gathers from B).  The products
+//              STAY IN REGISTERS (composite key, value, table slot): nothing is walked twice
+//   accumulate the table is keyed by BLOCK -- (local row, column / 16) -- and holds a 16-bit mask of the columns seen in the block
+//              (ds_cmpst on the key, ds_or on the mask).  The number of new mask bits is the task's output count: published
+//              to the chain (one-pass mode) as soon as the expansion is done
+//   order      only the BLOCKS are sorted (count / scan / scatter into monotone per-row buckets, rank inside the bucket): runs
+//              of consecutive columns -- link lists into one site, mesh neighbourhoods -- collapse into a few blocks, so the
+//              buckets stay short whatever the column pattern is (the rank loop over whole COLUMNS of round 2 waited for the
+//              longest bucket of 64 lanes: 60 consecutive columns of one row fell into one bucket).  A prefix sum of the masks'
+//              popcounts in block order gives every block its first output; the output of a product is
+//              first(block) + popcount(mask below its bit): no search, no comparison
+//   scale-add  the retained products add their value at that rank (ds_add_f64 into a dense array in OUTPUT order) and leave
+//              their column there; simulator.rs:213-218 adds left to right, here the order is arbitrary (1e-9)
+//   emit       after the look-back: the dense arrays are stored as they are (neighbouring lanes, neighbouring addresses), the
+//              retained products of COPY rows go straight to their place
+// LDS (40 320 bytes, four workgroups per CU; regions are reused by the stages):
+//   hdr 256 | MB u32[2048]: mask | first output << 16 | K 8 KB: keys, then (popcounts, slots) in block order | X 8 KB: entry
+//   records, then bucket counters | Y 8 KB: head bits, then keys in bucket order | Z 4 KB: slots in bucket order | rows 3.2 KB;
+//   the dense output arrays of the last stages lie over K + X (values) and Y (composite keys).
+#pragma once
+
+#ifndef SPADA_BT_STOP
+#define SPADA_BT_STOP 0
+#endif
+
+namespace spada {
+
+constexpr int BT_BSHIFT = 4;                                  // a block = 16 consecutive columns of one row of C
+constexpr uint32_t BT_H_COPY = 0xFFFFu, BT_H_NONE = 0xFFFEu;  // `slot` of a retained product that is copied / of a lane without a product
+constexpr size_t BT_OFF_MB = 256, BT_OFF_K = BT_OFF_MB + 8192, BT_OFF_X = BT_OFF_K + 8192, BT_OFF_Y = BT_OFF_X + 8192,
+                 BT_OFF_Z = BT_OFF_Y + 8192, BT_OFF_ROWS = BT_OFF_Z + 4096;
+struct BtRow {          // bucket parameters of a row (blocks): first bucket, buckets = blocks of the row, first block, buckets per block
+    uint16_t boff, nb;
+    uint32_t bmin;
+    float scale;
+};
+__host__ __device__ constexpr size_t batch_lds()
+{
+    return BT_OFF_ROWS + (size_t)TK_RMAX * (sizeof(BtRow) + 4 + 4 + 1);
+}
+static_assert(batch_lds() <= 40960, "four workgroups per CU");
+static_assert(TK_T == 2048 && BT_PMAX == 2048 && TK_BLOCK == 256, "the LDS map and the per-thread arrays are written for these sizes");
+
+// ---- scans on DPP (data-parallel primitives of the vector ALU: one instruction per step, no LDS round trip) -------------------
+// inclusive sum over the 64 lanes of a wave: row_shr 1 / 2 / 4 / 8 inside the rows of 16 lanes, then lane 15 of rows 0 and 2 to
+// rows 1 and 3 (row_bcast:15), then lane 31 to the upper half (row_bcast:31)
+__device__ inline uint32_t wave_scan_incl_u32(uint32_t v)
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
+    return v;
+}
+// exclusive sum over the 256 threads; ONE barrier.  `slot` = four LDS words (16-byte aligned) that no other scan of the same
+// barrier interval uses: consecutive scans take different slots, so none has to wait for the readers of the one before.
+__device__ inline uint32_t block_scan_excl_dpp(uint32_t v, uint32_t *slot, uint32_t *total)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint32_t inc = wave_scan_incl_u32(v);
+    if (lane == 63) slot[w] = inc;
+    __syncthreads();
+    const uint4 t = *(const uint4 *)slot;
+    *total = t.x + t.y + t.z + t.w;
+    return inc - v + (w > 0 ? t.x : 0u) + (w > 1 ? t.y : 0u) + (w > 2 ? t.z : 0u);
+}
+
+// exclusive scan of arr[0 .. N), N <= 2048 (u32 or u16 elements): every thread PER = ceil(N / 256) consecutive elements, kept in
+// loc[]; *first_excl = prefix of the thread's first element; prefixes written back in place if asked.  No barrier after the
+// write-back (the caller's next barrier covers it).
+template <class T>
+__device__ inline uint32_t batch_scan(T *arr, uint32_t N, uint32_t *slot, uint32_t (&loc)[8], uint32_t *first_excl, bool write_back)
+{
+    const int tid = threadIdx.x;
+    const uint32_t PER = (N + 255u) >> 8;
+    uint32_t tot = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < 8; ++j) {
+        const uint32_t idx = tid * PER + j;
+        loc[j] = (j < PER && idx < N) ? (uint32_t)arr[idx] : 0u;
+        tot += loc[j];
+    }
+    uint32_t total;
+    uint32_t ex = block_scan_excl_dpp(tot, slot, &total);   // (its barrier comes after every thread has read its elements)
+    *first_excl = ex;
+    if (write_back) {
+#pragma unroll
+        for (uint32_t j = 0; j < 8; ++j) {
+            const uint32_t idx = tid * PER + j;
+            if (j < PER && idx < N) {
+                arr[idx] = (T)ex;
+                ex += loc[j];
+            }
+        }
+    }
+    return total;
+}
+
+template <int MODE>
+__device__ inline void batch_task(const TaskArgs &g, const TaskDesc &td, uint32_t t, uint32_t ntasks, unsigned char *smem,
+                                  unsigned long long (&dbg_ph)[9])
+{
+    constexpr bool VALUES = MODE != MODE_COUNT;
+    constexpr int BLOCK = TK_BLOCK, T = TK_T;
+    uint32_t *hdr = (uint32_t *)smem;
+    uint32_t *mb = (uint32_t *)(smem + BT_OFF_MB);
+    uint32_t *keys = (uint32_t *)(smem + BT_OFF_K);
+    uint16_t *pcs = (uint16_t *)(smem + BT_OFF_K), *hs = pcs + T;
+    EntryRecNum *w_ent = (EntryRecNum *)(smem + BT_OFF_X);
+    uint32_t *bcnt = (uint32_t *)(smem + BT_OFF_X);
+    uint32_t *bm32 = (uint32_t *)(smem + BT_OFF_Y);                            // head bits of the products: 64 words
+    const unsigned long long *bm64 = (const unsigned long long *)(smem + BT_OFF_Y);
+    uint32_t *bpre = bm32 + 64;                                                 // heads before every 64-bit word: 32 words
+    uint32_t *lk = (uint32_t *)(smem + BT_OFF_Y);
+    uint16_t *ls = (uint16_t *)(smem + BT_OFF_Z);
+    double *vals = (double *)(smem + BT_OFF_K);                                 // K + X: 2048 values in output order
+    uint32_t *cols = (uint32_t *)(smem + BT_OFF_Y);                             // composite keys in output order
+    BtRow *s_emit = (BtRow *)(smem + BT_OFF_ROWS);
+    int32_t *s_delta = (int32_t *)(s_emit + TK_RMAX);
+    uint32_t *s_n = (uint32_t *)(s_delta + TK_RMAX);
+    uint8_t *s_cls = (uint8_t *)(s_n + TK_RMAX);
+    // scan slots (four words each) in the header; hdr[48 .. 50] belong to the chain and the ticket, hdr[52 .. 53] to the numeric base
+    uint32_t *slot_rows = hdr + 4, *slot_ent = hdr + 8, *slot_cnt = hdr + 12, *slot_bk = hdr + 16, *slot_pc = hdr + 20, *slot_cr = hdr + 24;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t wave_u = __builtin_amdgcn_readfirstlane(wave);
+    // stage boundaries: a comment in the ISA (static instruction counts per stage: scripts/dev/isa_stages.py) and, in SPADA_TASK_DBG
+    // builds, the cycles of thread 0 per stage, summed per workgroup in `dbg_ph` (k_task adds them to TaskCounters::dbg at its end)
+    unsigned long long ph_prev = SPADA_TASK_DBG ? __builtin_amdgcn_s_memtime() : 0;
+#define BPH(i)                                                                  \
+    do {                                                                        \
+        if (MODE == MODE_NUMERIC && SPADA_BT_STOP == (i) + 1) return; /* development: numeric mode cut short here (counts per stage) */ \
+        asm volatile("; BT_MARK " #i ::: "memory");                             \
+        if (SPADA_TASK_DBG && tid == 0) {                                       \
+            const unsigned long long n_ = __builtin_amdgcn_s_memtime();         \
+            dbg_ph[i] += n_ - ph_prev;                                          \
+            ph_prev = n_;                                                       \
+        }                                                                       \
+    } while (0)
+    if (SPADA_TASK_DBG && tid == 0) dbg_ph[8] += 1;
+    const uint32_t rb = td.row, R = td.np & 0xFFu, E = (td.np >> 8) & 0x3FFu, PT = td.np >> 18;
+    const uint64_t e0 = td.src;
+    const uint32_t colbits = g.colbits;                       // >= BT_BSHIFT (the engine sees to it)
+    const uint32_t colmask = colbits >= 32 ? 0xFFFFFFFFu : ((1u << colbits) - 1u);
+    const uint32_t hshift = colbits >= 32 ? 0u : colbits - BT_BSHIFT;   // block key = composite key >> 4 = local row << hshift | block
+    const uint32_t blkmask = colbits >= 32 ? 0xFFFFFFFFu : ((1u << hshift) - 1u);
+    auto lr_of_ck = [&](uint32_t ck) { return colbits >= 32 ? 0u : ck >> colbits; };
+    auto lr_of_hk = [&](uint32_t hk) { return colbits >= 32 ? 0u : hk >> hshift; };
+    const bool wave_has_entries = wave_u * 128u < E;          // (two entries per thread)
+
+    // ---- prologue: everything the walk needs in ONE round trip; the table is cleared while the loads are in flight ------------
+    RowRec rr{0u, 0u, 0u, (uint32_t)CLS_EMPTY};
+    if ((uint32_t)tid < R) rr = g.row_rec[rb + tid];
+    uint64_t b0[2] = {0, 0};
+    uint32_t len[2] = {0, 0}, elr[2] = {0, 0};
+    double av[2] = {0.0, 0.0};
+    if (PT && wave_has_entries) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const uint32_t ei = 2u * tid + i;
+            if (ei < E) {
+                const uint64_t q = e0 + ei;
+                b0[i] = g.eb0[q];
+                len[i] = g.elen[q];
+                elr[i] = g.arow[q] - (uint32_t)g.r0 - rb;
+                if constexpr (VALUES) av[i] = g.aval[q];
+            }
+        }
+    }
+    if (MODE == MODE_NUMERIC && tid == 0) {
+        const uint64_t c0 = g.cptr[rb];
+        hdr[52] = (uint32_t)c0;
+        hdr[53] = (uint32_t)(c0 >> 32);
+    }
+    {
+        uint4 *k4 = (uint4 *)keys, *m4 = (uint4 *)mb;
+#pragma unroll
+        for (int s = 0; s < T / 4 / BLOCK; ++s) {
+            k4[tid + s * BLOCK] = make_uint4(EMPTY_KEY, EMPTY_KEY, EMPTY_KEY, EMPTY_KEY);
+            m4[tid + s * BLOCK] = make_uint4(0u, 0u, 0u, 0u);
+        }
+        if (tid < 64) bm32[tid] = 0u;
+    }
+    // rows: buckets of the block order are allotted by the rows' PRODUCTS (known before anything is expanded: a block holds at
+    // least one product, so a row has at most as many blocks as buckets), the outputs of COPY rows before every row likewise
+    const bool row_hashed = rr.cls == CLS_SMALL || rr.cls == CLS_SOLO;
+    const uint32_t row_pr = row_hashed ? rr.nprod : 0u, row_cp = rr.cls == CLS_COPY ? rr.nprod : 0u;
+    uint32_t row_tot;
+    const uint32_t row_ex = block_scan_excl_dpp(row_pr | (row_cp << 16), slot_rows, &row_tot);   // (barrier: the table is cleared)
+    const uint32_t boff = row_ex & 0xFFFFu, cpre = row_ex >> 16, NBK = row_tot & 0xFFFFu;         // buckets before the row, copied outputs before it
+    if ((uint32_t)tid < R) {
+        const uint32_t bmin = rr.kmin >> BT_BSHIFT, bmax = rr.kmax >> BT_BSHIFT;
+        s_emit[tid] = BtRow{(uint16_t)boff, (uint16_t)row_pr, bmin, (float)row_pr / ((float)(bmax - bmin) + 1.0f)};
+        s_cls[tid] = (uint8_t)rr.cls;
+        s_n[tid] = 0u;
+        // position of an output = position of the task + its number among the hashed outputs (or among the products) + delta
+        s_delta[tid] = (int32_t)cpre;
+    }
+    __syncthreads();
+    BPH(0);
+
+    // ---- expand - scale - accumulate keys (scheduler.rs:482-606, simulator.rs:892-953, :86-111) ---------------------------
+    uint32_t r_ck[8], r_h[8];   // the products of this thread: composite key (local row << colbits | column), table slot
+    double r_v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        r_ck[i] = 0u;
+        r_h[i] = BT_H_NONE;
+        r_v[i] = 0.0;
+    }
+    uint32_t mynew = 0, mycopy = 0;   // mask bits this lane has set | products of COPY rows this thread's entries select
+    uint32_t P = 0;
+    if (PT) {
+        bool ecopy[2] = {false, false};
+        uint32_t mine = 0;
+        if (wave_has_entries) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                if (len[i]) {
+                    const uint8_t cls = s_cls[elr[i] < (uint32_t)TK_RMAX ? elr[i] : 0u];
+                    ecopy[i] = cls == CLS_COPY;
+                    if (!(ecopy[i] || cls == CLS_SMALL || cls == CLS_SOLO)) len[i] = 0u;   // (cannot happen: such rows have no products)
+                    if (ecopy[i]) mycopy += len[i];
+                }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) mine += len[i] ? ((1u << 16) | len[i]) : 0u;   // entries with products << 16 | products
+        }
+        uint32_t tot32;
+        const uint32_t ex32 = block_scan_excl_dpp(mine, slot_ent, &tot32);
+        P = tot32 & 0xFFFFu;
+        if (P > BT_PMAX) {   // the cut guarantees it; a batch that does not fit is an internal error, not a memory fault
+            if (tid == 0) atomicOr(&g.ctr->abort_flag, 32u);
+            P = 0;
+        }
+        if (P && wave_has_entries) {
+            uint32_t ci = ex32 >> 16, po = ex32 & 0xFFFFu;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                if (len[i]) {
+                    // record: (begin - first product) mod 2^48 | local row << 48 | copy << 55, A value
+                    const uint64_t pack = ((b0[i] - po) & M48) | ((uint64_t)elr[i] << 48) | ((uint64_t)(ecopy[i] ? 1u : 0u) << 55);
+                    w_ent[ci] = EntryRecNum{pack, av[i]};
+                    atomicOr(&bm32[po >> 5], 1u << (po & 31));
+                    if (ecopy[i]) s_delta[elr[i]] -= (int32_t)po;   // (the row's one entry: product number - first product = place in the row)
+                    ++ci;
+                    po += len[i];
+                }
+        }
+        __syncthreads();
+        if (wave == 0) {   // heads before every 64-bit word of the bitmap (32 words: half a wave)
+            const uint32_t c = lane < 32 ? (uint32_t)__popcll(bm64[lane & 31]) : 0u;
+            const uint32_t inc = wave_scan_incl_u32(c);
+            if (lane < 32) bpre[lane] = inc - c;
+        }
+        __syncthreads();
+        BPH(1);
+        const unsigned long long lane_bit = 1ull << lane;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            if ((uint32_t)r * 1024u < P) {   // (uniform)
+                // lane l of a segment holds product seg + l, i.e. bit l of one bitmap word: the word and its prefix are wave-uniform
+                // reads, the rank a v_mbcnt pair.  Lanes past the end fall back to product 0 of record 0 (a valid address).
+                unsigned long long bits[4];
+                uint32_t bp[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t w = (uint32_t)r * 16u + (uint32_t)u * 4u + wave_u;   // = segment / 64
+                    bits[u] = bm64[w];
+                    bp[u] = bpre[w];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) asm volatile("" : "+v"(bits[u]), "+v"(bp[u]));
+                uint32_t pp[4], j[4];
+                bool act[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t p = (uint32_t)r * 1024u + ((uint32_t)u * 4u + wave_u) * 64u + lane;
+                    act[u] = p < P;
+                    const uint32_t below =
+                        __builtin_amdgcn_mbcnt_hi((uint32_t)(bits[u] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bits[u], 0u));
+                    const uint32_t self = (bits[u] & lane_bit) ? 1u : 0u;
+                    j[u] = act[u] ? bp[u] + below + self - 1u : 0u;
+                    pp[u] = act[u] ? p : 0u;
+                }
+                uint64_t pack[4];
+                double a_[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const EntryRecNum er = w_ent[j[u]];
+                    pack[u] = er.pack;
+                    a_[u] = er.av;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    asm volatile("" : "+v"(pack[u]));
+                    if constexpr (VALUES) asm volatile("" : "+v"(a_[u]));
+                }
+                uint64_t q[4];
+                uint32_t col[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) q[u] = ((pack[u] & M48) + pp[u]) & M48;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) col[u] = g.bidx[q[u]];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if constexpr (VALUES) r_v[r * 4 + u] = a_[u] * g.bval[q[u]];   // simulator.rs:100-101
+                uint32_t hk[4], h[4], old[4];
+                bool hashed[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t lr = (uint32_t)(pack[u] >> 48) & 127u;
+                    const bool copy = ((pack[u] >> 55) & 1ull) != 0;
+                    const uint32_t ck = compose_key(lr, col[u], colbits);
+                    r_ck[r * 4 + u] = ck;
+                    hashed[u] = act[u] && !copy;
+                    if (act[u] && copy) r_h[r * 4 + u] = BT_H_COPY;
+                    hk[u] = ck >> BT_BSHIFT;
+                    h[u] = hash_slot<TK_LOG_T>(hk[u]);
+                    old[u] = hk[u];
+                    if (hashed[u]) old[u] = atomicCAS(&keys[h[u]], EMPTY_KEY, hk[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (hashed[u] && old[u] != EMPTY_KEY && old[u] != hk[u]) {
+                        const uint32_t step = probe_step(hk[u]);
+                        for (;;) {
+                            h[u] = (h[u] + step) & (T - 1);
+                            const uint32_t o = atomicCAS(&keys[h[u]], EMPTY_KEY, hk[u]);
+                            if (o == EMPTY_KEY || o == hk[u]) break;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (hashed[u]) {
+                        const uint32_t bit = 1u << (col[u] & 15u);
+                        const uint32_t was = atomicOr(&mb[h[u]], bit);
+                        mynew += (was & bit) ? 0u : 1u;
+                        r_h[r * 4 + u] = h[u];
+                    }
+            }
+        }
+        __syncthreads();
+        BPH(2);
+    }
+
+    // ---- the count of the task: new mask bits + copied products; published as soon as it is known -----------------------------
+    uint32_t NO, total;
+    {
+        uint32_t tot32;
+        (void)block_scan_excl_dpp(mynew | (mycopy << 16), slot_cnt, &tot32);
+        NO = tot32 & 0xFFFFu;
+        total = NO + (tot32 >> 16);
+    }
+    if constexpr (MODE != MODE_NUMERIC) task_publish<MODE>(g, t, total);
+#if SPADA_PRIO
+    if constexpr (MODE == MODE_FUSED) __builtin_amdgcn_s_setprio(0);
+#endif
+    uint32_t myk[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) myk[i] = NO ? keys[tid + i * BLOCK] : EMPTY_KEY;
+
+    if constexpr (MODE == MODE_COUNT) {
+        // the symbolic phase wants the outputs of every ROW: popcounts of the masks summed per row (the other modes get them from
+        // the scans of the block order); offsets of the rows inside the batch -- k_pos4 adds the position of the batch afterwards
+        if (NO) {
+            if (R > 1) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    if (myk[i] != EMPTY_KEY) atomicAdd(&s_n[lr_of_hk(myk[i])], (uint32_t)__popc(mb[tid + i * BLOCK] & 0xFFFFu));
+            } else if (tid == 0) {
+                s_n[0] = NO;
+            }
+        }
+        __syncthreads();
+        const uint32_t n = (uint32_t)tid < R ? (row_hashed ? s_n[tid] : row_cp) : 0u;
+        uint32_t tot32;
+        const uint32_t ooff = block_scan_excl_dpp(n, slot_cr, &tot32);
+        if ((uint32_t)tid < R) g.cptr[rb + tid] = ooff;
+        return;
+    }
+    BPH(3);
+
+    // ---- order: the blocks in (row, block) order; first output of every block ---------------------------------------------------
+    uint32_t hoff = 0;   // hashed outputs of the batch before this thread's row
+    if (NO) {
+        for (uint32_t s = tid; s < NBK; s += BLOCK) bcnt[s] = 0u;
+        __syncthreads();
+        uint16_t myb[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            myb[i] = 0;
+            if (myk[i] != EMPTY_KEY) {
+                const BtRow e = s_emit[lr_of_hk(myk[i])];
+                uint32_t bk = (uint32_t)((float)((myk[i] & blkmask) - e.bmin) * e.scale);
+                bk = bk < e.nb ? bk : (uint32_t)e.nb - 1u;
+                myb[i] = (uint16_t)(e.boff + bk);
+                atomicAdd(&bcnt[myb[i]], 1u);
+            }
+        }
+        __syncthreads();
+        uint32_t NBt;   // blocks of the batch
+        {
+            uint32_t loc[8], fe;
+            NBt = batch_scan<uint32_t>(bcnt, NBK, slot_bk, loc, &fe, true);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (myk[i] != EMPTY_KEY) {
+                const uint32_t p = atomicAdd(&bcnt[myb[i]], 1u);   // afterwards bcnt[b] = end of bucket b
+                lk[p] = myk[i];
+                ls[p] = (uint16_t)(tid + i * BLOCK);
+            }
+        __syncthreads();
+        uint16_t spv[8], hsv[8], pcv[8];
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {
+            const uint32_t p = tid + w * BLOCK;
+            spv[w] = 0xFFFFu;
+            hsv[w] = 0;
+            pcv[w] = 0;
+            if (p < NBt) {
+                const uint32_t k = lk[p];
+                const BtRow e = s_emit[lr_of_hk(k)];
+                uint32_t bk = (uint32_t)((float)((k & blkmask) - e.bmin) * e.scale);
+                bk = e.boff + (bk < e.nb ? bk : (uint32_t)e.nb - 1u);
+                const uint32_t lo = bk ? bcnt[bk - 1] : 0u, hi = bcnt[bk];
+                uint32_t rnk = lo;
+#pragma clang loop unroll(disable) vectorize(disable)
+                for (uint32_t jj = lo; jj < hi; ++jj) rnk += (lk[jj] < k) ? 1u : 0u;
+                spv[w] = (uint16_t)rnk;
+                hsv[w] = ls[p];
+                pcv[w] = (uint16_t)__popc(mb[hsv[w]] & 0xFFFFu);
+            }
+        }
+        // first block of this thread's row in block order = start of the row's first bucket
+        const uint32_t fpos = (uint32_t)tid < R ? (boff ? bcnt[boff - 1] : 0u) : 0u;
+        __syncthreads();   // the table's keys (region K) are not read again: popcounts and slots in block order take their place
+#pragma unroll
+        for (int w = 0; w < 8; ++w)
+            if (spv[w] != 0xFFFFu) {
+                hs[spv[w]] = hsv[w];
+                pcs[spv[w]] = pcv[w];
+            }
+        __syncthreads();
+        {
+            uint32_t loc[8], ex;
+            (void)batch_scan<uint16_t>(pcs, NBt, slot_pc, loc, &ex, true);   // pcs[i] = outputs of the blocks before block i
+            const uint32_t PER = (NBt + 255u) >> 8;
+#pragma unroll
+            for (uint32_t jj = 0; jj < 8; ++jj) {
+                const uint32_t idx = tid * PER + jj;
+                if (jj < PER && idx < NBt) {
+                    mb[hs[idx]] |= ex << 16;   // (one thread per slot)
+                    ex += loc[jj];
+                }
+            }
+        }
+        __syncthreads();
+        hoff = (uint32_t)tid < R ? (fpos < NBt ? (uint32_t)pcs[fpos] : NO) : 0u;
+        __syncthreads();   // pcs (region K) read: the values may take its place
+        BPH(4);
+        // ---- scale - add: every retained product adds its value at its output (simulator.rs:213-218; order differs) -----------
+        for (uint32_t s = tid; s < NO; s += BLOCK) vals[s] = 0.0;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (r_h[i] < BT_H_NONE) {
+                const uint32_t w = mb[r_h[i]];
+                const uint32_t rank = (w >> 16) + (uint32_t)__popc(w & ((1u << (r_ck[i] & 15u)) - 1u));
+                atomicAdd(&vals[rank], r_v[i]);
+                cols[rank] = r_ck[i];
+            }
+    }
+    // the rows' first outputs inside the batch: hashed outputs before the row + copied outputs before it
+    const uint32_t ooff = hoff + cpre;
+    if ((uint32_t)tid < R && rr.cls == CLS_COPY) s_delta[tid] += (int32_t)hoff;
+    __syncthreads();
+    BPH(5);
+
+    // ---- position of the task's slice of C (the chain), then the stores -------------------------------------------------------
+    unsigned long long base;
+    if constexpr (MODE == MODE_NUMERIC) {
+        base = ((unsigned long long)hdr[53] << 32) | hdr[52];
+    } else {
+        base = task_position<MODE>(g, t, total, hdr);
+        if ((uint32_t)tid < R) g.cptr[rb + tid] = base + ooff;
+        if (t == ntasks - 1 && tid == 0) {
+            g.cptr[g.nrows] = base + total;
+            g.ctr->nnz_c = base + total;
+        }
+        if (base + total > g.capacity) {
+            if (tid == 0) atomicOr(&g.ctr->cap_overflow, 1u);
+            return;
+        }
+    }
+    BPH(6);
+    for (uint32_t p = tid; p < NO; p += BLOCK) {
+        const uint32_t ck = cols[p];
+        const unsigned long long pos = base + p + (long long)s_delta[lr_of_ck(ck)];
+#if SPADA_NT_STORE
+        __builtin_nontemporal_store(ck & colmask, &g.c_idx[pos]);
+        __builtin_nontemporal_store(vals[p], &g.c_val[pos]);
+#else
+        g.c_idx[pos] = ck & colmask;
+        g.c_val[pos] = vals[p];
+#endif
+    }
+    if (total > NO) {   // COPY rows: C_i = a * B_k, already ascending: product number - first product of the row = place in the row
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (r_h[i] == BT_H_COPY) {
+                const uint32_t p = (uint32_t)(i >> 2) * 1024u + ((uint32_t)(i & 3) * 4u + wave_u) * 64u + lane;
+                const unsigned long long pos = base + (long long)((int32_t)p + s_delta[lr_of_ck(r_ck[i])]);
+#if SPADA_NT_STORE
+                __builtin_nontemporal_store(r_ck[i] & colmask, &g.c_idx[pos]);
+                __builtin_nontemporal_store(r_v[i], &g.c_val[pos]);
+#else
+                g.c_idx[pos] = r_ck[i] & colmask;
+                g.c_val[pos] = r_v[i];
+#endif
+            }
+    }
+    BPH(7);
+#undef BPH
+}
+
+}  // namespace spada

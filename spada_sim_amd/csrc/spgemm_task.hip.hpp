@@ -65,9 +65,9 @@ static_assert(TK_LIMIT_LO <= TK_LIMIT_HI && TK_LIMIT_HI + 8 <= (uint32_t)TK_T &&
 struct TaskDesc {
     uint32_t kind;      // TASK_BATCH: rows [row, row of the next task) | TASK_RANGE: columns [col_lo, col_hi] of BIG row `row`
     uint32_t row;
-    uint32_t np;        // RANGE: products of the slice
+    uint32_t np;        // RANGE: products of the slice | BATCH: batch_info(rows, A entries, products)
     uint32_t first;     // RANGE: bit 0 = first range of its row (writes C.indptr[row]); DIRECT: the row's A entries above it
-    uint64_t src;       // RANGE: first product of the slice in the scratch arrays
+    uint64_t src;       // RANGE: first product of the slice in the scratch arrays | BATCH, DIRECT: first A entry
     uint32_t col_lo, col_hi;
 };
 constexpr uint32_t TASK_BATCH = 1, TASK_RANGE = 2, TASK_RANGE_DIRECT = 3;   // (DIRECT: the products are taken from B, not from the scratch)
@@ -94,10 +94,25 @@ struct TaskCounters {   // (a multiple of 8 bytes: k_init clears it in 8-byte wo
                                  // of the task loop, [4] cycles before the chain (expand + accumulate), [5] cycles after it (emit)
 };
 
+// A batch is sized so that ONE chunk of the walk holds its A entries and the registers of the workgroup hold its products
+// (spgemm_batch.hip.hpp): at most BT_EMAX entries (hashed, copied and empty ones alike: the entries of consecutive rows are
+// contiguous) and at most BT_PMAX products (hashed + copied: two rounds of four per thread).  Rows that cannot be part of such a
+// batch -- more than BT_EMAX entries, or one entry that selects more than BT_PMAX products -- are BIG whatever their products.
+constexpr uint32_t BT_EMAX = 512, BT_PMAX = 2048;
+static_assert(BT_EMAX == (uint32_t)TK_BLOCK * TK_EPT && BT_PMAX == 2u * 4u * TK_BLOCK && TK_LIMIT_HI <= BT_PMAX, "one chunk, two rounds");
+
+// what a task needs to know about a row, in one 16-byte load (written by k_row_class)
+struct __attribute__((aligned(16))) RowRec {
+    uint32_t kmin, kmax;   // first / last column that can occur in the row of C
+    uint32_t nprod;        // products (saturated at 2^32 - 1)
+    uint32_t cls;
+};
+
 __device__ inline uint8_t row_class(uint64_t P, uint32_t L, uint32_t rmax, uint32_t lim)
 {
     if (P == 0) return CLS_EMPTY;
-    if (L == 1) return CLS_COPY;
+    if (L > BT_EMAX) return CLS_BIG;
+    if (L == 1) return P <= BT_PMAX ? CLS_COPY : CLS_BIG;
     if (P <= TK_SMALL_MAX && rmax > 1) return CLS_SMALL;
     if (P <= lim) return CLS_SOLO;
     return CLS_BIG;
@@ -265,8 +280,10 @@ __global__ __launch_bounds__(256) void k_entry_stats(const uint64_t *__restrict_
 }
 
 __global__ __launch_bounds__(256) void k_row_class(const uint64_t *__restrict__ aptr, uint64_t r0, uint32_t nrows, uint32_t rmax,
-                                                   const unsigned long long *__restrict__ row_P, uint32_t *__restrict__ row_nprod,
-                                                   uint8_t *__restrict__ row_cls, uint32_t *__restrict__ row_m,
+                                                   const unsigned long long *__restrict__ row_P, const uint32_t *__restrict__ row_kmin,
+                                                   const uint32_t *__restrict__ row_kmax, uint32_t *__restrict__ row_nprod,
+                                                   uint8_t *__restrict__ row_cls, uint32_t *__restrict__ row_cl,
+                                                   RowRec *__restrict__ row_rec, uint32_t *__restrict__ row_m,
                                                    uint32_t *__restrict__ big_rows, TaskCounters *__restrict__ ctr)
 {
     const uint32_t lim = ctr->prod_limit;
@@ -283,8 +300,11 @@ __global__ __launch_bounds__(256) void k_row_class(const uint64_t *__restrict__ 
             const unsigned long long P = row_P[i];
             const uint32_t L = (uint32_t)(aptr[r0 + i + 1] - aptr[r0 + i]);
             cls = row_class(P, L, rmax, lim);
-            row_nprod[i] = P > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)P;
+            const uint32_t P32 = P > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)P;
+            row_nprod[i] = P32;
             row_cls[i] = cls;
+            row_cl[i] = (uint32_t)cls | (min(L, 0x1FFFFFFFu) << 3);   // class and length in one word (the cut)
+            row_rec[i] = RowRec{row_kmin[i], row_kmax[i], P32, (uint32_t)cls};
             row_m[i] = 0;
 #pragma unroll
             for (int k = 0; k < N_CLS; ++k) {   // (a run-time index would push the counters out of the registers)
@@ -837,14 +857,14 @@ __global__ __launch_bounds__(TK_BLOCK) void k_big_scatter(const double *__restri
 
 // ---- 3. the cut: rows -> tasks in output order ---------------------------------------------------------------------------
 // Tiles of CUT_TILE consecutive rows.  A BIG row is row_m[i] range tasks of its own.  The other rows are packed greedily, in
-// row order, into batches that are as full as the table allows: a batch is a maximal run of rows with at most TK_SOLO_MAX
-// products to hash (COPY rows do not count: they never touch the table), at most `rmax` rows and at most CUT_COPY_MAX copied
-// products.  Full batches mean fewer tasks and -- what matters to the chain -- tasks of equal length.  nxt[i] (first row
-// after a batch that starts at row i) is found for all rows in parallel by binary search over the tile's prefix sums; one
-// thread then follows the chain from the tile's first row (batches do not cross tiles).
+// row order, into batches that are as full as the table allows: a batch is a maximal run of rows with at most `limit`
+// products to hash, at most BT_PMAX products in all (the products of COPY rows never touch the table, but like the hashed ones
+// they wait in the registers of the task for their position), at most BT_EMAX A entries and at most `rmax` rows.
+// Full batches mean fewer tasks and -- what matters to the chain -- tasks of equal length.  nxt[i] (first row
+// after a batch that starts at row i) is found for all rows in parallel by binary search over the tile's prefix sums; the
+// starts are what the walks along nxt reach (pointer doubling; batches do not cross tiles).
 constexpr int CUT_ITEMS = 4, CUT_TILE = 256 * CUT_ITEMS;   // (tiles of 1024 rows: 2048 leaves too few workgroups on the smaller inputs,
                                                            // 512 cuts too many batches at tile borders -- +11 % tasks on the stencil input)
-constexpr uint32_t CUT_COPY_MAX = 8192;
 
 __device__ inline uint32_t block_scan_excl_u32(uint32_t v, uint32_t *s_w /*[4]*/, uint32_t *total)
 {
@@ -874,59 +894,97 @@ struct CutRow {
 };
 constexpr uint32_t CUT_END = 0xFFFFFFFFu;
 struct CutLds {
-    uint32_t pc[CUT_TILE + 1], pw[CUT_TILE + 1];   // prefix sums: products to hash, products to copy
+    uint32_t pc[CUT_TILE + 1], pw[CUT_TILE + 1], pe[CUT_TILE + 1];   // prefix sums: products to hash, products to copy, A entries
     uint32_t nxt[CUT_TILE];
     uint8_t mark[CUT_TILE];
     uint32_t s_w[4];
 };
 
-// tasks started by every row of the tile; returns the exclusive prefix of this thread's first row and the tile total
-__device__ inline uint32_t cut_tile(const uint8_t *__restrict__ row_cls, const uint32_t *__restrict__ row_nprod,
+// exclusive suffix minimum across the workgroup (the minimum of v over the threads behind this one; none: 0xFFFFFFFF)
+__device__ inline uint32_t block_suffix_min_excl_u32(uint32_t v, uint32_t *s_w /*[4]*/)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_down(inc, o);
+        if (lane + o < 64) inc = min(inc, t);
+    }
+    __syncthreads();
+    if (lane == 0) s_w[w] = inc;
+    __syncthreads();
+    uint32_t ex = __shfl_down(inc, 1);
+    if (lane == 63) ex = 0xFFFFFFFFu;
+    for (int k = w + 1; k < 4; ++k) ex = min(ex, s_w[k]);
+    return ex;
+}
+
+// batch descriptor word (TaskDesc::np of a TASK_BATCH): rows | A entries << 8 | products (hashed + copied) << 18
+__host__ __device__ inline uint32_t batch_info(uint32_t R, uint32_t E, uint32_t P) { return R | (E << 8) | (P << 18); }
+static_assert(TK_RMAX <= 255 && BT_EMAX <= 1023 && BT_PMAX <= 4095, "batch_info fields");
+
+// tasks started by every row of the tile; returns the exclusive prefix of this thread's first row and the tile total.
+// A batch is a maximal run of non-BIG rows (greedy, in row order) with at most `lim` products to hash, at most BT_PMAX products in
+// all (hashed + copied: the task keeps them in registers), at most BT_EMAX A entries (one chunk of the walk) and at most `rmax`
+// rows.  binfo[j] (batch starts only) = batch_info(rows, entries, products) of the batch that starts at the thread's row j.
+__device__ inline uint32_t cut_tile(const uint32_t *__restrict__ row_cl, const uint32_t *__restrict__ row_nprod,
                                     const uint32_t *__restrict__ row_m, uint32_t n, uint32_t rmax, uint32_t lim, CutLds &L,
-                                    CutRow &cr, uint32_t *tile_total)
+                                    CutRow &cr, uint32_t *tile_total, uint32_t (&binfo)[CUT_ITEMS])
 {
     const uint32_t tile_base = blockIdx.x * CUT_TILE, base = tile_base + threadIdx.x * CUT_ITEMS;
     const uint32_t cnt = min((uint32_t)CUT_TILE, n - tile_base);
     uint8_t cls[CUT_ITEMS];
-    uint32_t c[CUT_ITEMS], w[CUT_ITEMS], sc = 0, sw = 0;
+    bool fat[CUT_ITEMS];   // EMPTY row with more entries than a chunk holds: a batch of its own that has nothing to do
+    uint32_t c[CUT_ITEMS], w[CUT_ITEMS], e[CUT_ITEMS], sc = 0, sw = 0, se = 0;
 #pragma unroll
     for (int j = 0; j < CUT_ITEMS; ++j) {
         const uint32_t i = base + j;
-        cls[j] = i < n ? row_cls[i] : CLS_EMPTY;
+        const uint32_t cl = i < n ? row_cl[i] : (uint32_t)CLS_EMPTY;
+        cls[j] = (uint8_t)(cl & 7u);
+        const uint32_t len = cl >> 3;
         const uint32_t P = i < n ? row_nprod[i] : 0u;
-        c[j] = cls[j] == CLS_BIG ? lim + 1 : ((cls[j] == CLS_SMALL || cls[j] == CLS_SOLO) ? P : 0u);
-        w[j] = cls[j] == CLS_COPY ? min(P, CUT_COPY_MAX) : 0u;
+        fat[j] = cls[j] == CLS_EMPTY && len > BT_EMAX;
+        c[j] = (cls[j] == CLS_BIG || fat[j]) ? lim + 1 : ((cls[j] == CLS_SMALL || cls[j] == CLS_SOLO) ? P : 0u);
+        w[j] = cls[j] == CLS_COPY ? P : 0u;
+        e[j] = (cls[j] == CLS_BIG || fat[j]) ? 0u : len;
         L.mark[threadIdx.x * CUT_ITEMS + j] = 0;
         sc += c[j];
         sw += w[j];
+        se += e[j];
     }
     uint32_t tot;
     uint32_t ec = block_scan_excl_u32(sc, L.s_w, &tot);
     __syncthreads();
     uint32_t ew = block_scan_excl_u32(sw, L.s_w, &tot);
+    __syncthreads();
+    uint32_t ee = block_scan_excl_u32(se, L.s_w, &tot);
 #pragma unroll
     for (int j = 0; j < CUT_ITEMS; ++j) {
         L.pc[threadIdx.x * CUT_ITEMS + j] = ec;
         L.pw[threadIdx.x * CUT_ITEMS + j] = ew;
+        L.pe[threadIdx.x * CUT_ITEMS + j] = ee;
         ec += c[j];
         ew += w[j];
+        ee += e[j];
     }
     if (threadIdx.x == 255) {
         L.pc[CUT_TILE] = ec;
         L.pw[CUT_TILE] = ew;
+        L.pe[CUT_TILE] = ee;
     }
     __syncthreads();
-    // nxt[i]: largest j <= cnt with pc[j] - pc[i] <= TK_SOLO_MAX, pw[j] - pw[i] <= CUT_COPY_MAX, j - i <= rmax (j >= i + 1 always)
+    // nxt[i]: largest j <= cnt with pc[j] - pc[i] <= lim, (pc + pw)[j] - (pc + pw)[i] <= BT_PMAX, pe[j] - pe[i] <= BT_EMAX, j - i <= rmax
+    // (j = i + 1 is always feasible: a row that is not BIG fits a batch by its class)
 #pragma unroll
     for (int j = 0; j < CUT_ITEMS; ++j) {
         const uint32_t li = threadIdx.x * CUT_ITEMS + j;
         uint32_t nx = li + 1;
         if (li < cnt && cls[j] != CLS_BIG) {
-            const uint32_t limc = L.pc[li] + lim, limw = L.pw[li] + CUT_COPY_MAX;
+            const uint32_t limc = L.pc[li] + lim, limp = L.pc[li] + L.pw[li] + BT_PMAX, lime = L.pe[li] + BT_EMAX;
             uint32_t lo = li + 1, hi = min(cnt, li + rmax);   // invariant: lo is feasible
             while (lo < hi) {
                 const uint32_t mid = (lo + hi + 1) >> 1;
-                if (L.pc[mid] <= limc && L.pw[mid] <= limw) lo = mid;
+                if (L.pc[mid] <= limc && L.pc[mid] + L.pw[mid] <= limp && L.pe[mid] <= lime) lo = mid;
                 else hi = mid - 1;
             }
             nx = lo;
@@ -958,15 +1016,38 @@ __device__ inline uint32_t cut_tile(const uint8_t *__restrict__ row_cls, const u
         }
         __syncthreads();
     }
+    // where the batch that starts at a row ends: the next start behind it (or the end of the tile)
+    uint32_t nm[CUT_ITEMS];
+    {
+        uint32_t first = CUT_END;
+#pragma unroll
+        for (int j = CUT_ITEMS - 1; j >= 0; --j) {
+            const uint32_t li = threadIdx.x * CUT_ITEMS + j;
+            if (li < cnt && L.mark[li]) first = li;
+        }
+        uint32_t run = block_suffix_min_excl_u32(first, L.s_w);
+#pragma unroll
+        for (int j = CUT_ITEMS - 1; j >= 0; --j) {
+            const uint32_t li = threadIdx.x * CUT_ITEMS + j;
+            nm[j] = run == CUT_END ? cnt : run;
+            if (li < cnt && L.mark[li]) run = li;
+        }
+    }
     uint32_t local = 0;
 #pragma unroll
     for (int j = 0; j < CUT_ITEMS; ++j) {
-        const uint32_t i = base + j;
+        const uint32_t i = base + j, li = threadIdx.x * CUT_ITEMS + j;
         cr.t[j] = 0;
         cr.kind[j] = 0;
-        if (i < n && L.mark[threadIdx.x * CUT_ITEMS + j]) {
+        binfo[j] = 0;
+        if (i < n && L.mark[li]) {
             cr.kind[j] = cls[j] == CLS_BIG ? 2u : 1u;
             cr.t[j] = cls[j] == CLS_BIG ? row_m[i] : 1u;
+            if (cls[j] != CLS_BIG) {
+                const uint32_t end = nm[j];
+                binfo[j] = fat[j] ? batch_info(1u, 0u, 0u)
+                                  : batch_info(end - li, L.pe[end] - L.pe[li], (L.pc[end] - L.pc[li]) + (L.pw[end] - L.pw[li]));
+            }
         }
         local += cr.t[j];
     }
@@ -975,21 +1056,24 @@ __device__ inline uint32_t cut_tile(const uint8_t *__restrict__ row_cls, const u
 }
 
 // k_cut1: tasks started by every row -> row_t (0: none; BIG rows: their range tasks; else 1) and the tile totals
-__global__ __launch_bounds__(256) void k_cut1(const uint8_t *__restrict__ row_cls, const uint32_t *__restrict__ row_nprod,
+__global__ __launch_bounds__(256) void k_cut1(const uint32_t *__restrict__ row_cl, const uint32_t *__restrict__ row_nprod,
                                               const uint32_t *__restrict__ row_m, uint32_t n, uint32_t rmax,
                                               const TaskCounters *__restrict__ ctr, uint32_t *__restrict__ tile_tasks,
-                                              uint32_t *__restrict__ row_t)
+                                              uint32_t *__restrict__ row_t, uint32_t *__restrict__ row_binfo)
 {
     const uint32_t lim = ctr->prod_limit;
     __shared__ CutLds L;
     CutRow cr;
-    uint32_t tot;
-    (void)cut_tile(row_cls, row_nprod, row_m, n, rmax, lim, L, cr, &tot);
+    uint32_t tot, binfo[CUT_ITEMS];
+    (void)cut_tile(row_cl, row_nprod, row_m, n, rmax, lim, L, cr, &tot, binfo);
     if (threadIdx.x == 0) tile_tasks[blockIdx.x] = tot;
     const uint32_t base = blockIdx.x * CUT_TILE + threadIdx.x * CUT_ITEMS;
 #pragma unroll
     for (int j = 0; j < CUT_ITEMS; ++j)
-        if (base + j < n) row_t[base + j] = cr.t[j];
+        if (base + j < n) {
+            row_t[base + j] = cr.t[j];
+            row_binfo[base + j] = binfo[j];
+        }
 }
 
 // single workgroup: exclusive scan of the tile totals in place; total -> ctr->ntasks
@@ -1016,6 +1100,7 @@ __global__ __launch_bounds__(256) void k_cut2(uint32_t *__restrict__ tile_tasks,
 
 // k_cut3: task descriptors at their final place: tile offset + prefix of row_t inside the tile
 __global__ __launch_bounds__(256) void k_cut3(const uint8_t *__restrict__ row_cls, const uint32_t *__restrict__ row_t,
+                                              const uint32_t *__restrict__ row_binfo, const uint64_t *__restrict__ aptr, uint64_t r0,
                                               const uint32_t *__restrict__ row_tmp, uint32_t n,
                                               const uint32_t *__restrict__ tile_tasks, const TaskDesc *__restrict__ tmp,
                                               TaskDesc *__restrict__ tasks, uint32_t task_cap,
@@ -1044,12 +1129,12 @@ __global__ __launch_bounds__(256) void k_cut3(const uint8_t *__restrict__ row_cl
         kb[j] = 0xFFFFFFFFu;
         idxb[j] = 0;
         if (cr.kind[j] == 1 && idx < task_cap) {
-            TaskDesc d;
+            TaskDesc d;      // everything the task needs to start its loads: rows, entries, products, first A entry
             d.kind = TASK_BATCH;
             d.row = base + j;
-            d.np = 0;
+            d.np = row_binfo[base + j];
             d.first = 0;
-            d.src = 0;
+            d.src = aptr[r0 + base + j];
             d.col_lo = d.col_hi = 0;
             tasks[idx] = d;
         } else if (cr.kind[j] == 2 && cr.t[j]) {
@@ -1113,6 +1198,8 @@ struct TaskArgs {
     uint32_t colbits;
     const uint8_t *row_cls;
     const uint32_t *row_kmin, *row_kmax, *row_nprod;
+    const uint32_t *arow;           // row of every A entry (spada_dev_csr::rowid)
+    const RowRec *row_rec;          // per row: column bounds, products, class (k_row_class)
     const TaskDesc *tasks;
     const uint32_t *scr_col;
     const double *scr_val;
@@ -1662,6 +1749,14 @@ __device__ inline uint32_t direct_accumulate(unsigned char *smem, unsigned char 
     return n;
 }
 
+}  // namespace spada
+#include "spgemm_batch.hip.hpp"
+namespace spada {
+
+// dynamic LDS of k_task: its RANGE tasks use the layout of task_lds(), its BATCH tasks the one of spgemm_batch.hip.hpp
+__host__ __device__ constexpr size_t task_kernel_lds() { return task_lds() > batch_lds() ? task_lds() : batch_lds(); }
+static_assert(task_kernel_lds() <= 40960, "four workgroups per CU");
+
 template <int MODE, int NOUT>
 __global__ __launch_bounds__(TK_BLOCK, 4) void k_task(const TaskArgs g)
 {
@@ -1692,7 +1787,7 @@ __global__ __launch_bounds__(TK_BLOCK, 4) void k_task(const TaskArgs g)
     uint32_t t = hdr[50];
     __syncthreads();
     unsigned long long dbg_t0 = SPADA_TASK_DBG ? __builtin_amdgcn_s_memtime() : 0, dbg_acc = 0, dbg_chain = 0, dbg_emit = 0;
-    unsigned long long dbg_ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long dbg_ph[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     while (t < task_end) {
         unsigned long long dbg_a = SPADA_TASK_DBG ? __builtin_amdgcn_s_memtime() : 0, dbg_b = dbg_a, dbg_c = dbg_a;
         // (tickets are taken when the work starts: one taken earlier -- even only across this task's stores, to hide its
@@ -1702,235 +1797,9 @@ __global__ __launch_bounds__(TK_BLOCK, 4) void k_task(const TaskArgs g)
         if constexpr (MODE == MODE_FUSED) __builtin_amdgcn_s_setprio(SPADA_PRIO);
 #endif
         const TaskDesc td = g.tasks[t];
-        const uint32_t next_row = t + 1 < ntasks ? g.tasks[t + 1].row : g.nrows;   // (with the descriptor: not a round trip of its own)
-        unsigned long long ph_prev = dbg_a;
-#define PHASE(i) do { if (SPADA_TASK_DBG && tid == 0) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); dbg_ph[i] += n_ - ph_prev; ph_prev = n_; } } while (0)
         if (td.kind == TASK_BATCH) {
-            const uint32_t rb = td.row;
-            const uint32_t R = next_row - rb;   // 1 .. RMAX
-            PHASE(0);
-            // ---- rows of the batch ------------------------------------------------------------------------------------
-            uint32_t L = 0, n = 0, kmin = 0, kmax = 0, rid = 0, clen = 0;
-            uint64_t cb0 = 0, c0 = 0;
-            double cav = 0.0;
-            uint8_t cls = CLS_EMPTY;
-            // one round trip for everything a row needs before the walk: the loads are independent of each other (class, column
-            // bounds and product count are fetched for every row of the batch, whatever its class turns out to be), and the table
-            // is cleared while they are in flight -- all of this sits before the publication of the count
-            uint64_t a0 = 0, a1 = 0;
-            uint32_t np_row = 0;
-            if ((uint32_t)tid < R) {
-                rid = rb + tid;
-                a0 = g.aptr[g.r0 + rid];
-                a1 = g.aptr[g.r0 + rid + 1];
-                cls = g.row_cls[rid];
-                kmin = g.row_kmin[rid];
-                kmax = g.row_kmax[rid];
-                np_row = g.row_nprod[rid];
-                if constexpr (MODE == MODE_NUMERIC) {
-                    c0 = g.cptr[rid];
-                    n = (uint32_t)(g.cptr[rid + 1] - c0);
-                }
-            }
-            table_clear(smem);
-            if ((uint32_t)tid < R) {
-                s_a0[tid] = a0;
-                s_cnt[tid] = 0;
-                if (cls == CLS_SMALL || cls == CLS_SOLO) L = (uint32_t)(a1 - a0);
-                // COPY row: the length of the one selected B row = the row's products.  Where that B row starts and the A value
-                // are only needed for the copy itself: they are fetched after the count has been published
-                else if (cls == CLS_COPY) clen = np_row;
-            }
-            uint32_t E;
-            const uint32_t exl = group_scan_excl<BLOCK>(L, tid, hdr + 2, &E);
-            if ((uint32_t)tid < R) s_re[tid] = exl;
-            if (tid == 0) s_re[R] = E;
-            __syncthreads();
-            PHASE(1);
-            // ---- expand - scale - accumulate (simulator.rs:86-111, :199-230) ---------------------------------------------
-            uint32_t mynew = 0;   // keys this lane has put into the table
-            if (E)
-                flat_walk<BLOCK, EPT, RMAX, VALUES, U>(
-                    s_re, s_a0, R, E, g.eb0, g.elen, g.aval, g.bidx, g.bval, region2, hdr,
-                    [&](uint32_t(&col)[U], uint32_t(&plr)[U], double(&v)[U], uint32_t(&)[U]) {
-                        uint32_t key[U], h[U], old[U];
-#pragma unroll
-                        for (int u = 0; u < U; ++u) {
-                            key[u] = compose_key(plr[u], col[u], g.colbits);
-                            h[u] = hash_slot<TK_LOG_T>(key[u]);
-                            old[u] = key[u];
-                            if (plr[u] != LR_NONE) old[u] = atomicCAS(&keys[h[u]], EMPTY_KEY, key[u]);
-                        }
-#pragma unroll
-                        for (int u = 0; u < U; ++u) {
-                            bool isnew = old[u] == EMPTY_KEY;
-                            if (!isnew && old[u] != key[u]) {
-                                const uint32_t step = probe_step(key[u]);
-                                for (;;) {
-                                    h[u] = (h[u] + step) & (T - 1);
-                                    const uint32_t o = atomicCAS(&keys[h[u]], EMPTY_KEY, key[u]);
-                                    if (o == EMPTY_KEY) { isnew = true; break; }
-                                    if (o == key[u]) break;
-                                }
-                            }
-                            if constexpr (MODE != MODE_NUMERIC) mynew += isnew && plr[u] != LR_NONE ? 1u : 0u;
-                        }
-                        if constexpr (VALUES) {
-#pragma unroll
-                            for (int u = 0; u < U; ++u)
-                                if (plr[u] != LR_NONE) atomicAdd(&vals[h[u]], v[u]);   // simulator.rs:213-218
-                        }
-                    });
-            __syncthreads();
-            PHASE(2);
-            // ---- outputs per row, offsets inside the batch ------------------------------------------------------------------
-            const bool hashed = cls == CLS_SMALL || cls == CLS_SOLO;
-            // The count of the task -- all the chain needs -- is the number of keys the lanes have inserted plus the lengths of the
-            // COPY rows; how the keys spread over the rows is only needed for the emission and is counted after the publication.
-            uint32_t boff = 0, ooff = 0, NO, total;
-            if constexpr (MODE != MODE_NUMERIC) {
-                unsigned long long tot64;
-                group_scan_excl_u64<BLOCK>(((unsigned long long)clen << 32) | mynew, tid, (unsigned long long *)(hdr + 4), &tot64);
-                NO = (uint32_t)tot64;
-                total = NO + (uint32_t)(tot64 >> 32);
-            } else {
-                unsigned long long tot64;
-                const unsigned long long ex64 = group_scan_excl_u64<BLOCK>(((unsigned long long)n << 32) | (hashed ? n : 0u), tid,
-                                                                           (unsigned long long *)(hdr + 4), &tot64);
-                boff = (uint32_t)ex64, ooff = (uint32_t)(ex64 >> 32);
-                NO = (uint32_t)tot64, total = (uint32_t)(tot64 >> 32);
-            }
-            __syncthreads();
-            // ---- chain: publish the count now, look back as late as possible ------------------------------------------------
-            if (SPADA_TASK_DBG) dbg_b = dbg_c = __builtin_amdgcn_s_memtime();
-            if constexpr (MODE != MODE_NUMERIC) task_publish<MODE>(g, t, total);
-#if SPADA_PRIO
-            if constexpr (MODE == MODE_FUSED) __builtin_amdgcn_s_setprio(0);
-#endif
-#if SPADA_TASK_DBG
-            if (tid == 0) {
-                const unsigned long long w_ = __builtin_amdgcn_s_memtime() - dbg_a;
-                const int kd_ = (int)td.kind - 1;
-                atomicAdd(&g.ctr->dbgh[kd_][w_ / 4096 < 19 ? w_ / 4096 : 19], 1ull);
-                atomicAdd(&g.ctr->dbgh[kd_][20], w_);
-                atomicAdd(&g.ctr->dbgh[kd_][21], 1ull);
-                atomicMax(&g.ctr->dbgh[kd_][22], w_);
-            }
-#endif
-            PHASE(3);
-            if constexpr (MODE != MODE_NUMERIC) {
-                // ---- outputs per row (one LDS atomic per occupied slot), offsets inside the batch ---------------------------
-                if (R > 1) {
-                    if (NO) {
-                        for (uint32_t sl = tid; sl < (uint32_t)T; sl += BLOCK) {
-                            const uint32_t k = keys[sl];
-                            if (k != EMPTY_KEY) atomicAdd(&s_cnt[k >> g.colbits], 1u);
-                        }
-                        __syncthreads();
-                    }
-                    n = hashed ? s_cnt[tid < RMAX ? tid : 0] : clen;
-                } else {
-                    n = hashed ? NO : clen;
-                }
-                unsigned long long tot64;
-                const unsigned long long ex64 = group_scan_excl_u64<BLOCK>(((unsigned long long)n << 32) | (hashed ? n : 0u), tid,
-                                                                           (unsigned long long *)(hdr + 4), &tot64);
-                boff = (uint32_t)ex64, ooff = (uint32_t)(ex64 >> 32);
-                __syncthreads();
-            }
-            unsigned long long dbg_w = 0;
-            auto resolve = [&]() -> unsigned long long {
-                if constexpr (MODE == MODE_NUMERIC) {
-                    return 0ull;
-                } else {
-                    const unsigned long long w0 = SPADA_TASK_DBG ? __builtin_amdgcn_s_memtime() : 0;
-                    const unsigned long long b0 = task_position<MODE>(g, t, total, hdr);
-                    if (SPADA_TASK_DBG) dbg_w = __builtin_amdgcn_s_memtime() - w0;
-                    if ((uint32_t)tid < R) g.cptr[rid] = b0 + ooff;
-                    if (MODE != MODE_COUNT && t == ntasks - 1 && tid == 0) {
-                        g.cptr[g.nrows] = b0 + total;
-                        g.ctr->nnz_c = b0 + total;
-                    }
-                    if constexpr (MODE == MODE_FUSED) {
-                        if (b0 + total > g.capacity) {
-                            if (tid == 0) atomicOr(&g.ctr->cap_overflow, 1u);
-                            return NO_STORE;
-                        }
-                    }
-                    return b0;
-                }
-            };
-            unsigned long long base;
-            if (MODE != MODE_COUNT && NO) {
-                // s_out: first output of the row relative to the task's slice (NUMERIC: absolute, the slice starts at 0)
-                if ((uint32_t)tid < R) {
-                    s_row[tid] = RowEmit{boff, hashed ? n : 0u, kmin, (float)n / ((float)(kmax - kmin) + 1.0f)};
-                    s_out[tid] = MODE == MODE_NUMERIC ? c0 : (uint64_t)ooff;
-                }
-                __syncthreads();
-                base = emit_table<false, NOUT>(smem, NO, g.colbits, g.c_idx, g.c_val, resolve);
-            } else {
-                base = resolve();
-            }
-            if (SPADA_TASK_DBG) dbg_c = dbg_b + dbg_w;
-            PHASE(4);
-            if constexpr (MODE != MODE_NUMERIC) c0 = base + ooff;
-            if (MODE != MODE_COUNT && base != NO_STORE) {
-                // COPY rows: C_i = a * B_k, already ascending.  Their products form one flat list (prefix sums of the row
-                // lengths in LDS, region 2 is free by now): every lane copies products, whatever the row lengths are.
-                uint32_t *s_cpre = (uint32_t *)region2;                       // [RMAX + 1]
-                uint64_t *s_cb0 = (uint64_t *)(region2 + (RMAX + 2) * 4);     // [RMAX]  (8-byte aligned: RMAX is even)
-                double *s_cav = (double *)(s_cb0 + RMAX);
-                uint64_t *s_cc0 = (uint64_t *)(s_cav + RMAX);
-                const bool copy = (uint32_t)tid < R && cls == CLS_COPY;
-                if (copy) {
-                    const uint64_t a0 = s_a0[tid];
-                    cb0 = g.eb0[a0];
-                    if constexpr (VALUES) cav = g.aval[a0];
-                }
-                uint32_t Cp;
-                const uint32_t cex = group_scan_excl<BLOCK>(copy ? clen : 0u, tid, hdr + 2, &Cp);
-                if (Cp) {   // uniform
-                    if ((uint32_t)tid < R) {
-                        s_cpre[tid] = cex;
-                        s_cb0[tid] = cb0;
-                        s_cav[tid] = cav;
-                        s_cc0[tid] = c0;
-                    }
-                    if (tid == 0) s_cpre[R] = Cp;
-                    __syncthreads();
-                    for (uint32_t p0 = tid; p0 < Cp; p0 += 4 * BLOCK) {
-                        uint32_t k4[4], off4[4], lr4[4];
-                        double v4[4];
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            const uint32_t p = min(p0 + u * BLOCK, Cp - 1);
-                            uint32_t lo = 0;   // largest lr with s_cpre[lr] <= p (rows without copy products repeat a value)
-#pragma unroll
-                            for (int step = RMAX / 2; step >= 1; step >>= 1)
-                                if (lo + step < R && s_cpre[lo + step] <= p) lo += step;
-                            lr4[u] = lo;
-                            off4[u] = p - s_cpre[lo];
-                        }
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            k4[u] = g.bidx[s_cb0[lr4[u]] + off4[u]];
-                            v4[u] = g.bval[s_cb0[lr4[u]] + off4[u]];
-                        }
-#pragma unroll
-                        for (int u = 0; u < 4; ++u)
-                            if (p0 + u * BLOCK < Cp) {
-#if SPADA_NT_STORE
-                                __builtin_nontemporal_store(k4[u], &g.c_idx[s_cc0[lr4[u]] + off4[u]]);
-                                __builtin_nontemporal_store(s_cav[lr4[u]] * v4[u], &g.c_val[s_cc0[lr4[u]] + off4[u]]);
-#else
-                                g.c_idx[s_cc0[lr4[u]] + off4[u]] = k4[u];
-                                g.c_val[s_cc0[lr4[u]] + off4[u]] = s_cav[lr4[u]] * v4[u];
-#endif
-                            }
-                    }
-                }
-            }
+            // consecutive non-BIG rows: spgemm_batch.hip.hpp
+            batch_task<MODE>(g, td, t, ntasks, smem, dbg_ph);
         } else {
             // ---- RANGE task: columns [col_lo, col_hi] of a BIG row, products in the scratch slice -----------------------------
             // Single pass when the slice cannot overflow the table (at most NOUT products or columns; a column sub-range of a heavy
@@ -2001,16 +1870,10 @@ __global__ __launch_bounds__(TK_BLOCK, 4) void k_task(const TaskArgs g)
             if (SPADA_TASK_DBG) dbg_c = dbg_b + dbg_w;
         }
         __syncthreads();
-        if (td.kind == TASK_BATCH) {
-            PHASE(5);
-            if (SPADA_TASK_DBG && tid == 0) dbg_ph[7] += 1;
-        }
         if (tid == 0) hdr[50] = g.task_lo + atomicAdd(my_ticket, 1u) * TK_NQ + blockIdx.x % TK_NQ;
         __syncthreads();
         t = hdr[50];
         __syncthreads();
-        if (td.kind == TASK_BATCH) PHASE(6);
-#undef PHASE
         if (SPADA_TASK_DBG) {
             const unsigned long long e = __builtin_amdgcn_s_memtime();
             dbg_acc += dbg_b - dbg_a;
@@ -2025,6 +1888,7 @@ __global__ __launch_bounds__(TK_BLOCK, 4) void k_task(const TaskArgs g)
         atomicAdd(&g.ctr->dbg[5], dbg_emit);
 #pragma unroll
         for (int k = 0; k < 8; ++k) atomicAdd(&g.ctr->dbg[8 + k], dbg_ph[k]);
+        atomicAdd(&g.ctr->dbg[6], dbg_ph[8]);
     }
 }
 

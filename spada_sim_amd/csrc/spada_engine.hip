@@ -418,6 +418,10 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
         if (!h.abort_flag) break;
         if (attempt == 3) return fail(SPADA_ERR_HIP, "task pipeline: workspaces still too small after three retries (flag %u)", h.abort_flag);
         if (h.abort_flag & 4u) return fail(SPADA_ERR_UNSUPPORTED, "a row of C has 2^32 or more products");
+        if (h.abort_flag & 32u)
+            return fail(SPADA_ERR_HIP, "internal error: task %llu (kind %llu, %llu rows, %llu entries, descriptor word %llu) expands to %llu "
+                        "products in %llu entries, more than a batch holds", h.dbg[3], h.dbg[0] & 0xFF, h.dbg[0] >> 32, (h.dbg[0] >> 8) & 0xFFFFFF,
+                        h.dbg[2], h.dbg[1] & 0xFFFF, h.dbg[1] >> 16);
         c->t_cap_scr = std::max<uint64_t>(c->t_cap_scr, h.scratch_cursor + h.scratch_cursor / 16 + 1024);
         c->t_cap_tmp = std::max<uint64_t>(c->t_cap_tmp, (uint64_t)h.tmp_cursor + h.tmp_cursor / 16 + 1024);
         c->t_cap_parts = std::max<uint64_t>(c->t_cap_parts, (uint64_t)h.n_parts + h.n_parts / 16 + 256);
@@ -446,12 +450,6 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
         st.cls_rows[k] = h.cls_rows[k];
         st.cls_prod[k] = h.cls_prod[k];
     }
-    if (SPADA_TASK_DBG)
-        std::fprintf(stderr, "[task dbg] tasks %u  loop cycles/WG %.0f  accumulate %.1f%%  chain %.1f%%  emit %.1f%%  windows/task %.2f  spins/task %.2f  waits/task %.2f  mean distance of the awaited task %.1f\n",
-                     h.ntasks, (double)h.dbg[3] / (c->n_cu * 4.0), 100.0 * h.dbg[4] / std::max<double>(1, h.dbg[3]),
-                     100.0 * h.dbg[0] / std::max<double>(1, h.dbg[3]), 100.0 * h.dbg[5] / std::max<double>(1, h.dbg[3]),
-                     (double)h.dbg[1] / std::max(1u, h.ntasks), (double)h.dbg[2] / std::max(1u, h.ntasks),
-                     (double)h.dbg[7] / std::max(1u, h.ntasks), (double)h.dbg[6] / std::max<double>(1, h.dbg[7]));
 #if SPADA_TASK_DBG
     for (int k = 0; k < 3; ++k) {
         if (!h.dbgh[k][21]) continue;
@@ -461,6 +459,10 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
         std::fprintf(stderr, "\n");
     }
 #endif
+    if (SPADA_TASK_DBG && h.dbg[5])
+        std::fprintf(stderr, "[shape dbg] %llu tasks through the batch path: products %.0f, hashed outputs %.0f, blocks %.0f, rows %.1f, entries %.0f per task\n",
+                     h.dbg[5], (double)h.dbg[0] / h.dbg[5], (double)h.dbg[1] / h.dbg[5], (double)h.dbg[2] / h.dbg[5], (double)h.dbg[3] / h.dbg[5],
+                     (double)h.dbg[4] / h.dbg[5]);
     if (SPADA_TASK_DBG && h.dbg[6])
         std::fprintf(stderr, "[batch dbg] %llu batches, cycles each: prologue %.0f | records + head bits %.0f | rounds (gather, keys, masks) %.0f | "
                      "counts, publish, rows %.0f | block sort %.0f | scale-add %.0f | look-back %.0f | stores %.0f\n", h.dbg[6],

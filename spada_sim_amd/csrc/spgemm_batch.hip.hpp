@@ -27,6 +27,9 @@
 //              their column there; simulator.rs:213-218 adds left to right, here the order is arbitrary (1e-9)
 //   emit       after the look-back: the dense arrays are stored as they are (neighbouring lanes, neighbouring addresses), the
 //              retained products of COPY rows go straight to their place
+// The DIRECT RANGE tasks of BIG rows (columns [col_lo, col_hi] of one row whose products exceed a table; the row's entries are
+// narrowed to the range by two binary searches each: B rows are ascending) run through the same stages whenever the row has at
+// most BT_EMAX entries: one row, no COPY entries, the range as the row's column bounds.
 // LDS (40 320 bytes, four workgroups per CU; regions are reused by the stages):
 //   hdr 256 | MB u32[2048]: mask | first output << 16 | K 8 KB: keys, then (popcounts, slots) in block order | X 8 KB: entry
 //   records, then bucket counters | Y 8 KB: head bits, then keys in bucket order | Z 4 KB: slots in bucket order | rows 3.2 KB;
@@ -81,15 +84,14 @@ __device__ inline uint32_t block_scan_excl_dpp(uint32_t v, uint32_t *slot, uint3
     return inc - v + (w > 0 ? t.x : 0u) + (w > 1 ? t.y : 0u) + (w > 2 ? t.z : 0u);
 }
 
-// exclusive scan of arr[0 .. N), N <= 2048 (u32 or u16 elements): every thread PER = ceil(N / 256) consecutive elements, kept in
-// loc[]; *first_excl = prefix of the thread's first element; prefixes written back in place if asked.  No barrier after the
-// write-back (the caller's next barrier covers it).
+// exclusive scan of arr[0 .. N), N <= 2048 (u32 or u16 elements): every thread PER = ceil(N / 256) consecutive elements; the
+// prefixes go to out[] (which may be arr itself).  Returns the total.  No barrier after the stores (the caller's next one covers them).
 template <class T>
-__device__ inline uint32_t batch_scan(T *arr, uint32_t N, uint32_t *slot, uint32_t (&loc)[8], uint32_t *first_excl, bool write_back)
+__device__ inline uint32_t batch_scan(const T *arr, T *out, uint32_t N, uint32_t *slot)
 {
     const int tid = threadIdx.x;
     const uint32_t PER = (N + 255u) >> 8;
-    uint32_t tot = 0;
+    uint32_t loc[8], tot = 0;
 #pragma unroll
     for (uint32_t j = 0; j < 8; ++j) {
         const uint32_t idx = tid * PER + j;
@@ -98,15 +100,12 @@ __device__ inline uint32_t batch_scan(T *arr, uint32_t N, uint32_t *slot, uint32
     }
     uint32_t total;
     uint32_t ex = block_scan_excl_dpp(tot, slot, &total);   // (its barrier comes after every thread has read its elements)
-    *first_excl = ex;
-    if (write_back) {
 #pragma unroll
-        for (uint32_t j = 0; j < 8; ++j) {
-            const uint32_t idx = tid * PER + j;
-            if (j < PER && idx < N) {
-                arr[idx] = (T)ex;
-                ex += loc[j];
-            }
+    for (uint32_t j = 0; j < 8; ++j) {
+        const uint32_t idx = tid * PER + j;
+        if (j < PER && idx < N) {
+            out[idx] = (T)ex;
+            ex += loc[j];
         }
     }
     return total;
@@ -121,12 +120,11 @@ __device__ inline void batch_task(const TaskArgs &g, const TaskDesc &td, uint32_
     uint32_t *hdr = (uint32_t *)smem;
     uint32_t *mb = (uint32_t *)(smem + BT_OFF_MB);
     uint32_t *keys = (uint32_t *)(smem + BT_OFF_K);
-    uint16_t *pcs = (uint16_t *)(smem + BT_OFF_K), *hs = pcs + T;
+    uint16_t *pc = (uint16_t *)(smem + BT_OFF_K), *pcx = pc + T;   // outputs of the blocks in bucket order | outputs before them
     EntryRecNum *w_ent = (EntryRecNum *)(smem + BT_OFF_X);
     uint32_t *bcnt = (uint32_t *)(smem + BT_OFF_X);
-    uint32_t *bm32 = (uint32_t *)(smem + BT_OFF_Y);                            // head bits of the products: 64 words
+    uint32_t *bm32 = (uint32_t *)(smem + BT_OFF_Y);                            // tail bits (last product of every entry): 64 words
     const unsigned long long *bm64 = (const unsigned long long *)(smem + BT_OFF_Y);
-    uint32_t *bpre = bm32 + 64;                                                 // heads before every 64-bit word: 32 words
     uint32_t *lk = (uint32_t *)(smem + BT_OFF_Y);
     uint16_t *ls = (uint16_t *)(smem + BT_OFF_Z);
     double *vals = (double *)(smem + BT_OFF_K);                                 // K + X: 2048 values in output order
@@ -154,7 +152,11 @@ __device__ inline void batch_task(const TaskArgs &g, const TaskDesc &td, uint32_
         }                                                                       \
     } while (0)
     if (SPADA_TASK_DBG && tid == 0) dbg_ph[8] += 1;
-    const uint32_t rb = td.row, R = td.np & 0xFFu, E = (td.np >> 8) & 0x3FFu, PT = td.np >> 18;
+#define BSTOP(id) do { if (MODE == MODE_NUMERIC && SPADA_BT_STOP == (id)) return; asm volatile("; BT_MARK s" #id ::: "memory"); } while (0)   /* development: finer cut points */
+    // BATCH: rows, entries, products from batch_info | DIRECT RANGE: one row, its entries (descriptor), the products of the range
+    const bool range = td.kind != TASK_BATCH;
+    const uint32_t rb = td.row, R = range ? 1u : (td.np & 0xFFu), E = range ? (td.first >> 1) : ((td.np >> 8) & 0x3FFu),
+                   PT = range ? td.np : (td.np >> 18);
     const uint64_t e0 = td.src;
     const uint32_t colbits = g.colbits;                       // >= BT_BSHIFT (the engine sees to it)
     const uint32_t colmask = colbits >= 32 ? 0xFFFFFFFFu : ((1u << colbits) - 1u);
@@ -166,7 +168,11 @@ __device__ inline void batch_task(const TaskArgs &g, const TaskDesc &td, uint32_
 
     // ---- prologue: everything the walk needs in ONE round trip; the table is cleared while the loads are in flight ------------
     RowRec rr{0u, 0u, 0u, (uint32_t)CLS_EMPTY};
-    if ((uint32_t)tid < R) rr = g.row_rec[rb + tid];
+    if (range) {
+        if (tid == 0) rr = RowRec{td.col_lo, td.col_hi, td.np, (uint32_t)CLS_SOLO};
+    } else if ((uint32_t)tid < R) {
+        rr = g.row_rec[rb + tid];
+    }
     uint64_t b0[2] = {0, 0};
     uint32_t len[2] = {0, 0}, elr[2] = {0, 0};
     double av[2] = {0.0, 0.0};
@@ -178,13 +184,13 @@ __device__ inline void batch_task(const TaskArgs &g, const TaskDesc &td, uint32_
                 const uint64_t q = e0 + ei;
                 b0[i] = g.eb0[q];
                 len[i] = g.elen[q];
-                elr[i] = g.arow[q] - (uint32_t)g.r0 - rb;
+                if (!range) elr[i] = g.arow[q] - (uint32_t)g.r0 - rb;
                 if constexpr (VALUES) av[i] = g.aval[q];
             }
         }
     }
     if (MODE == MODE_NUMERIC && tid == 0) {
-        const uint64_t c0 = g.cptr[rb];
+        const uint64_t c0 = range ? g.range_out[t] : g.cptr[rb];
         hdr[52] = (uint32_t)c0;
         hdr[53] = (uint32_t)(c0 >> 32);
     }
@@ -197,16 +203,15 @@ __device__ inline void batch_task(const TaskArgs &g, const TaskDesc &td, uint32_
         }
         if (tid < 64) bm32[tid] = 0u;
     }
-    // rows: buckets of the block order are allotted by the rows' PRODUCTS (known before anything is expanded: a block holds at
-    // least one product, so a row has at most as many blocks as buckets), the outputs of COPY rows before every row likewise
+    BSTOP(10);
+    // rows: the hashed products before every row (the buckets of the block order are laid out in proportion to them, below) and
+    // the outputs of COPY rows before it -- both known before anything is expanded
     const bool row_hashed = rr.cls == CLS_SMALL || rr.cls == CLS_SOLO;
     const uint32_t row_pr = row_hashed ? rr.nprod : 0u, row_cp = rr.cls == CLS_COPY ? rr.nprod : 0u;
     uint32_t row_tot;
     const uint32_t row_ex = block_scan_excl_dpp(row_pr | (row_cp << 16), slot_rows, &row_tot);   // (barrier: the table is cleared)
     const uint32_t boff = row_ex & 0xFFFFu, cpre = row_ex >> 16, NBK = row_tot & 0xFFFFu;         // buckets before the row, copied outputs before it
     if ((uint32_t)tid < R) {
-        const uint32_t bmin = rr.kmin >> BT_BSHIFT, bmax = rr.kmax >> BT_BSHIFT;
-        s_emit[tid] = BtRow{(uint16_t)boff, (uint16_t)row_pr, bmin, (float)row_pr / ((float)(bmax - bmin) + 1.0f)};
         s_cls[tid] = (uint8_t)rr.cls;
         s_n[tid] = 0u;
         // position of an output = position of the task + its number among the hashed outputs (or among the products) + delta
@@ -224,11 +229,61 @@ __device__ inline void batch_task(const TaskArgs &g, const TaskDesc &td, uint32_
         r_h[i] = BT_H_NONE;
         r_v[i] = 0.0;
     }
-    uint32_t mynew = 0, mycopy = 0;   // mask bits this lane has set | products of COPY rows this thread's entries select
+    uint32_t mynew = 0, mykeys = 0;   // mask bits this lane has set | blocks (table keys) this lane has created
     uint32_t P = 0;
     if (PT) {
         bool ecopy[2] = {false, false};
         uint32_t mine = 0;
+        if (range && wave_has_entries) {
+            // DIRECT RANGE: every selected B row narrowed to [col_lo, col_hi]: l1 = first position with column >= lo, l2 = first with
+            // column > hi, all searches of the wave in lock step (binary: K-ary searches were slower -- more scattered loads)
+            const uint32_t lo = td.col_lo, hi = td.col_hi;
+            const uint32_t *__restrict__ bidx = g.bidx;
+            uint32_t l1[2], n1[2], l2[2], n2[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                l1[i] = l2[i] = 0;
+                n1[i] = n2[i] = len[i];
+            }
+            for (;;) {
+                uint32_t any = 0;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) any |= n1[i] | n2[i];
+                if (!any) break;
+                uint32_t c1[2], c2[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    c1[i] = n1[i] ? bidx[b0[i] + l1[i] + (n1[i] >> 1)] : 0u;
+                    c2[i] = n2[i] ? bidx[b0[i] + l2[i] + (n2[i] >> 1)] : 0u;
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    if (n1[i]) {
+                        const uint32_t hh = n1[i] >> 1;
+                        if (c1[i] < lo) {
+                            l1[i] += hh + 1;
+                            n1[i] -= hh + 1;
+                        } else {
+                            n1[i] = hh;
+                        }
+                    }
+                    if (n2[i]) {
+                        const uint32_t hh = n2[i] >> 1;
+                        if (c2[i] <= hi) {
+                            l2[i] += hh + 1;
+                            n2[i] -= hh + 1;
+                        } else {
+                            n2[i] = hh;
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                b0[i] += l1[i];
+                len[i] = l2[i] - l1[i];
+            }
+        }
         if (wave_has_entries) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -236,16 +291,23 @@ __device__ inline void batch_task(const TaskArgs &g, const TaskDesc &td, uint32_
                     const uint8_t cls = s_cls[elr[i] < (uint32_t)TK_RMAX ? elr[i] : 0u];
                     ecopy[i] = cls == CLS_COPY;
                     if (!(ecopy[i] || cls == CLS_SMALL || cls == CLS_SOLO)) len[i] = 0u;   // (cannot happen: such rows have no products)
-                    if (ecopy[i]) mycopy += len[i];
                 }
 #pragma unroll
             for (int i = 0; i < 2; ++i) mine += len[i] ? ((1u << 16) | len[i]) : 0u;   // entries with products << 16 | products
         }
+        BSTOP(11);
         uint32_t tot32;
         const uint32_t ex32 = block_scan_excl_dpp(mine, slot_ent, &tot32);
         P = tot32 & 0xFFFFu;
+        const uint32_t nent = tot32 >> 16;   // entries with products
+        BSTOP(12);
         if (P > BT_PMAX) {   // the cut guarantees it; a batch that does not fit is an internal error, not a memory fault
-            if (tid == 0) atomicOr(&g.ctr->abort_flag, 32u);
+            if (tid == 0 && atomicOr(&g.ctr->abort_flag, 32u) == 0u) {   // what did not fit (reported by the host)
+                g.ctr->dbg[0] = td.kind | ((unsigned long long)E << 8) | ((unsigned long long)R << 32);
+                g.ctr->dbg[1] = tot32;
+                g.ctr->dbg[2] = td.np;
+                g.ctr->dbg[3] = t;
+            }
             P = 0;
         }
         if (P && wave_has_entries) {
@@ -256,47 +318,51 @@ __device__ inline void batch_task(const TaskArgs &g, const TaskDesc &td, uint32_
                     // record: (begin - first product) mod 2^48 | local row << 48 | copy << 55, A value
                     const uint64_t pack = ((b0[i] - po) & M48) | ((uint64_t)elr[i] << 48) | ((uint64_t)(ecopy[i] ? 1u : 0u) << 55);
                     w_ent[ci] = EntryRecNum{pack, av[i]};
-                    atomicOr(&bm32[po >> 5], 1u << (po & 31));
+                    atomicOr(&bm32[(po + len[i] - 1u) >> 5], 1u << ((po + len[i] - 1u) & 31));   // TAIL bit: the entry's last product
                     if (ecopy[i]) s_delta[elr[i]] -= (int32_t)po;   // (the row's one entry: product number - first product = place in the row)
                     ++ci;
                     po += len[i];
                 }
         }
+        BSTOP(13);
         __syncthreads();
-        if (wave == 0) {   // heads before every 64-bit word of the bitmap (32 words: half a wave)
-            const uint32_t c = lane < 32 ? (uint32_t)__popcll(bm64[lane & 31]) : 0u;
-            const uint32_t inc = wave_scan_incl_u32(c);
-            if (lane < 32) bpre[lane] = inc - c;
+        // tails before every 64-bit word of the bitmap (32 words): every wave scans them for itself and keeps the prefixes in the
+        // lanes of one register (word w in lane w): the per-segment values are then scalar reads, and no second barrier is needed
+        uint32_t tail_pre;
+        {
+            const uint32_t c = (uint32_t)__popcll(bm64[lane & 31]);
+            const uint32_t inc = wave_scan_incl_u32(lane < 32 ? c : 0u);
+            tail_pre = inc - c;
         }
-        __syncthreads();
         BPH(1);
-        const unsigned long long lane_bit = 1ull << lane;
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             if ((uint32_t)r * 1024u < P) {   // (uniform)
                 // lane l of a segment holds product seg + l, i.e. bit l of one bitmap word: the word and its prefix are wave-uniform
-                // reads, the rank a v_mbcnt pair.  Lanes past the end fall back to product 0 of record 0 (a valid address).
+                // reads; the entry of a product = the entries that END before it = tails before the word + tails below the lane (a
+                // v_mbcnt pair).  Lanes past the end take the last product (a valid address; only their atomics are switched off).
                 unsigned long long bits[4];
                 uint32_t bp[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const uint32_t w = (uint32_t)r * 16u + (uint32_t)u * 4u + wave_u;   // = segment / 64
                     bits[u] = bm64[w];
-                    bp[u] = bpre[w];
+                    bp[u] = (uint32_t)__builtin_amdgcn_readlane((int)tail_pre, (int)w);
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) asm volatile("" : "+v"(bits[u]), "+v"(bp[u]));
+                for (int u = 0; u < 4; ++u) asm volatile("" : "+v"(bits[u]));
                 uint32_t pp[4], j[4];
                 bool act[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const uint32_t p = (uint32_t)r * 1024u + ((uint32_t)u * 4u + wave_u) * 64u + lane;
                     act[u] = p < P;
+                    pp[u] = min(p, P - 1u);
+                    // (a clamped lane sits past the last tail of its word: it counts every tail of the word, i.e. one entry too many
+                    // whenever the last product is in this word -- min() with the last entry puts it back)
                     const uint32_t below =
                         __builtin_amdgcn_mbcnt_hi((uint32_t)(bits[u] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bits[u], 0u));
-                    const uint32_t self = (bits[u] & lane_bit) ? 1u : 0u;
-                    j[u] = act[u] ? bp[u] + below + self - 1u : 0u;
-                    pp[u] = act[u] ? p : 0u;
+                    j[u] = min(bp[u] + below, nent - 1u);
                 }
                 uint64_t pack[4];
                 double a_[4];
@@ -341,11 +407,13 @@ __device__ inline void batch_task(const TaskArgs &g, const TaskDesc &td, uint32_
                         const uint32_t step = probe_step(hk[u]);
                         for (;;) {
                             h[u] = (h[u] + step) & (T - 1);
-                            const uint32_t o = atomicCAS(&keys[h[u]], EMPTY_KEY, hk[u]);
-                            if (o == EMPTY_KEY || o == hk[u]) break;
+                            old[u] = atomicCAS(&keys[h[u]], EMPTY_KEY, hk[u]);
+                            if (old[u] == EMPTY_KEY || old[u] == hk[u]) break;
                         }
                     }
+                    mykeys += (hashed[u] && old[u] == EMPTY_KEY) ? 1u : 0u;
                 }
+                if (r == 0) BSTOP(14);
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
                     if (hashed[u]) {
@@ -360,23 +428,34 @@ __device__ inline void batch_task(const TaskArgs &g, const TaskDesc &td, uint32_
         BPH(2);
     }
 
-    // ---- the count of the task: new mask bits + copied products; published as soon as it is known -----------------------------
-    uint32_t NO, total;
+    // ---- the count of the task: new mask bits + copied products (known from the rows); published as soon as it is known ----------
+    uint32_t NO, NBt, total;   // hashed outputs, blocks, outputs of the task
     {
         uint32_t tot32;
-        (void)block_scan_excl_dpp(mynew | (mycopy << 16), slot_cnt, &tot32);
+        (void)block_scan_excl_dpp(mynew | (mykeys << 16), slot_cnt, &tot32);
         NO = tot32 & 0xFFFFu;
-        total = NO + (tot32 >> 16);
+        NBt = tot32 >> 16;
+        total = NO + (row_tot >> 16);   // + the products of the COPY rows
     }
     if constexpr (MODE != MODE_NUMERIC) task_publish<MODE>(g, t, total);
 #if SPADA_PRIO
     if constexpr (MODE == MODE_FUSED) __builtin_amdgcn_s_setprio(0);
 #endif
+    if (SPADA_TASK_DBG && tid == 0) {   // shape of the tasks: products, hashed outputs, blocks, rows, entries
+        atomicAdd(&g.ctr->dbg[0], (unsigned long long)P);
+        atomicAdd(&g.ctr->dbg[1], (unsigned long long)NO);
+        atomicAdd(&g.ctr->dbg[2], (unsigned long long)NBt);
+        atomicAdd(&g.ctr->dbg[3], (unsigned long long)R);
+        atomicAdd(&g.ctr->dbg[4], (unsigned long long)E);
+        atomicAdd(&g.ctr->dbg[5], 1ull);
+    }
     uint32_t myk[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) myk[i] = NO ? keys[tid + i * BLOCK] : EMPTY_KEY;
 
+    BSTOP(15);
     if constexpr (MODE == MODE_COUNT) {
+        if (range) return;   // (the count of a range task is all the position kernels need)
         // the symbolic phase wants the outputs of every ROW: popcounts of the masks summed per row (the other modes get them from
         // the scans of the block order); offsets of the rows inside the batch -- k_pos4 adds the position of the batch afterwards
         if (NO) {
@@ -397,89 +476,124 @@ __device__ inline void batch_task(const TaskArgs &g, const TaskDesc &td, uint32_
     }
     BPH(3);
 
-    // ---- order: the blocks in (row, block) order; first output of every block ---------------------------------------------------
+    // ---- order: first output of every block = outputs of the blocks before it in (row, block) order ----------------------------
+    // NBt buckets (one block per bucket on average), laid out over the rows in proportion to their products; a row that gets no
+    // bucket of its own shares one with its neighbours (the keys decide inside a bucket).  The blocks are scattered into bucket
+    // order together with their popcounts; one prefix sum in that order, then every block adds the popcounts of the smaller
+    // keys of its own bucket: no exact rank, no second ordering pass.
     uint32_t hoff = 0;   // hashed outputs of the batch before this thread's row
     if (NO) {
-        for (uint32_t s = tid; s < NBK; s += BLOCK) bcnt[s] = 0u;
+        uint32_t b_lo = 0;
+        if ((uint32_t)tid < R) {
+            // (floor(x * f) is monotone in x, and the row behind starts where this one ends: the same expression of the same number)
+            const float f = (float)NBt / (float)NBK;
+            b_lo = min((uint32_t)((float)boff * f), NBt);
+            const uint32_t b_hi = min((uint32_t)((float)(boff + row_pr) * f), NBt), cnt = max(b_hi - b_lo, 1u);
+            const uint32_t bmin = rr.kmin >> BT_BSHIFT, bmax = rr.kmax >> BT_BSHIFT;
+            s_emit[tid] = BtRow{(uint16_t)b_lo, (uint16_t)cnt, bmin, (float)cnt / ((float)(bmax - bmin) + 1.0f)};
+        }
+        for (uint32_t s2 = tid; s2 < NBt; s2 += BLOCK) bcnt[s2] = 0u;
         __syncthreads();
+        auto bucket_of = [&](uint32_t k, const BtRow &e) {
+            uint32_t bk = (uint32_t)((float)((k & blkmask) - e.bmin) * e.scale);
+            bk = bk < e.nb ? bk : (uint32_t)e.nb - 1u;
+            return e.boff + bk;
+        };
+        const bool one_row = R == 1;
+        const BtRow e_one = s_emit[0];
         uint16_t myb[8];
+        if (one_row) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            myb[i] = 0;
-            if (myk[i] != EMPTY_KEY) {
-                const BtRow e = s_emit[lr_of_hk(myk[i])];
-                uint32_t bk = (uint32_t)((float)((myk[i] & blkmask) - e.bmin) * e.scale);
-                bk = bk < e.nb ? bk : (uint32_t)e.nb - 1u;
-                myb[i] = (uint16_t)(e.boff + bk);
-                atomicAdd(&bcnt[myb[i]], 1u);
+            for (int i = 0; i < 8; ++i) {
+                myb[i] = 0;
+                if (myk[i] != EMPTY_KEY) {
+                    myb[i] = (uint16_t)bucket_of(myk[i], e_one);
+                    atomicAdd(&bcnt[myb[i]], 1u);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                myb[i] = 0;
+                if (myk[i] != EMPTY_KEY) {
+                    myb[i] = (uint16_t)bucket_of(myk[i], s_emit[lr_of_hk(myk[i])]);
+                    atomicAdd(&bcnt[myb[i]], 1u);
+                }
             }
         }
+        BSTOP(16);
         __syncthreads();
-        uint32_t NBt;   // blocks of the batch
-        {
-            uint32_t loc[8], fe;
-            NBt = batch_scan<uint32_t>(bcnt, NBK, slot_bk, loc, &fe, true);
-        }
+        (void)batch_scan<uint32_t>(bcnt, bcnt, NBt, slot_bk);
         __syncthreads();
+        BSTOP(17);
 #pragma unroll
         for (int i = 0; i < 8; ++i)
             if (myk[i] != EMPTY_KEY) {
                 const uint32_t p = atomicAdd(&bcnt[myb[i]], 1u);   // afterwards bcnt[b] = end of bucket b
                 lk[p] = myk[i];
                 ls[p] = (uint16_t)(tid + i * BLOCK);
+                pc[p] = (uint16_t)__popc(mb[tid + i * BLOCK] & 0xFFFFu);   // (region K: the table's keys are in registers by now)
             }
+        BSTOP(18);
         __syncthreads();
-        uint16_t spv[8], hsv[8], pcv[8];
-#pragma unroll
-        for (int w = 0; w < 8; ++w) {
-            const uint32_t p = tid + w * BLOCK;
-            spv[w] = 0xFFFFu;
-            hsv[w] = 0;
-            pcv[w] = 0;
-            if (p < NBt) {
-                const uint32_t k = lk[p];
-                const BtRow e = s_emit[lr_of_hk(k)];
-                uint32_t bk = (uint32_t)((float)((k & blkmask) - e.bmin) * e.scale);
-                bk = e.boff + (bk < e.nb ? bk : (uint32_t)e.nb - 1u);
-                const uint32_t lo = bk ? bcnt[bk - 1] : 0u, hi = bcnt[bk];
-                uint32_t rnk = lo;
+        (void)batch_scan<uint16_t>(pc, pcx, NBt, slot_pc);
+        __syncthreads();
+        BSTOP(19);
+        // outputs before key k: those of the buckets before its bucket + those of the smaller keys inside it.  The loads of all
+        // the blocks of a thread are issued together (bucket bounds, then the prefix at the bucket's start); the walk over the bucket
+        // is left to the blocks that share theirs (one block per bucket on average)
+        auto smaller_in_bucket = [&](uint32_t k, uint32_t lo, uint32_t hi) {
+            uint32_t add = 0;
 #pragma clang loop unroll(disable) vectorize(disable)
-                for (uint32_t jj = lo; jj < hi; ++jj) rnk += (lk[jj] < k) ? 1u : 0u;
-                spv[w] = (uint16_t)rnk;
-                hsv[w] = ls[p];
-                pcv[w] = (uint16_t)__popc(mb[hsv[w]] & 0xFFFFu);
-            }
-        }
-        // first block of this thread's row in block order = start of the row's first bucket
-        const uint32_t fpos = (uint32_t)tid < R ? (boff ? bcnt[boff - 1] : 0u) : 0u;
-        __syncthreads();   // the table's keys (region K) are not read again: popcounts and slots in block order take their place
-#pragma unroll
-        for (int w = 0; w < 8; ++w)
-            if (spv[w] != 0xFFFFu) {
-                hs[spv[w]] = hsv[w];
-                pcs[spv[w]] = pcv[w];
-            }
-        __syncthreads();
+            for (uint32_t jj = lo; jj < hi; ++jj) add += (lk[jj] < k) ? (uint32_t)pc[jj] : 0u;
+            return add;
+        };
         {
-            uint32_t loc[8], ex;
-            (void)batch_scan<uint16_t>(pcs, NBt, slot_pc, loc, &ex, true);   // pcs[i] = outputs of the blocks before block i
-            const uint32_t PER = (NBt + 255u) >> 8;
+            uint32_t kk[8], blo[8], bhi[8], fst[8];
+            uint16_t slt[8];
 #pragma unroll
-            for (uint32_t jj = 0; jj < 8; ++jj) {
-                const uint32_t idx = tid * PER + jj;
-                if (jj < PER && idx < NBt) {
-                    mb[hs[idx]] |= ex << 16;   // (one thread per slot)
-                    ex += loc[jj];
+            for (int w = 0; w < 8; ++w) {
+                const uint32_t p = tid + w * BLOCK;
+                kk[w] = 0;
+                slt[w] = 0;
+                if (p < NBt) {
+                    kk[w] = lk[p];
+                    slt[w] = ls[p];
                 }
             }
+#pragma unroll
+            for (int w = 0; w < 8; ++w) {
+                blo[w] = bhi[w] = 0;
+                if (tid + w * BLOCK < NBt) {
+                    const uint32_t bk = one_row ? bucket_of(kk[w], e_one) : bucket_of(kk[w], s_emit[lr_of_hk(kk[w])]);
+                    blo[w] = bk ? bcnt[bk - 1] : 0u;
+                    bhi[w] = bcnt[bk];
+                }
+            }
+#pragma unroll
+            for (int w = 0; w < 8; ++w) fst[w] = (tid + w * BLOCK < NBt) ? (uint32_t)pcx[blo[w]] : 0u;
+#pragma unroll
+            for (int w = 0; w < 8; ++w)
+                if (tid + w * BLOCK < NBt) {
+                    if (bhi[w] - blo[w] > 1u) fst[w] += smaller_in_bucket(kk[w], blo[w], bhi[w]);
+                    mb[slt[w]] |= fst[w] << 16;   // (one thread per slot)
+                }
         }
-        __syncthreads();
-        hoff = (uint32_t)tid < R ? (fpos < NBt ? (uint32_t)pcs[fpos] : NO) : 0u;
-        __syncthreads();   // pcs (region K) read: the values may take its place
+        // the rows' first hashed outputs: the outputs before the (virtual) smallest key of the row
+        if (!one_row && (uint32_t)tid < R) {
+            if (b_lo < NBt) {
+                const uint32_t lo = b_lo ? bcnt[b_lo - 1] : 0u, hi = bcnt[b_lo];
+                hoff = (lo < NBt ? (uint32_t)pcx[lo] : NO) + smaller_in_bucket((uint32_t)tid << hshift, lo, hi);
+            } else {
+                hoff = NO;
+            }
+        }
+        __syncthreads();   // pc / pcx (region K) are read: the values may take their place
         BPH(4);
         // ---- scale - add: every retained product adds its value at its output (simulator.rs:213-218; order differs) -----------
         for (uint32_t s = tid; s < NO; s += BLOCK) vals[s] = 0.0;
         __syncthreads();
+        BSTOP(20);
 #pragma unroll
         for (int i = 0; i < 8; ++i)
             if (r_h[i] < BT_H_NONE) {
@@ -501,7 +615,14 @@ __device__ inline void batch_task(const TaskArgs &g, const TaskDesc &td, uint32_
         base = ((unsigned long long)hdr[53] << 32) | hdr[52];
     } else {
         base = task_position<MODE>(g, t, total, hdr);
-        if ((uint32_t)tid < R) g.cptr[rb + tid] = base + ooff;
+        if (range) {
+            if (tid == 0) {
+                if (td.first & 1u) g.cptr[rb] = base;   // first range of its row
+                g.range_out[t] = base;
+            }
+        } else if ((uint32_t)tid < R) {
+            g.cptr[rb + tid] = base + ooff;
+        }
         if (t == ntasks - 1 && tid == 0) {
             g.cptr[g.nrows] = base + total;
             g.ctr->nnz_c = base + total;
@@ -523,6 +644,7 @@ __device__ inline void batch_task(const TaskArgs &g, const TaskDesc &td, uint32_
         g.c_val[pos] = vals[p];
 #endif
     }
+    BSTOP(21);
     if (total > NO) {   // COPY rows: C_i = a * B_k, already ascending: product number - first product of the row = place in the row
 #pragma unroll
         for (int i = 0; i < 8; ++i)
@@ -540,6 +662,7 @@ __device__ inline void batch_task(const TaskArgs &g, const TaskDesc &td, uint32_
     }
     BPH(7);
 #undef BPH
+#undef BSTOP
 }
 
 }  // namespace spada

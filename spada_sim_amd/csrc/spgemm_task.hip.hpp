@@ -1797,8 +1797,9 @@ __global__ __launch_bounds__(TK_BLOCK, 4) void k_task(const TaskArgs g)
         if constexpr (MODE == MODE_FUSED) __builtin_amdgcn_s_setprio(SPADA_PRIO);
 #endif
         const TaskDesc td = g.tasks[t];
-        if (td.kind == TASK_BATCH) {
-            // consecutive non-BIG rows: spgemm_batch.hip.hpp
+        if (td.kind == TASK_BATCH || (td.kind == TASK_RANGE_DIRECT && (td.first >> 1) <= BT_EMAX && td.np <= BT_PMAX)) {
+            // consecutive non-BIG rows, or a column range of a BIG row with at most one chunk of entries and at most as many products
+            // as the registers hold (a heavy histogram bucket -- many products on few columns -- may have more): spgemm_batch.hip.hpp
             batch_task<MODE>(g, td, t, ntasks, smem, dbg_ph);
         } else {
             // ---- RANGE task: columns [col_lo, col_hi] of a BIG row, products in the scratch slice -----------------------------
@@ -1882,10 +1883,6 @@ __global__ __launch_bounds__(TK_BLOCK, 4) void k_task(const TaskArgs g)
         }
     }
     if (SPADA_TASK_DBG && tid == 0) {
-        atomicAdd(&g.ctr->dbg[0], dbg_chain);
-        atomicAdd(&g.ctr->dbg[3], __builtin_amdgcn_s_memtime() - dbg_t0);
-        atomicAdd(&g.ctr->dbg[4], dbg_acc);
-        atomicAdd(&g.ctr->dbg[5], dbg_emit);
 #pragma unroll
         for (int k = 0; k < 8; ++k) atomicAdd(&g.ctr->dbg[8 + k], dbg_ph[k]);
         atomicAdd(&g.ctr->dbg[6], dbg_ph[8]);

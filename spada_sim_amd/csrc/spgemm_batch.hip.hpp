@@ -58,32 +58,6 @@ __host__ __device__ constexpr size_t batch_lds()
 static_assert(batch_lds() <= 40960, "four workgroups per CU");
 static_assert(TK_T == 2048 && BT_PMAX == 2048 && TK_BLOCK == 256, "the LDS map and the per-thread arrays are written for these sizes");
 
-// ---- scans on DPP (data-parallel primitives of the vector ALU: one instruction per step, no LDS round trip) -------------------
-// inclusive sum over the 64 lanes of a wave: row_shr 1 / 2 / 4 / 8 inside the rows of 16 lanes, then lane 15 of rows 0 and 2 to
-// rows 1 and 3 (row_bcast:15), then lane 31 to the upper half (row_bcast:31)
-__device__ inline uint32_t wave_scan_incl_u32(uint32_t v)
-{
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
-    return v;
-}
-// exclusive sum over the 256 threads; ONE barrier.  `slot` = four LDS words (16-byte aligned) that no other scan of the same
-// barrier interval uses: consecutive scans take different slots, so none has to wait for the readers of the one before.
-__device__ inline uint32_t block_scan_excl_dpp(uint32_t v, uint32_t *slot, uint32_t *total)
-{
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const uint32_t inc = wave_scan_incl_u32(v);
-    if (lane == 63) slot[w] = inc;
-    __syncthreads();
-    const uint4 t = *(const uint4 *)slot;
-    *total = t.x + t.y + t.z + t.w;
-    return inc - v + (w > 0 ? t.x : 0u) + (w > 1 ? t.y : 0u) + (w > 2 ? t.z : 0u);
-}
-
 // exclusive scan of arr[0 .. N), N <= 2048 (u32 or u16 elements): every thread PER = ceil(N / 256) consecutive elements; the
 // prefixes go to out[] (which may be arr itself).  Returns the total.  No barrier after the stores (the caller's next one covers them).
 template <class T>

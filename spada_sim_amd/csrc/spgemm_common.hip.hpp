@@ -180,6 +180,46 @@ __device__ inline unsigned long long group_scan_excl_u64(unsigned long long v, i
     return inc - v + add;
 }
 
+// ---- scans on DPP (data-parallel primitives of the vector ALU: one instruction per step, no LDS round trip) -------------------
+// inclusive sum over the 64 lanes of a wave: row_shr 1 / 2 / 4 / 8 inside the rows of 16 lanes, then lane 15 of rows 0 and 2 to
+// rows 1 and 3 (row_bcast:15), then lane 31 to the upper half (row_bcast:31)
+__device__ inline uint32_t wave_scan_incl_u32(uint32_t v)
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
+    return v;
+}
+// exclusive sum over the 256 threads; ONE barrier.  `slot` = four LDS words (16-byte aligned) that no other scan of the same
+// barrier interval uses: consecutive scans take different slots, so none has to wait for the readers of the one before.
+__device__ inline uint32_t block_scan_excl_dpp(uint32_t v, uint32_t *slot, uint32_t *total)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint32_t inc = wave_scan_incl_u32(v);
+    if (lane == 63) slot[w] = inc;
+    __syncthreads();
+    const uint4 t = *(const uint4 *)slot;
+    *total = t.x + t.y + t.z + t.w;
+    return inc - v + (w > 0 ? t.x : 0u) + (w > 1 ? t.y : 0u) + (w > 2 ? t.z : 0u);
+}
+
+// in-place exclusive scan of arr[0 .. 4 * 256) by a workgroup of 256 threads (four consecutive elements each); ends with a barrier
+__device__ inline void block_exclusive_scan4_dpp(uint32_t *arr, uint32_t *slot)
+{
+    const int tid = threadIdx.x;
+    const uint32_t a = arr[tid * 4 + 0], b = arr[tid * 4 + 1], c = arr[tid * 4 + 2], d = arr[tid * 4 + 3];
+    uint32_t total;
+    const uint32_t ex = block_scan_excl_dpp(a + b + c + d, slot, &total);
+    arr[tid * 4 + 0] = ex;
+    arr[tid * 4 + 1] = ex + a;
+    arr[tid * 4 + 2] = ex + a + b;
+    arr[tid * 4 + 3] = ex + a + b + c;
+    __syncthreads();
+}
+
 constexpr uint32_t LR_NONE = 0xFFFFFFFFu;
 
 // ---- the flat product walk -----------------------------------------------------------------------------------------

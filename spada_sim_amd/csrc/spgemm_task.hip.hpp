@@ -623,7 +623,7 @@ __global__ __launch_bounds__(TK_BLOCK) void k_big_plan(const uint64_t *__restric
             pre[tid * 4 + 3] = acc.w;
         }
         __syncthreads();
-        group_exclusive_scan<TK_BLOCK, NB>(pre, tid, hdr + 2);
+        block_exclusive_scan4_dpp(pre, hdr + 4);
         if (tid == TK_BLOCK - 1) pre[NB] = pre[NB - 1] + cnt[NB - 1];
         __syncthreads();
         // range starts: a heavy bucket is a range of its own; the light buckets between heavy ones are packed greedily, as many
@@ -643,7 +643,7 @@ __global__ __launch_bounds__(TK_BLOCK) void k_big_plan(const uint64_t *__restric
 #pragma unroll
             for (int k = 0; k < BPT; ++k) aux[tid * BPT + k] = forced[k];
             __syncthreads();
-            group_exclusive_scan<TK_BLOCK, NB>(aux, tid, hdr + 2);
+            block_exclusive_scan4_dpp(aux, hdr + 4);
 #pragma unroll
             for (int k = 0; k < BPT; ++k) {
                 fex[k] = aux[tid * BPT + k];
@@ -683,7 +683,7 @@ __global__ __launch_bounds__(TK_BLOCK) void k_big_plan(const uint64_t *__restric
 #pragma unroll
         for (int k = 0; k < BPT; ++k) stf[k] = aux[tid * BPT + k];
         __syncthreads();
-        group_exclusive_scan<TK_BLOCK, NB>(aux, tid, hdr + 2);
+        block_exclusive_scan4_dpp(aux, hdr + 4);
 #pragma unroll
         for (int k = 0; k < BPT; ++k)
             if (stf[k]) rfirst[aux[tid * BPT + k]] = tid * BPT + k;
@@ -729,7 +729,7 @@ __global__ __launch_bounds__(TK_BLOCK) void k_big_plan(const uint64_t *__restric
                 const uint32_t r = tid * BPT + k, f0 = rfirst[r], f1 = rfirst[r + 1];
                 if (pre[f1] - pre[f0] > lim && ((uint64_t)(f1 - f0) << wshift) > lim) hdr[47] = 1;
             }
-        group_exclusive_scan<TK_BLOCK, NB>(aux, tid, hdr + 2);
+        block_exclusive_scan4_dpp(aux, hdr + 4);
         if (tid == TK_BLOCK - 1) {
             const uint32_t m = aux[NB - 1] + wgt[BPT - 1];
             const unsigned long long P = pre[NB];

@@ -350,7 +350,7 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
                                c->eb0.as<uint64_t>(), c->elen.as<uint32_t>(), c->t_rowP.as<unsigned long long>(),
                                c->row_kmin.as<uint32_t>(), c->row_kmax.as<uint32_t>(), gent,
                                c->accumulator == SPADA_ACC_SORT_MERGE ? (uint32_t)TK_SOLO_MAX : 0u, dc);
-            hipLaunchKernelGGL(k_row_class, dim3(std::min<uint32_t>((n + 255) / 256, c->n_cu)), dim3(256), 0, s, a->ptr, c->r0,
+            hipLaunchKernelGGL(k_row_class, dim3(std::min<uint32_t>((n + 255) / 256, c->n_cu * 8)), dim3(256), 0, s, a->ptr, c->r0,
                                n, rmax, c->t_rowP.as<unsigned long long>(), c->row_kmin.as<uint32_t>(), c->row_kmax.as<uint32_t>(),
                                c->row_nprod.as<uint32_t>(), c->row_bin.as<uint8_t>(), c->row_cl.as<uint32_t>(),
                                c->row_rec.as<RowRec>(), c->t_rowm.as<uint32_t>(), c->t_big.as<uint32_t>(), dc);
@@ -412,6 +412,15 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
         HIP_TRY(hipMemcpyAsync(c->h_tctr, dc, sizeof(TaskCounters), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
         TaskCounters &h = *c->h_tctr;
+        h.a_nnz = 0;
+        for (int k = 0; k < N_CLS; ++k) h.cls_rows[k] = h.cls_prod[k] = 0;
+        for (int sl = 0; sl < CLS_SLOTS; ++sl) {   // (k_row_class leaves its statistics spread over the slots)
+            for (int k = 0; k < N_CLS; ++k) {
+                h.cls_rows[k] += h.cls_part[sl][k];
+                h.cls_prod[k] += h.cls_part[sl][N_CLS + k];
+            }
+            h.a_nnz += h.cls_part[sl][2 * N_CLS];
+        }
         h.nprod = 0;
         for (int k = 0; k < N_CLS; ++k) h.nprod += h.cls_prod[k];
         h.nprod_big = h.cls_prod[CLS_BIG];

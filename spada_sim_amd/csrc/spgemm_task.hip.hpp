@@ -46,7 +46,7 @@
 namespace spada {
 
 constexpr uint8_t CLS_EMPTY = 0, CLS_COPY = 1, CLS_SMALL = 2, CLS_SOLO = 3, CLS_BIG = 4;
-constexpr int N_CLS = 5;
+constexpr int N_CLS = 5, CLS_SLOTS = 64;
 constexpr int TK_BLOCK = 256, TK_EPT = 2, TK_LOG_T = 11, TK_T = 1 << TK_LOG_T, TK_RMAX = 128;
 // Products a task hashes at most (`limit`): the table has TK_T = 2048 slots and is probed by double hashing, which stays cheap up to
 // high fills, so fuller tables win -- fewer tasks, fewer chain hops -- until the probe sequences of a table that REALLY fills up
@@ -90,6 +90,10 @@ struct TaskCounters {   // (a multiple of 8 bytes: k_init clears it in 8-byte wo
 #if SPADA_TASK_DBG
     unsigned long long dbgh[3][24];  // per task kind: [0..19] histogram of the cycles from ticket to publish (4096-cycle bins), [20] sum, [21] tasks, [22] max
 #endif
+    // statistics of k_row_class, spread over CLS_SLOTS lines (workgroup b adds to slot b % CLS_SLOTS; the host sums them): rows per
+    // class [0 .. 4], products per class [5 .. 9], A entries [10].  One hot word takes ~90 atomics per microsecond: with the
+    // sums in one place the kernel had to run on one workgroup per CU (29 us for a million rows, a third of its memory rate)
+    unsigned long long cls_part[64][16];
     unsigned long long dbg[16];  // SPADA_TASK_DBG builds: [0] cycles in the chain, [1] look-back windows, [2] spin retries, [3] cycles
                                  // of the task loop, [4] cycles before the chain (expand + accumulate), [5] cycles after it (emit)
 };
@@ -333,12 +337,12 @@ __global__ __launch_bounds__(256) void k_row_class(const uint64_t *__restrict__ 
     const unsigned long long wl = wave_sum_u64(tot_l);
     if (lane == 0 && wl) atomicAdd(&s_tot, wl);
     __syncthreads();
+    unsigned long long *part = ctr->cls_part[blockIdx.x % CLS_SLOTS];
     if (threadIdx.x < N_CLS && s_rows[threadIdx.x]) {
-        // (few workgroups, few atomics: one hot word takes ~90 atomics per microsecond; nprod / nprod_big = sums of cls_prod)
-        atomicAdd(&ctr->cls_rows[threadIdx.x], s_rows[threadIdx.x]);
-        atomicAdd(&ctr->cls_prod[threadIdx.x], s_prod[threadIdx.x]);
+        atomicAdd(&part[threadIdx.x], s_rows[threadIdx.x]);
+        atomicAdd(&part[N_CLS + threadIdx.x], s_prod[threadIdx.x]);
     }
-    if (threadIdx.x == 0 && s_tot) atomicAdd(&ctr->a_nnz, s_tot);
+    if (threadIdx.x == 0 && s_tot) atomicAdd(&part[2 * N_CLS], s_tot);
 }
 
 // ---- 2. BIG rows: histogram, column ranges, spill of the largest rows into HBM scratch --------------------------------------

@@ -87,11 +87,13 @@ def cpu_baseline(a, budget_s=12.0):
 
 
 def load_traffic(workload):
-    """HBM bytes per launch of every kernel from the committed PMC passes (profiles/r02_traffic_<workload>.json, written by
+    """HBM bytes per launch of every kernel from the committed PMC passes (profiles/rNN_traffic_<workload>.json, written by
     scripts/collect_traffic.sh on the GPU box); (None, None) when that file is absent."""
-    path = os.path.join(ROOT, "profiles", f"r02_traffic_{workload}.json")
-    if not os.path.exists(path):
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_traffic_{workload}.json")))   # the latest round's file
+    if not found:
         return None, None
+    path = found[-1]
     with open(path) as f:
         d = json.load(f)
     return d, path

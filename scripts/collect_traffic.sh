@@ -6,7 +6,7 @@
 # FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KiB.
 set -e
 WL=${1:-webbase-1M}
-TAG=${2:-r02}
+TAG=${2:-r03}
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/traffic_$WL
 mkdir -p $OUT

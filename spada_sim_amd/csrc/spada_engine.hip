@@ -308,7 +308,7 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
     if ((rc = c->eb0.ensure(std::max<uint64_t>(a->nnz, 1) * 8, false, s, &c->ws_bytes))) return rc;
     if ((rc = c->elen.ensure(std::max<uint64_t>(a->nnz, 1) * 4, false, s, &c->ws_bytes))) return rc;
     const uint32_t ntiles = std::max<uint32_t>((n + CUT_TILE - 1) / CUT_TILE, 1);
-    if ((rc = c->t_tiles.ensure(((size_t)ntiles + 2) * 4, false, s, &c->ws_bytes))) return rc;
+    if ((rc = c->t_tiles.ensure(((size_t)ntiles + 2) * 8, false, s, &c->ws_bytes))) return rc;   // per tile: tasks | first task
     // composite hash keys of a batch: (local row << colbits) | column
     uint32_t cb = BT_BSHIFT;   // (at least the bits of a block of columns: the batch tasks key their table by column >> BT_BSHIFT)
     while (cb < 32 && (1ull << cb) < b->cols) ++cb;
@@ -349,7 +349,11 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
             hipLaunchKernelGGL(k_entry_stats, dim3(gent + EST_ROWS), dim3(256), 0, s, a->ptr, a->idx, a->rowid, b->ptr, b->idx, c->r0, n,
                                c->eb0.as<uint64_t>(), c->elen.as<uint32_t>(), c->t_rowP.as<unsigned long long>(),
                                c->row_kmin.as<uint32_t>(), c->row_kmax.as<uint32_t>(), gent,
-                               c->accumulator == SPADA_ACC_SORT_MERGE ? (uint32_t)TK_SOLO_MAX : 0u, dc);
+                               // products a task hashes at most.  Since the table of the batch tasks is keyed by BLOCKS of columns it
+                               // never gets full (a third of its slots on the web surrogate), and the fullest tasks win on every input:
+                               // 2040 / 1920 / 1792 / 1536 -> web 0.826 / 0.844 / 0.882 / 0.965 ms, R-MAT 16 4.81 / 5.00 / 5.22 / 5.98 ms
+                               // (round 2 sampled the products / outputs ratio to choose between 1920 and 2040: estimate_block)
+                               c->accumulator == SPADA_ACC_SORT_MERGE ? (uint32_t)TK_SOLO_MAX : TK_LIMIT_HI, dc);
             hipLaunchKernelGGL(k_row_class, dim3(std::min<uint32_t>((n + 255) / 256, c->n_cu * 8)), dim3(256), 0, s, a->ptr, c->r0,
                                n, rmax, c->t_rowP.as<unsigned long long>(), c->row_kmin.as<uint32_t>(), c->row_kmax.as<uint32_t>(),
                                c->row_nprod.as<uint32_t>(), c->row_bin.as<uint8_t>(), c->row_cl.as<uint32_t>(),
@@ -382,10 +386,12 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
             hipLaunchKernelGGL(k_cut1, dim3(ntiles), dim3(256), 0, s, c->row_cl.as<uint32_t>(), c->row_nprod.as<uint32_t>(),
                                c->t_rowm.as<uint32_t>(), n, rmax, dc, c->t_tiles.as<uint32_t>(), c->t_rowt.as<uint32_t>(),
                                c->row_binfo.as<uint32_t>());
-            hipLaunchKernelGGL(k_cut2, dim3(1), dim3(256), 0, s, c->t_tiles.as<uint32_t>(), ntiles, cap_tasks, dc);
+            const bool fold = ntiles <= CUT_FOLD_TILES;
+            if (!fold) hipLaunchKernelGGL(k_cut2, dim3(1), dim3(256), 0, s, c->t_tiles.as<uint32_t>(), ntiles, cap_tasks, dc);
             hipLaunchKernelGGL(k_cut3, dim3(ntiles), dim3(256), 0, s, c->row_bin.as<uint8_t>(), c->t_rowt.as<uint32_t>(),
                                c->row_binfo.as<uint32_t>(), a->ptr, c->r0, c->t_rowtmp.as<uint32_t>(), n, c->t_tiles.as<uint32_t>(),
-                               c->t_tmp.as<TaskDesc>(), c->t_tasks.as<TaskDesc>(), cap_tasks, dc);
+                               c->t_tmp.as<TaskDesc>(), c->t_tasks.as<TaskDesc>(), cap_tasks, fold ? 1u : 0u,
+                               c->t_tiles.as<uint32_t>() + ntiles + 2, dc);
             HIP_TRY(hipGetLastError());
         }
         HIP_TRY(hipEventRecord(c->tev[3], s));
@@ -400,7 +406,7 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
                 hipLaunchKernelGGL(k_pos2, dim3(1), dim3(256), 0, s, tsum, cptr, n, dc);
                 hipLaunchKernelGGL(k_pos3, dim3(ptiles), dim3(256), 0, s, g.tasks, tsum, dc, g.range_out, cptr);
                 hipLaunchKernelGGL(k_pos4, dim3(ntiles), dim3(256), 0, s, c->row_bin.as<uint8_t>(), c->t_rowt.as<uint32_t>(),
-                                   c->t_tiles.as<uint32_t>(), n, g.range_out, dc, cptr);
+                                   c->t_tiles.as<uint32_t>() + ntiles + 2, n, g.range_out, dc, cptr);
             } else {
                 launch_task<MODE_FUSED>(c, g);
             }

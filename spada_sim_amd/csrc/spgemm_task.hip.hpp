@@ -55,7 +55,10 @@ constexpr int TK_BLOCK = 256, TK_EPT = 2, TK_LOG_T = 11, TK_T = 1 << TK_LOG_T, T
 // the products / outputs ratio of the input and picks the limit on the device (TaskCounters::prod_limit); classification, ranges
 // and batches follow it.  At most TK_T - 8 products per task: the table keeps empty slots, so every probe sequence ends.
 constexpr int TK_NOUT = TK_T;                          // outputs the emission's LDS arrays are sized for
-constexpr uint32_t TK_LIMIT_LO = 1920, TK_LIMIT_HI = 2040;
+#ifndef SPADA_LIMIT_LO
+#define SPADA_LIMIT_LO 1920
+#endif
+constexpr uint32_t TK_LIMIT_LO = SPADA_LIMIT_LO, TK_LIMIT_HI = 2040;
 constexpr uint32_t TK_SMALL_MAX = 512;   // class boundary SMALL | SOLO (statistics only: both are packed into batches)
 constexpr uint32_t TK_SOLO_MAX = 1536;   // the sort-merge accumulator's limit (its network holds 2048 pairs)
 constexpr int TK_NQ = 16;                // ticket queues: task t belongs to queue t % TK_NQ, workgroup b serves queue b % TK_NQ
@@ -867,6 +870,7 @@ __global__ __launch_bounds__(TK_BLOCK) void k_big_scatter(const double *__restri
 // Full batches mean fewer tasks and -- what matters to the chain -- tasks of equal length.  nxt[i] (first row
 // after a batch that starts at row i) is found for all rows in parallel by binary search over the tile's prefix sums; the
 // starts are what the walks along nxt reach (pointer doubling; batches do not cross tiles).
+constexpr uint32_t CUT_FOLD_TILES = 2048;   // (k_cut3 adds up the tile counts itself up to here: O(tiles^2) words read in all)
 constexpr int CUT_ITEMS = 4, CUT_TILE = 256 * CUT_ITEMS;   // (tiles of 1024 rows: 2048 leaves too few workgroups on the smaller inputs,
                                                            // 512 cuts too many batches at tile borders -- +11 % tasks on the stencil input)
 
@@ -1106,13 +1110,38 @@ __global__ __launch_bounds__(256) void k_cut2(uint32_t *__restrict__ tile_tasks,
 __global__ __launch_bounds__(256) void k_cut3(const uint8_t *__restrict__ row_cls, const uint32_t *__restrict__ row_t,
                                               const uint32_t *__restrict__ row_binfo, const uint64_t *__restrict__ aptr, uint64_t r0,
                                               const uint32_t *__restrict__ row_tmp, uint32_t n,
-                                              const uint32_t *__restrict__ tile_tasks, const TaskDesc *__restrict__ tmp,
-                                              TaskDesc *__restrict__ tasks, uint32_t task_cap,
-                                              const TaskCounters *__restrict__ ctr)
+                                              uint32_t *__restrict__ tile_tasks, const TaskDesc *__restrict__ tmp,
+                                              TaskDesc *__restrict__ tasks, uint32_t task_cap, uint32_t fold /* no k_cut2 has run */,
+                                              uint32_t *__restrict__ tile_first, TaskCounters *__restrict__ ctr)
 {
     __shared__ CutLds L;
     __shared__ uint32_t s_nbig;
     if (threadIdx.x == 0) s_nbig = 0;
+    // first task of the tile.  Up to CUT_FOLD_TILES tiles every workgroup adds up the counts of the tiles before its own itself (a
+    // few KB of L2-resident words) and the one-workgroup scan kernel between k_cut1 and k_cut3 is not launched: one launch and its
+    // gap less on the critical path of every call (~7 us; what matters once a GPU holds an eighth of the rows).  tile_first keeps the
+    // result for k_pos4.
+    uint32_t first;
+    if (fold) {
+        uint32_t mine = 0;
+        for (uint32_t i = threadIdx.x; i < blockIdx.x; i += 256) mine += tile_tasks[i];
+        uint32_t before;
+        (void)block_scan_excl_u32(mine, L.s_w, &before);
+        first = before;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            tile_first[blockIdx.x] = first;
+            if (blockIdx.x == gridDim.x - 1) {
+                const uint32_t all = first + tile_tasks[blockIdx.x];
+                ctr->ntasks = all;
+                ctr->need_tasks = all;
+                if (all > task_cap) atomicOr(&ctr->abort_flag, 2u);
+            }
+        }
+    } else {
+        first = tile_tasks[blockIdx.x];
+        if (threadIdx.x == 0) tile_first[blockIdx.x] = first;
+    }
     CutRow cr;
     uint32_t tot, local = 0;
     {
@@ -1124,8 +1153,8 @@ __global__ __launch_bounds__(256) void k_cut3(const uint8_t *__restrict__ row_cl
             local += cr.t[j];
         }
     }
-    uint32_t idx = block_scan_excl_u32(local, L.s_w, &tot) + tile_tasks[blockIdx.x];
-    if (ctr->abort_flag) return;   // a workspace overflowed upstream: nothing below may be trusted
+    uint32_t idx = block_scan_excl_u32(local, L.s_w, &tot) + first;
+    if (ctr->abort_flag & ~2u) return;   // a workspace overflowed upstream: nothing below may be trusted (every write is bounded by task_cap)
     const uint32_t base = blockIdx.x * CUT_TILE + threadIdx.x * CUT_ITEMS;
     uint32_t kb[CUT_ITEMS], idxb[CUT_ITEMS];
 #pragma unroll

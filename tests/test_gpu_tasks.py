@@ -61,21 +61,18 @@ def test_fused_generated_workloads(engine, name, kind, p0, p1, seed):
     assert st["scratch_products"] <= st["cls_prod"][4] and st["spill_rows"] <= st["cls_rows"][4]
 
 
-def test_task_capacity_follows_the_sampled_compression(engine):
-    """The sampling workgroups of the statistics launch pick 2040 products per task where products collapse onto few outputs
-    (mesh-like inputs: compression 4.3 / 2.2) and 1920 where they do not (web-like 1.4, stencil 1.6); both give the oracle's
-    product."""
+def test_task_capacity_is_the_register_budget(engine):
+    """A task hashes at most 2040 products on every input (round 2 chose between 1920 and 2040 from a sampled products / outputs
+    ratio; with the table keyed by blocks of columns it never fills, and the fullest tasks are fastest everywhere); mesh-like and
+    web-like inputs alike give the oracle's product."""
     import spada_sim_amd as S
-    seen = {}
     for name, kind, p0, p1, seed in (("cop20k", S.GEN_COP20K_LIKE, 20000, 0, 5), ("cage12", S.GEN_CAGE12_LIKE, 20000, 0, 6),
                                      ("web", S.GEN_WEBBASE_LIKE, 50000, 155000, 4), ("mc2depi", S.GEN_MC2DEPI_LIKE, 779 * 40, 0, 7)):
         m = S.generate(kind, p0, p1, seed)
         c, st = fused(engine, m, m)
         a = to_oracle(m)
         assert_parity(c, oracle.spgemm_spa(a, a), a, a, RTOL)
-        seen[name] = st["task_product_limit"]
-    assert seen["cop20k"] == 2040 and seen["cage12"] == 2040, seen
-    assert seen["web"] == 1920 and seen["mc2depi"] == 1920, seen
+        assert st["task_product_limit"] == 2040, (name, st["task_product_limit"])
 
 
 @pytest.mark.parametrize("seed", range(24))

@@ -170,6 +170,9 @@ def main():
         if chunk_bounds[-1] != r1:
             chunk_bounds.append(r1)
     one_pass = not args.two_phase and args.accumulator == "lds_hash"
+    # (one-pass mode: the capacity of a chunk's C buffers = its product count, known to the host before anything runs)
+    chunk_caps = ([S.count_products(a, a, chunk_bounds[i], chunk_bounds[i + 1]) for i in range(len(chunk_bounds) - 1)]
+                  if chunk_bounds is not None and one_pass else None)
     cap = my_products      # capacity of the C buffers of the one-pass entry point: one entry per product at most
     checksum = torch.zeros(1, dtype=torch.float64, device=dev)
     gather_s = [0.0]   # seconds spent in the allgatherv of C (N > 1, exchange after the compute), timed steps only
@@ -230,6 +233,15 @@ def main():
             tms = {}
 
             def alloc(nrows, nnz):
+                if chunk_caps is not None:
+                    # one-pass mode: the buffers are sized once, for the largest chunk, and every chunk is written into them
+                    if "p" not in out_bufs:
+                        mrows = max(chunk_bounds[i + 1] - chunk_bounds[i] for i in range(len(chunk_bounds) - 1))
+                        out_bufs["p"] = torch.empty(mrows + 1, dtype=torch.int64, device=dev)
+                        out_bufs["i"] = torch.empty(max(max(chunk_caps), 1), dtype=torch.int32, device=dev)
+                        out_bufs["v"] = torch.empty(max(max(chunk_caps), 1), dtype=torch.float64, device=dev)
+                    bufs.update(out_bufs)
+                    return bufs["p"].data_ptr(), bufs["i"].data_ptr(), bufs["v"].data_ptr()
                 bufs["p"] = torch.empty(nrows + 1, dtype=torch.int64, device=dev)
                 bufs["i"] = torch.empty(max(nnz, 1), dtype=torch.int32, device=dev)
                 bufs["v"] = torch.empty(max(nnz, 1), dtype=torch.float64, device=dev)
@@ -249,7 +261,10 @@ def main():
                     agg[k] = [x + y for x, y in zip(agg.get(k, [0] * len(st[k])), st[k])]
                 agg["n_tasks"] = agg.get("n_tasks", 0) + st["n_tasks"]
 
-            nnz = eng.spgemm_row_chunks(da, da, chunk_bounds, alloc, consume)
+            if chunk_caps is not None:
+                nnz = eng.fused_row_chunks(da, da, chunk_bounds, chunk_caps, alloc, consume)
+            else:
+                nnz = eng.spgemm_row_chunks(da, da, chunk_bounds, alloc, consume)
             st = dict(agg)
             st.update(tms)
             return st, nnz, None
@@ -429,6 +444,33 @@ def main():
         except Exception as e:      # a failed check must not lose the measurement: the line says what happened
             verified = {"ok": False, "error": f"{type(e).__name__}: {e}"}
 
+    elif world == 1 and one_pass:
+        # chunked steps: the whole C is never resident; the first chunk through both entry points (the full-size parity tests of
+        # this configuration: tests/test_gpu_tasks.py::test_rmat22_row_ranges_against_oracle)
+        verified = {}
+        try:
+            b0, b1, cap0 = int(chunk_bounds[0]), int(chunk_bounds[1]), int(chunk_caps[0])
+            t_ptr = torch.empty(b1 - b0 + 1, dtype=torch.int64, device=dev)
+            t_idx = torch.empty(max(cap0, 1), dtype=torch.int32, device=dev)
+            t_val = torch.empty(max(cap0, 1), dtype=torch.float64, device=dev)
+            nnz_t = eng.fused(da, da, b0, b1, t_ptr.data_ptr(), t_idx.data_ptr(), t_val.data_ptr(), cap0)
+            o_nnz = eng.symbolic(da, da, b0, b1)
+            o_ptr = torch.empty(b1 - b0 + 1, dtype=torch.int64, device=dev)
+            o_idx = torch.empty(max(o_nnz, 1), dtype=torch.int32, device=dev)
+            o_val = torch.empty(max(o_nnz, 1), dtype=torch.float64, device=dev)
+            eng.numeric(o_ptr.data_ptr(), o_idx.data_ptr(), o_val.data_ptr())
+            torch.cuda.synchronize()
+            verified["other_entry_point"] = "spada_dev_spgemm_symbolic + _numeric (first chunk: rows %d .. %d)" % (b0, b1)
+            verified["entry_points_agree"] = bool(
+                o_nnz == nnz_t and torch.equal(o_ptr, t_ptr) and torch.equal(o_idx, t_idx[:nnz_t]) and
+                torch.all((o_val - t_val[:nnz_t]).abs() <= 1e-9 * o_val.abs()).item())
+            verified["oracle_agrees"] = None
+            verified["nnz_c"] = int(nnz_t)
+            verified["ok"] = verified["entry_points_agree"]
+            del t_ptr, t_idx, t_val, o_ptr, o_idx, o_val
+        except Exception as e:
+            verified = {"ok": False, "error": f"{type(e).__name__}: {e}"}
+
     if rank == 0:
         K = args.steps
         ms_step = elapsed / K * 1e3
@@ -442,7 +484,7 @@ def main():
         # the step (all rows; 60-70 % of the device time).  Its average duration comes from HIP events recorded around it on
         # the stream it is launched on; its algorithmic bytes are those of the whole step (12 B per product,
         # 28 B per A entry, 8 B per row read; 12 B per nnz(C) written), the other kernels are listed under `kernels`.
-        k_ms = ms["ms_task"] if chunk_bounds is None and ms["ms_fused_call"] > 0 else dev_ms
+        k_ms = ms["ms_task"] if ms["ms_fused_call"] > 0 else dev_ms     # (chunked steps: summed over the chunks)
         achieved = st["bytes_read"] / (k_ms * 1e-3) / 1e9
         traffic, traffic_src = load_traffic(args.workload)
         cls_names = ["empty", "copy (one A entry)", "small", "solo", "big (column-range tasks)"]
@@ -479,7 +521,7 @@ def main():
             "ms_per_step_median": float(np.median(step_wall)) * 1e3,   # per-step wall times on rank 0 (every step drains its stream)
             "verified": None if verified is None else bool(verified.get("ok")),
             "verification": verified,
-            "c_alloc": "reused" if one_pass and chunk_bounds is None and comm is None and world == 1 else "per_step",
+            "c_alloc": "reused" if one_pass and comm is None and (world == 1 or chunk_bounds is not None) else "per_step",
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
@@ -501,7 +543,7 @@ def main():
                        "entry_point": ("spada_dist_spgemm_symbolic + spada_dist_spgemm_numeric (libspada_comm.so: two-phase, numeric phase in "
                                        f"{args.exchange_chunks} pieces overlapped with their broadcast)") if exchange == "overlap" else
                                       "spada_dev_spgemm_fused (one pass, C buffers sized by the product count)"
-                                      if one_pass and chunk_bounds is None
+                                      if one_pass
                                       else "spada_dev_spgemm_symbolic + spada_dev_spgemm_numeric",
                        "parallelism": f"row-block x{world}, B replicated" +
                                       (f", C streamed in {len(chunk_bounds) - 1} row chunks per rank and not gathered"

@@ -5,6 +5,7 @@ the shared object is missing -- there is no Python or CPU stand-in for the HIP p
 """
 import ctypes
 import os
+import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SPADA_LIB_PATH") or os.path.join(_HERE, "lib", "libspada_spgemm.so")   # env: development A/B builds
@@ -166,6 +167,26 @@ def comm_lib():
     return _comm_lib
 
 
+def _share_torch_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm wheels carry their own libamdhip64.so (soname libamdhip64.so.7, asked for by
+    torch as plain `libamdhip64.so`): if this package's library pulls in /opt/rocm's copy first, a later `import torch` loads
+    the wheel's copy as a SECOND runtime, which then finds no GPU ("No HIP GPUs are available").  The other order is harmless
+    (our NEEDED entry matches the soname of the copy torch loaded).  So when a torch wheel with its own runtime is installed, its
+    copy is mapped first -- without importing torch.  SPADA_HIP_RUNTIME=system switches this off."""
+    if os.environ.get("SPADA_HIP_RUNTIME", "") == "system" or "torch" in sys.modules:
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        for root in (spec.submodule_search_locations if spec is not None else []):
+            cand = os.path.join(root, "lib", "libamdhip64.so")
+            if os.path.exists(cand):
+                ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+                return
+    except (ImportError, OSError, ValueError):
+        pass   # no torch, or an unusual layout: the system runtime is used
+
+
 def lib():
     """Load the shared library (once).  Raises ImportError if it has not been built."""
     global _lib
@@ -174,6 +195,7 @@ def lib():
             raise ImportError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(or `make -C spada_sim_amd/csrc`).  spada_sim_amd has no fallback path.")
+        _share_torch_hip_runtime()
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)

@@ -367,9 +367,15 @@ __global__ __launch_bounds__(256) void k_row_class(const uint64_t *__restrict__ 
 //   k_big_scatter one workgroup per part of a spilled row: walks its products again and stores (column, a * b) at the bucket's
 //                 cursor: afterwards the scratch slice of every range is contiguous
 // k_cut3 copies the range descriptors into the task list in row order.
-constexpr uint32_t BX_PART = 8192;
+#ifndef SPADA_BX_PART
+#define SPADA_BX_PART 8192
+#endif
+#ifndef SPADA_BX_RUN
+#define SPADA_BX_RUN 8
+#endif
+constexpr uint32_t BX_PART = SPADA_BX_PART;
 constexpr uint32_t BX_NOPART = 0xFFFFFFFFu;
-constexpr uint32_t BX_RUN = 8;   // consecutive part records per workgroup (k_big_scatter)
+constexpr uint32_t BX_RUN = SPADA_BX_RUN;   // consecutive part records per workgroup (k_big_scatter)
 struct BigPart {
     uint32_t slot;      // position of the row in big_rows; BX_NOPART: sentinel / unused record
     uint32_t p_begin;   // products of the row before the part (sort-merge: product numbers)
@@ -790,17 +796,55 @@ __global__ __launch_bounds__(TK_BLOCK) void k_big_plan(const uint64_t *__restric
                     }
                 }
         }
-        if (ok && !direct) {   // spilled: the counts of every part become its cursors (part order = product order)
-            uint4 run = make_uint4(pre[tid * 4 + 0], pre[tid * 4 + 1], pre[tid * 4 + 2], pre[tid * 4 + 3]);
+        if (ok && !direct) {
+            // spilled: the counts of every part become its cursors.  Layout of the row's slice: RANGE major (a range task reads one
+            // contiguous slice), inside a range PART major, inside (range, part) by bucket -- the products a part sends to a range
+            // form ONE run, and the runs of consecutive parts (which one workgroup of k_big_scatter writes one after the other) are
+            // neighbours: a hub row with 10^6 products has ~500 ranges but 2048 buckets, so the runs are four times as long as
+            // with one run per (bucket, part)
+            __syncthreads();   // (aux: the descriptors above are written)
+#pragma unroll
+            for (int k = 0; k < BPT; ++k) aux[tid * BPT + k] = stf[k];
+            __syncthreads();
+            block_exclusive_scan4_dpp(aux, hdr + 4);
+            uint32_t rng[BPT], rf[BPT];   // range of the bucket, first bucket of that range
+#pragma unroll
+            for (int k = 0; k < BPT; ++k) {
+                rng[k] = aux[tid * BPT + k] + stf[k] - 1u;   // (bucket 0 starts a range)
+                rf[k] = rfirst[rng[k]];
+            }
+            __syncthreads();
+            uint32_t *base = cnt;   // position of the next part's run in range r, relative to the row's slice
+#pragma unroll
+            for (int k = 0; k < BPT; ++k) {
+                const uint32_t r = tid * BPT + k;
+                if (r < NR) base[r] = pre[rfirst[r]];
+            }
             for (uint32_t k = 0; k < pc; ++k) {
                 if (parts[pb + k].slot == BX_NOPART) break;
                 uint4 *hp = (uint4 *)(part_hist + (size_t)(pb + k) * NB) + tid;
                 const uint4 h = *hp;
-                *hp = run;
-                run.x += h.x;
-                run.y += h.y;
-                run.z += h.z;
-                run.w += h.w;
+                aux[tid * 4 + 0] = h.x;
+                aux[tid * 4 + 1] = h.y;
+                aux[tid * 4 + 2] = h.z;
+                aux[tid * 4 + 3] = h.w;
+                __syncthreads();
+                block_exclusive_scan4_dpp(aux, hdr + 4);   // products of the part before every bucket
+                if (tid == TK_BLOCK - 1) aux[NB] = aux[NB - 1] + h.w;
+                __syncthreads();
+                uint4 c;
+                c.x = base[rng[0]] + aux[tid * 4 + 0] - aux[rf[0]];
+                c.y = base[rng[1]] + aux[tid * 4 + 1] - aux[rf[1]];
+                c.z = base[rng[2]] + aux[tid * 4 + 2] - aux[rf[2]];
+                c.w = base[rng[3]] + aux[tid * 4 + 3] - aux[rf[3]];
+                *hp = c;
+                __syncthreads();
+#pragma unroll
+                for (int j = 0; j < BPT; ++j) {
+                    const uint32_t r = tid * BPT + j;
+                    if (r < NR) base[r] += aux[rfirst[r + 1]] - aux[rfirst[r]];
+                }
+                __syncthreads();
             }
         }
         __syncthreads();

@@ -358,6 +358,21 @@ class Engine:
             total += nnz
         return total
 
+    def fused_row_chunks(self, da, db, bounds, caps, alloc, consume):
+        """The one-pass variant of spgemm_row_chunks: every chunk through spada_dev_spgemm_fused.  `caps[i]` is the capacity of
+        the C buffers of chunk i -- an upper bound of its nnz(C) the caller knows beforehand (its product count: count_products);
+        `alloc(rows, cap)` and `consume(row_begin, row_end, nnz, stats)` as above.  Returns the total nnz(C)."""
+        total = 0
+        for i in range(len(bounds) - 1):
+            b0, b1 = int(bounds[i]), int(bounds[i + 1])
+            if b1 <= b0:
+                continue
+            p, ix, v = alloc(b1 - b0, int(caps[i]))
+            nnz = self.fused(da, db, b0, b1, p, ix, v, int(caps[i]))
+            consume(b0, b1, nnz, self.stats())
+            total += nnz
+        return total
+
     def set_phase_timing(self, enabled):
         """Event records between the small kernels of a call (ms_row_stats / ms_big_expand / ms_cut) on or off: each idles the
         stream for about 5 us (spada_set_phase_timing)."""

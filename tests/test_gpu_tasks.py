@@ -334,3 +334,24 @@ def test_rccl_exchange_single_rank(engine):
     finally:
         engine.free(d)
         comm.close()
+
+
+def test_engine_first_then_torch_in_one_process():
+    """The engine's library and PyTorch share ONE HIP runtime whichever is loaded first (a torch wheel carries its own copy; two
+    runtimes in a process leave the second without a GPU): a fresh process runs the engine, then imports torch and uses the GPU."""
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import spada_sim_amd as S\n"
+        "assert 'torch' not in sys.modules\n"
+        "eng = S.Engine(); m = S.generate(S.GEN_RMAT, 8, 4, 3); c = eng.spgemm(m, m); n = c.nnz()\n"
+        "import torch\n"
+        "x = torch.arange(8, device='cuda:0').sum().item()\n"
+        "c2 = eng.spgemm(m, m)\n"
+        "assert x == 28 and c2.nnz() == n and n > 0\n"
+        "print('ok', n)\n" % repo)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().startswith("ok"), r.stdout + r.stderr

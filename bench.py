@@ -116,6 +116,8 @@ def main():
     ap.add_argument("--exercise-exchange", action="store_true",
                     help="N = 1 only: run both libspada_comm.so exchange forms on a one-rank RCCL communicator, check them against the "
                          "plain one-pass result and exit (the code path the driver's multi-GPU runs take, on the one GPU a builder has)")
+    ap.add_argument("--chunk-one-pass", action="store_true",
+                    help="chunked steps (R-MAT 22) through spada_dev_spgemm_fused with reused buffers instead of symbolic + numeric")
     ap.add_argument("--chunk-products", type=float, default=0,
                     help="stream C in A-row chunks of about this many products (0 = automatic: chunk when the product "
                          "count of a rank exceeds 3e9, i.e. when C would not fit next to the inputs)")
@@ -172,7 +174,12 @@ def main():
     one_pass = not args.two_phase and args.accumulator == "lds_hash"
     # (one-pass mode: the capacity of a chunk's C buffers = its product count, known to the host before anything runs)
     chunk_caps = ([S.count_products(a, a, chunk_bounds[i], chunk_bounds[i + 1]) for i in range(len(chunk_bounds) - 1)]
-                  if chunk_bounds is not None and one_pass else None)
+                  if chunk_bounds is not None and one_pass and args.chunk_one_pass else None)
+    if chunk_bounds is not None and chunk_caps is None:
+        # chunked steps run the two-phase contract: measured on R-MAT 22, the one-pass call is TWICE as slow there (7.2 s against
+        # 3.5 s per step: hub rows are thousands of range tasks, some of them multi-pass, and every task behind them in the
+        # chain waits for their counts); --chunk-one-pass times it anyway
+        one_pass = False
     cap = my_products      # capacity of the C buffers of the one-pass entry point: one entry per product at most
     checksum = torch.zeros(1, dtype=torch.float64, device=dev)
     gather_s = [0.0]   # seconds spent in the allgatherv of C (N > 1, exchange after the compute), timed steps only
@@ -444,12 +451,13 @@ def main():
         except Exception as e:      # a failed check must not lose the measurement: the line says what happened
             verified = {"ok": False, "error": f"{type(e).__name__}: {e}"}
 
-    elif world == 1 and one_pass:
+    elif world == 1 and args.accumulator == "lds_hash":
         # chunked steps: the whole C is never resident; the first chunk through both entry points (the full-size parity tests of
         # this configuration: tests/test_gpu_tasks.py::test_rmat22_row_ranges_against_oracle)
         verified = {}
         try:
-            b0, b1, cap0 = int(chunk_bounds[0]), int(chunk_bounds[1]), int(chunk_caps[0])
+            b0, b1 = int(chunk_bounds[0]), int(chunk_bounds[1])
+            cap0 = int(S.count_products(a, a, b0, b1))
             t_ptr = torch.empty(b1 - b0 + 1, dtype=torch.int64, device=dev)
             t_idx = torch.empty(max(cap0, 1), dtype=torch.int32, device=dev)
             t_val = torch.empty(max(cap0, 1), dtype=torch.float64, device=dev)

@@ -536,6 +536,28 @@ __global__ __launch_bounds__(256) void k_big_parts(const uint64_t *__restrict__ 
     }
 }
 
+// Runs of equal buckets in a wave.  The lanes of a wave hold consecutive products, i.e. (mostly) consecutive entries of ONE sorted B
+// row: on a skewed input -- the popular columns of an R-MAT graph -- dozens of neighbouring lanes fall into the same bucket and an
+// LDS atomic per lane serialises on one address.  The first lane of every run speaks for the run: `head`, the run's length, and
+// for every lane the lane of its head.  key = 0xFFFFFFFF marks a lane without a product (such lanes form runs that add nothing).
+#ifndef SPADA_BX_RUNS
+#define SPADA_BX_RUNS 1
+#endif
+// Returns false -- and nothing else -- when no two neighbouring lanes share a bucket (meshes: the check costs three instructions,
+// the run bookkeeping a dozen and a cross-lane read).
+__device__ inline bool wave_runs(uint32_t key, bool &head, uint32_t &len, uint32_t &head_lane)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t prev = (uint32_t)__shfl_up((int)key, 1);
+    head = lane == 0 || prev != key;
+    const unsigned long long heads = __ballot(head);
+    if (heads == ~0ull) return false;
+    const unsigned long long above = (heads >> lane) >> 1;   // heads in the lanes above this one
+    len = above ? (uint32_t)__ffsll((long long)above) : 64u - lane;
+    head_lane = 63u - (uint32_t)__clzll((long long)(heads & ((2ull << lane) - 1ull)));   // (lane 0 is always a head)
+    return true;
+}
+
 // LDS of k_big_hist / k_big_scatter: 256 B hdr | cnt u32[NB] | s_re u32[4], s_a0 u64[2] | walk scratch
 constexpr size_t BX_WALK_LDS = 256 + (size_t)BX_NB * 4 + 32 + flat_walk_bytes<TK_BLOCK, TK_EPT, true>() + 16;
 
@@ -571,8 +593,17 @@ __global__ __launch_bounds__(TK_BLOCK) void k_big_hist(const uint32_t *__restric
         flat_walk<TK_BLOCK, TK_EPT, 1, false, U>(s_re, s_a0, 1u, e_count, eb0, elen, nullptr, bidx, nullptr, scratch, hdr,
                                                  [&](uint32_t(&col)[U], uint32_t(&plr)[U], double(&)[U], uint32_t(&)[U]) {
 #pragma unroll
-                                                     for (int u = 0; u < U; ++u)
+                                                     for (int u = 0; u < U; ++u) {
+#if SPADA_BX_RUNS
+                                                         const uint32_t bk = plr[u] != LR_NONE ? (col[u] - kmin) >> wshift : 0xFFFFFFFFu;
+                                                         bool head;
+                                                         uint32_t len, hl;
+                                                         if (!wave_runs(bk, head, len, hl)) len = 1u;   // (every lane its own run)
+                                                         if (head && bk != 0xFFFFFFFFu) atomicAdd(&cnt[bk], len);
+#else
                                                          if (plr[u] != LR_NONE) atomicAdd(&cnt[(col[u] - kmin) >> wshift], 1u);
+#endif
+                                                     }
                                                  });
         __syncthreads();
         ((uint4 *)(part_hist + (size_t)pi * NB))[tid] = ((const uint4 *)cnt)[tid];
@@ -872,6 +903,7 @@ __global__ __launch_bounds__(TK_BLOCK) void k_big_scatter(const double *__restri
     const uint32_t nparts = ctr->n_parts;
     // a workgroup takes BX_RUN consecutive records: the parts of one row (or of neighbouring rows), whose scattered stores fall into
     // the same lines of the row's scratch slice, go through one CU and one L2 one after the other
+    // (measured: giving every XCD a contiguous eighth of the records, so that neighbouring runs meet in one L2, is 3 - 8 % SLOWER)
     for (uint32_t pi0 = blockIdx.x * BX_RUN; pi0 < nparts; pi0 += gridDim.x * BX_RUN)
     for (uint32_t pi = pi0; pi < min(pi0 + BX_RUN, nparts); ++pi) {
         const BigPart pt = parts[pi];
@@ -892,15 +924,33 @@ __global__ __launch_bounds__(TK_BLOCK) void k_big_scatter(const double *__restri
         flat_walk<TK_BLOCK, TK_EPT, 1, true, U>(s_re, s_a0, 1u, e_count, eb0, elen, aval, bidx, bval, scratch, hdr,
                                                 [&](uint32_t(&col)[U], uint32_t(&plr)[U], double(&v)[U], uint32_t(&pp)[U]) {
 #pragma unroll
-                                                    for (int u = 0; u < U; ++u)
+                                                    for (int u = 0; u < U; ++u) {
+#if SPADA_BX_RUNS
+                                                        const uint32_t bk = plr[u] != LR_NONE ? (col[u] - kmin) >> wshift : 0xFFFFFFFFu;
+                                                        bool head;
+                                                        uint32_t len, hl;
+                                                        const bool runs = wave_runs(bk, head, len, hl);
+                                                        if (!runs) {
+                                                            len = 1u;
+                                                            hl = threadIdx.x & 63;
+                                                        }
+                                                        uint32_t pbase = 0;
+                                                        if (head && bk != 0xFFFFFFFFu) pbase = atomicAdd(&cur[bk], len);
+                                                        if (runs) pbase = (uint32_t)__shfl((int)pbase, (int)hl);
+#endif
                                                         if (plr[u] != LR_NONE) {
+#if SPADA_BX_RUNS
+                                                            const uint32_t p = pbase + ((threadIdx.x & 63) - hl);
+#else
                                                             const uint32_t p = atomicAdd(&cur[(col[u] - kmin) >> wshift], 1u);
+#endif
                                                             // (plain stores: the runs of a range are completed in the caches;
                                                             // non-temporal ones made the stage 1.4 - 2 x slower)
                                                             scr_col[sb + p] = col[u];
                                                             scr_val[sb + p] = v[u];
                                                             if (scr_seq) scr_seq[sb + p] = pt.p_begin + pp[u];
                                                         }
+                                                    }
                                                 });
         __syncthreads();
     }

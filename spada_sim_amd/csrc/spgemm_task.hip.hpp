@@ -606,6 +606,9 @@ __global__ __launch_bounds__(TK_BLOCK) void k_big_hist(const uint32_t *__restric
                                                      }
                                                  });
         __syncthreads();
+        // stored as EXCLUSIVE PREFIXES over the buckets (the part's products before every bucket): the sums over the parts that
+        // k_big_plan forms are then the row's prefixes, and the cursors of a part need no scan in its serial loop over the parts
+        block_exclusive_scan4_dpp(cnt, hdr + 4);
         ((uint4 *)(part_hist + (size_t)pi * NB))[tid] = ((const uint4 *)cnt)[tid];
         __syncthreads();
     }
@@ -650,9 +653,10 @@ __global__ __launch_bounds__(TK_BLOCK) void k_big_plan(const uint64_t *__restric
         const uint32_t row = big_rows[slot];
         const uint32_t kmin = row_kmin[row], kmax = row_kmax[row], wshift = big_wshift(kmin, kmax);
         const uint32_t pb = slots[slot].part_begin, pc = slots[slot].part_count;
-        {   // bucket counts of the row
+        {   // products of the row before every bucket = the sum of the parts' prefixes (k_big_hist); the bucket counts are its differences
             uint4 acc = make_uint4(0u, 0u, 0u, 0u);
-            for (uint32_t k = 0; k < pc; ++k) {
+            uint32_t k = 0;
+            for (; k < pc; ++k) {
                 if (parts[pb + k].slot == BX_NOPART) break;   // (uniform; the records of a row are its parts, then sentinels)
                 const uint4 h = ((const uint4 *)(part_hist + (size_t)(pb + k) * NB))[tid];
                 acc.x += h.x;
@@ -660,15 +664,15 @@ __global__ __launch_bounds__(TK_BLOCK) void k_big_plan(const uint64_t *__restric
                 acc.z += h.z;
                 acc.w += h.w;
             }
-            ((uint4 *)cnt)[tid] = acc;
             pre[tid * 4 + 0] = acc.x;
             pre[tid * 4 + 1] = acc.y;
             pre[tid * 4 + 2] = acc.z;
             pre[tid * 4 + 3] = acc.w;
+            if (tid == 0) pre[NB] = parts[pb + k].p_begin;   // (the record behind the last part: products before it = all of the row)
         }
         __syncthreads();
-        block_exclusive_scan4_dpp(pre, hdr + 4);
-        if (tid == TK_BLOCK - 1) pre[NB] = pre[NB - 1] + cnt[NB - 1];
+#pragma unroll
+        for (int k = 0; k < BPT; ++k) cnt[tid * BPT + k] = pre[tid * BPT + k + 1] - pre[tid * BPT + k];
         __syncthreads();
         // range starts: a heavy bucket is a range of its own; the light buckets between heavy ones are packed greedily, as many
         // as fit one task's table (<= TK_SOLO_MAX products: a range is closed when the next bucket does not fit, so two consecutive
@@ -851,31 +855,32 @@ __global__ __launch_bounds__(TK_BLOCK) void k_big_plan(const uint64_t *__restric
                 const uint32_t r = tid * BPT + k;
                 if (r < NR) base[r] = pre[rfirst[r]];
             }
+            __syncthreads();   // (pre is read above; from here on it is the second buffer of the loop)
             for (uint32_t k = 0; k < pc; ++k) {
                 if (parts[pb + k].slot == BX_NOPART) break;
+                // e[b] = products of the part before bucket b (k_big_hist), e[NB] = all of them: in LDS for the reads at the range
+                // starts; two buffers in turn, so that the next part may be written while the range bases take this one in
+                uint32_t *e = (k & 1u) ? pre : aux;
                 uint4 *hp = (uint4 *)(part_hist + (size_t)(pb + k) * NB) + tid;
                 const uint4 h = *hp;
-                aux[tid * 4 + 0] = h.x;
-                aux[tid * 4 + 1] = h.y;
-                aux[tid * 4 + 2] = h.z;
-                aux[tid * 4 + 3] = h.w;
-                __syncthreads();
-                block_exclusive_scan4_dpp(aux, hdr + 4);   // products of the part before every bucket
-                if (tid == TK_BLOCK - 1) aux[NB] = aux[NB - 1] + h.w;
+                e[tid * 4 + 0] = h.x;
+                e[tid * 4 + 1] = h.y;
+                e[tid * 4 + 2] = h.z;
+                e[tid * 4 + 3] = h.w;
+                if (tid == 0) e[NB] = parts[pb + k + 1].p_begin - parts[pb + k].p_begin;
                 __syncthreads();
                 uint4 c;
-                c.x = base[rng[0]] + aux[tid * 4 + 0] - aux[rf[0]];
-                c.y = base[rng[1]] + aux[tid * 4 + 1] - aux[rf[1]];
-                c.z = base[rng[2]] + aux[tid * 4 + 2] - aux[rf[2]];
-                c.w = base[rng[3]] + aux[tid * 4 + 3] - aux[rf[3]];
+                c.x = base[rng[0]] + h.x - e[rf[0]];
+                c.y = base[rng[1]] + h.y - e[rf[1]];
+                c.z = base[rng[2]] + h.z - e[rf[2]];
+                c.w = base[rng[3]] + h.w - e[rf[3]];
                 *hp = c;
                 __syncthreads();
 #pragma unroll
                 for (int j = 0; j < BPT; ++j) {
                     const uint32_t r = tid * BPT + j;
-                    if (r < NR) base[r] += aux[rfirst[r + 1]] - aux[rfirst[r]];
+                    if (r < NR) base[r] += e[rfirst[r + 1]] - e[rfirst[r]];
                 }
-                __syncthreads();
             }
         }
         __syncthreads();

@@ -39,6 +39,9 @@
 #ifndef SPADA_BT_STOP
 #define SPADA_BT_STOP 0
 #endif
+#ifndef SPADA_BT_FIRST_ROLLED
+#define SPADA_BT_FIRST_ROLLED 1
+#endif
 
 namespace spada {
 
@@ -60,14 +63,14 @@ static_assert(TK_T == 2048 && BT_PMAX == 2048 && TK_BLOCK == 256, "the LDS map a
 
 // exclusive scan of arr[0 .. N), N <= 2048 (u32 or u16 elements): every thread PER = ceil(N / 256) consecutive elements; the
 // prefixes go to out[] (which may be arr itself).  Returns the total.  No barrier after the stores (the caller's next one covers them).
-template <class T>
-__device__ inline uint32_t batch_scan(const T *arr, T *out, uint32_t N, uint32_t *slot)
+template <class T, uint32_t MAXPER>
+__device__ inline uint32_t batch_scan_n(const T *arr, T *out, uint32_t N, uint32_t *slot)
 {
     const int tid = threadIdx.x;
     const uint32_t PER = (N + 255u) >> 8;
-    uint32_t loc[8], tot = 0;
+    uint32_t loc[MAXPER], tot = 0;
 #pragma unroll
-    for (uint32_t j = 0; j < 8; ++j) {
+    for (uint32_t j = 0; j < MAXPER; ++j) {
         const uint32_t idx = tid * PER + j;
         loc[j] = (j < PER && idx < N) ? (uint32_t)arr[idx] : 0u;
         tot += loc[j];
@@ -75,7 +78,7 @@ __device__ inline uint32_t batch_scan(const T *arr, T *out, uint32_t N, uint32_t
     uint32_t total;
     uint32_t ex = block_scan_excl_dpp(tot, slot, &total);   // (its barrier comes after every thread has read its elements)
 #pragma unroll
-    for (uint32_t j = 0; j < 8; ++j) {
+    for (uint32_t j = 0; j < MAXPER; ++j) {
         const uint32_t idx = tid * PER + j;
         if (j < PER && idx < N) {
             out[idx] = (T)ex;
@@ -83,6 +86,15 @@ __device__ inline uint32_t batch_scan(const T *arr, T *out, uint32_t N, uint32_t
         }
     }
     return total;
+}
+// (most tasks have fewer than 1024 blocks: half of the straight-line code is skipped for them)
+template <class T>
+__device__ inline uint32_t batch_scan(const T *arr, T *out, uint32_t N, uint32_t *slot)
+{
+#if SPADA_BT_FIRST_ROLLED
+    if (N <= 1024u) return batch_scan_n<T, 4>(arr, out, N, slot);
+#endif
+    return batch_scan_n<T, 8>(arr, out, N, slot);
 }
 
 template <int MODE>
@@ -522,6 +534,45 @@ __device__ inline void batch_task(const TaskArgs &g, const TaskDesc &td, uint32_
             for (uint32_t jj = lo; jj < hi; ++jj) add += (lk[jj] < k) ? (uint32_t)pc[jj] : 0u;
             return add;
         };
+#if SPADA_BT_FIRST_ROLLED
+        // (a loop over pairs of blocks, as many as the task has: the straight-line version for 8 blocks per thread spent more on the
+        // skeleton of the blocks a task does not have -- a third of the slots on the web input -- than it gained from issuing all loads together)
+        const uint32_t nper = (NBt + (uint32_t)BLOCK - 1u) / (uint32_t)BLOCK;   // (uniform)
+#pragma clang loop unroll(disable)
+        for (uint32_t w0 = 0; w0 < nper; w0 += 2) {
+            uint32_t kk[2], blo[2], bhi[2], fst[2];
+            uint16_t slt[2];
+            bool on[2];
+#pragma unroll
+            for (int w = 0; w < 2; ++w) {
+                const uint32_t p = tid + (w0 + w) * BLOCK;
+                on[w] = p < NBt;
+                kk[w] = 0;
+                slt[w] = 0;
+                if (on[w]) {
+                    kk[w] = lk[p];
+                    slt[w] = ls[p];
+                }
+            }
+#pragma unroll
+            for (int w = 0; w < 2; ++w) {
+                blo[w] = bhi[w] = 0;
+                if (on[w]) {
+                    const uint32_t bk = one_row ? bucket_of(kk[w], e_one) : bucket_of(kk[w], s_emit[lr_of_hk(kk[w])]);
+                    blo[w] = bk ? bcnt[bk - 1] : 0u;
+                    bhi[w] = bcnt[bk];
+                }
+            }
+#pragma unroll
+            for (int w = 0; w < 2; ++w) fst[w] = on[w] ? (uint32_t)pcx[blo[w]] : 0u;
+#pragma unroll
+            for (int w = 0; w < 2; ++w)
+                if (on[w]) {
+                    if (bhi[w] - blo[w] > 1u) fst[w] += smaller_in_bucket(kk[w], blo[w], bhi[w]);
+                    mb[slt[w]] |= fst[w] << 16;   // (one thread per slot)
+                }
+        }
+#else
         {
             uint32_t kk[8], blo[8], bhi[8], fst[8];
             uint16_t slt[8];
@@ -553,6 +604,7 @@ __device__ inline void batch_task(const TaskArgs &g, const TaskDesc &td, uint32_
                     mb[slt[w]] |= fst[w] << 16;   // (one thread per slot)
                 }
         }
+#endif
         // the rows' first hashed outputs: the outputs before the (virtual) smallest key of the row
         if (!one_row && (uint32_t)tid < R) {
             if (b_lo < NBt) {

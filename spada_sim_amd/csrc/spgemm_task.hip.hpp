@@ -1892,19 +1892,16 @@ static_assert(task_kernel_lds() <= 40960, "four workgroups per CU");
 template <int MODE, int NOUT>
 __global__ __launch_bounds__(TK_BLOCK, 4) void k_task(const TaskArgs g)
 {
-    constexpr int BLOCK = TK_BLOCK, EPT = TK_EPT, T = TK_T, RMAX = TK_RMAX, U = SPADA_FLAT_U;
+    constexpr int RMAX = TK_RMAX;
     constexpr bool VALUES = MODE != MODE_COUNT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *hdr = (uint32_t *)smem;
-    uint32_t *keys = (uint32_t *)(smem + 256);
-    double *vals = (double *)(keys + T);
     unsigned char *region2 = smem + 256 + ((size_t)12 << TK_LOG_T);
     unsigned char *rows = region2 + ((task_region2() + 15) & ~(size_t)15);
     RowEmit *s_row = (RowEmit *)rows;
     uint64_t *s_a0 = (uint64_t *)(s_row + RMAX + 1);
     uint64_t *s_out = s_a0 + RMAX;
     uint32_t *s_re = (uint32_t *)(s_out + RMAX);
-    uint32_t *s_cnt = s_re + RMAX + 1;
     const int tid = threadIdx.x;
     const uint32_t ntasks = g.ctr->ntasks, task_end = min(ntasks, g.task_hi);
     if (g.ctr->abort_flag) return;
@@ -1918,7 +1915,6 @@ __global__ __launch_bounds__(TK_BLOCK, 4) void k_task(const TaskArgs g)
     __syncthreads();
     uint32_t t = hdr[50];
     __syncthreads();
-    unsigned long long dbg_t0 = SPADA_TASK_DBG ? __builtin_amdgcn_s_memtime() : 0, dbg_acc = 0, dbg_chain = 0, dbg_emit = 0;
     unsigned long long dbg_ph[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     while (t < task_end) {
         unsigned long long dbg_a = SPADA_TASK_DBG ? __builtin_amdgcn_s_memtime() : 0, dbg_b = dbg_a, dbg_c = dbg_a;
@@ -2007,12 +2003,6 @@ __global__ __launch_bounds__(TK_BLOCK, 4) void k_task(const TaskArgs g)
         __syncthreads();
         t = hdr[50];
         __syncthreads();
-        if (SPADA_TASK_DBG) {
-            const unsigned long long e = __builtin_amdgcn_s_memtime();
-            dbg_acc += dbg_b - dbg_a;
-            dbg_chain += dbg_c - dbg_b;
-            dbg_emit += e - dbg_c;
-        }
     }
     if (SPADA_TASK_DBG && tid == 0) {
 #pragma unroll

@@ -384,7 +384,7 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
         if (c->phase_timing) HIP_TRY(hipEventRecord(c->tev[2], s));
         if (n) {
             hipLaunchKernelGGL(k_cut1, dim3(ntiles), dim3(256), 0, s, c->row_cl.as<uint32_t>(), c->row_nprod.as<uint32_t>(),
-                               c->t_rowm.as<uint32_t>(), n, rmax, dc, c->t_tiles.as<uint32_t>(), c->t_rowt.as<uint32_t>(),
+                               c->row_rec.as<RowRec>(), c->t_rowm.as<uint32_t>(), n, rmax, dc, c->t_tiles.as<uint32_t>(), c->t_rowt.as<uint32_t>(),
                                c->row_binfo.as<uint32_t>());
             const bool fold = ntiles <= CUT_FOLD_TILES;
             if (!fold) hipLaunchKernelGGL(k_cut2, dim3(1), dim3(256), 0, s, c->t_tiles.as<uint32_t>(), ntiles, cap_tasks, dc);

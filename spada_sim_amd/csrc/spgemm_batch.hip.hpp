@@ -45,7 +45,6 @@
 
 namespace spada {
 
-constexpr int BT_BSHIFT = 4;                                  // a block = 16 consecutive columns of one row of C
 constexpr uint32_t BT_H_COPY = 0xFFFFu, BT_H_NONE = 0xFFFEu;  // `slot` of a retained product that is copied / of a lane without a product
 constexpr size_t BT_OFF_MB = 256, BT_OFF_K = BT_OFF_MB + 8192, BT_OFF_X = BT_OFF_K + 8192, BT_OFF_Y = BT_OFF_X + 8192,
                  BT_OFF_Z = BT_OFF_Y + 8192, BT_OFF_ROWS = BT_OFF_Z + 4096;
@@ -56,7 +55,7 @@ struct BtRow {          // bucket parameters of a row (blocks): first bucket, bu
 };
 __host__ __device__ constexpr size_t batch_lds()
 {
-    return BT_OFF_ROWS + (size_t)TK_RMAX * (sizeof(BtRow) + 4 + 4 + 1);
+    return BT_OFF_ROWS + (size_t)TK_RMAX * (sizeof(BtRow) + 4 + 4 + 1 + 4);
 }
 static_assert(batch_lds() <= 40960, "four workgroups per CU");
 static_assert(TK_T == 2048 && BT_PMAX == 2048 && TK_BLOCK == 256, "the LDS map and the per-thread arrays are written for these sizes");
@@ -97,7 +96,11 @@ __device__ inline uint32_t batch_scan(const T *arr, T *out, uint32_t N, uint32_t
     return batch_scan_n<T, 8>(arr, out, N, slot);
 }
 
-template <int MODE>
+// DENSE (k_cut1 / the range's bounds decide): the blocks between the first and the last column of every hashed row, added up over
+// the rows, are at most the table's slots.  Then the table needs no keys: block b of row r lives in slot soff[r] + b - bmin[r], the
+// slots are in output order as they are, and the whole order stage is ONE prefix sum over the popcounts of the 2048 masks (meshes
+// and banded matrices: half of the batches of the cop20k_A surrogate).
+template <int MODE, bool DENSE>
 __device__ inline void batch_task(const TaskArgs &g, const TaskDesc &td, uint32_t t, uint32_t ntasks, unsigned char *smem,
                                   unsigned long long (&dbg_ph)[9])
 {
@@ -119,8 +122,10 @@ __device__ inline void batch_task(const TaskArgs &g, const TaskDesc &td, uint32_
     int32_t *s_delta = (int32_t *)(s_emit + TK_RMAX);
     uint32_t *s_n = (uint32_t *)(s_delta + TK_RMAX);
     uint8_t *s_cls = (uint8_t *)(s_n + TK_RMAX);
+    uint32_t *s_dense = (uint32_t *)(s_cls + TK_RMAX);   // DENSE: first slot of the row - its first block (mod 2^32)
     // scan slots (four words each) in the header; hdr[48 .. 50] belong to the chain and the ticket, hdr[52 .. 53] to the numeric base
-    uint32_t *slot_rows = hdr + 4, *slot_ent = hdr + 8, *slot_cnt = hdr + 12, *slot_bk = hdr + 16, *slot_pc = hdr + 20, *slot_cr = hdr + 24;
+    uint32_t *slot_rows = hdr + 4, *slot_ent = hdr + 8, *slot_cnt = hdr + 12, *slot_bk = hdr + 16, *slot_pc = hdr + 20, *slot_cr = hdr + 24,
+             *slot_sp = hdr + 28;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t wave_u = __builtin_amdgcn_readfirstlane(wave);
@@ -142,7 +147,7 @@ __device__ inline void batch_task(const TaskArgs &g, const TaskDesc &td, uint32_
     // BATCH: rows, entries, products from batch_info | DIRECT RANGE: one row, its entries (descriptor), the products of the range
     const bool range = td.kind != TASK_BATCH;
     const uint32_t rb = td.row, R = range ? 1u : (td.np & 0xFFu), E = range ? (td.first >> 1) : ((td.np >> 8) & 0x3FFu),
-                   PT = range ? td.np : (td.np >> 18);
+                   PT = range ? td.np : ((td.np >> 18) & 0xFFFu);
     const uint64_t e0 = td.src;
     const uint32_t colbits = g.colbits;                       // >= BT_BSHIFT (the engine sees to it)
     const uint32_t colmask = colbits >= 32 ? 0xFFFFFFFFu : ((1u << colbits) - 1u);
@@ -184,7 +189,7 @@ __device__ inline void batch_task(const TaskArgs &g, const TaskDesc &td, uint32_
         uint4 *k4 = (uint4 *)keys, *m4 = (uint4 *)mb;
 #pragma unroll
         for (int s = 0; s < T / 4 / BLOCK; ++s) {
-            k4[tid + s * BLOCK] = make_uint4(EMPTY_KEY, EMPTY_KEY, EMPTY_KEY, EMPTY_KEY);
+            if constexpr (!DENSE) k4[tid + s * BLOCK] = make_uint4(EMPTY_KEY, EMPTY_KEY, EMPTY_KEY, EMPTY_KEY);
             m4[tid + s * BLOCK] = make_uint4(0u, 0u, 0u, 0u);
         }
         if (tid < 64) bm32[tid] = 0u;
@@ -197,6 +202,15 @@ __device__ inline void batch_task(const TaskArgs &g, const TaskDesc &td, uint32_
     uint32_t row_tot;
     const uint32_t row_ex = block_scan_excl_dpp(row_pr | (row_cp << 16), slot_rows, &row_tot);   // (barrier: the table is cleared)
     const uint32_t boff = row_ex & 0xFFFFu, cpre = row_ex >> 16, NBK = row_tot & 0xFFFFu;         // buckets before the row, copied outputs before it
+    uint32_t soff = 0, spanb = 0;   // DENSE: first slot of the row, its slots
+    bool dense_ok = true;
+    if constexpr (DENSE) {
+        spanb = row_hashed && rr.nprod ? (rr.kmax >> BT_BSHIFT) - (rr.kmin >> BT_BSHIFT) + 1u : 0u;
+        uint32_t sp_tot;
+        soff = block_scan_excl_dpp(min(spanb, 2u * (uint32_t)T), slot_sp, &sp_tot);
+        dense_ok = sp_tot <= (uint32_t)T;   // (the cut / the dispatch guarantee it)
+        if ((uint32_t)tid < R) s_dense[tid] = soff - (rr.kmin >> BT_BSHIFT);
+    }
     if ((uint32_t)tid < R) {
         s_cls[tid] = (uint8_t)rr.cls;
         s_n[tid] = 0u;
@@ -287,7 +301,7 @@ __device__ inline void batch_task(const TaskArgs &g, const TaskDesc &td, uint32_
         P = tot32 & 0xFFFFu;
         const uint32_t nent = tot32 >> 16;   // entries with products
         BSTOP(12);
-        if (P > BT_PMAX) {   // the cut guarantees it; a batch that does not fit is an internal error, not a memory fault
+        if (P > BT_PMAX || !dense_ok) {   // the cut guarantees it; a batch that does not fit is an internal error, not a memory fault
             if (tid == 0 && atomicOr(&g.ctr->abort_flag, 32u) == 0u) {   // what did not fit (reported by the host)
                 g.ctr->dbg[0] = td.kind | ((unsigned long long)E << 8) | ((unsigned long long)R << 32);
                 g.ctr->dbg[1] = tot32;
@@ -383,21 +397,30 @@ __device__ inline void batch_task(const TaskArgs &g, const TaskDesc &td, uint32_
                     hashed[u] = act[u] && !copy;
                     if (act[u] && copy) r_h[r * 4 + u] = BT_H_COPY;
                     hk[u] = ck >> BT_BSHIFT;
-                    h[u] = hash_slot<TK_LOG_T>(hk[u]);
-                    old[u] = hk[u];
-                    if (hashed[u]) old[u] = atomicCAS(&keys[h[u]], EMPTY_KEY, hk[u]);
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    if (hashed[u] && old[u] != EMPTY_KEY && old[u] != hk[u]) {
-                        const uint32_t step = probe_step(hk[u]);
-                        for (;;) {
-                            h[u] = (h[u] + step) & (T - 1);
-                            old[u] = atomicCAS(&keys[h[u]], EMPTY_KEY, hk[u]);
-                            if (old[u] == EMPTY_KEY || old[u] == hk[u]) break;
-                        }
+                    if constexpr (DENSE) {
+                        // the slot is the block's place in the row: nothing to insert, nothing to probe (masked: a lane without a hashed
+                        // product computes one from a stale record)
+                        h[u] = (s_dense[R == 1 ? 0u : lr] + (col[u] >> BT_BSHIFT)) & (uint32_t)(T - 1);
+                        old[u] = hk[u];
+                    } else {
+                        h[u] = hash_slot<TK_LOG_T>(hk[u]);
+                        old[u] = hk[u];
+                        if (hashed[u]) old[u] = atomicCAS(&keys[h[u]], EMPTY_KEY, hk[u]);
                     }
-                    mykeys += (hashed[u] && old[u] == EMPTY_KEY) ? 1u : 0u;
+                }
+                if constexpr (!DENSE) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (hashed[u] && old[u] != EMPTY_KEY && old[u] != hk[u]) {
+                            const uint32_t step = probe_step(hk[u]);
+                            for (;;) {
+                                h[u] = (h[u] + step) & (T - 1);
+                                old[u] = atomicCAS(&keys[h[u]], EMPTY_KEY, hk[u]);
+                                if (old[u] == EMPTY_KEY || old[u] == hk[u]) break;
+                            }
+                        }
+                        mykeys += (hashed[u] && old[u] == EMPTY_KEY) ? 1u : 0u;
+                    }
                 }
                 if (r == 0) BSTOP(14);
 #pragma unroll
@@ -437,14 +460,42 @@ __device__ inline void batch_task(const TaskArgs &g, const TaskDesc &td, uint32_
     }
     uint32_t myk[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) myk[i] = NO ? keys[tid + i * BLOCK] : EMPTY_KEY;
+    for (int i = 0; i < 8; ++i) myk[i] = (!DENSE && NO) ? keys[tid + i * BLOCK] : EMPTY_KEY;
+    // DENSE: the slots ARE in (row, block) order: first output of a slot = outputs of the slots before it, one prefix sum over the
+    // popcounts (eight consecutive slots per thread), written into the upper halves like the sorted path does
+    auto dense_first_outputs = [&]() {
+        uint4 *m4 = (uint4 *)mb;
+        uint4 wa = m4[2 * tid], wb = m4[2 * tid + 1];
+        uint32_t w[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w}, sum = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sum += (uint32_t)__popc(w[j] & 0xFFFFu);
+        uint32_t tot;
+        uint32_t ex = block_scan_excl_dpp(sum, slot_bk, &tot);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t c = (uint32_t)__popc(w[j] & 0xFFFFu);
+            w[j] |= ex << 16;
+            ex += c;
+        }
+        m4[2 * tid] = make_uint4(w[0], w[1], w[2], w[3]);
+        m4[2 * tid + 1] = make_uint4(w[4], w[5], w[6], w[7]);
+        __syncthreads();
+    };
+    auto dense_first_of = [&](uint32_t slot) { return slot < (uint32_t)T ? mb[slot] >> 16 : NO; };   // hashed outputs before a slot
 
     BSTOP(15);
     if constexpr (MODE == MODE_COUNT) {
         if (range) return;   // (the count of a range task is all the position kernels need)
         // the symbolic phase wants the outputs of every ROW: popcounts of the masks summed per row (the other modes get them from
         // the scans of the block order); offsets of the rows inside the batch -- k_pos4 adds the position of the batch afterwards
-        if (NO) {
+        if constexpr (DENSE) {
+            if (NO && R > 1) {
+                dense_first_outputs();
+                if ((uint32_t)tid < R && row_hashed) s_n[tid] = dense_first_of(soff + spanb) - dense_first_of(soff);
+            } else if (tid == 0) {
+                s_n[0] = NO;
+            }
+        } else if (NO) {
             if (R > 1) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i)
@@ -469,6 +520,10 @@ __device__ inline void batch_task(const TaskArgs &g, const TaskDesc &td, uint32_
     // keys of its own bucket: no exact rank, no second ordering pass.
     uint32_t hoff = 0;   // hashed outputs of the batch before this thread's row
     if (NO) {
+      if constexpr (DENSE) {
+        dense_first_outputs();
+        if (R > 1 && (uint32_t)tid < R) hoff = dense_first_of(soff);
+      } else {
         uint32_t b_lo = 0;
         if ((uint32_t)tid < R) {
             // (floor(x * f) is monotone in x, and the row behind starts where this one ends: the same expression of the same number)
@@ -614,6 +669,7 @@ __device__ inline void batch_task(const TaskArgs &g, const TaskDesc &td, uint32_
                 hoff = NO;
             }
         }
+      }
         __syncthreads();   // pc / pcx (region K) are read: the values may take their place
         BPH(4);
         // ---- scale - add: every retained product adds its value at its output (simulator.rs:213-218; order differs) -----------

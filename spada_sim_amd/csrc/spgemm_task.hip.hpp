@@ -106,6 +106,10 @@ struct TaskCounters {   // (a multiple of 8 bytes: k_init clears it in 8-byte wo
 // contiguous) and at most BT_PMAX products (hashed + copied: two rounds of four per thread).  Rows that cannot be part of such a
 // batch -- more than BT_EMAX entries, or one entry that selects more than BT_PMAX products -- are BIG whatever their products.
 constexpr uint32_t BT_EMAX = 512, BT_PMAX = 2048;
+constexpr int BT_BSHIFT = 4;   // a block = 16 consecutive columns of one row of C (the batch tasks key their table by blocks)
+#ifndef SPADA_BT_DENSE
+#define SPADA_BT_DENSE 1       // batches / ranges whose blocks fit the table slot for slot skip hashing and sorting (spgemm_batch.hip.hpp)
+#endif
 static_assert(BT_EMAX == (uint32_t)TK_BLOCK * TK_EPT && BT_PMAX == 2u * 4u * TK_BLOCK && TK_LIMIT_HI <= BT_PMAX, "one chunk, two rounds");
 
 // what a task needs to know about a row, in one 16-byte load (written by k_row_class)
@@ -1002,6 +1006,7 @@ struct CutRow {
 constexpr uint32_t CUT_END = 0xFFFFFFFFu;
 struct CutLds {
     uint32_t pc[CUT_TILE + 1], pw[CUT_TILE + 1], pe[CUT_TILE + 1];   // prefix sums: products to hash, products to copy, A entries
+    uint32_t ps[CUT_TILE + 1];                                       // ... blocks of columns between the first and last column of the hashed rows
     uint32_t nxt[CUT_TILE];
     uint8_t mark[CUT_TILE];
     uint32_t s_w[4];
@@ -1026,7 +1031,9 @@ __device__ inline uint32_t block_suffix_min_excl_u32(uint32_t v, uint32_t *s_w /
     return ex;
 }
 
-// batch descriptor word (TaskDesc::np of a TASK_BATCH): rows | A entries << 8 | products (hashed + copied) << 18
+// batch descriptor word (TaskDesc::np of a TASK_BATCH): rows | A entries << 8 | products (hashed + copied) << 18 | DENSE << 31: the
+// column spans of its hashed rows, in blocks, fit the table one slot per block
+constexpr uint32_t BINFO_DENSE = 1u << 31;
 __host__ __device__ inline uint32_t batch_info(uint32_t R, uint32_t E, uint32_t P) { return R | (E << 8) | (P << 18); }
 static_assert(TK_RMAX <= 255 && BT_EMAX <= 1023 && BT_PMAX <= 4095, "batch_info fields");
 
@@ -1035,6 +1042,7 @@ static_assert(TK_RMAX <= 255 && BT_EMAX <= 1023 && BT_PMAX <= 4095, "batch_info 
 // all (hashed + copied: the task keeps them in registers), at most BT_EMAX A entries (one chunk of the walk) and at most `rmax`
 // rows.  binfo[j] (batch starts only) = batch_info(rows, entries, products) of the batch that starts at the thread's row j.
 __device__ inline uint32_t cut_tile(const uint32_t *__restrict__ row_cl, const uint32_t *__restrict__ row_nprod,
+                                    const RowRec *__restrict__ row_rec,
                                     const uint32_t *__restrict__ row_m, uint32_t n, uint32_t rmax, uint32_t lim, CutLds &L,
                                     CutRow &cr, uint32_t *tile_total, uint32_t (&binfo)[CUT_ITEMS])
 {
@@ -1042,7 +1050,7 @@ __device__ inline uint32_t cut_tile(const uint32_t *__restrict__ row_cl, const u
     const uint32_t cnt = min((uint32_t)CUT_TILE, n - tile_base);
     uint8_t cls[CUT_ITEMS];
     bool fat[CUT_ITEMS];   // EMPTY row with more entries than a chunk holds: a batch of its own that has nothing to do
-    uint32_t c[CUT_ITEMS], w[CUT_ITEMS], e[CUT_ITEMS], sc = 0, sw = 0, se = 0;
+    uint32_t c[CUT_ITEMS], w[CUT_ITEMS], e[CUT_ITEMS], sp[CUT_ITEMS], sc = 0, sw = 0, se = 0, ss = 0;
 #pragma unroll
     for (int j = 0; j < CUT_ITEMS; ++j) {
         const uint32_t i = base + j;
@@ -1054,10 +1062,16 @@ __device__ inline uint32_t cut_tile(const uint32_t *__restrict__ row_cl, const u
         c[j] = (cls[j] == CLS_BIG || fat[j]) ? lim + 1 : ((cls[j] == CLS_SMALL || cls[j] == CLS_SOLO) ? P : 0u);
         w[j] = cls[j] == CLS_COPY ? P : 0u;
         e[j] = (cls[j] == CLS_BIG || fat[j]) ? 0u : len;
+        sp[j] = 0;
+        if (SPADA_BT_DENSE && (cls[j] == CLS_SMALL || cls[j] == CLS_SOLO)) {   // blocks a table addressed by column would need for the row
+            const RowRec rr = row_rec[i];
+            sp[j] = min((rr.kmax >> BT_BSHIFT) - (rr.kmin >> BT_BSHIFT) + 1u, 2u * (uint32_t)TK_T);
+        }
         L.mark[threadIdx.x * CUT_ITEMS + j] = 0;
         sc += c[j];
         sw += w[j];
         se += e[j];
+        ss += sp[j];
     }
     uint32_t tot;
     uint32_t ec = block_scan_excl_u32(sc, L.s_w, &tot);
@@ -1065,19 +1079,24 @@ __device__ inline uint32_t cut_tile(const uint32_t *__restrict__ row_cl, const u
     uint32_t ew = block_scan_excl_u32(sw, L.s_w, &tot);
     __syncthreads();
     uint32_t ee = block_scan_excl_u32(se, L.s_w, &tot);
+    __syncthreads();
+    uint32_t es = block_scan_excl_u32(ss, L.s_w, &tot);
 #pragma unroll
     for (int j = 0; j < CUT_ITEMS; ++j) {
         L.pc[threadIdx.x * CUT_ITEMS + j] = ec;
         L.pw[threadIdx.x * CUT_ITEMS + j] = ew;
         L.pe[threadIdx.x * CUT_ITEMS + j] = ee;
+        L.ps[threadIdx.x * CUT_ITEMS + j] = es;
         ec += c[j];
         ew += w[j];
         ee += e[j];
+        es += sp[j];
     }
     if (threadIdx.x == 255) {
         L.pc[CUT_TILE] = ec;
         L.pw[CUT_TILE] = ew;
         L.pe[CUT_TILE] = ee;
+        L.ps[CUT_TILE] = es;
     }
     __syncthreads();
     // nxt[i]: largest j <= cnt with pc[j] - pc[i] <= lim, (pc + pw)[j] - (pc + pw)[i] <= BT_PMAX, pe[j] - pe[i] <= BT_EMAX, j - i <= rmax
@@ -1154,6 +1173,7 @@ __device__ inline uint32_t cut_tile(const uint32_t *__restrict__ row_cl, const u
                 const uint32_t end = nm[j];
                 binfo[j] = fat[j] ? batch_info(1u, 0u, 0u)
                                   : batch_info(end - li, L.pe[end] - L.pe[li], (L.pc[end] - L.pc[li]) + (L.pw[end] - L.pw[li]));
+                if (SPADA_BT_DENSE && !fat[j] && L.pc[end] > L.pc[li] && L.ps[end] - L.ps[li] <= (uint32_t)TK_T) binfo[j] |= BINFO_DENSE;
             }
         }
         local += cr.t[j];
@@ -1164,6 +1184,7 @@ __device__ inline uint32_t cut_tile(const uint32_t *__restrict__ row_cl, const u
 
 // k_cut1: tasks started by every row -> row_t (0: none; BIG rows: their range tasks; else 1) and the tile totals
 __global__ __launch_bounds__(256) void k_cut1(const uint32_t *__restrict__ row_cl, const uint32_t *__restrict__ row_nprod,
+                                              const RowRec *__restrict__ row_rec,
                                               const uint32_t *__restrict__ row_m, uint32_t n, uint32_t rmax,
                                               const TaskCounters *__restrict__ ctr, uint32_t *__restrict__ tile_tasks,
                                               uint32_t *__restrict__ row_t, uint32_t *__restrict__ row_binfo)
@@ -1172,7 +1193,7 @@ __global__ __launch_bounds__(256) void k_cut1(const uint32_t *__restrict__ row_c
     __shared__ CutLds L;
     CutRow cr;
     uint32_t tot, binfo[CUT_ITEMS];
-    (void)cut_tile(row_cl, row_nprod, row_m, n, rmax, lim, L, cr, &tot, binfo);
+    (void)cut_tile(row_cl, row_nprod, row_rec, row_m, n, rmax, lim, L, cr, &tot, binfo);
     if (threadIdx.x == 0) tile_tasks[blockIdx.x] = tot;
     const uint32_t base = blockIdx.x * CUT_TILE + threadIdx.x * CUT_ITEMS;
 #pragma unroll
@@ -1928,7 +1949,11 @@ __global__ __launch_bounds__(TK_BLOCK, 4) void k_task(const TaskArgs g)
         if (td.kind == TASK_BATCH || (td.kind == TASK_RANGE_DIRECT && (td.first >> 1) <= BT_EMAX && td.np <= BT_PMAX)) {
             // consecutive non-BIG rows, or a column range of a BIG row with at most one chunk of entries and at most as many products
             // as the registers hold (a heavy histogram bucket -- many products on few columns -- may have more): spgemm_batch.hip.hpp
-            batch_task<MODE>(g, td, t, ntasks, smem, dbg_ph);
+            // DENSE: the blocks between the first and the last column of every hashed row fit the table slot for slot
+            const bool dense = SPADA_BT_DENSE && (td.kind == TASK_BATCH ? (td.np & BINFO_DENSE) != 0
+                                                                         : (td.col_hi >> BT_BSHIFT) - (td.col_lo >> BT_BSHIFT) < (uint32_t)TK_T);
+            if (dense) batch_task<MODE, true>(g, td, t, ntasks, smem, dbg_ph);
+            else batch_task<MODE, false>(g, td, t, ntasks, smem, dbg_ph);
         } else {
             // ---- RANGE task: columns [col_lo, col_hi] of a BIG row, products in the scratch slice -----------------------------
             // Single pass when the slice cannot overflow the table (at most NOUT products or columns; a column sub-range of a heavy

@@ -371,6 +371,9 @@ __global__ __launch_bounds__(256) void k_row_class(const uint64_t *__restrict__ 
 //   k_big_scatter one workgroup per part of a spilled row: walks its products again and stores (column, a * b) at the bucket's
 //                 cursor: afterwards the scratch slice of every range is contiguous
 // k_cut3 copies the range descriptors into the task list in row order.
+#ifndef SPADA_LB_PAUSE_MAX
+#define SPADA_LB_PAUSE_MAX 6   // the pause between two polls of a missing predecessor grows to s_sleep(8) + this many s_sleep(16)
+#endif
 #ifndef SPADA_BX_PART
 #define SPADA_BX_PART 8192
 #endif
@@ -1544,7 +1547,7 @@ __device__ inline unsigned long long chain_lookback(unsigned long long *status, 
                         while ((__hip_atomic_load(&status[idx * ST_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & ST_MASK) == 0) {
                             ++spins;
                             __builtin_amdgcn_s_sleep(8);
-                            if (pause < 6) ++pause;
+                            if (pause < SPADA_LB_PAUSE_MAX) ++pause;
                             for (uint32_t z = 0; z < pause; ++z) __builtin_amdgcn_s_sleep(16);
                         }
                     }

@@ -355,3 +355,41 @@ def test_engine_first_then_torch_in_one_process():
         "print('ok', n)\n" % repo)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and r.stdout.strip().startswith("ok"), r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("span_blocks", [40, 81, 82, 83, 120, 700, 2047, 2048, 2049])
+def test_dense_tasks_at_the_slot_boundary(engine, span_blocks):
+    """Batches whose rows' column spans, in blocks of 16 columns, add up to about the table's 2048 slots: below the bound a batch
+    (or a single row) takes the DENSE path of the batch task (slot = place of the block in its row, no keys, no sorting), above
+    it the hashed one; every row of C spans exactly `span_blocks` blocks, ~25 rows make a batch.  Both entry points against the
+    oracle."""
+    import spada_sim_amd as S
+    rng = np.random.default_rng(span_blocks)
+    rows, k = 3000, 1500
+    width = span_blocks * 16
+    n = 200000 + width
+    # B: rows 2 i and 2 i + 1 share a window of `width` columns that starts at a multiple of 16: first entry at its first column,
+    # last entry at its last, 38 random ones in between
+    b_ptr = np.zeros(k + 1, np.uint64)
+    b_idx, b_val = [], []
+    lo = 0
+    for j in range(k):
+        if j % 2 == 0:
+            lo = int(rng.integers(0, (n - width) // 16)) * 16
+        inner = np.unique(rng.integers(lo + 1, lo + width - 1, 38)) if width > 2 else np.zeros(0, np.int64)
+        c = np.unique(np.concatenate([[lo, lo + width - 1], inner]))
+        b_idx.append(c.astype(np.uint64))
+        b_val.append(rng.uniform(0.5, 1.5, len(c)))
+        b_ptr[j + 1] = b_ptr[j] + len(c)
+    b = S.CsMat((k, n), b_ptr, np.concatenate(b_idx), np.concatenate(b_val))
+    # A: every row selects one such pair of B rows: its row of C spans the pair's window, i.e. exactly span_blocks blocks
+    a_ptr = np.arange(0, 2 * rows + 1, 2, dtype=np.uint64)
+    sel = 2 * rng.integers(0, k // 2, rows)
+    a_idx = np.stack([sel, sel + 1], 1).reshape(-1).astype(np.uint64)
+    a = S.CsMat((rows, k), a_ptr, a_idx, rng.uniform(0.5, 1.5, 2 * rows))
+    ao, bo = to_oracle(a), to_oracle(b)
+    ref = oracle.spgemm_sortmerge(ao, bo)
+    c, st = fused(engine, a, b)
+    assert_parity(c, ref, ao, bo, RTOL)
+    c2 = engine.spgemm(a, b)
+    assert_parity(c2, ref, ao, bo, RTOL)

@@ -1509,10 +1509,68 @@ __host__ __device__ constexpr size_t task_lds()
 // chain_publish: the task's own count, as soon as it is known (thread 0).  chain_lookback: the exclusive prefix, as late as it is
 // needed (all threads) -- the LDS half of the emission sits between the two, so the wait for predecessors that are still
 // accumulating is mostly over by the time the look-back starts.
+//
+// SPADA_CHAIN_SCANNER (default): the walking is taken away from the tasks.  Workgroup 0 of the kernel takes no tasks; its first
+// wave reads the status words in task order, SCAN_WIN windows of 64 per step with all loads in flight together, and turns every
+// count it finds (AGG) into the inclusive prefix (INC) in place.  A task then waits for ITS OWN word with one lane.  Why: a status
+// word is an agent-scope access that no L2 serves (about a microsecond), and with tasks walking back 64 predecessors per round
+// trip the front of known prefixes cannot advance faster than 64 tasks per round trip, while a thousand workgroups re-read the
+// windows in front of it -- measured (development build with a look-back that costs nothing): 85 of 818 us on the web input, 150 of
+// 654 us on the mesh input were spent waiting there.  The scanner reads every word about once and keeps 256 of them in flight.
+#ifndef SPADA_CHAIN_SCANNER
+#define SPADA_CHAIN_SCANNER 1
+#endif
+constexpr int SCAN_WIN = 4;
 __device__ inline void chain_publish(unsigned long long *status, uint32_t t, unsigned long long count)
 {
     if (threadIdx.x == 0)
-        __hip_atomic_store(&status[(size_t)t * ST_STRIDE], (t == 0 ? ST_INC : ST_AGG) | count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&status[(size_t)t * ST_STRIDE], ((t == 0 && !SPADA_CHAIN_SCANNER) ? ST_INC : ST_AGG) | count, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// the scanner (first wave of workgroup 0, one-pass mode): tasks [t_lo, t_end) in order
+__device__ inline void chain_scanner(unsigned long long *status, uint32_t t_lo, uint32_t t_end)
+{
+    if (threadIdx.x >= 64) return;
+    const uint32_t lane = threadIdx.x;
+    unsigned long long run = 0;   // counts of the tasks before `next`
+    uint32_t next = t_lo, idle = 0;
+    while (next < t_end) {
+        unsigned long long sv[SCAN_WIN];
+#pragma unroll
+        for (int j = 0; j < SCAN_WIN; ++j) {
+            const uint32_t idx = next + (uint32_t)j * 64u + lane;
+            sv[j] = 0ull;
+            if (idx < t_end && idx >= next) sv[j] = __hip_atomic_load(&status[(size_t)idx * ST_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        uint32_t adv = 0;
+        bool open = true;
+#pragma unroll
+        for (int j = 0; j < SCAN_WIN; ++j) {
+            if (!open) continue;   // (uniform)
+            const uint32_t idx = next + (uint32_t)j * 64u + lane;
+            const unsigned long long ready = __ballot((sv[j] & ST_MASK) == ST_AGG);
+            const uint32_t lead = ready == ~0ull ? 64u : (uint32_t)__ffsll((long long)~ready) - 1u;   // leading lanes with a count
+            unsigned long long v = lane < lead ? (sv[j] & ~ST_MASK) : 0ull, inc = v;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned long long u = __shfl_up(inc, o);
+                if ((int)lane >= o) inc += u;
+            }
+            if (lane < lead) __hip_atomic_store(&status[(size_t)idx * ST_STRIDE], ST_INC | (run + inc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            run += __shfl(inc, 63);
+            adv += lead;
+            open = lead == 64u;
+        }
+        next += adv;
+        if (adv) {
+            idle = 0;
+        } else {
+            __builtin_amdgcn_s_sleep(2);
+            if (idle < 8) ++idle;
+            for (uint32_t z = 0; z < idle; ++z) __builtin_amdgcn_s_sleep(4);
+        }
+    }
 }
 
 __device__ inline unsigned long long chain_lookback(unsigned long long *status, uint32_t t, unsigned long long count, uint32_t *hdr,
@@ -1520,6 +1578,37 @@ __device__ inline unsigned long long chain_lookback(unsigned long long *status, 
 {
     const int tid = threadIdx.x, lane = tid & 63;
     unsigned long long dbg_win = 0, dbg_spin = 0;
+#if SPADA_CHAIN_SCANNER
+    // wait for the scanner to turn this task's own count into the inclusive prefix (one lane, one word)
+    if (tid == 0) {
+        unsigned long long s;
+        uint32_t pause = 0;
+        for (;;) {
+            s = __hip_atomic_load(&status[(size_t)t * ST_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((s & ST_MASK) == ST_INC) break;
+            __builtin_amdgcn_s_sleep(2);
+            if (pause < SPADA_LB_PAUSE_MAX) ++pause;
+            for (uint32_t z = 0; z < pause; ++z) __builtin_amdgcn_s_sleep(4);
+        }
+        const unsigned long long excl = (s & ~ST_MASK) - count;
+        hdr[48] = (uint32_t)excl;
+        hdr[49] = (uint32_t)(excl >> 32);
+    }
+    __syncthreads();
+    {
+        const unsigned long long base_ = ((unsigned long long)hdr[49] << 32) | hdr[48];
+        __syncthreads();
+        return base_;
+    }
+#endif
+#ifdef SPADA_FAKE_CHAIN   /* development: what the one-pass mode would take if the look-back cost nothing (WRONG positions) */
+    if (tid == 0) {
+        hdr[48] = 0;
+        hdr[49] = 0;
+    }
+    __syncthreads();
+    return 0ull;
+#endif
     if (tid < 64) {
         if (t == 0) {
             if (lane == 0) {
@@ -1929,6 +2018,10 @@ __global__ __launch_bounds__(TK_BLOCK, 4) void k_task(const TaskArgs g)
     const int tid = threadIdx.x;
     const uint32_t ntasks = g.ctr->ntasks, task_end = min(ntasks, g.task_hi);
     if (g.ctr->abort_flag) return;
+    if (SPADA_CHAIN_SCANNER && MODE == MODE_FUSED && blockIdx.x == 0) {   // the chain's scanner: this workgroup takes no tasks
+        chain_scanner(g.status, g.task_lo, task_end);
+        return;
+    }
 
     // Tasks are taken by ticket, in (almost) chain order: queue q hands out tasks q, q + NQ, q + 2 NQ, ...  The smallest task that
     // is not finished is either running -- it waits for finished tasks only -- or the next one of its queue, whose workgroups
@@ -2128,6 +2221,10 @@ __global__ __launch_bounds__(TK_BLOCK, 3) void k_task_sm(const TaskArgs g)
     const int tid = threadIdx.x;
     const uint32_t ntasks = g.ctr->ntasks, task_end = min(ntasks, g.task_hi);
     if (g.ctr->abort_flag) return;
+    if (SPADA_CHAIN_SCANNER && MODE == MODE_FUSED && blockIdx.x == 0) {   // the chain's scanner (see k_task)
+        chain_scanner(g.status, g.task_lo, task_end);
+        return;
+    }
     const uint32_t colmask = g.colbits >= 32 ? 0xFFFFFFFFu : ((1u << g.colbits) - 1u);
     uint32_t *my_ticket = &g.ctr->ticket[(blockIdx.x % TK_NQ) * 32];
     if (tid == 0) hdr[50] = g.task_lo + atomicAdd(my_ticket, 1u) * TK_NQ + blockIdx.x % TK_NQ;

@@ -372,7 +372,7 @@ __global__ __launch_bounds__(256) void k_row_class(const uint64_t *__restrict__ 
 //                 cursor: afterwards the scratch slice of every range is contiguous
 // k_cut3 copies the range descriptors into the task list in row order.
 #ifndef SPADA_LB_PAUSE_MAX
-#define SPADA_LB_PAUSE_MAX 6   // the pause between two polls of a missing predecessor grows to s_sleep(8) + this many s_sleep(16)
+#define SPADA_LB_PAUSE_MAX 2   // a task polls its status word with a pause that grows by this many steps (0 .. 12: within 1 %)
 #endif
 #ifndef SPADA_BX_PART
 #define SPADA_BX_PART 8192

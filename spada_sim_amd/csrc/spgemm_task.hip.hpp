@@ -842,7 +842,7 @@ __global__ __launch_bounds__(TK_BLOCK) void k_big_plan(const uint64_t *__restric
             // spilled: the counts of every part become its cursors.  Layout of the row's slice: RANGE major (a range task reads one
             // contiguous slice), inside a range PART major, inside (range, part) by bucket -- the products a part sends to a range
             // form ONE run, and the runs of consecutive parts (which one workgroup of k_big_scatter writes one after the other) are
-            // neighbours: a hub row with 10^6 products has ~500 ranges but 2048 buckets, so the runs are four times as long as
+            // neighbours: a hub row with 10^6 products has ~500 ranges but 1024 buckets, so the runs are twice as long as
             // with one run per (bucket, part)
             __syncthreads();   // (aux: the descriptors above are written)
 #pragma unroll
@@ -1058,6 +1058,8 @@ __device__ inline uint32_t cut_tile(const uint32_t *__restrict__ row_cl, const u
     for (int j = 0; j < CUT_ITEMS; ++j) {
         const uint32_t i = base + j;
         const uint32_t cl = i < n ? row_cl[i] : (uint32_t)CLS_EMPTY;
+        RowRec rr{0u, 0u, 0u, (uint32_t)CLS_EMPTY};
+        if (SPADA_BT_DENSE && i < n) rr = row_rec[i];   // (issued with the other loads of the row, not behind its class)
         cls[j] = (uint8_t)(cl & 7u);
         const uint32_t len = cl >> 3;
         const uint32_t P = i < n ? row_nprod[i] : 0u;
@@ -1066,10 +1068,8 @@ __device__ inline uint32_t cut_tile(const uint32_t *__restrict__ row_cl, const u
         w[j] = cls[j] == CLS_COPY ? P : 0u;
         e[j] = (cls[j] == CLS_BIG || fat[j]) ? 0u : len;
         sp[j] = 0;
-        if (SPADA_BT_DENSE && (cls[j] == CLS_SMALL || cls[j] == CLS_SOLO)) {   // blocks a table addressed by column would need for the row
-            const RowRec rr = row_rec[i];
+        if (SPADA_BT_DENSE && (cls[j] == CLS_SMALL || cls[j] == CLS_SOLO))   // blocks a table addressed by column would need for the row
             sp[j] = min((rr.kmax >> BT_BSHIFT) - (rr.kmin >> BT_BSHIFT) + 1u, 2u * (uint32_t)TK_T);
-        }
         L.mark[threadIdx.x * CUT_ITEMS + j] = 0;
         sc += c[j];
         sw += w[j];

@@ -100,7 +100,7 @@ __device__ inline uint32_t batch_scan(const T *arr, T *out, uint32_t N, uint32_t
 // the rows, are at most the table's slots.  Then the table needs no keys: block b of row r lives in slot soff[r] + b - bmin[r], the
 // slots are in output order as they are, and the whole order stage is ONE prefix sum over the popcounts of the 2048 masks (meshes
 // and banded matrices: half of the batches of the cop20k_A surrogate).
-template <int MODE, bool DENSE>
+template <int MODE, bool DENSE, bool SPILL = false>
 __device__ inline void batch_task(const TaskArgs &g, const TaskDesc &td, uint32_t t, uint32_t ntasks, unsigned char *smem,
                                   unsigned long long (&dbg_ph)[9])
 {
@@ -145,8 +145,11 @@ __device__ inline void batch_task(const TaskArgs &g, const TaskDesc &td, uint32_
     if (SPADA_TASK_DBG && tid == 0) dbg_ph[8] += 1;
 #define BSTOP(id) do { if (MODE == MODE_NUMERIC && SPADA_BT_STOP == (id)) return; asm volatile("; BT_MARK s" #id ::: "memory"); } while (0)   /* development: finer cut points */
     // BATCH: rows, entries, products from batch_info | DIRECT RANGE: one row, its entries (descriptor), the products of the range
+    // SPILLED RANGE (DENSE only): one row, no entries -- its products (column, scaled value) are a contiguous slice of the scratch arrays
+    static_assert(!SPILL || DENSE, "spilled ranges take the dense path only");
+    constexpr bool spill = SPILL;   // (td.kind == TASK_RANGE: the dispatch in k_task)
     const bool range = td.kind != TASK_BATCH;
-    const uint32_t rb = td.row, R = range ? 1u : (td.np & 0xFFu), E = range ? (td.first >> 1) : ((td.np >> 8) & 0x3FFu),
+    const uint32_t rb = td.row, R = range ? 1u : (td.np & 0xFFu), E = spill ? 0u : range ? (td.first >> 1) : ((td.np >> 8) & 0x3FFu),
                    PT = range ? td.np : ((td.np >> 18) & 0xFFFu);
     const uint64_t e0 = td.src;
     const uint32_t colbits = g.colbits;                       // >= BT_BSHIFT (the engine sees to it)
@@ -296,8 +299,8 @@ __device__ inline void batch_task(const TaskArgs &g, const TaskDesc &td, uint32_
             for (int i = 0; i < 2; ++i) mine += len[i] ? ((1u << 16) | len[i]) : 0u;   // entries with products << 16 | products
         }
         BSTOP(11);
-        uint32_t tot32;
-        const uint32_t ex32 = block_scan_excl_dpp(mine, slot_ent, &tot32);
+        uint32_t tot32 = PT, ex32 = 0;   // (a spilled range: PT <= BT_PMAX products, no entries -- the dispatch in k_task sees to it)
+        if (!spill) ex32 = block_scan_excl_dpp(mine, slot_ent, &tot32);
         P = tot32 & 0xFFFFu;
         const uint32_t nent = tot32 >> 16;   // entries with products
         BSTOP(12);
@@ -325,11 +328,11 @@ __device__ inline void batch_task(const TaskArgs &g, const TaskDesc &td, uint32_
                 }
         }
         BSTOP(13);
-        __syncthreads();
+        if (!spill) __syncthreads();
         // tails before every 64-bit word of the bitmap (32 words): every wave scans them for itself and keeps the prefixes in the
         // lanes of one register (word w in lane w): the per-segment values are then scalar reads, and no second barrier is needed
-        uint32_t tail_pre;
-        {
+        uint32_t tail_pre = 0;
+        if (!spill) {
             const uint32_t c = (uint32_t)__popcll(bm64[lane & 31]);
             const uint32_t inc = wave_scan_incl_u32(lane < 32 ? c : 0u);
             tail_pre = inc - c;
@@ -341,51 +344,64 @@ __device__ inline void batch_task(const TaskArgs &g, const TaskDesc &td, uint32_
                 // lane l of a segment holds product seg + l, i.e. bit l of one bitmap word: the word and its prefix are wave-uniform
                 // reads; the entry of a product = the entries that END before it = tails before the word + tails below the lane (a
                 // v_mbcnt pair).  Lanes past the end take the last product (a valid address; only their atomics are switched off).
-                unsigned long long bits[4];
-                uint32_t bp[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const uint32_t w = (uint32_t)r * 16u + (uint32_t)u * 4u + wave_u;   // = segment / 64
-                    bits[u] = bm64[w];
-                    bp[u] = (uint32_t)__builtin_amdgcn_readlane((int)tail_pre, (int)w);
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) asm volatile("" : "+v"(bits[u]));
-                uint32_t pp[4], j[4];
+                uint32_t pp[4];
                 bool act[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const uint32_t p = (uint32_t)r * 1024u + ((uint32_t)u * 4u + wave_u) * 64u + lane;
                     act[u] = p < P;
                     pp[u] = min(p, P - 1u);
-                    // (a clamped lane sits past the last tail of its word: it counts every tail of the word, i.e. one entry too many
-                    // whenever the last product is in this word -- min() with the last entry puts it back)
-                    const uint32_t below =
-                        __builtin_amdgcn_mbcnt_hi((uint32_t)(bits[u] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bits[u], 0u));
-                    j[u] = min(bp[u] + below, nent - 1u);
                 }
-                uint64_t pack[4];
-                double a_[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const EntryRecNum er = w_ent[j[u]];
-                    pack[u] = er.pack;
-                    a_[u] = er.av;
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    asm volatile("" : "+v"(pack[u]));
-                    if constexpr (VALUES) asm volatile("" : "+v"(a_[u]));
-                }
-                uint64_t q[4];
+                uint64_t pack[4] = {0, 0, 0, 0}, q[4];   // (a spilled range: local row 0, not copied)
                 uint32_t col[4];
+                if (spill) {
+                    // the slice holds (column, a * b) of the range's products in any order: product p is element p
 #pragma unroll
-                for (int u = 0; u < 4; ++u) q[u] = ((pack[u] & M48) + pp[u]) & M48;
+                    for (int u = 0; u < 4; ++u) q[u] = td.src + pp[u];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) col[u] = g.bidx[q[u]];
+                    for (int u = 0; u < 4; ++u) col[u] = g.scr_col[q[u]];
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    if constexpr (VALUES) r_v[r * 4 + u] = a_[u] * g.bval[q[u]];   // simulator.rs:100-101
+                    for (int u = 0; u < 4; ++u)
+                        if constexpr (VALUES) r_v[r * 4 + u] = g.scr_val[q[u]];
+                } else {
+                    unsigned long long bits[4];
+                    uint32_t bp[4], j[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const uint32_t w = (uint32_t)r * 16u + (uint32_t)u * 4u + wave_u;   // = segment / 64
+                        bits[u] = bm64[w];
+                        bp[u] = (uint32_t)__builtin_amdgcn_readlane((int)tail_pre, (int)w);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) asm volatile("" : "+v"(bits[u]));
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        // (a clamped lane sits past the last tail of its word: it counts every tail of the word, i.e. one entry too
+                        // many whenever the last product is in this word -- min() with the last entry puts it back)
+                        const uint32_t below =
+                            __builtin_amdgcn_mbcnt_hi((uint32_t)(bits[u] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bits[u], 0u));
+                        j[u] = min(bp[u] + below, nent - 1u);
+                    }
+                    double a_[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const EntryRecNum er = w_ent[j[u]];
+                        pack[u] = er.pack;
+                        a_[u] = er.av;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        asm volatile("" : "+v"(pack[u]));
+                        if constexpr (VALUES) asm volatile("" : "+v"(a_[u]));
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) q[u] = ((pack[u] & M48) + pp[u]) & M48;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) col[u] = g.bidx[q[u]];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if constexpr (VALUES) r_v[r * 4 + u] = a_[u] * g.bval[q[u]];   // simulator.rs:100-101
+                }
                 uint32_t hk[4], h[4], old[4];
                 bool hashed[4];
 #pragma unroll

@@ -107,6 +107,9 @@ struct TaskCounters {   // (a multiple of 8 bytes: k_init clears it in 8-byte wo
 // batch -- more than BT_EMAX entries, or one entry that selects more than BT_PMAX products -- are BIG whatever their products.
 constexpr uint32_t BT_EMAX = 512, BT_PMAX = 2048;
 constexpr int BT_BSHIFT = 4;   // a block = 16 consecutive columns of one row of C (the batch tasks key their table by blocks)
+#ifndef SPADA_SPILL_DENSE
+#define SPADA_SPILL_DENSE 1
+#endif
 #ifndef SPADA_BT_DENSE
 #define SPADA_BT_DENSE 1       // batches / ranges whose blocks fit the table slot for slot skip hashing and sorting (spgemm_batch.hip.hpp)
 #endif
@@ -2042,13 +2045,17 @@ __global__ __launch_bounds__(TK_BLOCK, 4) void k_task(const TaskArgs g)
         if constexpr (MODE == MODE_FUSED) __builtin_amdgcn_s_setprio(SPADA_PRIO);
 #endif
         const TaskDesc td = g.tasks[t];
-        if (td.kind == TASK_BATCH || (td.kind == TASK_RANGE_DIRECT && (td.first >> 1) <= BT_EMAX && td.np <= BT_PMAX)) {
+        // (SPADA_SPILL_DENSE: a single-pass spilled range that fits the registers and whose blocks fit the table slot for slot)
+        const bool spill_dense = SPADA_BT_DENSE && SPADA_SPILL_DENSE && td.kind == TASK_RANGE && !(td.first & 2u) && td.np <= BT_PMAX &&
+                                 (td.col_hi >> BT_BSHIFT) - (td.col_lo >> BT_BSHIFT) < (uint32_t)TK_T;
+        if (td.kind == TASK_BATCH || (td.kind == TASK_RANGE_DIRECT && (td.first >> 1) <= BT_EMAX && td.np <= BT_PMAX) || spill_dense) {
             // consecutive non-BIG rows, or a column range of a BIG row with at most one chunk of entries and at most as many products
             // as the registers hold (a heavy histogram bucket -- many products on few columns -- may have more): spgemm_batch.hip.hpp
             // DENSE: the blocks between the first and the last column of every hashed row fit the table slot for slot
             const bool dense = SPADA_BT_DENSE && (td.kind == TASK_BATCH ? (td.np & BINFO_DENSE) != 0
                                                                          : (td.col_hi >> BT_BSHIFT) - (td.col_lo >> BT_BSHIFT) < (uint32_t)TK_T);
-            if (dense) batch_task<MODE, true>(g, td, t, ntasks, smem, dbg_ph);
+            if (spill_dense) batch_task<MODE, true, true>(g, td, t, ntasks, smem, dbg_ph);
+            else if (dense) batch_task<MODE, true>(g, td, t, ntasks, smem, dbg_ph);
             else batch_task<MODE, false>(g, td, t, ntasks, smem, dbg_ph);
         } else {
             // ---- RANGE task: columns [col_lo, col_hi] of a BIG row, products in the scratch slice -----------------------------

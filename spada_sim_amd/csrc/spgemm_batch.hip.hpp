@@ -25,12 +25,12 @@
 //              first(block) + popcount(mask below its bit): no search, no comparison
 //   scale-add  the retained products add their value at that rank (ds_add_f64 into a dense array in OUTPUT order) and leave
 //              their column there; simulator.rs:213-218 adds left to right, here the order is arbitrary (1e-9)
-//   emit       after the look-back: the dense arrays are stored as they are (neighbouring lanes, neighbouring addresses), the
+//   emit       once the task's position is known (the chain): the dense arrays are stored as they are (neighbouring lanes, neighbouring addresses), the
 //              retained products of COPY rows go straight to their place
 // The DIRECT RANGE tasks of BIG rows (columns [col_lo, col_hi] of one row whose products exceed a table; the row's entries are
 // narrowed to the range by two binary searches each: B rows are ascending) run through the same stages whenever the row has at
 // most BT_EMAX entries: one row, no COPY entries, the range as the row's column bounds.
-// LDS (40 320 bytes, four workgroups per CU; regions are reused by the stages):
+// LDS (40 832 bytes, four workgroups per CU; regions are reused by the stages):
 //   hdr 256 | MB u32[2048]: mask | first output << 16 | K 8 KB: keys, then (popcounts, slots) in block order | X 8 KB: entry
 //   records, then bucket counters | Y 8 KB: head bits, then keys in bucket order | Z 4 KB: slots in bucket order | rows 3.2 KB;
 //   the dense output arrays of the last stages lie over K + X (values) and Y (composite keys).

@@ -21,7 +21,7 @@
 //   k_task               ->  persistent workgroups take tasks by ticket.  A task expands its products (flat walk over the A
 //                            entries of its rows, narrowed to a column range or not, or a stream over its scratch slice),
 //                            accumulates them in a 2048-slot LDS hash table (ds_cmpst / ds_add_f64), counts the distinct outputs per row, obtains the position
-//                            of its slice of C from the tasks before it by a decoupled look-back over per-task status words,
+//                            of its slice of C from the per-task status words of the chain (a scanner workgroup turns the tasks' counts into prefixes),
 //                            and emits its outputs in (row, column) order (monotone buckets + in-bucket rank).
 //                            MODE COUNT   : symbolic phase of the two-phase ABI -- counts only, no chain: the tasks leave their
 //                                           counts and k_pos1-4 scan them into C.indptr and the positions of the range tasks

@@ -284,10 +284,13 @@ def main():
             if "c_ptr" not in out_bufs:
                 out_bufs["c_ptr"] = torch.empty(r1 - r0 + 1, dtype=torch.int64, device=dev)
                 out_bufs["buf"] = torch.empty(max(cap, 1) * 12, dtype=torch.uint8, device=dev)
-            c_ptr, buf = out_bufs["c_ptr"], out_bufs["buf"]
-            c_val = buf[:max(cap, 1) * 8].view(torch.float64)
-            c_idx = buf[max(cap, 1) * 8:].view(torch.int32)
-            nnz = eng.fused(da, da, r0, r1, c_ptr.data_ptr(), c_idx.data_ptr(), c_val.data_ptr(), cap)
+                # (the views and their device pointers are taken once as well: three tensor operations per step are ~10 us of
+                # interpreter time that no caller of the C ABI spends)
+                out_bufs["c_val"] = out_bufs["buf"][:max(cap, 1) * 8].view(torch.float64)
+                out_bufs["c_idx"] = out_bufs["buf"][max(cap, 1) * 8:].view(torch.int32)
+                out_bufs["ptrs"] = (out_bufs["c_ptr"].data_ptr(), out_bufs["c_idx"].data_ptr(), out_bufs["c_val"].data_ptr())
+            c_ptr, c_idx, c_val = out_bufs["c_ptr"], out_bufs["c_idx"], out_bufs["c_val"]
+            nnz = eng.fused(da, da, r0, r1, *out_bufs["ptrs"], cap)
         else:
             c_ptr = torch.empty(r1 - r0 + 1, dtype=torch.int64, device=dev)
             nnz = eng.symbolic(da, da, r0, r1)

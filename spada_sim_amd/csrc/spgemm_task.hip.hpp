@@ -1524,10 +1524,12 @@ __host__ __device__ constexpr size_t task_lds()
 #define SPADA_CHAIN_SCANNER 1
 #endif
 constexpr int SCAN_WIN = 4;
+// (a grid too small to spare a workgroup -- every ticket queue must keep one that takes tasks -- walks back as before)
+__device__ inline bool chain_has_scanner() { return SPADA_CHAIN_SCANNER != 0 && gridDim.x >= 2u * (uint32_t)TK_NQ; }
 __device__ inline void chain_publish(unsigned long long *status, uint32_t t, unsigned long long count)
 {
     if (threadIdx.x == 0)
-        __hip_atomic_store(&status[(size_t)t * ST_STRIDE], ((t == 0 && !SPADA_CHAIN_SCANNER) ? ST_INC : ST_AGG) | count, __ATOMIC_RELAXED,
+        __hip_atomic_store(&status[(size_t)t * ST_STRIDE], ((t == 0 && !chain_has_scanner()) ? ST_INC : ST_AGG) | count, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
 }
 
@@ -1581,7 +1583,7 @@ __device__ inline unsigned long long chain_lookback(unsigned long long *status, 
 {
     const int tid = threadIdx.x, lane = tid & 63;
     unsigned long long dbg_win = 0, dbg_spin = 0;
-#if SPADA_CHAIN_SCANNER
+    if (chain_has_scanner()) {
     // wait for the scanner to turn this task's own count into the inclusive prefix (one lane, one word)
     if (tid == 0) {
         unsigned long long s;
@@ -1603,7 +1605,7 @@ __device__ inline unsigned long long chain_lookback(unsigned long long *status, 
         __syncthreads();
         return base_;
     }
-#endif
+    }
 #ifdef SPADA_FAKE_CHAIN   /* development: what the one-pass mode would take if the look-back cost nothing (WRONG positions) */
     if (tid == 0) {
         hdr[48] = 0;
@@ -2021,7 +2023,7 @@ __global__ __launch_bounds__(TK_BLOCK, 4) void k_task(const TaskArgs g)
     const int tid = threadIdx.x;
     const uint32_t ntasks = g.ctr->ntasks, task_end = min(ntasks, g.task_hi);
     if (g.ctr->abort_flag) return;
-    if (SPADA_CHAIN_SCANNER && MODE == MODE_FUSED && blockIdx.x == 0) {   // the chain's scanner: this workgroup takes no tasks
+    if (chain_has_scanner() && MODE == MODE_FUSED && blockIdx.x == 0) {   // the chain's scanner: this workgroup takes no tasks
         chain_scanner(g.status, g.task_lo, task_end);
         return;
     }
@@ -2228,7 +2230,7 @@ __global__ __launch_bounds__(TK_BLOCK, 3) void k_task_sm(const TaskArgs g)
     const int tid = threadIdx.x;
     const uint32_t ntasks = g.ctr->ntasks, task_end = min(ntasks, g.task_hi);
     if (g.ctr->abort_flag) return;
-    if (SPADA_CHAIN_SCANNER && MODE == MODE_FUSED && blockIdx.x == 0) {   // the chain's scanner (see k_task)
+    if (chain_has_scanner() && MODE == MODE_FUSED && blockIdx.x == 0) {   // the chain's scanner (see k_task)
         chain_scanner(g.status, g.task_lo, task_end);
         return;
     }

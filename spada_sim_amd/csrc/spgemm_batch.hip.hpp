@@ -147,6 +147,11 @@ __device__ inline void batch_task(const TaskArgs &g, const TaskDesc &td, uint32_
     // BATCH: rows, entries, products from batch_info | DIRECT RANGE: one row, its entries (descriptor), the products of the range
     // SPILLED RANGE (DENSE only): one row, no entries -- its products (column, scaled value) are a contiguous slice of the scratch arrays
     static_assert(!SPILL || DENSE, "spilled ranges take the dense path only");
+    // a spilled range uses slots of 32 columns (the whole mask word; the slots' first outputs in an array of their own): twice the
+    // column range fits the table.  DSH / DMASK: columns per slot of the DENSE layouts.
+    constexpr int DSH = SPILL ? BT_BSHIFT + 1 : BT_BSHIFT;
+    constexpr uint32_t DMASK = SPILL ? 0xFFFFFFFFu : 0xFFFFu;
+    uint16_t *fo = (uint16_t *)(smem + BT_OFF_Z);   // SPILL: first output of every slot (region Z: the dense paths do not sort)
     constexpr bool spill = SPILL;   // (td.kind == TASK_RANGE: the dispatch in k_task)
     const bool range = td.kind != TASK_BATCH;
     const uint32_t rb = td.row, R = range ? 1u : (td.np & 0xFFu), E = spill ? 0u : range ? (td.first >> 1) : ((td.np >> 8) & 0x3FFu),
@@ -208,11 +213,11 @@ __device__ inline void batch_task(const TaskArgs &g, const TaskDesc &td, uint32_
     uint32_t soff = 0, spanb = 0;   // DENSE: first slot of the row, its slots
     bool dense_ok = true;
     if constexpr (DENSE) {
-        spanb = row_hashed && rr.nprod ? (rr.kmax >> BT_BSHIFT) - (rr.kmin >> BT_BSHIFT) + 1u : 0u;
+        spanb = row_hashed && rr.nprod ? (rr.kmax >> DSH) - (rr.kmin >> DSH) + 1u : 0u;
         uint32_t sp_tot;
         soff = block_scan_excl_dpp(min(spanb, 2u * (uint32_t)T), slot_sp, &sp_tot);
         dense_ok = sp_tot <= (uint32_t)T;   // (the cut / the dispatch guarantee it)
-        if ((uint32_t)tid < R) s_dense[tid] = soff - (rr.kmin >> BT_BSHIFT);
+        if ((uint32_t)tid < R) s_dense[tid] = soff - (rr.kmin >> DSH);
     }
     if ((uint32_t)tid < R) {
         s_cls[tid] = (uint8_t)rr.cls;
@@ -416,7 +421,7 @@ __device__ inline void batch_task(const TaskArgs &g, const TaskDesc &td, uint32_
                     if constexpr (DENSE) {
                         // the slot is the block's place in the row: nothing to insert, nothing to probe (masked: a lane without a hashed
                         // product computes one from a stale record)
-                        h[u] = (s_dense[R == 1 ? 0u : lr] + (col[u] >> BT_BSHIFT)) & (uint32_t)(T - 1);
+                        h[u] = (s_dense[R == 1 ? 0u : lr] + (col[u] >> DSH)) & (uint32_t)(T - 1);
                         old[u] = hk[u];
                     } else {
                         h[u] = hash_slot<TK_LOG_T>(hk[u]);
@@ -442,7 +447,7 @@ __device__ inline void batch_task(const TaskArgs &g, const TaskDesc &td, uint32_
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
                     if (hashed[u]) {
-                        const uint32_t bit = 1u << (col[u] & 15u);
+                        const uint32_t bit = 1u << (col[u] & (DENSE ? (1u << DSH) - 1u : 15u));
                         const uint32_t was = atomicOr(&mb[h[u]], bit);
                         mynew += (was & bit) ? 0u : 1u;
                         r_h[r * 4 + u] = h[u];
@@ -484,20 +489,27 @@ __device__ inline void batch_task(const TaskArgs &g, const TaskDesc &td, uint32_
         uint4 wa = m4[2 * tid], wb = m4[2 * tid + 1];
         uint32_t w[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w}, sum = 0;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) sum += (uint32_t)__popc(w[j] & 0xFFFFu);
+        for (int j = 0; j < 8; ++j) sum += (uint32_t)__popc(w[j] & DMASK);
         uint32_t tot;
         uint32_t ex = block_scan_excl_dpp(sum, slot_bk, &tot);
+        uint32_t f[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const uint32_t c = (uint32_t)__popc(w[j] & 0xFFFFu);
+            const uint32_t c = (uint32_t)__popc(w[j] & DMASK);
+            f[j] = ex;
             w[j] |= ex << 16;
             ex += c;
         }
-        m4[2 * tid] = make_uint4(w[0], w[1], w[2], w[3]);
-        m4[2 * tid + 1] = make_uint4(w[4], w[5], w[6], w[7]);
+        if constexpr (SPILL) {
+            ((uint4 *)fo)[tid] = make_uint4(f[0] | (f[1] << 16), f[2] | (f[3] << 16), f[4] | (f[5] << 16), f[6] | (f[7] << 16));
+        } else {
+            m4[2 * tid] = make_uint4(w[0], w[1], w[2], w[3]);
+            m4[2 * tid + 1] = make_uint4(w[4], w[5], w[6], w[7]);
+        }
         __syncthreads();
     };
-    auto dense_first_of = [&](uint32_t slot) { return slot < (uint32_t)T ? mb[slot] >> 16 : NO; };   // hashed outputs before a slot
+    // hashed outputs before a slot
+    auto dense_first_of = [&](uint32_t slot) { return slot < (uint32_t)T ? (SPILL ? (uint32_t)fo[slot] : mb[slot] >> 16) : NO; };
 
     BSTOP(15);
     if constexpr (MODE == MODE_COUNT) {
@@ -696,7 +708,8 @@ __device__ inline void batch_task(const TaskArgs &g, const TaskDesc &td, uint32_
         for (int i = 0; i < 8; ++i)
             if (r_h[i] < BT_H_NONE) {
                 const uint32_t w = mb[r_h[i]];
-                const uint32_t rank = (w >> 16) + (uint32_t)__popc(w & ((1u << (r_ck[i] & 15u)) - 1u));
+                const uint32_t rank = SPILL ? (uint32_t)fo[r_h[i]] + (uint32_t)__popc(w & ((1u << (r_ck[i] & 31u)) - 1u))
+                                            : (w >> 16) + (uint32_t)__popc(w & ((1u << (r_ck[i] & 15u)) - 1u));
                 atomicAdd(&vals[rank], r_v[i]);
                 cols[rank] = r_ck[i];
             }

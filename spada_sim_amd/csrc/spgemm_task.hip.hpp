@@ -2049,7 +2049,7 @@ __global__ __launch_bounds__(TK_BLOCK, 4) void k_task(const TaskArgs g)
         const TaskDesc td = g.tasks[t];
         // (SPADA_SPILL_DENSE: a single-pass spilled range that fits the registers and whose blocks fit the table slot for slot)
         const bool spill_dense = SPADA_BT_DENSE && SPADA_SPILL_DENSE && td.kind == TASK_RANGE && !(td.first & 2u) && td.np <= BT_PMAX &&
-                                 (td.col_hi >> BT_BSHIFT) - (td.col_lo >> BT_BSHIFT) < (uint32_t)TK_T;
+                                 (td.col_hi >> (BT_BSHIFT + 1)) - (td.col_lo >> (BT_BSHIFT + 1)) < (uint32_t)TK_T;   // (slots of 32 columns)
         if (td.kind == TASK_BATCH || (td.kind == TASK_RANGE_DIRECT && (td.first >> 1) <= BT_EMAX && td.np <= BT_PMAX) || spill_dense) {
             // consecutive non-BIG rows, or a column range of a BIG row with at most one chunk of entries and at most as many products
             // as the registers hold (a heavy histogram bucket -- many products on few columns -- may have more): spgemm_batch.hip.hpp

@@ -310,7 +310,7 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
     const uint32_t ntiles = std::max<uint32_t>((n + CUT_TILE - 1) / CUT_TILE, 1);
     if ((rc = c->t_tiles.ensure(((size_t)ntiles + 2) * 8, false, s, &c->ws_bytes))) return rc;   // per tile: tasks | first task
     // composite hash keys of a batch: (local row << colbits) | column
-    uint32_t cb = BT_BSHIFT;   // (at least the bits of a block of columns: the batch tasks key their table by column >> BT_BSHIFT)
+    uint32_t cb = BT_BSHIFT + 1;   // (at least the bits of a dense slot of 32 columns: the batch tasks take column bits of the composite key)
     while (cb < 32 && (1ull << cb) < b->cols) ++cb;
     c->colbits = cb;
     const uint32_t rmax = cb >= 32 ? 1u : (uint32_t)std::min<uint64_t>((1ull << (32 - cb)) - 1, TK_RMAX);

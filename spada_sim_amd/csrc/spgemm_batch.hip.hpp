@@ -39,6 +39,9 @@
 #ifndef SPADA_BT_STOP
 #define SPADA_BT_STOP 0
 #endif
+#ifndef SPADA_DENSE_WIDE
+#define SPADA_DENSE_WIDE 1
+#endif
 #ifndef SPADA_BT_FIRST_ROLLED
 #define SPADA_BT_FIRST_ROLLED 1
 #endif
@@ -149,15 +152,16 @@ __device__ inline void batch_task(const TaskArgs &g, const TaskDesc &td, uint32_
     static_assert(!SPILL || DENSE, "spilled ranges take the dense path only");
     // a spilled range uses slots of 32 columns (the whole mask word; the slots' first outputs in an array of their own): twice the
     // column range fits the table.  DSH / DMASK: columns per slot of the DENSE layouts.
-    constexpr int DSH = SPILL ? BT_BSHIFT + 1 : BT_BSHIFT;
-    constexpr uint32_t DMASK = SPILL ? 0xFFFFFFFFu : 0xFFFFu;
+    constexpr bool WIDE = SPILL || (DENSE && SPADA_DENSE_WIDE != 0);   // (SPADA_DENSE_WIDE: every dense task, not only the spilled ranges)
+    constexpr int DSH = WIDE ? BT_BSHIFT + 1 : BT_BSHIFT;
+    constexpr uint32_t DMASK = WIDE ? 0xFFFFFFFFu : 0xFFFFu;
     uint16_t *fo = (uint16_t *)(smem + BT_OFF_Z);   // SPILL: first output of every slot (region Z: the dense paths do not sort)
     constexpr bool spill = SPILL;   // (td.kind == TASK_RANGE: the dispatch in k_task)
     const bool range = td.kind != TASK_BATCH;
     const uint32_t rb = td.row, R = range ? 1u : (td.np & 0xFFu), E = spill ? 0u : range ? (td.first >> 1) : ((td.np >> 8) & 0x3FFu),
                    PT = range ? td.np : ((td.np >> 18) & 0xFFFu);
     const uint64_t e0 = td.src;
-    const uint32_t colbits = g.colbits;                       // >= BT_BSHIFT (the engine sees to it)
+    const uint32_t colbits = g.colbits;                       // >= BT_BSHIFT + 1 (the engine sees to it)
     const uint32_t colmask = colbits >= 32 ? 0xFFFFFFFFu : ((1u << colbits) - 1u);
     const uint32_t hshift = colbits >= 32 ? 0u : colbits - BT_BSHIFT;   // block key = composite key >> 4 = local row << hshift | block
     const uint32_t blkmask = colbits >= 32 ? 0xFFFFFFFFu : ((1u << hshift) - 1u);
@@ -500,7 +504,7 @@ __device__ inline void batch_task(const TaskArgs &g, const TaskDesc &td, uint32_
             w[j] |= ex << 16;
             ex += c;
         }
-        if constexpr (SPILL) {
+        if constexpr (WIDE) {
             ((uint4 *)fo)[tid] = make_uint4(f[0] | (f[1] << 16), f[2] | (f[3] << 16), f[4] | (f[5] << 16), f[6] | (f[7] << 16));
         } else {
             m4[2 * tid] = make_uint4(w[0], w[1], w[2], w[3]);
@@ -509,7 +513,7 @@ __device__ inline void batch_task(const TaskArgs &g, const TaskDesc &td, uint32_
         __syncthreads();
     };
     // hashed outputs before a slot
-    auto dense_first_of = [&](uint32_t slot) { return slot < (uint32_t)T ? (SPILL ? (uint32_t)fo[slot] : mb[slot] >> 16) : NO; };
+    auto dense_first_of = [&](uint32_t slot) { return slot < (uint32_t)T ? (WIDE ? (uint32_t)fo[slot] : mb[slot] >> 16) : NO; };
 
     BSTOP(15);
     if constexpr (MODE == MODE_COUNT) {
@@ -708,7 +712,7 @@ __device__ inline void batch_task(const TaskArgs &g, const TaskDesc &td, uint32_
         for (int i = 0; i < 8; ++i)
             if (r_h[i] < BT_H_NONE) {
                 const uint32_t w = mb[r_h[i]];
-                const uint32_t rank = SPILL ? (uint32_t)fo[r_h[i]] + (uint32_t)__popc(w & ((1u << (r_ck[i] & 31u)) - 1u))
+                const uint32_t rank = WIDE ? (uint32_t)fo[r_h[i]] + (uint32_t)__popc(w & ((1u << (r_ck[i] & 31u)) - 1u))
                                             : (w >> 16) + (uint32_t)__popc(w & ((1u << (r_ck[i] & 15u)) - 1u));
                 atomicAdd(&vals[rank], r_v[i]);
                 cols[rank] = r_ck[i];

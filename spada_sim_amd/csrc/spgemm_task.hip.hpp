@@ -110,6 +110,10 @@ constexpr int BT_BSHIFT = 4;   // a block = 16 consecutive columns of one row of
 #ifndef SPADA_SPILL_DENSE
 #define SPADA_SPILL_DENSE 1
 #endif
+#ifndef SPADA_DENSE_WIDE
+#define SPADA_DENSE_WIDE 1     // slots of 32 columns for every dense task (0: 16 columns, the mask and the first output in one word)
+#endif
+constexpr int BT_DSHIFT = BT_BSHIFT + (SPADA_DENSE_WIDE ? 1 : 0);   // columns per slot of a dense batch / direct range: 2^BT_DSHIFT
 #ifndef SPADA_BT_DENSE
 #define SPADA_BT_DENSE 1       // batches / ranges whose blocks fit the table slot for slot skip hashing and sorting (spgemm_batch.hip.hpp)
 #endif
@@ -1072,7 +1076,7 @@ __device__ inline uint32_t cut_tile(const uint32_t *__restrict__ row_cl, const u
         e[j] = (cls[j] == CLS_BIG || fat[j]) ? 0u : len;
         sp[j] = 0;
         if (SPADA_BT_DENSE && (cls[j] == CLS_SMALL || cls[j] == CLS_SOLO))   // blocks a table addressed by column would need for the row
-            sp[j] = min((rr.kmax >> BT_BSHIFT) - (rr.kmin >> BT_BSHIFT) + 1u, 2u * (uint32_t)TK_T);
+            sp[j] = min((rr.kmax >> BT_DSHIFT) - (rr.kmin >> BT_DSHIFT) + 1u, 2u * (uint32_t)TK_T);
         L.mark[threadIdx.x * CUT_ITEMS + j] = 0;
         sc += c[j];
         sw += w[j];
@@ -2055,7 +2059,7 @@ __global__ __launch_bounds__(TK_BLOCK, 4) void k_task(const TaskArgs g)
             // as the registers hold (a heavy histogram bucket -- many products on few columns -- may have more): spgemm_batch.hip.hpp
             // DENSE: the blocks between the first and the last column of every hashed row fit the table slot for slot
             const bool dense = SPADA_BT_DENSE && (td.kind == TASK_BATCH ? (td.np & BINFO_DENSE) != 0
-                                                                         : (td.col_hi >> BT_BSHIFT) - (td.col_lo >> BT_BSHIFT) < (uint32_t)TK_T);
+                                                                         : (td.col_hi >> BT_DSHIFT) - (td.col_lo >> BT_DSHIFT) < (uint32_t)TK_T);
             if (spill_dense) batch_task<MODE, true, true>(g, td, t, ntasks, smem, dbg_ph);
             else if (dense) batch_task<MODE, true>(g, td, t, ntasks, smem, dbg_ph);
             else batch_task<MODE, false>(g, td, t, ntasks, smem, dbg_ph);

@@ -357,12 +357,12 @@ def test_engine_first_then_torch_in_one_process():
     assert r.returncode == 0 and r.stdout.strip().startswith("ok"), r.stdout + r.stderr
 
 
-@pytest.mark.parametrize("span_blocks", [40, 81, 82, 83, 120, 700, 2047, 2048, 2049])
+@pytest.mark.parametrize("span_blocks", [40, 81, 82, 83, 120, 163, 164, 165, 700, 2047, 2048, 2049, 4094, 4096, 4098])
 def test_dense_tasks_at_the_slot_boundary(engine, span_blocks):
-    """Batches whose rows' column spans, in blocks of 16 columns, add up to about the table's 2048 slots: below the bound a batch
-    (or a single row) takes the DENSE path of the batch task (slot = place of the block in its row, no keys, no sorting), above
-    it the hashed one; every row of C spans exactly `span_blocks` blocks, ~25 rows make a batch.  Both entry points against the
-    oracle."""
+    """Batches whose rows' column spans add up to about the table's 2048 slots (a slot of the dense layout covers 32 columns, i.e.
+    two of the 16-column blocks counted here): below the bound a batch (or a single row) takes the DENSE path of the batch task
+    (slot = place of the columns in their row, no keys, no sorting), above it the hashed one; every row of C spans exactly
+    `span_blocks` blocks, ~25 rows make a batch.  Both entry points against the oracle."""
     import spada_sim_amd as S
     rng = np.random.default_rng(span_blocks)
     rows, k = 3000, 1500

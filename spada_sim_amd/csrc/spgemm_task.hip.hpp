@@ -110,6 +110,9 @@ constexpr int BT_BSHIFT = 4;   // a block = 16 consecutive columns of one row of
 #ifndef SPADA_SPILL_DENSE
 #define SPADA_SPILL_DENSE 1
 #endif
+#ifndef SPADA_DIRECT_BATCH_ONLY
+#define SPADA_DIRECT_BATCH_ONLY 1   // a BIG row goes direct only if its range tasks fit the batch stages (one chunk of entries); 0: up to BX_DIRECT_MAX_SEARCH
+#endif
 #ifndef SPADA_DENSE_WIDE
 #define SPADA_DENSE_WIDE 1     // slots of 32 columns for every dense task (0: 16 columns, the mask and the first output in one word)
 #endif
@@ -802,7 +805,7 @@ __global__ __launch_bounds__(TK_BLOCK) void k_big_plan(const uint64_t *__restric
             const uint32_t avg_len = (uint32_t)min(P / max(E, 1ull), 0xFFFFFFFFull);
             const unsigned long long steps = 1ull + (avg_len ? 31u - (uint32_t)__clz((int)avg_len) : 0u);   // of one binary search
             const bool direct = allow_direct && hdr[47] == 0 && (unsigned long long)m * E * steps <= (unsigned long long)BX_DIRECT_FACTOR * P &&
-                                E * steps <= BX_DIRECT_MAX_SEARCH;
+                                E * steps <= BX_DIRECT_MAX_SEARCH && (!SPADA_DIRECT_BATCH_ONLY || E <= (unsigned long long)BT_EMAX);
             const uint32_t tb = row_tmp[row];   // big_max_ranges(P) >= m records, allocated by k_big_parts
             const unsigned long long sb = direct ? 0ull : atomicAdd(&ctr->scratch_cursor, P);
             hdr[46] = direct ? 1u : 0u;
@@ -923,8 +926,11 @@ __global__ __launch_bounds__(TK_BLOCK) void k_big_scatter(const double *__restri
     // a workgroup takes BX_RUN consecutive records: the parts of one row (or of neighbouring rows), whose scattered stores fall into
     // the same lines of the row's scratch slice, go through one CU and one L2 one after the other
     // (measured: giving every XCD a contiguous eighth of the records, so that neighbouring runs meet in one L2, is 3 - 8 % SLOWER)
-    for (uint32_t pi0 = blockIdx.x * BX_RUN; pi0 < nparts; pi0 += gridDim.x * BX_RUN)
-    for (uint32_t pi = pi0; pi < min(pi0 + BX_RUN, nparts); ++pi) {
+    // (runs only when many rows are spilled: the parts of a few dozen rows -- the web input's rows with more than 512 entries --
+    // are better spread over as many workgroups than done eight in a row by one)
+    const uint32_t run = ctr->n_spilled > gridDim.x / 8u ? BX_RUN : 1u;
+    for (uint32_t pi0 = blockIdx.x * run; pi0 < nparts; pi0 += gridDim.x * run)
+    for (uint32_t pi = pi0; pi < min(pi0 + run, nparts); ++pi) {
         const BigPart pt = parts[pi];
         if (pt.slot == BX_NOPART) continue;   // (uniform over the workgroup, like the next one)
         const BigSlot sl = slots[pt.slot];

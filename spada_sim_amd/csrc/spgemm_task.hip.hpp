@@ -113,6 +113,9 @@ constexpr int BT_BSHIFT = 4;   // a block = 16 consecutive columns of one row of
 #ifndef SPADA_DIRECT_BATCH_ONLY
 #define SPADA_DIRECT_BATCH_ONLY 1   // a BIG row goes direct only if its range tasks fit the batch stages (one chunk of entries); 0: up to BX_DIRECT_MAX_SEARCH
 #endif
+#ifndef SPADA_DIRECT_EMAX
+#define SPADA_DIRECT_EMAX 512       // (= BT_EMAX; 384 / 256 measured: see profiles/r03_experiments.txt)
+#endif
 #ifndef SPADA_DENSE_WIDE
 #define SPADA_DENSE_WIDE 1     // slots of 32 columns for every dense task (0: 16 columns, the mask and the first output in one word)
 #endif
@@ -805,7 +808,7 @@ __global__ __launch_bounds__(TK_BLOCK) void k_big_plan(const uint64_t *__restric
             const uint32_t avg_len = (uint32_t)min(P / max(E, 1ull), 0xFFFFFFFFull);
             const unsigned long long steps = 1ull + (avg_len ? 31u - (uint32_t)__clz((int)avg_len) : 0u);   // of one binary search
             const bool direct = allow_direct && hdr[47] == 0 && (unsigned long long)m * E * steps <= (unsigned long long)BX_DIRECT_FACTOR * P &&
-                                E * steps <= BX_DIRECT_MAX_SEARCH && (!SPADA_DIRECT_BATCH_ONLY || E <= (unsigned long long)BT_EMAX);
+                                E * steps <= BX_DIRECT_MAX_SEARCH && (!SPADA_DIRECT_BATCH_ONLY || E <= (unsigned long long)SPADA_DIRECT_EMAX);
             const uint32_t tb = row_tmp[row];   // big_max_ranges(P) >= m records, allocated by k_big_parts
             const unsigned long long sb = direct ? 0ull : atomicAdd(&ctr->scratch_cursor, P);
             hdr[46] = direct ? 1u : 0u;

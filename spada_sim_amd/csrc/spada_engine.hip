@@ -370,7 +370,7 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
             hipLaunchKernelGGL(k_big_hist, dim3(c->n_cu * SPADA_BH_GRID), dim3(TK_BLOCK), BX_WALK_LDS, s, b->idx, c->eb0.as<uint64_t>(),
                                c->elen.as<uint32_t>(), c->t_big.as<uint32_t>(), c->row_kmin.as<uint32_t>(),
                                c->row_kmax.as<uint32_t>(), c->t_parts.as<BigPart>(), c->t_parthist.as<uint32_t>(), dc);
-            hipLaunchKernelGGL(k_big_plan, dim3(c->n_cu * SPADA_BP_GRID), dim3(TK_BLOCK), BX_PLAN_LDS, s, a->ptr, c->r0,
+            hipLaunchKernelGGL(k_big_plan, dim3(c->n_cu * SPADA_BP_GRID), dim3(TK_BLOCK), BX_PLAN_LDS, s, a->ptr, c->r0, n,
                                c->accumulator == SPADA_ACC_SORT_MERGE ? 0u : 1u, c->t_big.as<uint32_t>(),
                                c->row_kmin.as<uint32_t>(), c->row_kmax.as<uint32_t>(), c->t_parts.as<BigPart>(),
                                c->t_parthist.as<uint32_t>(), c->t_rowm.as<uint32_t>(), c->t_rowtmp.as<uint32_t>(),

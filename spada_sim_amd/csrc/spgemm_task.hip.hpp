@@ -113,6 +113,10 @@ constexpr int BT_BSHIFT = 4;   // a block = 16 consecutive columns of one row of
 #ifndef SPADA_DIRECT_BATCH_ONLY
 #define SPADA_DIRECT_BATCH_ONLY 1   // a BIG row goes direct only if its range tasks fit the batch stages (one chunk of entries); 0: up to BX_DIRECT_MAX_SEARCH
 #endif
+#ifndef SPADA_DIRECT_ROWS
+#define SPADA_DIRECT_ROWS 400000u   // ... in calls over at least this many rows: on a small row block (an eighth of the web input) the scatter of
+                                    // the few spilled rows costs 20 us and the chain, with a few thousand tasks in all, gains nothing
+#endif
 #ifndef SPADA_DIRECT_EMAX
 #define SPADA_DIRECT_EMAX 512       // (= BT_EMAX; 384 / 256 measured: see profiles/r03_experiments.txt)
 #endif
@@ -649,7 +653,7 @@ static_assert(BX_NB == 4 * TK_BLOCK, "a thread owns four consecutive buckets (on
 // -- rows with few ranges (web graphs, meshes) go direct, rows with thousands of entries and hundreds of ranges (R-MAT hubs) are
 // spilled.  `allow_direct` = 0 spills every row (the sort-merge accumulator numbers the products of a slice in scratch order).
 constexpr uint32_t BX_DIRECT_FACTOR = 8, BX_DIRECT_MAX_SEARCH = 4096;
-__global__ __launch_bounds__(TK_BLOCK) void k_big_plan(const uint64_t *__restrict__ aptr, uint64_t r0, uint32_t allow_direct,
+__global__ __launch_bounds__(TK_BLOCK) void k_big_plan(const uint64_t *__restrict__ aptr, uint64_t r0, uint32_t nrows_call, uint32_t allow_direct,
                                                        const uint32_t *__restrict__ big_rows, const uint32_t *__restrict__ row_kmin,
                                                        const uint32_t *__restrict__ row_kmax, const BigPart *__restrict__ parts,
                                                        uint32_t *__restrict__ part_hist, uint32_t *__restrict__ row_m,
@@ -808,7 +812,7 @@ __global__ __launch_bounds__(TK_BLOCK) void k_big_plan(const uint64_t *__restric
             const uint32_t avg_len = (uint32_t)min(P / max(E, 1ull), 0xFFFFFFFFull);
             const unsigned long long steps = 1ull + (avg_len ? 31u - (uint32_t)__clz((int)avg_len) : 0u);   // of one binary search
             const bool direct = allow_direct && hdr[47] == 0 && (unsigned long long)m * E * steps <= (unsigned long long)BX_DIRECT_FACTOR * P &&
-                                E * steps <= BX_DIRECT_MAX_SEARCH && (!SPADA_DIRECT_BATCH_ONLY || E <= (unsigned long long)SPADA_DIRECT_EMAX);
+                                E * steps <= BX_DIRECT_MAX_SEARCH && (!SPADA_DIRECT_BATCH_ONLY || E <= (unsigned long long)SPADA_DIRECT_EMAX || nrows_call < SPADA_DIRECT_ROWS);
             const uint32_t tb = row_tmp[row];   // big_max_ranges(P) >= m records, allocated by k_big_parts
             const unsigned long long sb = direct ? 0ull : atomicAdd(&ctr->scratch_cursor, P);
             hdr[46] = direct ? 1u : 0u;

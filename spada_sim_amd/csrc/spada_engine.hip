@@ -82,6 +82,9 @@ struct spada_ctx {
     hipStream_t stream = nullptr;     // everything of one SpGEMM is queued on this stream, in order
     int accumulator = SPADA_ACC_LDS_HASH;
     uint32_t n_cu = 256;
+    hipStream_t stream2 = nullptr;    // k_big_scatter runs next to the cut kernels (neither needs the other): fork / join events below
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    uint32_t last_spilled = 0;        // rows the previous pipeline run spilled: the fork / join costs ~10 us and pays only if there is a scatter
     hipEvent_t tev[6] = {};           // phase boundaries of the last pipeline run
     bool phase_timing = true;         // record tev[1], tev[2] (spada_set_phase_timing)
     // state carried from the symbolic to the numeric call
@@ -340,6 +343,7 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
         const uint32_t cap_tmp = (uint32_t)std::min<uint64_t>(c->t_cap_tmp, 0xFFFFFFF0u);
         const uint32_t cap_parts = (uint32_t)std::min<uint64_t>(c->t_cap_parts, 0xFFFFFFF0u);
         ++c->stats.pipeline_runs;
+        bool scatter_on_side = false;
         HIP_TRY(hipEventRecord(c->tev[0], s));
         static_assert(sizeof(TaskCounters) % 8 == 0, "k_init clears the counters in 8-byte words");
         hipLaunchKernelGGL(k_init, dim3(c->n_cu * 4), dim3(256), 0, s, dc, c->t_rowP.as<unsigned long long>(), c->row_kmin.as<uint32_t>(),
@@ -375,11 +379,21 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
                                c->row_kmin.as<uint32_t>(), c->row_kmax.as<uint32_t>(), c->t_parts.as<BigPart>(),
                                c->t_parthist.as<uint32_t>(), c->t_rowm.as<uint32_t>(), c->t_rowtmp.as<uint32_t>(),
                                c->t_tmp.as<TaskDesc>(), cap_tmp, c->t_slots.as<BigSlot>(), c->t_cap_scr, dc);
-            hipLaunchKernelGGL(k_big_scatter, dim3(c->n_cu * 8), dim3(TK_BLOCK), BX_WALK_LDS, s, a->val, b->idx, b->val,
+            // the scatter of the spilled rows runs NEXT to the cut (second stream): the cut needs the range descriptors k_big_plan
+            // wrote, not the scratch; the task kernel waits for both
+            // (only if the previous run of this context spilled anything: without a scatter there is nothing to hide behind the events)
+            const bool side = c->last_spilled != 0;
+            if (side) {
+                HIP_TRY(hipEventRecord(c->ev_fork, s));
+                HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+            }
+            hipLaunchKernelGGL(k_big_scatter, dim3(c->n_cu * 8), dim3(TK_BLOCK), BX_WALK_LDS, side ? c->stream2 : s, a->val, b->idx, b->val,
                                c->eb0.as<uint64_t>(), c->elen.as<uint32_t>(), c->t_big.as<uint32_t>(), c->row_kmin.as<uint32_t>(),
                                c->row_kmax.as<uint32_t>(), c->t_parts.as<BigPart>(), c->t_parthist.as<uint32_t>(),
                                c->t_slots.as<BigSlot>(), c->t_scrcol.as<uint32_t>(), c->t_scrval.as<double>(), seq, dc);
             HIP_TRY(hipGetLastError());
+            if (side) HIP_TRY(hipEventRecord(c->ev_join, c->stream2));
+            scatter_on_side = side;
         }
         if (c->phase_timing) HIP_TRY(hipEventRecord(c->tev[2], s));
         if (n) {
@@ -393,6 +407,7 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
                                c->t_tmp.as<TaskDesc>(), c->t_tasks.as<TaskDesc>(), cap_tasks, fold ? 1u : 0u,
                                c->t_tiles.as<uint32_t>() + ntiles + 2, dc);
             HIP_TRY(hipGetLastError());
+            if (scatter_on_side) HIP_TRY(hipStreamWaitEvent(s, c->ev_join, 0));
         }
         HIP_TRY(hipEventRecord(c->tev[3], s));
         if (n) {
@@ -430,6 +445,7 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
         h.nprod = 0;
         for (int k = 0; k < N_CLS; ++k) h.nprod += h.cls_prod[k];
         h.nprod_big = h.cls_prod[CLS_BIG];
+        c->last_spilled = h.n_spilled;
         if (!h.abort_flag) break;
         if (attempt == 3) return fail(SPADA_ERR_HIP, "task pipeline: workspaces still too small after three retries (flag %u)", h.abort_flag);
         if (h.abort_flag & 4u) return fail(SPADA_ERR_UNSUPPORTED, "a row of C has 2^32 or more products");
@@ -572,6 +588,9 @@ int spada_create(const spada_options *opts, spada_ctx **out)
     c->device = dev;
     c->accumulator = o.accumulator;
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     HIP_TRY(hipHostMalloc((void **)&c->h_tctr, sizeof(TaskCounters), hipHostMallocDefault));
     for (auto &e : c->tev) HIP_TRY(hipEventCreate(&e));
     c->n_cu = (uint32_t)std::max(1, prop.multiProcessorCount);
@@ -592,6 +611,7 @@ void spada_destroy(spada_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->stream2) (void)hipStreamSynchronize(c->stream2);
     dev_free(c->hA);
     if (c->hB != c->hA) dev_free(c->hB);
     dev_free(c->hAr);
@@ -608,6 +628,9 @@ void spada_destroy(spada_ctx *c)
     for (auto &e : c->chunk_ev)
         if (e) (void)hipEventDestroy(e);
     c->t_chunk.release();
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }

@@ -504,7 +504,8 @@ def main():
             {"kernel": "k_big_parts/hist/plan/scatter (big rows: column histograms, ranges; spilled rows scattered into HBM scratch)",
              "ms": ms["ms_big_expand"], "products": st["cls_prod"][4] if "cls_prod" in st else None,
              "spilled_products": st.get("scratch_products"), "spilled_rows": st.get("spill_rows")},
-            {"kernel": "k_cut1/2/3 (task list)", "ms": ms["ms_cut"]},
+            {"kernel": "k_cut1/2/3 (task list; where the scatter of spilled rows runs next to them on the side stream: what they add behind it)",
+             "ms": ms["ms_cut"]},
         ]
         two_phase = not (ms["ms_fused_call"] > 0)
         # a two-phase step whose numeric phase was not timed (0 ms) would price the whole step at the symbolic time alone: no

@@ -84,6 +84,7 @@ struct spada_ctx {
     uint32_t n_cu = 256;
     hipStream_t stream2 = nullptr;    // k_big_scatter runs next to the cut kernels (neither needs the other): fork / join events below
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool scatter_on_side = false;     // the last pipeline run had its scatter on the side stream (phase times below)
     uint32_t last_spilled = 0;        // rows the previous pipeline run spilled: the fork / join costs ~10 us and pays only if there is a scatter
     hipEvent_t tev[6] = {};           // phase boundaries of the last pipeline run
     bool phase_timing = true;         // record tev[1], tev[2] (spada_set_phase_timing)
@@ -343,7 +344,7 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
         const uint32_t cap_tmp = (uint32_t)std::min<uint64_t>(c->t_cap_tmp, 0xFFFFFFF0u);
         const uint32_t cap_parts = (uint32_t)std::min<uint64_t>(c->t_cap_parts, 0xFFFFFFF0u);
         ++c->stats.pipeline_runs;
-        bool scatter_on_side = false;
+        c->scatter_on_side = false;
         HIP_TRY(hipEventRecord(c->tev[0], s));
         static_assert(sizeof(TaskCounters) % 8 == 0, "k_init clears the counters in 8-byte words");
         hipLaunchKernelGGL(k_init, dim3(c->n_cu * 4), dim3(256), 0, s, dc, c->t_rowP.as<unsigned long long>(), c->row_kmin.as<uint32_t>(),
@@ -393,7 +394,7 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
                                c->t_slots.as<BigSlot>(), c->t_scrcol.as<uint32_t>(), c->t_scrval.as<double>(), seq, dc);
             HIP_TRY(hipGetLastError());
             if (side) HIP_TRY(hipEventRecord(c->ev_join, c->stream2));
-            scatter_on_side = side;
+            c->scatter_on_side = side;
         }
         if (c->phase_timing) HIP_TRY(hipEventRecord(c->tev[2], s));
         if (n) {
@@ -407,7 +408,7 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
                                c->t_tmp.as<TaskDesc>(), c->t_tasks.as<TaskDesc>(), cap_tasks, fold ? 1u : 0u,
                                c->t_tiles.as<uint32_t>() + ntiles + 2, dc);
             HIP_TRY(hipGetLastError());
-            if (scatter_on_side) HIP_TRY(hipStreamWaitEvent(s, c->ev_join, 0));
+            if (c->scatter_on_side) HIP_TRY(hipStreamWaitEvent(s, c->ev_join, 0));
         }
         HIP_TRY(hipEventRecord(c->tev[3], s));
         if (n) {
@@ -476,6 +477,15 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
     st.ms_row_stats = c->phase_timing ? tev_ms(c, 0, 1) : 0.f;
     st.ms_big_expand = c->phase_timing ? tev_ms(c, 1, 2) : 0.f;
     st.ms_cut = c->phase_timing ? tev_ms(c, 2, 3) : 0.f;
+    if (c->phase_timing && c->scatter_on_side) {
+        // the scatter ran on the side stream, under the cut: it belongs to the BIG-row stage; what is left for the cut is the time
+        // its kernels ADD behind the scatter (nothing, where the scatter is the longer of the two)
+        float sc = 0.f;
+        if (hipEventElapsedTime(&sc, c->ev_fork, c->ev_join) == hipSuccess && sc > 0.f) {
+            st.ms_big_expand += sc;
+            st.ms_cut = std::max(0.0, (double)st.ms_cut - (double)sc);
+        }
+    }
     st.ms_task = tev_ms(c, 3, 4);
     for (int k = 0; k < N_CLS; ++k) {
         st.cls_rows[k] = h.cls_rows[k];
@@ -589,8 +599,8 @@ int spada_create(const spada_options *opts, spada_ctx **out)
     c->accumulator = o.accumulator;
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
-    HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+    HIP_TRY(hipEventCreate(&c->ev_fork));   // (with timing: the pair brackets the scatter on the side stream)
+    HIP_TRY(hipEventCreate(&c->ev_join));
     HIP_TRY(hipHostMalloc((void **)&c->h_tctr, sizeof(TaskCounters), hipHostMallocDefault));
     for (auto &e : c->tev) HIP_TRY(hipEventCreate(&e));
     c->n_cu = (uint32_t)std::max(1, prop.multiProcessorCount);

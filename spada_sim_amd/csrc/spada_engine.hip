@@ -100,7 +100,7 @@ struct spada_ctx {
     DevBuf row_nprod, row_bin, row_kmin, row_kmax, cptr, t_rowP, t_rowm, t_rowt, t_rowtmp, t_big, t_tiles;
     DevBuf row_cl, row_rec, row_binfo;   // per row: class | length; RowRec; batch_info of the batch that starts at the row
     DevBuf eb0, elen;
-    DevBuf t_tmp, t_tasks, t_status, t_rangeout, t_scrcol, t_scrval, t_scrseq, t_ctr;
+    DevBuf t_tmp, t_tasks, t_status, t_rangeout, t_scrcol, t_scrval, t_scrseq, t_ctr, t_args;
     DevBuf t_possum;                                          // COUNT mode: sums of the tasks' counts per tile
     DevBuf t_parts, t_parthist, t_slots;                      // BIG rows: parts, bucket counts (then cursors) per part, row records
     DevBuf own_idx, own_val, own_ptr, wide_idx;
@@ -245,7 +245,12 @@ void launch_task(spada_ctx *c, const TaskArgs &g)
     if (c->accumulator == SPADA_ACC_SORT_MERGE)
         hipLaunchKernelGGL(k_task_sm<MODE>, dim3(c->n_cu * 3), dim3(TK_BLOCK), task_sm_lds(), c->stream, g);
     else
-        hipLaunchKernelGGL((k_task<MODE, TK_NOUT>), dim3(c->n_cu * 4), dim3(TK_BLOCK), task_kernel_lds(), c->stream, g);
+    {
+        // (the arguments go through device memory: see k_task)
+        hipLaunchKernelGGL(k_task_args, dim3(1), dim3(64), 0, c->stream, g, c->t_args.as<TaskArgs>());
+        hipLaunchKernelGGL((k_task<MODE, TK_NOUT>), dim3(c->n_cu * (SPADA_TASK_WAVES / 2)), dim3(TKW), task_kernel_lds(), c->stream,
+                           (const TaskArgs *)c->t_args.as<TaskArgs>());
+    }
 }
 
 TaskArgs task_args(spada_ctx *c, uint64_t *cptr, uint32_t *d_idx, double *d_val, uint64_t capacity)
@@ -309,6 +314,7 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
     if ((rc = c->t_slots.ensure(n1 * sizeof(BigSlot), false, s, &c->ws_bytes))) return rc;
     if ((rc = c->cptr.ensure(n1 * 8, false, s, &c->ws_bytes))) return rc;
     if ((rc = c->t_ctr.ensure(sizeof(TaskCounters), false, s, &c->ws_bytes))) return rc;
+    if ((rc = c->t_args.ensure(sizeof(TaskArgs), false, s, &c->ws_bytes))) return rc;
     if ((rc = c->eb0.ensure(std::max<uint64_t>(a->nnz, 1) * 8, false, s, &c->ws_bytes))) return rc;
     if ((rc = c->elen.ensure(std::max<uint64_t>(a->nnz, 1) * 4, false, s, &c->ws_bytes))) return rc;
     const uint32_t ntiles = std::max<uint32_t>((n + CUT_TILE - 1) / CUT_TILE, 1);
@@ -501,14 +507,15 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
     }
 #endif
     if (SPADA_TASK_DBG && h.dbg[5])
-        std::fprintf(stderr, "[shape dbg] %llu tasks through the batch path: products %.0f, hashed outputs %.0f, blocks %.0f, rows %.1f, entries %.0f per task\n",
+        std::fprintf(stderr, "[shape dbg] %llu tasks through the batch path: products %.0f, hashed outputs %.0f, blocks %.0f, slots between home and place %.1f, entries %.0f per task\n",
                      h.dbg[5], (double)h.dbg[0] / h.dbg[5], (double)h.dbg[1] / h.dbg[5], (double)h.dbg[2] / h.dbg[5], (double)h.dbg[3] / h.dbg[5],
                      (double)h.dbg[4] / h.dbg[5]);
     if (SPADA_TASK_DBG && h.dbg[6])
-        std::fprintf(stderr, "[batch dbg] %llu batches, cycles each: prologue %.0f | records + head bits %.0f | rounds (gather, keys, masks) %.0f | "
-                     "counts, publish, rows %.0f | block sort %.0f | scale-add %.0f | look-back %.0f | stores %.0f\n", h.dbg[6],
-                     (double)h.dbg[8] / h.dbg[6], (double)h.dbg[9] / h.dbg[6], (double)h.dbg[10] / h.dbg[6], (double)h.dbg[11] / h.dbg[6],
-                     (double)h.dbg[12] / h.dbg[6], (double)h.dbg[13] / h.dbg[6], (double)h.dbg[14] / h.dbg[6], (double)h.dbg[15] / h.dbg[6]);
+        std::fprintf(stderr, "[batch dbg] %llu batches on %llu workgroups, clock ticks each: loads issued, table cleared %.0f | scans, records, tail bits %.0f | "
+                     "expand + accumulate %.0f | count, publish %.0f | prefix sum + displaced blocks %.0f | ranks, values %.0f | chain %.0f | stores %.0f\n",
+                     h.dbg[6], h.dbg[7], (double)h.dbg[8] / h.dbg[6], (double)h.dbg[9] / h.dbg[6], (double)h.dbg[10] / h.dbg[6],
+                     (double)h.dbg[11] / h.dbg[6], (double)h.dbg[12] / h.dbg[6], (double)h.dbg[13] / h.dbg[6], (double)h.dbg[14] / h.dbg[6],
+                     (double)h.dbg[15] / h.dbg[6]);
     st.n_tasks = h.ntasks;
     st.multi_pass_tasks = h.multi_pass_tasks;
     st.scratch_products = h.scratch_cursor;
@@ -630,7 +637,7 @@ void spada_destroy(spada_ctx *c)
     c->un_val.release();
     for (DevBuf *b : {&c->row_cl, &c->row_rec, &c->row_binfo, &c->row_nprod, &c->row_bin, &c->row_kmin, &c->row_kmax, &c->cptr, &c->t_rowP, &c->t_rowm, &c->t_rowt, &c->t_rowtmp,
                       &c->t_big, &c->t_tiles, &c->eb0, &c->elen, &c->t_tmp, &c->t_tasks, &c->t_status, &c->t_rangeout, &c->t_possum, &c->t_scrcol,
-                      &c->t_scrval, &c->t_scrseq, &c->t_ctr, &c->t_parts, &c->t_parthist, &c->t_slots, &c->own_idx, &c->own_val, &c->own_ptr, &c->wide_idx})
+                      &c->t_scrval, &c->t_scrseq, &c->t_ctr, &c->t_args, &c->t_parts, &c->t_parthist, &c->t_slots, &c->own_idx, &c->own_val, &c->own_ptr, &c->wide_idx})
         b->release();
     if (c->h_tctr) (void)hipHostFree(c->h_tctr);
     for (auto &e : c->tev)

@@ -206,6 +206,39 @@ __device__ inline uint32_t block_scan_excl_dpp(uint32_t v, uint32_t *slot, uint3
     return inc - v + (w > 0 ? t.x : 0u) + (w > 1 ? t.y : 0u) + (w > 2 ? t.z : 0u);
 }
 
+// The same for a workgroup of NW waves, in two halves, so that several scans can share ONE barrier: scan_part() before the barrier
+// (wave scan; the wave's total goes to slot[wave]), scan_done() after it (the totals of the waves before this one are added).
+// `slot` = NW words, 16-byte aligned, not used by another scan of the same barrier interval.
+// (`tid` = the caller's thread number: a caller that keeps it opaque per task -- spgemm_batch.hip.hpp -- passes its own)
+__device__ inline uint32_t scan_part(uint32_t v, uint32_t *slot, uint32_t tid)
+{
+    const uint32_t inc = wave_scan_incl_u32(v);
+    if ((tid & 63u) == 63u) slot[tid >> 6] = inc;
+    return inc;
+}
+template <int NW>
+__device__ inline uint32_t scan_done(uint32_t inc, uint32_t v, const uint32_t *slot, uint32_t *total, uint32_t tid)
+{
+    static_assert(NW % 4 == 0, "whole uint4 reads");
+    const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    uint32_t add = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < NW; k += 4) {
+        const uint4 t = *(const uint4 *)(slot + k);
+        add += ((uint32_t)k + 0u < w ? t.x : 0u) + ((uint32_t)k + 1u < w ? t.y : 0u) + ((uint32_t)k + 2u < w ? t.z : 0u) + ((uint32_t)k + 3u < w ? t.w : 0u);
+        tot += t.x + t.y + t.z + t.w;
+    }
+    *total = tot;
+    return inc - v + add;
+}
+template <int NW>
+__device__ inline uint32_t block_scan_excl_dpp_n(uint32_t v, uint32_t *slot, uint32_t *total, uint32_t tid)
+{
+    const uint32_t inc = scan_part(v, slot, tid);
+    __syncthreads();
+    return scan_done<NW>(inc, v, slot, total, tid);
+}
+
 // in-place exclusive scan of arr[0 .. 4 * 256) by a workgroup of 256 threads (four consecutive elements each); ends with a barrier
 __device__ inline void block_exclusive_scan4_dpp(uint32_t *arr, uint32_t *slot)
 {

@@ -48,6 +48,11 @@ namespace spada {
 constexpr uint8_t CLS_EMPTY = 0, CLS_COPY = 1, CLS_SMALL = 2, CLS_SOLO = 3, CLS_BIG = 4;
 constexpr int N_CLS = 5, CLS_SLOTS = 64;
 constexpr int TK_BLOCK = 256, TK_EPT = 2, TK_LOG_T = 11, TK_T = 1 << TK_LOG_T, TK_RMAX = 128;
+// The task kernel itself runs workgroups of TKW = 512 threads (eight waves), four per CU: eight waves per SIMD hide the dependent
+// round trips of a task (ticket -> descriptor -> entries -> B) that four could not (66 % of the wave cycles were waits), and a
+// task passes through its stages in half the time, which is what the tasks behind it in the chain wait for.  The BIG-row kernels
+// and the sort-merge variant keep TK_BLOCK = 256.
+constexpr int TKW = 512, TKW_EPT = 1;
 // Products a task hashes at most (`limit`): the table has TK_T = 2048 slots and is probed by double hashing, which stays cheap up to
 // high fills, so fuller tables win -- fewer tasks, fewer chain hops -- until the probe sequences of a table that REALLY fills up
 // get long: inputs whose products collapse onto few outputs (cop20k_A 4.3-fold, cage12 2.2) are fastest at 2040 products per
@@ -106,7 +111,8 @@ struct TaskCounters {   // (a multiple of 8 bytes: k_init clears it in 8-byte wo
 // contiguous) and at most BT_PMAX products (hashed + copied: two rounds of four per thread).  Rows that cannot be part of such a
 // batch -- more than BT_EMAX entries, or one entry that selects more than BT_PMAX products -- are BIG whatever their products.
 constexpr uint32_t BT_EMAX = 512, BT_PMAX = 2048;
-constexpr int BT_BSHIFT = 4;   // a block = 16 consecutive columns of one row of C (the batch tasks key their table by blocks)
+constexpr int BT_BSHIFT = 5;   // a block = 32 consecutive columns of one row of C (the batch tasks key their table by blocks)
+constexpr uint32_t BT_T = 3072;   // slots of the batch tasks' block table (at most `limit` = 2040 blocks: two thirds full at worst)
 #ifndef SPADA_SPILL_DENSE
 #define SPADA_SPILL_DENSE 1
 #endif
@@ -120,14 +126,11 @@ constexpr int BT_BSHIFT = 4;   // a block = 16 consecutive columns of one row of
 #ifndef SPADA_DIRECT_EMAX
 #define SPADA_DIRECT_EMAX 512       // (= BT_EMAX; 384 / 256 measured: see profiles/r03_experiments.txt)
 #endif
-#ifndef SPADA_DENSE_WIDE
-#define SPADA_DENSE_WIDE 1     // slots of 32 columns for every dense task (0: 16 columns, the mask and the first output in one word)
-#endif
-constexpr int BT_DSHIFT = BT_BSHIFT + (SPADA_DENSE_WIDE ? 1 : 0);   // columns per slot of a dense batch / direct range: 2^BT_DSHIFT
+constexpr int BT_DSHIFT = BT_BSHIFT;   // columns per slot of a dense batch / direct range: 2^BT_DSHIFT
 #ifndef SPADA_BT_DENSE
 #define SPADA_BT_DENSE 1       // batches / ranges whose blocks fit the table slot for slot skip hashing and sorting (spgemm_batch.hip.hpp)
 #endif
-static_assert(BT_EMAX == (uint32_t)TK_BLOCK * TK_EPT && BT_PMAX == 2u * 4u * TK_BLOCK && TK_LIMIT_HI <= BT_PMAX, "one chunk, two rounds");
+static_assert(BT_EMAX == (uint32_t)TKW * TKW_EPT && BT_PMAX == 4u * TKW && TK_LIMIT_HI <= BT_PMAX, "one entry and four products per thread");
 
 // what a task needs to know about a row, in one 16-byte load (written by k_row_class)
 struct __attribute__((aligned(16))) RowRec {
@@ -1089,7 +1092,7 @@ __device__ inline uint32_t cut_tile(const uint32_t *__restrict__ row_cl, const u
         e[j] = (cls[j] == CLS_BIG || fat[j]) ? 0u : len;
         sp[j] = 0;
         if (SPADA_BT_DENSE && (cls[j] == CLS_SMALL || cls[j] == CLS_SOLO))   // blocks a table addressed by column would need for the row
-            sp[j] = min((rr.kmax >> BT_DSHIFT) - (rr.kmin >> BT_DSHIFT) + 1u, 2u * (uint32_t)TK_T);
+            sp[j] = min((rr.kmax >> BT_DSHIFT) - (rr.kmin >> BT_DSHIFT) + 1u, 2u * BT_T);
         L.mark[threadIdx.x * CUT_ITEMS + j] = 0;
         sc += c[j];
         sw += w[j];
@@ -1196,7 +1199,7 @@ __device__ inline uint32_t cut_tile(const uint32_t *__restrict__ row_cl, const u
                 const uint32_t end = nm[j];
                 binfo[j] = fat[j] ? batch_info(1u, 0u, 0u)
                                   : batch_info(end - li, L.pe[end] - L.pe[li], (L.pc[end] - L.pc[li]) + (L.pw[end] - L.pw[li]));
-                if (SPADA_BT_DENSE && !fat[j] && L.pc[end] > L.pc[li] && L.ps[end] - L.ps[li] <= (uint32_t)TK_T) binfo[j] |= BINFO_DENSE;
+                if (SPADA_BT_DENSE && !fat[j] && L.pc[end] > L.pc[li] && L.ps[end] - L.ps[li] <= BT_T) binfo[j] |= BINFO_DENSE;
             }
         }
         local += cr.t[j];
@@ -1692,8 +1695,8 @@ __device__ inline unsigned long long chain_lookback(unsigned long long *status, 
 // offsets of its rows inside the batch in C.indptr) and k_pos1/2/3 turn the counts into positions afterwards.  With the chain,
 // one task that takes long to count -- a multi-pass range of an R-MAT hub -- holds up every task behind it while they occupy
 // the workgroup slots: measured 7x on the hub chunks of R-MAT 22 (277 ms against 38 ms for the numeric phase over the same tasks).
-template <int MODE>
-__device__ inline void task_publish(const TaskArgs &g, uint32_t t, unsigned long long count)
+template <int MODE, class G>
+__device__ inline void task_publish(const G &g, uint32_t t, unsigned long long count)
 {
     if constexpr (MODE == MODE_COUNT) {
         if (threadIdx.x == 0) g.range_out[t] = count;
@@ -1701,8 +1704,8 @@ __device__ inline void task_publish(const TaskArgs &g, uint32_t t, unsigned long
         chain_publish(g.status, t, count);
     }
 }
-template <int MODE>
-__device__ inline unsigned long long task_position(const TaskArgs &g, uint32_t t, unsigned long long count, uint32_t *hdr)
+template <int MODE, class G>
+__device__ inline unsigned long long task_position(const G &g, uint32_t t, unsigned long long count, uint32_t *hdr)
 {
     if constexpr (MODE == MODE_COUNT) return 0ull;
     else return chain_lookback(g.status, t, count, hdr, g.ctr);
@@ -1715,11 +1718,11 @@ __device__ inline unsigned long long task_position(const TaskArgs &g, uint32_t t
 // caller's buffers are too small) and the outputs are stored.  Returns what resolve() returned.
 // s_row[lr] = {boff, n, kmin, scale}, s_out[lr] = first output of the row relative to that position.  NO = outputs in the table.
 constexpr unsigned long long NO_STORE = ~0ull;
-template <bool SINGLE_ROW, int NOUT, class Resolve>
+template <int BLOCK, bool SINGLE_ROW, int NOUT, class Resolve>
 __device__ inline unsigned long long emit_table(unsigned char *smem, uint32_t NO, uint32_t colbits, uint32_t *__restrict__ c_idx,
                                                 double *__restrict__ c_val, Resolve &&resolve)
 {
-    constexpr int BLOCK = TK_BLOCK, T = TK_T, SPT = T / BLOCK, OPT = NOUT / BLOCK;
+    constexpr int T = TK_T, SPT = T / BLOCK, OPT = NOUT / BLOCK;
     uint32_t *hdr = (uint32_t *)smem;
     uint32_t *keys = (uint32_t *)(smem + 256);
     double *vals = (double *)(keys + T);
@@ -1809,12 +1812,13 @@ __device__ inline unsigned long long emit_table(unsigned char *smem, uint32_t NO
 // table).  A wave waits for the longest probe sequence among its 64 lanes, and linear probing's clusters make that tail long.
 __device__ inline uint32_t probe_step(uint32_t key) { return ((key * 0x85EBCA6Bu) >> (32 - TK_LOG_T)) | 1u; }
 
+template <int BLOCK>
 __device__ inline void table_clear(unsigned char *smem)
 {
     uint4 *k4 = (uint4 *)(smem + 256);
-    for (int s = threadIdx.x; s < TK_T / 4; s += TK_BLOCK) k4[s] = make_uint4(EMPTY_KEY, EMPTY_KEY, EMPTY_KEY, EMPTY_KEY);
+    for (int s = threadIdx.x; s < TK_T / 4; s += BLOCK) k4[s] = make_uint4(EMPTY_KEY, EMPTY_KEY, EMPTY_KEY, EMPTY_KEY);
     double2 *v2 = (double2 *)(smem + 256 + (size_t)TK_T * 4);
-    for (int s = threadIdx.x; s < TK_T / 2; s += TK_BLOCK) v2[s] = make_double2(0.0, 0.0);
+    for (int s = threadIdx.x; s < TK_T / 2; s += BLOCK) v2[s] = make_double2(0.0, 0.0);
 }
 
 // insert `key`, add `v`; returns true when the key was new
@@ -1835,7 +1839,7 @@ __device__ inline bool table_insert(uint32_t *keys, double *vals, uint32_t key, 
 }
 
 // RANGE task: accumulate the products of the scratch slice whose column lies in [lo, hi]; returns the number of distinct columns
-template <bool VALUES>
+template <int BLOCK, bool VALUES>
 __device__ inline uint32_t range_accumulate(unsigned char *smem, const uint32_t *__restrict__ scr_col,
                                             const double *__restrict__ scr_val, uint64_t src, uint32_t np, uint32_t lo, uint32_t hi,
                                             bool filter)
@@ -1843,21 +1847,21 @@ __device__ inline uint32_t range_accumulate(unsigned char *smem, const uint32_t 
     uint32_t *hdr = (uint32_t *)smem;
     uint32_t *keys = (uint32_t *)(smem + 256);
     double *vals = (double *)(keys + TK_T);
-    table_clear(smem);
+    table_clear<BLOCK>(smem);
     __syncthreads();
     uint32_t mine = 0;
     constexpr int U = 4;
-    for (uint32_t p0 = threadIdx.x; p0 < np; p0 += U * TK_BLOCK) {
+    for (uint32_t p0 = threadIdx.x; p0 < np; p0 += U * BLOCK) {
         uint32_t c[U];
         double v[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const uint32_t p = p0 + u * TK_BLOCK;
+            const uint32_t p = p0 + u * BLOCK;
             c[u] = p < np ? scr_col[src + p] : EMPTY_KEY;
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const uint32_t p = p0 + u * TK_BLOCK;
+            const uint32_t p = p0 + u * BLOCK;
             v[u] = 0.0;
             if constexpr (VALUES) v[u] = p < np ? scr_val[src + p] : 0.0;
             if (filter && (c[u] < lo || c[u] > hi)) c[u] = EMPTY_KEY;
@@ -1866,20 +1870,21 @@ __device__ inline uint32_t range_accumulate(unsigned char *smem, const uint32_t 
         for (int u = 0; u < U; ++u)
             if (c[u] != EMPTY_KEY) mine += table_insert<VALUES>(keys, vals, c[u], v[u]) ? 1u : 0u;
     }
-    const uint32_t n = group_sum<TK_BLOCK>(mine, hdr);
+    const uint32_t n = group_sum<BLOCK>(mine, hdr);
     __syncthreads();
     return n;
 }
 
+template <int BLOCK>
 __device__ inline uint32_t range_count_products(unsigned char *smem, const uint32_t *__restrict__ scr_col, uint64_t src, uint32_t np,
                                                 uint32_t lo, uint32_t hi)
 {
     uint32_t mine = 0;
-    for (uint32_t p = threadIdx.x; p < np; p += TK_BLOCK) {
+    for (uint32_t p = threadIdx.x; p < np; p += BLOCK) {
         const uint32_t c = scr_col[src + p];
         mine += (c >= lo && c <= hi) ? 1u : 0u;
     }
-    const uint32_t n = group_sum<TK_BLOCK>(mine, (uint32_t *)smem);
+    const uint32_t n = group_sum<BLOCK>(mine, (uint32_t *)smem);
     __syncthreads();
     return n;
 }
@@ -1889,7 +1894,7 @@ __device__ inline uint32_t range_count_products(unsigned char *smem, const uint3
 // range, ascending; a leaf holds <= TK_SOLO_MAX products or <= TK_SOLO_MAX columns, so it fits.  The walk is deterministic: it is
 // run once to count (the chain needs the task's total before anything is stored) and once more to emit.
 // `stack` = 2 * 40 words of LDS that nothing else uses during a RANGE task.
-template <bool EMIT, int NOUT>
+template <int BLOCK, bool EMIT, int NOUT>
 __device__ inline uint32_t range_dfs(unsigned char *smem, uint32_t *stack, RowEmit *s_row, uint64_t *s_out, const TaskDesc &td,
                                      const uint32_t *__restrict__ scr_col, const double *__restrict__ scr_val,
                                      unsigned long long base, uint32_t *__restrict__ c_idx, double *__restrict__ c_val)
@@ -1905,7 +1910,7 @@ __device__ inline uint32_t range_dfs(unsigned char *smem, uint32_t *stack, RowEm
         --sp;
         const uint32_t lo = stack[2 * sp], hi = stack[2 * sp + 1];
         __syncthreads();
-        const uint32_t cntp = range_count_products(smem, scr_col, td.src, td.np, lo, hi);
+        const uint32_t cntp = range_count_products<BLOCK>(smem, scr_col, td.src, td.np, lo, hi);
         if (cntp == 0) continue;
         if (cntp > (uint32_t)NOUT && hi - lo >= (uint32_t)NOUT) {
             const uint32_t mid = lo + (hi - lo) / 2;
@@ -1919,7 +1924,7 @@ __device__ inline uint32_t range_dfs(unsigned char *smem, uint32_t *stack, RowEm
             __syncthreads();
             continue;
         }
-        const uint32_t nl = range_accumulate<EMIT>(smem, scr_col, scr_val, td.src, td.np, lo, hi, true);
+        const uint32_t nl = range_accumulate<BLOCK, EMIT>(smem, scr_col, scr_val, td.src, td.np, lo, hi, true);
         if constexpr (EMIT) {
             if (nl) {
                 if (tid == 0) {
@@ -1927,7 +1932,7 @@ __device__ inline uint32_t range_dfs(unsigned char *smem, uint32_t *stack, RowEm
                     s_out[0] = base + total;
                 }
                 __syncthreads();
-                (void)emit_table<true, NOUT>(smem, nl, 32u, c_idx, c_val, []() -> unsigned long long { return 0ull; });
+                (void)emit_table<BLOCK, true, NOUT>(smem, nl, 32u, c_idx, c_val, []() -> unsigned long long { return 0ull; });
             }
         }
         total += nl;
@@ -1937,17 +1942,17 @@ __device__ inline uint32_t range_dfs(unsigned char *smem, uint32_t *stack, RowEm
 
 // DIRECT range task: the products of BIG row `td.row` whose column lies in [col_lo, col_hi], taken from B itself: every entry's
 // B row is narrowed to the range by two binary searches (B rows are ascending), then the walk is the usual flat one.
-template <bool VALUES>
+template <int BLOCK, int EPT, bool VALUES, class G>
 __device__ inline uint32_t direct_accumulate(unsigned char *smem, unsigned char *region2, uint32_t *s_re, uint64_t *s_a0,
-                                             const TaskArgs &g, const TaskDesc &td)
+                                             const G &g, const TaskDesc &td)
 {
-    constexpr int U = SPADA_FLAT_U, EPT = TK_EPT;
+    constexpr int U = SPADA_FLAT_U;
     uint32_t *hdr = (uint32_t *)smem;
     uint32_t *keys = (uint32_t *)(smem + 256);
     double *vals = (double *)(keys + TK_T);
     const uint64_t a0 = td.src;          // (first entry and entry count travel in the descriptor: no look-up of A's row pointers)
     const uint32_t E = td.first >> 1;
-    table_clear(smem);
+    table_clear<BLOCK>(smem);
     if (threadIdx.x == 0) {
         s_re[0] = 0;
         s_re[1] = E;
@@ -1957,7 +1962,7 @@ __device__ inline uint32_t direct_accumulate(unsigned char *smem, unsigned char 
     const uint32_t lo = td.col_lo, hi = td.col_hi;
     const uint32_t *__restrict__ bidx = g.bidx;
     uint32_t mine = 0;
-    flat_walk<TK_BLOCK, EPT, 1, VALUES, U>(
+    flat_walk<BLOCK, EPT, 1, VALUES, U>(
         s_re, s_a0, 1u, E, g.eb0, g.elen, g.aval, g.bidx, g.bval, region2, hdr,
         [&](uint32_t(&col)[U], uint32_t(&plr)[U], double(&v)[U], uint32_t(&)[U]) {
 #pragma unroll
@@ -2011,7 +2016,7 @@ __device__ inline uint32_t direct_accumulate(unsigned char *smem, unsigned char 
                 len[i] = l2[i] - l1[i];
             }
         });
-    const uint32_t n = group_sum<TK_BLOCK>(mine, hdr);
+    const uint32_t n = group_sum<BLOCK>(mine, hdr);
     __syncthreads();
     return n;
 }
@@ -2021,15 +2026,60 @@ __device__ inline uint32_t direct_accumulate(unsigned char *smem, unsigned char 
 namespace spada {
 
 // dynamic LDS of k_task: its RANGE tasks use the layout of task_lds(), its BATCH tasks the one of spgemm_batch.hip.hpp
-__host__ __device__ constexpr size_t task_kernel_lds() { return task_lds() > batch_lds() ? task_lds() : batch_lds(); }
+// (SPADA_TASK_DBG builds: 32 more words behind everything for the per-workgroup counters -- phase ticks [0 .. 7], batch tasks [8],
+// task shapes [9 .. 13] -- that thread 0 adds to TaskCounters::dbg when the workgroup ends: one hot word takes ~90 atomics per
+// microsecond, per-task atomics made the instrumented kernel six times slower)
+__host__ __device__ constexpr size_t task_dbg_off() { return ((task_lds() > batch_lds() ? task_lds() : batch_lds()) + 15) & ~(size_t)15; }
+__host__ __device__ constexpr size_t task_kernel_lds() { return task_dbg_off() + (SPADA_TASK_DBG ? 128 : 0); }
 static_assert(task_kernel_lds() <= 40960, "four workgroups per CU");
+static_assert(flat_walk_bytes<TKW, TKW_EPT, true>() == flat_walk_bytes<TK_BLOCK, TK_EPT, true>(), "one walk scratch size for both workgroup shapes");
 
-template <int MODE, int NOUT>
-__global__ __launch_bounds__(TK_BLOCK, 4) void k_task(const TaskArgs g)
+#ifndef SPADA_TASK_WAVES
+#define SPADA_TASK_WAVES 8   /* waves per SIMD the task kernel is compiled for (HIP: second argument of __launch_bounds__): 8 = 64 VGPRs */
+#endif
+// ---- RANGE task of the older kind: columns [col_lo, col_hi] of a BIG row -- the products of a spilled row's scratch slice that do not
+// fit the batch stages (more products than the registers hold, sub-ranges of a heavy bucket, multi-pass ranges), or a direct range
+// of a row with more than BT_EMAX entries: table keyed by column, monotone buckets + in-bucket rank (emit_table).
+// NOT inlined into the task kernel: its registers (the flat walk holds four products and their entry records per thread) are
+// allocated on their own, and nothing of it is kept live across the batch tasks of the loop.
+// Single pass when the slice cannot overflow the table (at most NOUT products or columns; a column sub-range of a heavy
+// bucket keeps the products of its own columns), else range_dfs.
+// descriptor of task t (uniform).  The task list was written by the kernels before this one: read through the constant address
+// space, i.e. with one scalar load into scalar registers
+__device__ inline TaskDesc load_task(const TaskDesc *tasks, uint32_t t)
 {
-    constexpr int RMAX = TK_RMAX;
+    static_assert(sizeof(TaskDesc) == 32, "two 16-byte words");
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    typedef const u32x4 __attribute__((address_space(4))) *cptr4;
+    const cptr4 p = (cptr4)(unsigned long long)(tasks + t);
+    const u32x4 a = p[0], b = p[1];
+    TaskDesc d;
+    d.kind = a.x;
+    d.row = a.y;
+    d.np = a.z;
+    d.first = a.w;
+    d.src = ((uint64_t)b.y << 32) | b.x;
+    d.col_lo = b.z;
+    d.col_hi = b.w;
+    return d;
+}
+// (arguments of a function that is not inlined arrive in vector registers: what is uniform is made scalar again)
+typedef const TaskArgs __attribute__((address_space(4))) TaskArgsC;
+__device__ inline TaskArgsC &uniform_args(const TaskArgs *p)
+{
+    const unsigned long long v = (unsigned long long)p;
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+    return *(TaskArgsC *)(((unsigned long long)hi << 32) | lo);
+}
+template <int MODE, int NOUT>
+__device__ __attribute__((noinline)) void range_task(const TaskArgs *gp_, uint32_t t_, uint32_t ntasks_)
+{
+    constexpr int RMAX = TK_RMAX, BLOCK = TKW;
     constexpr bool VALUES = MODE != MODE_COUNT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    TaskArgsC &g = uniform_args(gp_);
+    const uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t_), ntasks = (uint32_t)__builtin_amdgcn_readfirstlane((int)ntasks_);
+    const TaskDesc td = load_task(g.tasks, t);
     uint32_t *hdr = (uint32_t *)smem;
     unsigned char *region2 = smem + 256 + ((size_t)12 << TK_LOG_T);
     unsigned char *rows = region2 + ((task_region2() + 15) & ~(size_t)15);
@@ -2037,6 +2087,117 @@ __global__ __launch_bounds__(TK_BLOCK, 4) void k_task(const TaskArgs g)
     uint64_t *s_a0 = (uint64_t *)(s_row + RMAX + 1);
     uint64_t *s_out = s_a0 + RMAX;
     uint32_t *s_re = (uint32_t *)(s_out + RMAX);
+    const int tid = threadIdx.x;
+    const bool direct = td.kind == TASK_RANGE_DIRECT;
+    const bool single = direct || td.np <= (uint32_t)NOUT || td.col_hi - td.col_lo < (uint32_t)NOUT;
+    uint32_t total;
+    if (direct) {
+        total = direct_accumulate<BLOCK, TKW_EPT, VALUES>(smem, region2, s_re, s_a0, g, td);
+    } else if (single) {
+        total = range_accumulate<BLOCK, VALUES>(smem, g.scr_col, g.scr_val, td.src, td.np, td.col_lo, td.col_hi, (td.first & 2u) != 0);
+    } else {
+        if (tid == 0) atomicAdd(&g.ctr->multi_pass_tasks, 1u);
+        total = range_dfs<BLOCK, false, NOUT>(smem, s_re, s_row, s_out, td, g.scr_col, g.scr_val, 0ull, nullptr, nullptr);
+    }
+    if constexpr (MODE != MODE_NUMERIC) task_publish<MODE>(g, t, total);
+#if SPADA_PRIO
+    if constexpr (MODE == MODE_FUSED) __builtin_amdgcn_s_setprio(0);
+#endif
+    auto resolve = [&]() -> unsigned long long {
+        if constexpr (MODE == MODE_NUMERIC) {
+            return g.range_out[t];
+        } else {
+            const unsigned long long b0 = task_position<MODE>(g, t, total, hdr);
+            if (MODE != MODE_COUNT && tid == 0) {
+                if (td.first & 1u) g.cptr[td.row] = b0;
+                g.range_out[t] = b0;
+                if (t == ntasks - 1) {
+                    g.cptr[g.nrows] = b0 + total;
+                    g.ctr->nnz_c = b0 + total;
+                }
+            }
+            if constexpr (MODE == MODE_FUSED) {
+                if (b0 + total > g.capacity) {
+                    if (tid == 0) atomicOr(&g.ctr->cap_overflow, 1u);
+                    return NO_STORE;
+                }
+            }
+            return b0;
+        }
+    };
+    if (MODE != MODE_COUNT && single && total) {
+        if (tid == 0) {
+            s_row[0] = RowEmit{0u, total, td.col_lo, (float)total / ((float)(td.col_hi - td.col_lo) + 1.0f)};
+            s_out[0] = 0;
+        }
+        __syncthreads();
+        (void)emit_table<BLOCK, true, NOUT>(smem, total, 32u, g.c_idx, g.c_val, resolve);
+    } else {
+        const unsigned long long base = resolve();
+        if (MODE != MODE_COUNT && !single && base != NO_STORE)
+            (void)range_dfs<BLOCK, true, NOUT>(smem, s_re, s_row, s_out, td, g.scr_col, g.scr_val, base, g.c_idx, g.c_val);
+    }
+}
+
+// Which tasks run through the batch stages (spgemm_batch.hip.hpp): consecutive non-BIG rows, a column range of a BIG row with at
+// most one chunk of entries and at most as many products as the registers hold (a heavy histogram bucket -- many products on few
+// columns -- may have more), or (SPADA_SPILL_DENSE) a single-pass spilled range that fits the registers and whose blocks fit the
+// table slot for slot
+__device__ inline bool task_spill_dense(const TaskDesc &td)
+{
+    return SPADA_BT_DENSE && SPADA_SPILL_DENSE && td.kind == TASK_RANGE && !(td.first & 2u) && td.np <= BT_PMAX &&
+           (td.col_hi >> BT_DSHIFT) - (td.col_lo >> BT_DSHIFT) < BT_T;   // (slots of 32 columns)
+}
+__device__ inline bool task_is_batch(const TaskDesc &td)
+{
+#ifdef SPADA_DEV_NO_LEGACY   /* development: resource usage of the batch stages alone */
+    return true;
+#endif
+    return td.kind == TASK_BATCH || (td.kind == TASK_RANGE_DIRECT && (td.first >> 1) <= BT_EMAX && td.np <= BT_PMAX) || task_spill_dense(td);
+}
+
+// which instantiation of the batch stages a descriptor takes.  DENSE: the blocks between the first and the last column of every
+// hashed row fit the table slot for slot
+__device__ inline int task_variant(const TaskDesc &d)
+{
+    if (task_spill_dense(d)) return 2;
+    const bool dense = SPADA_BT_DENSE && (d.kind == TASK_BATCH ? (d.np & BINFO_DENSE) != 0
+                                                                : (d.col_hi >> BT_DSHIFT) - (d.col_lo >> BT_DSHIFT) < BT_T);
+    return dense ? 1 : 0;
+}
+// The prologue of task t, if it is a batch task (else nothing).  A function of its own: it is called where the task before waits
+// for its position -- next to nothing is live there, and its saves and restores lie in the wait -- and ONE copy of the three
+// instantiations serves every call site.
+template <int MODE>
+__device__ __attribute__((noinline)) BatchHead task_prologue(const TaskArgs *gp_, uint32_t t_)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    TaskArgsC &g = uniform_args(gp_);
+    const uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t_);
+    const TaskDesc td = load_task(g.tasks, t);
+    if (!task_is_batch(td)) return BatchHead{0u, 0u, 0u, 0u};
+    const int v = task_variant(td);
+    if (v == 2) return batch_prologue<MODE, true, true>(g, td, t, smem);
+    if (v == 1) return batch_prologue<MODE, true>(g, td, t, smem);
+    return batch_prologue<MODE, false>(g, td, t, smem);
+}
+
+// The arguments live in device memory (TaskArgs written by k_task_args just before) and are read through the constant address
+// space where they are used: passed by value, the ~30 words would be loaded in the kernel's first block and stay live -- i.e.
+// spilled to VGPR lanes -- through the whole task loop (84 v_writelane, 308 v_readlane in the first build of this kernel).
+__global__ void k_task_args(const TaskArgs g, TaskArgs *__restrict__ dst)
+{
+    if (threadIdx.x == 0) *dst = g;
+}
+#ifndef SPADA_TASK_WAVES
+#define SPADA_TASK_WAVES 8   /* waves per SIMD the task kernel is compiled for (HIP: second argument of __launch_bounds__): 8 = 64 VGPRs */
+#endif
+template <int MODE, int NOUT>
+__global__ __launch_bounds__(TKW, SPADA_TASK_WAVES) void k_task(const TaskArgs *__restrict__ gp_)
+{
+    TaskArgsC &g = *(TaskArgsC *)gp_;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t *hdr = (uint32_t *)smem;
     const int tid = threadIdx.x;
     const uint32_t ntasks = g.ctr->ntasks, task_end = min(ntasks, g.task_hi);
     if (g.ctr->abort_flag) return;
@@ -2051,110 +2212,70 @@ __global__ __launch_bounds__(TK_BLOCK, 4) void k_task(const TaskArgs g)
     // every queue has a resident workgroup, which a grid of at least TK_NQ workgroups dispatched in order guarantees.
     uint32_t *my_ticket = &g.ctr->ticket[(blockIdx.x % TK_NQ) * 32];
     if (tid == 0) hdr[50] = g.task_lo + atomicAdd(my_ticket, 1u) * TK_NQ + blockIdx.x % TK_NQ;
+    if (SPADA_TASK_DBG && tid < 32) ((uint32_t *)(smem + task_dbg_off()))[tid] = 0u;
     __syncthreads();
-    uint32_t t = hdr[50];
-    __syncthreads();
-    unsigned long long dbg_ph[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    // (t is uniform: the descriptor is a scalar load, what is derived from it lives in scalar registers)
+    uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)hdr[50]);
+    uint32_t *dbg_ph = (uint32_t *)(smem + task_dbg_off());   // SPADA_TASK_DBG builds
+    TaskDesc td{};
+    BatchHead hd{0u, 0u, 0u, 0u};
+    bool bt = false;
+    auto uniform_head = [](const BatchHead &h) {   // (what a function returns arrives in vector registers)
+        return BatchHead{(uint32_t)__builtin_amdgcn_readfirstlane((int)h.P), (uint32_t)__builtin_amdgcn_readfirstlane((int)h.nent),
+                         (uint32_t)__builtin_amdgcn_readfirstlane((int)h.NBK), (uint32_t)__builtin_amdgcn_readfirstlane((int)h.ncopy)};
+    };
+    if (t < task_end) {
+        td = load_task(g.tasks, t);
+        bt = task_is_batch(td);
+        hd = uniform_head(task_prologue<MODE>(gp_, t));
+    }
+    // Nothing of a task may be computed once before this loop and held in registers across every task -- the kernel is compiled for
+    // 64 of them, such values are spilled, and a scratch reload waits for ALL vector loads in flight (one counter), which cut the
+    // one-round-trip prologue of the first build of this kernel into pieces: the batch task makes its thread number and its
+    // constants opaque per task, and the prologue and the older range path are functions of their own.
     while (t < task_end) {
-        unsigned long long dbg_a = SPADA_TASK_DBG ? __builtin_amdgcn_s_memtime() : 0, dbg_b = dbg_a, dbg_c = dbg_a;
-        // (tickets are taken when the work starts: one taken earlier -- even only across this task's stores, to hide its
-        // round trip -- sits unstarted in the chain, every later task waits for it, and the pipeline loses more than the
-        // round trip it saved: measured +6 % on the web surrogate, +30 % on R-MAT 16)
+        // The NEXT ticket is taken -- and the next task's prologue is run -- where this task has nothing left to do but wait for its
+        // position and store (`next`, called by the task).  Tickets taken earlier than that cost more than they hide: a task that
+        // sits unstarted in the chain holds up every task behind it (measured in rounds 2 and 3: +6 % on the web surrogate, +30 % on
+        // R-MAT 16 for a ticket taken across the stores); taken HERE the workgroup would otherwise idle.
 #if SPADA_PRIO
         if constexpr (MODE == MODE_FUSED) __builtin_amdgcn_s_setprio(SPADA_PRIO);
 #endif
-        const TaskDesc td = g.tasks[t];
-        // (SPADA_SPILL_DENSE: a single-pass spilled range that fits the registers and whose blocks fit the table slot for slot)
-        const bool spill_dense = SPADA_BT_DENSE && SPADA_SPILL_DENSE && td.kind == TASK_RANGE && !(td.first & 2u) && td.np <= BT_PMAX &&
-                                 (td.col_hi >> (BT_BSHIFT + 1)) - (td.col_lo >> (BT_BSHIFT + 1)) < (uint32_t)TK_T;   // (slots of 32 columns)
-        if (td.kind == TASK_BATCH || (td.kind == TASK_RANGE_DIRECT && (td.first >> 1) <= BT_EMAX && td.np <= BT_PMAX) || spill_dense) {
-            // consecutive non-BIG rows, or a column range of a BIG row with at most one chunk of entries and at most as many products
-            // as the registers hold (a heavy histogram bucket -- many products on few columns -- may have more): spgemm_batch.hip.hpp
-            // DENSE: the blocks between the first and the last column of every hashed row fit the table slot for slot
-            const bool dense = SPADA_BT_DENSE && (td.kind == TASK_BATCH ? (td.np & BINFO_DENSE) != 0
-                                                                         : (td.col_hi >> BT_DSHIFT) - (td.col_lo >> BT_DSHIFT) < (uint32_t)TK_T);
-            if (spill_dense) batch_task<MODE, true, true>(g, td, t, ntasks, smem, dbg_ph);
-            else if (dense) batch_task<MODE, true>(g, td, t, ntasks, smem, dbg_ph);
-            else batch_task<MODE, false>(g, td, t, ntasks, smem, dbg_ph);
+        uint32_t t2 = 0xFFFFFFFFu;
+        TaskDesc td2{};
+        BatchHead hd2{0u, 0u, 0u, 0u};
+        bool bt2 = false;
+        auto next = [&]() {
+            __syncthreads();   // (the ticket word of the task before has been read by everyone; this task's outputs are complete in LDS)
+            if (threadIdx.x == 0) hdr[50] = g.task_lo + atomicAdd(my_ticket, 1u) * TK_NQ + blockIdx.x % TK_NQ;
+            __syncthreads();
+            t2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)hdr[50]);
+            if (t2 < task_end) {
+                td2 = load_task(g.tasks, t2);
+                bt2 = task_is_batch(td2);
+                hd2 = uniform_head(task_prologue<MODE>(gp_, t2));
+            }
+        };
+        if (bt) {
+            const int v = task_variant(td);
+            if (v == 2) batch_main<MODE, true, true>(g, td, t, ntasks, smem, dbg_ph, hd, next);
+            else if (v == 1) batch_main<MODE, true>(g, td, t, ntasks, smem, dbg_ph, hd, next);
+            else batch_main<MODE, false>(g, td, t, ntasks, smem, dbg_ph, hd, next);
         } else {
-            // ---- RANGE task: columns [col_lo, col_hi] of a BIG row, products in the scratch slice -----------------------------
-            // Single pass when the slice cannot overflow the table (at most NOUT products or columns; a column sub-range of a heavy
-            // bucket keeps the products of its own columns), else range_dfs.
-            const bool direct = td.kind == TASK_RANGE_DIRECT;
-            const bool single = direct || td.np <= (uint32_t)NOUT || td.col_hi - td.col_lo < (uint32_t)NOUT;
-            uint32_t total;
-            if (direct) {
-                total = direct_accumulate<VALUES>(smem, region2, s_re, s_a0, g, td);
-            } else if (single) {
-                total = range_accumulate<VALUES>(smem, g.scr_col, g.scr_val, td.src, td.np, td.col_lo, td.col_hi, (td.first & 2u) != 0);
-            } else {
-                if (tid == 0) atomicAdd(&g.ctr->multi_pass_tasks, 1u);
-                total = range_dfs<false, NOUT>(smem, s_re, s_row, s_out, td, g.scr_col, g.scr_val, 0ull, nullptr, nullptr);
-            }
-            if (SPADA_TASK_DBG) dbg_b = dbg_c = __builtin_amdgcn_s_memtime();
-            if constexpr (MODE != MODE_NUMERIC) task_publish<MODE>(g, t, total);
-#if SPADA_PRIO
-            if constexpr (MODE == MODE_FUSED) __builtin_amdgcn_s_setprio(0);
-#endif
-#if SPADA_TASK_DBG
-            if (tid == 0) {
-                const unsigned long long w_ = __builtin_amdgcn_s_memtime() - dbg_a;
-                const int kd_ = (int)td.kind - 1;
-                atomicAdd(&g.ctr->dbgh[kd_][w_ / 4096 < 19 ? w_ / 4096 : 19], 1ull);
-                atomicAdd(&g.ctr->dbgh[kd_][20], w_);
-                atomicAdd(&g.ctr->dbgh[kd_][21], 1ull);
-                atomicMax(&g.ctr->dbgh[kd_][22], w_);
-            }
-#endif
-            unsigned long long dbg_w = 0;
-            auto resolve = [&]() -> unsigned long long {
-                if constexpr (MODE == MODE_NUMERIC) {
-                    return g.range_out[t];
-                } else {
-                    const unsigned long long w0 = SPADA_TASK_DBG ? __builtin_amdgcn_s_memtime() : 0;
-                    const unsigned long long b0 = task_position<MODE>(g, t, total, hdr);
-                    if (SPADA_TASK_DBG) dbg_w = __builtin_amdgcn_s_memtime() - w0;
-                    if (MODE != MODE_COUNT && tid == 0) {
-                        if (td.first & 1u) g.cptr[td.row] = b0;
-                        g.range_out[t] = b0;
-                        if (t == ntasks - 1) {
-                            g.cptr[g.nrows] = b0 + total;
-                            g.ctr->nnz_c = b0 + total;
-                        }
-                    }
-                    if constexpr (MODE == MODE_FUSED) {
-                        if (b0 + total > g.capacity) {
-                            if (tid == 0) atomicOr(&g.ctr->cap_overflow, 1u);
-                            return NO_STORE;
-                        }
-                    }
-                    return b0;
-                }
-            };
-            if (MODE != MODE_COUNT && single && total) {
-                if (tid == 0) {
-                    s_row[0] = RowEmit{0u, total, td.col_lo, (float)total / ((float)(td.col_hi - td.col_lo) + 1.0f)};
-                    s_out[0] = 0;
-                }
-                __syncthreads();
-                (void)emit_table<true, NOUT>(smem, total, 32u, g.c_idx, g.c_val, resolve);
-            } else {
-                const unsigned long long base = resolve();
-                if (MODE != MODE_COUNT && !single && base != NO_STORE)
-                    (void)range_dfs<true, NOUT>(smem, s_re, s_row, s_out, td, g.scr_col, g.scr_val, base, g.c_idx, g.c_val);
-            }
-            if (SPADA_TASK_DBG) dbg_c = dbg_b + dbg_w;
+            range_task<MODE, NOUT>(gp_, t, ntasks);
+            next();
         }
-        __syncthreads();
-        if (tid == 0) hdr[50] = g.task_lo + atomicAdd(my_ticket, 1u) * TK_NQ + blockIdx.x % TK_NQ;
-        __syncthreads();
-        t = hdr[50];
-        __syncthreads();
+        t = t2;
+        td = td2;
+        hd = hd2;
+        bt = bt2;
     }
     if (SPADA_TASK_DBG && tid == 0) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) atomicAdd(&g.ctr->dbg[8 + k], dbg_ph[k]);
-        atomicAdd(&g.ctr->dbg[6], dbg_ph[8]);
+        const uint32_t *d = (const uint32_t *)(smem + task_dbg_off());
+        for (int k = 0; k < 8; ++k) atomicAdd(&g.ctr->dbg[8 + k], (unsigned long long)d[k]);
+        atomicAdd(&g.ctr->dbg[6], (unsigned long long)d[8]);
+        if (d[8]) atomicAdd(&g.ctr->dbg[7], 1ull);   // workgroups that took a task: the resident ones
+        for (int k = 0; k < 6; ++k) atomicAdd(&g.ctr->dbg[k], (unsigned long long)d[9 + k]);   // shapes (spgemm_batch.hip.hpp)
     }
 }
 
@@ -2512,7 +2633,7 @@ __global__ __launch_bounds__(TK_BLOCK, 3) void k_task_sm(const TaskArgs g)
                     --sp;
                     const uint32_t lo = stack[2 * sp], hi = stack[2 * sp + 1];
                     __syncthreads();
-                    const uint32_t cntp = range_count_products(smem, g.scr_col, td.src, td.np, lo, hi);
+                    const uint32_t cntp = range_count_products<BLOCK>(smem, g.scr_col, td.src, td.np, lo, hi);
                     if (cntp == 0) continue;
                     if (cntp > TK_SOLO_MAX && hi > lo) {
                         const uint32_t mid = lo + (hi - lo) / 2;

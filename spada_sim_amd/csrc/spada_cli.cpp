@@ -152,14 +152,6 @@ int main(int argc, char **argv)
             else if (acc_name == "sort_merge") accumulator = SPADA_ACC_SORT_MERGE;
             else return usage("--accumulator must be lds_hash or sort_merge");
         }
-        if (cfg.gpus > 1) {
-            // the binary drives ONE GPU.  The sharded path (A-row blocks, B replicated, RCCL allgatherv of C) is a library interface
-            // -- include/spada_comm.h, one process per GPU, see INTEGRATION.md and `bench.py --gpus N` -- so a configuration that asks
-            // for more is refused instead of being silently run on one device
-            std::fprintf(stderr, "error: configuration key `gpus` = %u: spada-sim runs on one GPU; start one process per GPU and use "
-                                 "libspada_comm.so (include/spada_comm.h, INTEGRATION.md) for the sharded path\n", cfg.gpus);
-            return 101;
-        }
         if (category == "nn") {
             // main.rs:35-37 loads a pickled {name: (A, B)} dict through CPython; out of scope here
             std::fprintf(stderr, "error: workload category NN (pickled numpy matrices, py2rust.rs:5-60) is not supported "
@@ -181,6 +173,16 @@ int main(int argc, char **argv)
             std::fprintf(stderr, "Unimplemented simulator %s\n", pos[0].c_str());
             return 101;
         }
+        if (cfg.gpus > 1 && !cycle_model) {
+            // the binary drives ONE GPU.  The sharded path (A-row blocks, B replicated, RCCL allgatherv of C) is a library interface
+            // -- include/spada_comm.h, one process per GPU, see INTEGRATION.md and `bench.py --gpus N` -- so a configuration that asks
+            // for more is refused instead of being silently run on one device.  (The cycle-level model below never touches a
+            // device: there the key is ignored with a warning.)
+            std::fprintf(stderr, "error: configuration key `gpus` = %u: spada-sim runs on one GPU; start one process per GPU and use "
+                                 "libspada_comm.so (include/spada_comm.h, INTEGRATION.md) for the sharded path\n", cfg.gpus);
+            return 101;
+        }
+        if (cfg.gpus > 1) std::fprintf(stderr, "warning: configuration key `gpus` = %u is ignored by the cycle-level model (host only)\n", cfg.gpus);
         if (cycle_model) {
             // ---- the cycle-level model (host only) ----------------------------------------------------------------------
             spada_cycle_config cc{};

@@ -43,10 +43,12 @@ struct spada_comm {
 namespace {
 
 // segment r of the concatenated indptr holds block-local offsets: add the nnz of the blocks before it
+#ifndef SPADA_COMM_MOCK
 __global__ void k_shift_indptr(uint64_t *__restrict__ p, uint64_t n, uint64_t add)
 {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) p[i] += add;
 }
+#endif
 
 int ensure_small(spada_comm *m, size_t words)
 {
@@ -88,8 +90,12 @@ int gather_indptr(spada_comm *m, const uint64_t *d_local, const uint64_t *rows, 
     NCCL_TRY(ncclGroupEnd());
     for (int r = 0; r < m->nranks; ++r)
         if (rows[r] && nnz_off[r]) {
+#ifdef SPADA_COMM_MOCK   /* the sanitizer / call-sequence build (mock/): "device" memory is host memory */
+            for (uint64_t i = 0; i < rows[r]; ++i) d_full[row_off[r] + 1 + i] += nnz_off[r];
+#else
             const uint32_t grid = (uint32_t)std::min<uint64_t>((rows[r] + 255) / 256, 2048);
             hipLaunchKernelGGL(k_shift_indptr, dim3(grid), dim3(256), 0, m->stream, d_full + row_off[r] + 1, rows[r], nnz_off[r]);
+#endif
         }
     HIP_TRY(hipGetLastError());
     return SPADA_OK;

@@ -84,7 +84,10 @@ struct spada_ctx {
     uint32_t n_cu = 256;
     hipStream_t stream2 = nullptr;    // k_big_scatter runs next to the cut kernels (neither needs the other): fork / join events below
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t stream3 = nullptr;    // ... and so does k_big_cuts, next to both
+    hipEvent_t ev_join3 = nullptr;
     bool scatter_on_side = false;     // the last pipeline run had its scatter on the side stream (phase times below)
+    uint64_t last_cuts = 0;           // words of the cut table in the previous pipeline run (k_big_cuts runs next to the cut as well)
     uint32_t last_spilled = 0;        // rows the previous pipeline run spilled: the fork / join costs ~10 us and pays only if there is a scatter
     hipEvent_t tev[6] = {};           // phase boundaries of the last pipeline run
     bool phase_timing = true;         // record tev[1], tev[2] (spada_set_phase_timing)
@@ -100,11 +103,11 @@ struct spada_ctx {
     DevBuf row_nprod, row_bin, row_kmin, row_kmax, cptr, t_rowP, t_rowm, t_rowt, t_rowtmp, t_big, t_tiles;
     DevBuf row_cl, row_rec, row_binfo;   // per row: class | length; RowRec; batch_info of the batch that starts at the row
     DevBuf eb0, elen;
-    DevBuf t_tmp, t_tasks, t_status, t_rangeout, t_scrcol, t_scrval, t_scrseq, t_ctr, t_args;
+    DevBuf t_tmp, t_tasks, t_status, t_rangeout, t_scrcol, t_scrval, t_scrseq, t_ctr, t_args, t_cuts, t_cutitems, t_stagecol, t_stageval;
     DevBuf t_possum;                                          // COUNT mode: sums of the tasks' counts per tile
     DevBuf t_parts, t_parthist, t_slots;                      // BIG rows: parts, bucket counts (then cursors) per part, row records
     DevBuf own_idx, own_val, own_ptr, wide_idx;
-    uint64_t t_cap_tmp = 0, t_cap_tasks = 0, t_cap_scr = 0, t_cap_parts = 0;
+    uint64_t t_cap_tmp = 0, t_cap_tasks = 0, t_cap_scr = 0, t_cap_parts = 0, t_cap_cuts = 0;
     uint32_t prod_limit = TK_SOLO_MAX;   // capacities the kernels may rely on
     TaskCounters *h_tctr = nullptr;   // pinned
     // numeric phase in pieces (spada_dev_spgemm_numeric_plan / _chunk): task boundaries, one event per piece
@@ -275,6 +278,9 @@ TaskArgs task_args(spada_ctx *c, uint64_t *cptr, uint32_t *d_idx, double *d_val,
     g.scr_col = c->t_scrcol.as<uint32_t>();
     g.scr_val = c->t_scrval.as<double>();
     g.scr_seq = c->accumulator == SPADA_ACC_SORT_MERGE ? c->t_scrseq.as<uint32_t>() : nullptr;
+    g.cuts = c->t_cuts.as<uint32_t>();
+    g.stage_col = c->t_stagecol.as<uint32_t>();
+    g.stage_val = c->t_stageval.as<double>();
     g.cptr = cptr;
     g.range_out = c->t_rangeout.as<uint64_t>();
     g.status = c->t_status.as<unsigned long long>();
@@ -293,6 +299,7 @@ TaskArgs task_args(spada_ctx *c, uint64_t *cptr, uint32_t *d_idx, double *d_val,
 // more run with the sizes they report follows when that happened.
 int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, double *d_val, uint64_t capacity)
 {
+    c->chunk_timing_open = false;   // (a numeric phase in pieces whose caller waited on the pieces' events never closed its interval: tev[0 .. 4] are this run's now)
     const spada_dev_csr *a = c->A, *b = c->B;
     const uint32_t n = c->nrows;
     hipStream_t s = c->stream;
@@ -315,6 +322,11 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
     if ((rc = c->cptr.ensure(n1 * 8, false, s, &c->ws_bytes))) return rc;
     if ((rc = c->t_ctr.ensure(sizeof(TaskCounters), false, s, &c->ws_bytes))) return rc;
     if ((rc = c->t_args.ensure(sizeof(TaskArgs), false, s, &c->ws_bytes))) return rc;
+    {   // staging slices of the parked tasks (one-pass mode): one per workgroup of the task kernel
+        const size_t wgs = (size_t)c->n_cu * (SPADA_TASK_WAVES / 2);
+        if ((rc = c->t_stagecol.ensure(wgs * BT_PMAX * 4, false, s, &c->ws_bytes))) return rc;
+        if ((rc = c->t_stageval.ensure(wgs * BT_PMAX * 8, false, s, &c->ws_bytes))) return rc;
+    }
     if ((rc = c->eb0.ensure(std::max<uint64_t>(a->nnz, 1) * 8, false, s, &c->ws_bytes))) return rc;
     if ((rc = c->elen.ensure(std::max<uint64_t>(a->nnz, 1) * 4, false, s, &c->ws_bytes))) return rc;
     const uint32_t ntiles = std::max<uint32_t>((n + CUT_TILE - 1) / CUT_TILE, 1);
@@ -330,6 +342,7 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
         c->t_cap_tasks = n / 4 + 4096;
         c->t_cap_tmp = std::min<uint64_t>(std::max<uint64_t>(a->nnz / 16, 4096), 1u << 20);
         c->t_cap_scr = 1u << 20;
+        c->t_cap_cuts = 1u << 20;
         c->t_cap_parts = std::min<uint64_t>(std::max<uint64_t>(a->nnz / 128, 2048), 32768);   // (4 KB of bucket counts each)
     }
     c->stats.pipeline_runs = 0;
@@ -342,6 +355,9 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
         if ((rc = c->t_tmp.ensure(c->t_cap_tmp * sizeof(TaskDesc), false, s, &c->ws_bytes))) return rc;
         if ((rc = c->t_scrcol.ensure(c->t_cap_scr * 4, false, s, &c->ws_bytes))) return rc;
         if ((rc = c->t_scrval.ensure(c->t_cap_scr * 8, false, s, &c->ws_bytes))) return rc;
+        if ((rc = c->t_cuts.ensure(c->t_cap_cuts * 4, false, s, &c->ws_bytes))) return rc;
+        const uint64_t cap_cut_items = c->t_cap_cuts / BX_CUT_ITEM + (uint64_t)n + 16 * BX_ARENAS;   // (at most one partly filled item per row)
+        if ((rc = c->t_cutitems.ensure(cap_cut_items * sizeof(uint2), false, s, &c->ws_bytes))) return rc;
         if (c->accumulator == SPADA_ACC_SORT_MERGE && (rc = c->t_scrseq.ensure(c->t_cap_scr * 4, false, s, &c->ws_bytes))) return rc;
         if ((rc = c->t_parts.ensure(c->t_cap_parts * sizeof(BigPart), false, s, &c->ws_bytes))) return rc;
         if ((rc = c->t_parthist.ensure(c->t_cap_parts * BX_NB * 4, false, s, &c->ws_bytes))) return rc;
@@ -385,21 +401,29 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
                                c->accumulator == SPADA_ACC_SORT_MERGE ? 0u : 1u, c->t_big.as<uint32_t>(),
                                c->row_kmin.as<uint32_t>(), c->row_kmax.as<uint32_t>(), c->t_parts.as<BigPart>(),
                                c->t_parthist.as<uint32_t>(), c->t_rowm.as<uint32_t>(), c->t_rowtmp.as<uint32_t>(),
-                               c->t_tmp.as<TaskDesc>(), cap_tmp, c->t_slots.as<BigSlot>(), c->t_cap_scr, dc);
+                               c->t_tmp.as<TaskDesc>(), cap_tmp, c->t_slots.as<BigSlot>(), c->t_cap_scr, c->t_cap_cuts,
+                               c->t_cutitems.as<uint2>(), cap_cut_items, dc);
             // the scatter of the spilled rows runs NEXT to the cut (second stream): the cut needs the range descriptors k_big_plan
             // wrote, not the scratch; the task kernel waits for both
             // (only if the previous run of this context spilled anything: without a scatter there is nothing to hide behind the events)
-            const bool side = c->last_spilled != 0;
+            const bool side = c->last_spilled != 0 || c->last_cuts != 0;
             if (side) {
                 HIP_TRY(hipEventRecord(c->ev_fork, s));
                 HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+                HIP_TRY(hipStreamWaitEvent(c->stream3, c->ev_fork, 0));
             }
             hipLaunchKernelGGL(k_big_scatter, dim3(c->n_cu * 8), dim3(TK_BLOCK), BX_WALK_LDS, side ? c->stream2 : s, a->val, b->idx, b->val,
                                c->eb0.as<uint64_t>(), c->elen.as<uint32_t>(), c->t_big.as<uint32_t>(), c->row_kmin.as<uint32_t>(),
                                c->row_kmax.as<uint32_t>(), c->t_parts.as<BigPart>(), c->t_parthist.as<uint32_t>(),
                                c->t_slots.as<BigSlot>(), c->t_scrcol.as<uint32_t>(), c->t_scrval.as<double>(), seq, dc);
-            HIP_TRY(hipGetLastError());
+            // ... and so does the cut table of the direct rows (the cut needs the number of range tasks of a row, not their cuts)
             if (side) HIP_TRY(hipEventRecord(c->ev_join, c->stream2));
+            hipLaunchKernelGGL(k_big_cuts, dim3(c->n_cu * 8), dim3(256), 0, side ? c->stream3 : s, b->idx, c->eb0.as<uint64_t>(),
+                               c->elen.as<uint32_t>(), c->t_big.as<uint32_t>(), c->t_rowm.as<uint32_t>(), c->t_rowtmp.as<uint32_t>(),
+                               c->t_slots.as<BigSlot>(), c->t_tmp.as<TaskDesc>(), c->t_cutitems.as<uint2>(), cap_cut_items,
+                               c->t_cuts.as<uint32_t>(), dc);
+            HIP_TRY(hipGetLastError());
+            if (side) HIP_TRY(hipEventRecord(c->ev_join3, c->stream3));
             c->scatter_on_side = side;
         }
         if (c->phase_timing) HIP_TRY(hipEventRecord(c->tev[2], s));
@@ -414,7 +438,10 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
                                c->t_tmp.as<TaskDesc>(), c->t_tasks.as<TaskDesc>(), cap_tasks, fold ? 1u : 0u,
                                c->t_tiles.as<uint32_t>() + ntiles + 2, dc);
             HIP_TRY(hipGetLastError());
-            if (c->scatter_on_side) HIP_TRY(hipStreamWaitEvent(s, c->ev_join, 0));
+            if (c->scatter_on_side) {
+                HIP_TRY(hipStreamWaitEvent(s, c->ev_join, 0));
+                HIP_TRY(hipStreamWaitEvent(s, c->ev_join3, 0));
+            }
         }
         HIP_TRY(hipEventRecord(c->tev[3], s));
         if (n) {
@@ -453,6 +480,9 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
         for (int k = 0; k < N_CLS; ++k) h.nprod += h.cls_prod[k];
         h.nprod_big = h.cls_prod[CLS_BIG];
         c->last_spilled = h.n_spilled;
+        uint64_t cut_most = 0;   // (the fullest arena sets the size)
+        for (uint32_t a2 = 0; a2 < BX_ARENAS; ++a2) cut_most = std::max<uint64_t>(cut_most, h.cut_arena[a2][0]);
+        c->last_cuts = cut_most;
         if (!h.abort_flag) break;
         if (attempt == 3) return fail(SPADA_ERR_HIP, "task pipeline: workspaces still too small after three retries (flag %u)", h.abort_flag);
         if (h.abort_flag & 4u) return fail(SPADA_ERR_UNSUPPORTED, "a row of C has 2^32 or more products");
@@ -461,6 +491,7 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
                         "products in %llu entries, more than a batch holds", h.dbg[3], h.dbg[0] & 0xFF, h.dbg[0] >> 32, (h.dbg[0] >> 8) & 0xFFFFFF,
                         h.dbg[2], h.dbg[1] & 0xFFFF, h.dbg[1] >> 16);
         c->t_cap_scr = std::max<uint64_t>(c->t_cap_scr, h.scratch_cursor + h.scratch_cursor / 16 + 1024);
+        c->t_cap_cuts = std::max<uint64_t>(c->t_cap_cuts, BX_ARENAS * (cut_most + cut_most / 8 + 1024));
         c->t_cap_tmp = std::max<uint64_t>(c->t_cap_tmp, (uint64_t)h.tmp_cursor + h.tmp_cursor / 16 + 1024);
         c->t_cap_parts = std::max<uint64_t>(c->t_cap_parts, (uint64_t)h.n_parts + h.n_parts / 16 + 256);
         if ((h.abort_flag & 16u) && !h.scratch_cursor)   // the plan has not run: a guess, replaced by the exact size if it is too small
@@ -498,21 +529,28 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
         st.cls_prod[k] = h.cls_prod[k];
     }
 #if SPADA_TASK_DBG
-    for (int k = 0; k < 3; ++k) {
-        if (!h.dbgh[k][21]) continue;
-        std::fprintf(stderr, "[publish dbg] kind %d: %llu tasks, cycles to publish mean %.0f max %llu; histogram (4096-cycle bins):", k + 1,
-                     h.dbgh[k][21], (double)h.dbgh[k][20] / h.dbgh[k][21], h.dbgh[k][22]);
-        for (int b = 0; b < 20; ++b) std::fprintf(stderr, " %llu", h.dbgh[k][b]);
+    if (h.dbgh[2][0]) {
+        std::fprintf(stderr, "[publish dbg] %llu tasks took more than 60000 ticks to publish; the first:", h.dbgh[2][0]);
+        for (unsigned long long n = 0; n < std::min<unsigned long long>(h.dbgh[2][0], 7); ++n) {
+            const unsigned long long a = h.dbgh[2][1 + 3 * n], b = h.dbgh[2][2 + 3 * n], c = h.dbgh[2][3 + 3 * n];
+            std::fprintf(stderr, " [task %llu kind %llu dense %llu: products %llu blocks %llu displaced %llu entries %llu outputs %llu: %llu ticks]", a & 0xFFFFFFFFull,
+                         (a >> 32) & 0xFF, (a >> 40) & 1, b & 0xFFFF, (b >> 16) & 0xFFFF, (b >> 32) & 0xFFFF, b >> 48, c >> 32, c & 0xFFFFFFFFull);
+        }
         std::fprintf(stderr, "\n");
+    }
+    for (int k = 0; k < 2; ++k) {
+        if (!h.dbgh[k][1]) continue;
+        std::fprintf(stderr, "[publish dbg] %s tasks: %llu, clock ticks from ticket to publication: mean %.0f, largest %llu\n", k ? "range" : "batch",
+                     h.dbgh[k][1], 16.0 * (double)h.dbgh[k][0] / (double)h.dbgh[k][1], h.dbgh[k][2]);
     }
 #endif
     if (SPADA_TASK_DBG && h.dbg[5])
-        std::fprintf(stderr, "[shape dbg] %llu tasks through the batch path: products %.0f, hashed outputs %.0f, blocks %.0f, slots between home and place %.1f, entries %.0f per task\n",
+        std::fprintf(stderr, "[shape dbg] %llu tasks through the batch path: products %.0f, hashed outputs %.0f, blocks %.0f, displaced blocks %.1f, entries %.0f per task\n",
                      h.dbg[5], (double)h.dbg[0] / h.dbg[5], (double)h.dbg[1] / h.dbg[5], (double)h.dbg[2] / h.dbg[5], (double)h.dbg[3] / h.dbg[5],
                      (double)h.dbg[4] / h.dbg[5]);
     if (SPADA_TASK_DBG && h.dbg[6])
-        std::fprintf(stderr, "[batch dbg] %llu batches on %llu workgroups, clock ticks each: loads issued, table cleared %.0f | scans, records, tail bits %.0f | "
-                     "expand + accumulate %.0f | count, publish %.0f | prefix sum + displaced blocks %.0f | ranks, values %.0f | chain %.0f | stores %.0f\n",
+        std::fprintf(stderr, "[batch dbg] %llu batches on %llu workgroups, clock ticks each: table cleared %.0f | barrier, tail prefix %.0f | "
+                     "expand + accumulate %.0f | count, publish %.0f | prefix sum + displaced blocks %.0f | ranks, values %.0f | position (chain; NUMERIC: next prologue) %.0f | stores (FUSED: + next prologue) %.0f\n",
                      h.dbg[6], h.dbg[7], (double)h.dbg[8] / h.dbg[6], (double)h.dbg[9] / h.dbg[6], (double)h.dbg[10] / h.dbg[6],
                      (double)h.dbg[11] / h.dbg[6], (double)h.dbg[12] / h.dbg[6], (double)h.dbg[13] / h.dbg[6], (double)h.dbg[14] / h.dbg[6],
                      (double)h.dbg[15] / h.dbg[6]);
@@ -541,6 +579,7 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
 
 int task_numeric(spada_ctx *c, uint64_t *d_ptr, uint32_t *d_idx, double *d_val)
 {
+    c->chunk_timing_open = false;
     hipStream_t s = c->stream;
     HIP_TRY(hipEventRecord(c->tev[0], s));
     HIP_TRY(hipMemcpyAsync(d_ptr, c->cptr.p, ((size_t)c->nrows + 1) * 8, hipMemcpyDeviceToDevice, s));
@@ -608,6 +647,8 @@ int spada_create(const spada_options *opts, spada_ctx **out)
     HIP_TRY(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
     HIP_TRY(hipEventCreate(&c->ev_fork));   // (with timing: the pair brackets the scatter on the side stream)
     HIP_TRY(hipEventCreate(&c->ev_join));
+    HIP_TRY(hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_join3, hipEventDisableTiming));
     HIP_TRY(hipHostMalloc((void **)&c->h_tctr, sizeof(TaskCounters), hipHostMallocDefault));
     for (auto &e : c->tev) HIP_TRY(hipEventCreate(&e));
     c->n_cu = (uint32_t)std::max(1, prop.multiProcessorCount);
@@ -629,6 +670,7 @@ void spada_destroy(spada_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->stream2) (void)hipStreamSynchronize(c->stream2);
+    if (c->stream3) (void)hipStreamSynchronize(c->stream3);
     dev_free(c->hA);
     if (c->hB != c->hA) dev_free(c->hB);
     dev_free(c->hAr);
@@ -637,7 +679,7 @@ void spada_destroy(spada_ctx *c)
     c->un_val.release();
     for (DevBuf *b : {&c->row_cl, &c->row_rec, &c->row_binfo, &c->row_nprod, &c->row_bin, &c->row_kmin, &c->row_kmax, &c->cptr, &c->t_rowP, &c->t_rowm, &c->t_rowt, &c->t_rowtmp,
                       &c->t_big, &c->t_tiles, &c->eb0, &c->elen, &c->t_tmp, &c->t_tasks, &c->t_status, &c->t_rangeout, &c->t_possum, &c->t_scrcol,
-                      &c->t_scrval, &c->t_scrseq, &c->t_ctr, &c->t_args, &c->t_parts, &c->t_parthist, &c->t_slots, &c->own_idx, &c->own_val, &c->own_ptr, &c->wide_idx})
+                      &c->t_scrval, &c->t_scrseq, &c->t_ctr, &c->t_args, &c->t_cuts, &c->t_cutitems, &c->t_stagecol, &c->t_stageval, &c->t_parts, &c->t_parthist, &c->t_slots, &c->own_idx, &c->own_val, &c->own_ptr, &c->wide_idx})
         b->release();
     if (c->h_tctr) (void)hipHostFree(c->h_tctr);
     for (auto &e : c->tev)
@@ -648,6 +690,8 @@ void spada_destroy(spada_ctx *c)
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
+    if (c->ev_join3) (void)hipEventDestroy(c->ev_join3);
+    if (c->stream3) (void)hipStreamDestroy(c->stream3);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }

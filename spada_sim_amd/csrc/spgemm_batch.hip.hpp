@@ -42,14 +42,19 @@
 
 namespace spada {
 
+#ifndef SPADA_BT_STOP
+#define SPADA_BT_STOP 0   /* development: the counting mode cut short behind stage k of the batch task (instruction counts per stage) */
+#endif
+#ifndef SPADA_PARK
+#define SPADA_PARK 0   /* one-pass mode: a finished task is parked in registers and stored one task later instead of waiting for its position */
+#endif
 #ifndef SPADA_NEXT_EARLY
 #define SPADA_NEXT_EARLY (-1)   /* development: 1 / 0 = the next task's prologue under the stores / behind them in every mode */
 #endif
 constexpr int BW = TKW, BT_NWAVE = BW / 64;
 constexpr uint32_t BT_LAYOUT = BT_T - 32u;   // slots the rows' regions are laid out over; the rest takes the overflow of the last cluster
 constexpr uint32_t BT_H_NONE = 0xFFFFFFFFu, BT_H_COPY = 0xFFFFFFFEu;   // `state` of a lane without a product / of a copied product
-// state of a hashed product: slot (12 bits, later the output rank) | creator of the block << 12 | first to set its mask bit << 13 |
-// slots between the block's home and its place << 16
+// state of a hashed product: slot (12 bits) | creator of the block << 12 | first to set its mask bit << 13
 constexpr uint32_t BT_ST_CREATOR = 1u << 12, BT_ST_OWNER = 1u << 13, BT_ST_HASHED_MAX = 0x10000000u;
 constexpr size_t BT_OFF_KEYS = 256, BT_OFF_MASK = BT_OFF_KEYS + (size_t)BT_T * 4, BT_OFF_ENT = BT_OFF_MASK + (size_t)BT_T * 4,
                  BT_OFF_TAIL = BT_OFF_ENT + 8192, BT_OFF_ROWS = BT_OFF_TAIL + 256;
@@ -57,11 +62,93 @@ struct __attribute__((aligned(16))) BtRow {   // region of a row in the table: f
     uint32_t s, g, bmin;
     float scale;
 };
-__host__ __device__ constexpr size_t batch_lds() { return BT_OFF_ROWS + (size_t)TK_RMAX * (sizeof(BtRow) + 4 + 4 + 4); }
+constexpr size_t BT_OFF_LIST = BT_OFF_ROWS + (size_t)TK_RMAX * (sizeof(BtRow) + 4 + 4 + 4 + 4);   // the displaced blocks of the task
+constexpr uint32_t BT_LIST_CAP = (40960 - 128 - BT_OFF_LIST) / 4;   // (the last 128 bytes: the counters of SPADA_TASK_DBG builds)
+__host__ __device__ constexpr size_t batch_lds() { return BT_OFF_LIST + (size_t)BT_LIST_CAP * 4; }
 static_assert(batch_lds() <= 40960, "four workgroups per CU");
 static_assert(BT_T == 6 * BW && BT_PMAX == 4u * BW && BT_EMAX == (uint32_t)BW && BT_T * 8 == BT_PMAX * 12,
               "the LDS map and the per-thread arrays are written for these sizes");
 static_assert(TK_RMAX <= 128 && BT_T <= 4096 && BT_PMAX <= 4096, "field widths of the product state");
+
+// One-pass mode: a task that has assembled its slice of C in LDS does not WAIT for its position (the sum of the counts of all tasks
+// before it arrives some ten microseconds after its own count was published: two hand-offs between loaded CUs, and the publication
+// of the slowest task before it).  It is PARKED instead: its at most 2048 outputs go from LDS to the workgroup's staging slice in
+// global memory (24 KB; the slices of all workgroups stay in the L2 / Infinity Cache), and the NEXT task of the workgroup takes
+// them from there -- the loads are issued right after its own count is published and land under its order stages -- and stores
+// them to C where it would itself start to wait: by then the parked task's position has long arrived.  Tickets are still taken only
+// where a task really starts, so nothing sits unstarted in the chain; a workgroup has at most one parked task.
+// (Parked in registers -- twelve per thread -- the register allocator spilled them: web 0.76 -> 1.06 ms.)
+struct Parked {
+    uint32_t valid, t, total;      // the task, its outputs
+    uint32_t rb, R, first;         // rows [rb, rb + R) get their C.indptr from it (R = 0: a range task; first & 1: the first range of row rb)
+    uint32_t ooff;                 // thread tid < R: outputs of the task before row rb + tid
+};
+struct ParkedRegs {                // thread i: outputs i, i + 512, ... of the parked task, on their way from the staging slice
+    uint32_t col[BT_PMAX / BW];
+    double val[BT_PMAX / BW];
+};
+template <class ARGS>
+__device__ inline void batch_park_load(const ARGS &g, const Parked &pk, ParkedRegs &pr, uint32_t tid)
+{
+    const uint32_t *sc = g.stage_col + (size_t)blockIdx.x * BT_PMAX;
+    const double *sv = g.stage_val + (size_t)blockIdx.x * BT_PMAX;
+#pragma unroll
+    for (int k = 0; k < (int)(BT_PMAX / BW); ++k) {
+        const uint32_t i = tid + (uint32_t)k * BW;
+        pr.col[k] = 0u;
+        pr.val[k] = 0.0;
+        if (pk.valid && i < pk.total) {
+            pr.col[k] = sc[i];
+            pr.val[k] = sv[i];
+        }
+    }
+}
+template <int MODE, class ARGS>
+__device__ inline void batch_unpark(const ARGS &g, Parked &pk, const ParkedRegs &pr, uint32_t ntasks, uint32_t *hdr, uint32_t tid)
+{
+    if (!pk.valid) return;   // (uniform)
+    pk.valid = 0u;
+    const unsigned long long base = task_position<MODE>(g, pk.t, pk.total, hdr);
+    if (pk.R == 0u) {
+        if (tid == 0) {
+            if (pk.first & 1u) g.cptr[pk.rb] = base;   // first range of its row
+            g.range_out[pk.t] = base;
+        }
+    } else if (tid < pk.R) {
+        g.cptr[pk.rb + tid] = base + pk.ooff;
+    }
+    if (pk.t == ntasks - 1 && tid == 0) {
+        g.cptr[g.nrows] = base + pk.total;
+        g.ctr->nnz_c = base + pk.total;
+    }
+    if (base + pk.total > g.capacity) {
+        if (tid == 0) atomicOr(&g.ctr->cap_overflow, 1u);
+        return;
+    }
+    // the slice as it is: neighbouring lanes, neighbouring addresses
+#pragma unroll
+    for (int k = 0; k < (int)(BT_PMAX / BW); ++k) {
+        const uint32_t i = tid + (uint32_t)k * BW;
+        if (i < pk.total) {
+#if SPADA_NT_STORE
+            __builtin_nontemporal_store(pr.col[k], &g.c_idx[base + i]);
+            __builtin_nontemporal_store(pr.val[k], &g.c_val[base + i]);
+#else
+            g.c_idx[base + i] = pr.col[k];
+            g.c_val[base + i] = pr.val[k];
+#endif
+        }
+    }
+}
+// (where no task follows that could take the parked one along: before a task of the older range path, and at the end of the kernel)
+template <int MODE, class ARGS>
+__device__ inline void batch_unpark_now(const ARGS &g, Parked &pk, uint32_t ntasks, uint32_t *hdr)
+{
+    if (!pk.valid) return;
+    ParkedRegs pr;
+    batch_park_load(g, pk, pr, threadIdx.x);
+    batch_unpark<MODE>(g, pk, pr, ntasks, hdr, threadIdx.x);
+}
 
 // The task loop runs every batch task in two parts.  batch_prologue -- descriptor -> row records / A entries -> (range: narrowing
 // searches) -> scans -> entry records, tail bits and row regions in LDS -- touches neither the table nor the outputs of the task
@@ -89,11 +176,12 @@ struct BatchHead {
     uint32_t *s_cpo = (uint32_t *)(s_delta + TK_RMAX);          /* COPY rows: number of the row's first product */                    \
     uint32_t *s_hoff = s_cpo + TK_RMAX;                         /* hashed outputs before the row (COUNT: outputs of the row) */       \
     uint32_t *s_info = s_hoff + TK_RMAX;                        /* class | products << 3 of the row */                                \
+    uint32_t *dlist = (uint32_t *)((smem) + BT_OFF_LIST);       /* displaced blocks: slot | slots above the home << 12; hdr[41] of them */ \
     /* scan slots (eight words each) in the header; hdr[40] = a probe sequence reached the end of the table; hdr[48 .. 50] belong  \
        to the chain and the ticket, hdr[52 .. 53] to the numeric base */                                                             \
     uint32_t *slot_rows = hdr, *slot_ent = hdr + 8, *slot_sp = hdr + 16, *slot_cnt = hdr + 24, *slot_pc = hdr + 32;                  \
     (void)keys; (void)masks; (void)w_ent; (void)fo; (void)fo32; (void)bm32; (void)bm64; (void)vals; (void)cols; (void)s_emit;        \
-    (void)s_delta; (void)s_cpo; (void)s_hoff; (void)s_info; (void)slot_rows; (void)slot_ent; (void)slot_sp; (void)slot_cnt; (void)slot_pc
+    (void)s_delta; (void)s_cpo; (void)s_hoff; (void)s_info; (void)dlist; (void)slot_rows; (void)slot_ent; (void)slot_sp; (void)slot_cnt; (void)slot_pc
 
 template <int MODE, bool DENSE, bool SPILL = false, class ARGS>
 __device__ inline BatchHead batch_prologue(const ARGS &g, const TaskDesc &td, uint32_t t, unsigned char *smem)
@@ -113,6 +201,13 @@ __device__ inline BatchHead batch_prologue(const ARGS &g, const TaskDesc &td, ui
     const uint32_t rb = td.row, R = range ? 1u : (td.np & 0xFFu), E = spill ? 0u : range ? (td.first >> 1) : ((td.np >> 8) & 0x3FFu),
                    PT = range ? td.np : ((td.np >> 18) & 0xFFFu);
 
+    // Only the waves that hold a row or an entry of the task do any of this (a task of the web input has 22 rows and 108 entries:
+    // two of the eight waves); the others meet them at the barrier and read the totals.  Every instruction of a stage is paid once
+    // per WAVE, and with eight waves per task the stages' fixed costs, not the products, were most of the kernel's instructions.
+    const uint32_t wave_u = (uint32_t)__builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t nw = max(max((R + 63u) >> 6, (E + 63u) >> 6), 1u);
+    const bool busy = wave_u < nw;   // (uniform)
+
     // ---- everything the walk needs in ONE round trip ------------------------------------------------------------------------
     RowRec rr{0u, 0u, 0u, (uint32_t)CLS_EMPTY};
     if (range) {
@@ -124,11 +219,18 @@ __device__ inline BatchHead batch_prologue(const ARGS &g, const TaskDesc &td, ui
     uint32_t len = 0, elr = 0;
     double av = 0.0;
     bool ecopy = false;
-    if (PT && (uint32_t)tid < E) {
+    if (busy && PT && (uint32_t)tid < E) {
         const uint64_t q = td.src + (uint32_t)tid;
         b0 = g.eb0[q];
         len = g.elen[q];
         if constexpr (VALUES) av = g.aval[q];
+        if (range) {
+            // DIRECT RANGE: every selected B row narrowed to the range's columns -- B rows are ascending, and k_big_cuts has left
+            // the positions of the range's bounds in every one of them: the same round trip as the entry itself
+            const uint32_t c_lo = g.cuts[td.cut + (uint32_t)tid], c_hi = g.cuts[td.cut + E + (uint32_t)tid];
+            b0 += c_lo;
+            len = c_hi - c_lo;
+        }
         if (!range) {
             // a COPY row is a row with ONE entry (row_class): the entry's neighbours belong to other rows (batches hold whole rows)
             const uint32_t row = g.arow[q];
@@ -143,36 +245,9 @@ __device__ inline BatchHead batch_prologue(const ARGS &g, const TaskDesc &td, ui
         hdr[53] = (uint32_t)(c0 >> 32);
     }
     if (tid < 64) bm32[tid] = 0u;
-    if (tid == 0) hdr[40] = 0u;
-    if (range && PT && (uint32_t)tid < E) {
-        // DIRECT RANGE: every selected B row narrowed to [col_lo, col_hi]: l1 = first position with column >= lo, l2 = first with
-        // column > hi, all searches of the wave in lock step (binary: K-ary searches were slower -- more scattered loads)
-        const uint32_t lo = td.col_lo, hi = td.col_hi;
-        const uint32_t *__restrict__ bidx = g.bidx;
-        uint32_t l1 = 0, l2 = 0, n1 = len, n2 = len;
-        while (n1 | n2) {
-            const uint32_t c1 = n1 ? bidx[b0 + l1 + (n1 >> 1)] : 0u, c2 = n2 ? bidx[b0 + l2 + (n2 >> 1)] : 0u;
-            if (n1) {
-                const uint32_t hh = n1 >> 1;
-                if (c1 < lo) {
-                    l1 += hh + 1;
-                    n1 -= hh + 1;
-                } else {
-                    n1 = hh;
-                }
-            }
-            if (n2) {
-                const uint32_t hh = n2 >> 1;
-                if (c2 <= hi) {
-                    l2 += hh + 1;
-                    n2 -= hh + 1;
-                } else {
-                    n2 = hh;
-                }
-            }
-        }
-        b0 += l1;
-        len = l2 - l1;
+    if (tid == 0) {
+        hdr[40] = 0u;
+        hdr[41] = 0u;
     }
     asm volatile("; BT_MARK p1" ::: "memory");
     // rows: the hashed products before every row (the table's slots are laid out over the rows in proportion to them) and the
@@ -181,15 +256,17 @@ __device__ inline BatchHead batch_prologue(const ARGS &g, const TaskDesc &td, ui
     const uint32_t row_pr = row_hashed ? rr.nprod : 0u, row_cp = rr.cls == CLS_COPY ? rr.nprod : 0u;
     const uint32_t bmin = rr.kmin >> BT_BSHIFT, spanb = row_hashed && rr.nprod ? (rr.kmax >> BT_BSHIFT) - bmin + 1u : 0u;
     const uint32_t row_v = row_pr | (row_cp << 16), ent_v = len ? ((1u << 16) | len) : 0u, sp_v = min(spanb, 2u * T);
-    const uint32_t row_inc = scan_part(row_v, slot_rows, tid);
-    uint32_t ent_inc = 0, sp_inc = 0;
-    if (!spill) ent_inc = scan_part(ent_v, slot_ent, tid);
-    if constexpr (DENSE) sp_inc = scan_part(sp_v, slot_sp, tid);
+    uint32_t row_inc = 0, ent_inc = 0, sp_inc = 0;
+    if (busy) {
+        row_inc = scan_part(row_v, slot_rows, tid);
+        if (!spill) ent_inc = scan_part(ent_v, slot_ent, tid);
+        if constexpr (DENSE) sp_inc = scan_part(sp_v, slot_sp, tid);
+    }
     __syncthreads();   // (the tail bits are cleared)
     uint32_t row_tot, tot32 = PT, ex32 = 0, sp_tot = 0, soff = 0;   // (a spilled range: PT <= BT_PMAX products, no entries -- the dispatch in k_task sees to it)
-    const uint32_t row_ex = scan_done<BT_NWAVE>(row_inc, row_v, slot_rows, &row_tot, tid);
-    if (!spill) ex32 = scan_done<BT_NWAVE>(ent_inc, ent_v, slot_ent, &tot32, tid);
-    if constexpr (DENSE) soff = scan_done<BT_NWAVE>(sp_inc, sp_v, slot_sp, &sp_tot, tid);
+    const uint32_t row_ex = scan_done<BT_NWAVE>(row_inc, row_v, slot_rows, &row_tot, tid, nw);
+    if (!spill) ex32 = scan_done<BT_NWAVE>(ent_inc, ent_v, slot_ent, &tot32, tid, nw);
+    if constexpr (DENSE) soff = scan_done<BT_NWAVE>(sp_inc, sp_v, slot_sp, &sp_tot, tid, nw);
     const uint32_t boff = row_ex & 0xFFFFu, cpre = row_ex >> 16, NBK = row_tot & 0xFFFFu;   // hashed products before the row, copied outputs before it
     BatchHead hd{tot32 & 0xFFFFu, tot32 >> 16, NBK, row_tot >> 16};
     if ((uint32_t)tid < R) {
@@ -220,7 +297,7 @@ __device__ inline BatchHead batch_prologue(const ARGS &g, const TaskDesc &td, ui
         }
         hd.P = 0;
     }
-    if (hd.P && len) {
+    if (busy && hd.P && len) {
         // record: (begin - first product) mod 2^48 | local row << 48 | copy << 55, A value
         const uint32_t ci = ex32 >> 16, po = ex32 & 0xFFFFu;
         w_ent[ci] = EntryRecNum{((b0 - po) & M48) | ((uint64_t)elr << 48) | ((uint64_t)(ecopy ? 1u : 0u) << 55), av};
@@ -235,7 +312,7 @@ __device__ inline BatchHead batch_prologue(const ARGS &g, const TaskDesc &td, ui
 // next ticket and runs the next task's prologue
 template <int MODE, bool DENSE, bool SPILL = false, class ARGS, class NEXT>
 __device__ inline void batch_main(const ARGS &g, const TaskDesc &td, uint32_t t, uint32_t ntasks, unsigned char *smem,
-                                  uint32_t *dbg_ph /* LDS: SPADA_TASK_DBG builds */, const BatchHead hd, NEXT &&next)
+                                  uint32_t *dbg_ph /* LDS: SPADA_TASK_DBG builds */, const BatchHead hd, Parked &pk, NEXT &&next)
 {
     constexpr bool VALUES = MODE != MODE_COUNT;
     constexpr uint32_t T = BT_T;
@@ -258,6 +335,14 @@ __device__ inline void batch_main(const ARGS &g, const TaskDesc &td, uint32_t t,
     } while (0)
     if (SPADA_TASK_DBG && tid == 0) dbg_ph[8] += 1;
     BMARK(0);
+#define BSTOP(i)                                                \
+    do {                                                        \
+        if (MODE == MODE_COUNT && SPADA_BT_STOP == (i)) {       \
+            next();                                             \
+            return;                                             \
+        }                                                       \
+    } while (0)
+    BSTOP(1);
     constexpr bool spill = SPILL;
     const bool range = td.kind != TASK_BATCH;
     const uint32_t rb = td.row, R = range ? 1u : (td.np & 0xFFu), E = spill ? 0u : range ? (td.first >> 1) : ((td.np >> 8) & 0x3FFu);
@@ -279,6 +364,7 @@ __device__ inline void batch_main(const ARGS &g, const TaskDesc &td, uint32_t t,
         }
     }
     BMARK(1);
+    BSTOP(2);
     __syncthreads();   // the table is cleared; the prologue's records, tail bits and row regions are written
     // tails before every 64-bit word of the bitmap (32 words): every wave scans them for itself and keeps the prefixes in the
     // lanes of one register (word w in lane w): the per-segment values are then scalar reads, and no further barrier is needed
@@ -289,6 +375,7 @@ __device__ inline void batch_main(const ARGS &g, const TaskDesc &td, uint32_t t,
         tail_pre = inc - c;
     }
 
+    BSTOP(3);
     BMARK(2);
     // ---- expand - scale - accumulate blocks (scheduler.rs:482-606, simulator.rs:892-953, :86-111) ---------------------------
     uint32_t r_ck[4], r_st[4];   // the products of this thread: composite key (local row << colbits | column), state (above)
@@ -352,31 +439,51 @@ __device__ inline void batch_main(const ARGS &g, const TaskDesc &td, uint32_t t,
                 if constexpr (VALUES) r_v[u] = a_[u] * g.bval[q[u]];   // simulator.rs:100-101
             }
         }
+        if constexpr (DENSE) {
+            // no keys: the slot is the block's place in the row.  The four products of a thread go through the two steps -- row
+            // parameters, mask -- together, so that the four LDS operations of a step are in flight at once
+            bool hashed[4];
+            BtRow e[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const uint32_t lr = lrc[u] & 127u;
-            const bool copy = (lrc[u] & 128u) != 0u, hashed = act[u] && !copy;
-            const uint32_t ck = compose_key(lr, col[u], colbits);
-            r_ck[u] = ck;
-            r_st[u] = act[u] ? BT_H_COPY : BT_H_NONE;
-            if (hashed) {
-                const BtRow e = s_emit[lr];
-                const uint32_t d = (col[u] >> BT_BSHIFT) - e.bmin;
-                uint32_t h, st = 0;
-                if constexpr (DENSE) {
-                    // the slot is the block's place in the row: nothing to insert, nothing to probe
-                    h = e.s + d;
-                } else {
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t lr = lrc[u] & 127u;
+                hashed[u] = act[u] && !(lrc[u] & 128u);
+                r_ck[u] = compose_key(lr, col[u], colbits);
+                r_st[u] = act[u] ? BT_H_COPY : BT_H_NONE;
+                e[u] = s_emit[hashed[u] ? lr : 0u];
+            }
+            uint32_t was[4], h[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                h[u] = e[u].s + (col[u] >> BT_BSHIFT) - e[u].bmin;
+                was[u] = 0xFFFFFFFFu;
+                if (hashed[u]) was[u] = atomicOr(&masks[h[u]], 1u << (col[u] & 31u));
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t fresh = ((was[u] >> (col[u] & 31u)) & 1u) ^ 1u;
+                mynew += fresh;
+                if (hashed[u]) r_st[u] = h[u] | (fresh ? BT_ST_OWNER : 0u);
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t lr = lrc[u] & 127u;
+                const bool copy = (lrc[u] & 128u) != 0u, hashed = act[u] && !copy;
+                const uint32_t ck = compose_key(lr, col[u], colbits);
+                r_ck[u] = ck;
+                r_st[u] = act[u] ? BT_H_COPY : BT_H_NONE;
+                if (hashed) {
+                    const BtRow e = s_emit[lr];
+                    const uint32_t d = (col[u] >> BT_BSHIFT) - e.bmin;
                     const uint32_t hk = ck >> BT_BSHIFT;
                     const uint32_t home = e.s + min((uint32_t)((float)d * e.scale), e.g - 1u);
-                    h = home;
+                    uint32_t h = home, st = 0;
                     uint32_t old = atomicCAS(&keys[h], EMPTY_KEY, hk);
                     if (old != EMPTY_KEY && old != hk) {
-                        bool up = true;
-                        do {
-                            if (up) {
-                                if (++h == T) {   // the end of the table: the free slot below the home takes the block (the order stage then looks at whole clusters)
-                                    up = false;
+                        do {   // upwards; at the end of the table the free slot BELOW the home takes the block (the order stage then looks at whole clusters)
+                            if (h >= home) {
+                                if (++h == T) {
                                     h = home - 1u;
                                     hdr[40] = 1u;
                                 }
@@ -385,22 +492,27 @@ __device__ inline void batch_main(const ARGS &g, const TaskDesc &td, uint32_t t,
                             }
                             old = atomicCAS(&keys[h], EMPTY_KEY, hk);
                         } while (old != EMPTY_KEY && old != hk);
+                        if (old == EMPTY_KEY && h > home) {   // displaced: the order stage looks at the slots between its home and its place
+                            const uint32_t li = atomicAdd(&hdr[41], 1u);
+                            if (li < BT_LIST_CAP) dlist[li] = h | ((h - home) << 12);
+                        }
                     }
                     if (old == EMPTY_KEY) {
                         ++mykeys;
-                        st = BT_ST_CREATOR | ((h >= home ? h - home : 0u) << 16);   // (a block below its home: hdr[40] is set and the distance is not used)
+                        st = BT_ST_CREATOR;
                     }
+                    const uint32_t bit = 1u << (col[u] & 31u);
+                    const uint32_t was = atomicOr(&masks[h], bit);
+                    if (!(was & bit)) {
+                        ++mynew;
+                        st |= BT_ST_OWNER;
+                    }
+                    r_st[u] = h | st;
                 }
-                const uint32_t bit = 1u << (col[u] & 31u);
-                const uint32_t was = atomicOr(&masks[h], bit);
-                if (!(was & bit)) {
-                    ++mynew;
-                    st |= BT_ST_OWNER;
-                }
-                r_st[u] = h | st;
             }
         }
     }
+    BSTOP(4);
     BMARK(3);
     // ---- the count of the task: new mask bits + copied products (known from the rows); published as soon as it is known ----------
     uint32_t NO, NBt, total;   // hashed outputs, blocks, outputs of the task
@@ -413,13 +525,28 @@ __device__ inline void batch_main(const ARGS &g, const TaskDesc &td, uint32_t t,
     }
     (void)NBt;
     if constexpr (MODE != MODE_NUMERIC) task_publish<MODE>(g, t, total);
+    BSTOP(5);
+    ParkedRegs pr;
+    if constexpr (MODE == MODE_FUSED && SPADA_PARK) batch_park_load(g, pk, pr, (uint32_t)tid);   // (the task parked before this one: on its way back)
+    if (SPADA_TASK_DBG && tid == 0) {   // ticks from the task's ticket (dbg_ph[16], k_task) to its publication, per kind: sum, tasks, maximum
+        const uint32_t d = (uint32_t)__builtin_amdgcn_s_memtime() - dbg_ph[16], k = range ? 20u : 17u;
+        dbg_ph[k] += d >> 4;
+        dbg_ph[k + 1] += 1u;
+        dbg_ph[k + 2] = max(dbg_ph[k + 2], d);
+#if SPADA_TASK_DBG
+        if (d > 60000u) {   // the slowest tasks: what they are
+            const unsigned long long n = atomicAdd(&g.ctr->dbgh[2][0], 1ull);
+            if (n < 7) {
+                g.ctr->dbgh[2][1 + 3 * n] = t | ((unsigned long long)td.kind << 32) | ((unsigned long long)(DENSE ? 1 : 0) << 40);
+                g.ctr->dbgh[2][2 + 3 * n] = P | ((unsigned long long)NBt << 16) | ((unsigned long long)hdr[41] << 32) | ((unsigned long long)E << 48);
+                g.ctr->dbgh[2][3 + 3 * n] = d | ((unsigned long long)NO << 32);
+            }
+        }
+#endif
+    }
     if (SPADA_TASK_DBG) {   // shape of the tasks: products, hashed outputs, blocks, slots between home and place, entries
-        uint32_t disp = 0;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) disp += r_st[u] < BT_ST_HASHED_MAX ? (r_st[u] >> 16) : 0u;
-        disp = (uint32_t)wave_sum_u64(disp);
-        if (lane == 0 && disp) atomicAdd(&dbg_ph[9 + 3], disp);
         if (tid == 0) {
+            dbg_ph[9 + 3] += hdr[41];   // displaced blocks
             dbg_ph[9 + 0] += P;
             dbg_ph[9 + 1] += NO;
             dbg_ph[9 + 2] += NBt;
@@ -439,19 +566,38 @@ __device__ inline void batch_main(const ARGS &g, const TaskDesc &td, uint32_t t,
         // of the rows inside the batch -- k_pos4 adds the position of the batch afterwards
         if (NO) {
             if (R > 1) {
-                uint32_t cnt_lr = 0xFFFFFFFFu, cnt_n = 0;   // (runs of one row inside a thread: one LDS atomic per run)
+                if constexpr (DENSE) {
+                    // the slots are in (row, block) order: outputs of a row = sum of the popcounts of its slots -- every thread adds
+                    // up its six consecutive slots, a run of one row with one LDS atomic
+                    const uint2 *m2 = (const uint2 *)(masks + 6u * (uint32_t)tid);
+                    const uint2 wa = m2[0], wb = m2[1], wc = m2[2];
+                    const uint32_t c[6] = {(uint32_t)__popc(wa.x), (uint32_t)__popc(wa.y), (uint32_t)__popc(wb.x), (uint32_t)__popc(wb.y),
+                                           (uint32_t)__popc(wc.x), (uint32_t)__popc(wc.y)};
+                    if (c[0] | c[1] | c[2] | c[3] | c[4] | c[5]) {
+                        // row of slot x: the last row whose region starts at or before x (the regions of the hashed rows tile the slots)
+                        uint32_t r = 0;
+                        for (uint32_t stp = 64u; stp; stp >>= 1)
+                            if (r + stp < R && s_emit[r + stp].s <= 6u * (uint32_t)tid) r += stp;
+                        uint32_t acc = 0;
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    if (r_st[u] < BT_ST_HASHED_MAX && (r_st[u] & BT_ST_OWNER)) {
-                        const uint32_t lr = lr_of_ck(r_ck[u]);
-                        if (lr != cnt_lr) {
-                            if (cnt_n) atomicAdd(&s_hoff[cnt_lr], cnt_n);
-                            cnt_lr = lr;
-                            cnt_n = 0;
+                        for (int k = 0; k < 6; ++k) {
+                            const uint32_t x = 6u * (uint32_t)tid + (uint32_t)k;
+                            while (r + 1u < R && s_emit[r + 1u].s <= x) {
+                                if (acc) atomicAdd(&s_hoff[r], acc);
+                                acc = 0;
+                                ++r;
+                            }
+                            acc += c[k];
                         }
-                        ++cnt_n;
+                        if (acc) atomicAdd(&s_hoff[r], acc);
                     }
-                if (cnt_n) atomicAdd(&s_hoff[cnt_lr], cnt_n);
+                } else {
+                    // every block was created by exactly one product: it adds the block's columns to its row
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (r_st[u] < BT_ST_HASHED_MAX && (r_st[u] & BT_ST_CREATOR))
+                            atomicAdd(&s_hoff[lr_of_ck(r_ck[u])], (uint32_t)__popc(masks[r_st[u] & 0xFFFu]));
+                }
             } else if (tid == 0) {
                 s_hoff[0] = NO;
             }
@@ -497,21 +643,19 @@ __device__ inline void batch_main(const ARGS &g, const TaskDesc &td, uint32_t t,
             // output grows by this block's outputs), and this block moves in front of it.  The first outputs are 16-bit halves of
             // 32-bit words: an atomic add of a (possibly negative) amount to the word is exact for the half it is meant for as
             // long as the final values fit, whatever the intermediate carries are.
-            const bool whole_clusters = hdr[40] != 0u;   // (uniform) a block was placed BELOW its home
+            const uint32_t ndisp = hdr[41];
+            const bool whole_clusters = hdr[40] != 0u || ndisp > BT_LIST_CAP;   // (uniform) a block was placed BELOW its home, or the list is full
             if (!whole_clusters) {
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const uint32_t st = r_st[u];
-                    if (st < BT_ST_HASHED_MAX && (st >> 16) != 0u) {   // (only creators carry a distance)
-                        const uint32_t h = st & 0xFFFu, k = r_ck[u] >> BT_BSHIFT, mine = (uint32_t)__popc(masks[h]);
-                        uint32_t before = 0;
-                        for (uint32_t j = h - (st >> 16); j < h; ++j)
-                            if (keys[j] > k) {
-                                atomicAdd(&fo32[j >> 1], mine << ((j & 1u) * 16u));
-                                before += (uint32_t)__popc(masks[j]);
-                            }
-                        if (before) atomicAdd(&fo32[h >> 1], (0u - before) << ((h & 1u) * 16u));
-                    }
+                // (the list spread over the waves: entry e to lane e / 8 of wave e % 8 -- a wave waits for the longest walk among its lanes)
+                for (uint32_t e = (uint32_t)lane * BT_NWAVE + wave_u; e < ndisp; e += BW) {
+                    const uint32_t ent = dlist[e], h = ent & 0xFFFu, k = keys[h], mine = (uint32_t)__popc(masks[h]);
+                    uint32_t before = 0;
+                    for (uint32_t j = h - (ent >> 12); j < h; ++j)
+                        if (keys[j] > k) {
+                            atomicAdd(&fo32[j >> 1], mine << ((j & 1u) * 16u));
+                            before += (uint32_t)__popc(masks[j]);
+                        }
+                    if (before) atomicAdd(&fo32[h >> 1], (0u - before) << ((h & 1u) * 16u));
                 }
             } else {
                 // any arrangement inside a cluster: first output = outputs before the cluster + outputs of its smaller keys
@@ -613,11 +757,33 @@ __device__ inline void batch_main(const ARGS &g, const TaskDesc &td, uint32_t t,
     if constexpr (MODE == MODE_NUMERIC) base = ((unsigned long long)hdr[53] << 32) | hdr[52];   // (before the next task's prologue writes its own)
     const uint32_t my_ooff = ooff;
 
-    // ---- position of the task's slice of C (the chain), then the stores -------------------------------------------------------
+    // ---- position of the task's slice of C, then the stores --------------------------------------------------------------------
+    if constexpr (MODE == MODE_FUSED && SPADA_PARK) {
+        // the chain: the task parked before this one is stored (its position is there by now), this one is parked in its place
+        __syncthreads();   // (the task's outputs are complete in LDS)
+        batch_unpark<MODE>(g, pk, pr, ntasks, hdr, (uint32_t)tid);
+        BMARK(7);
+        pk.valid = 1u;
+        pk.t = t;
+        pk.total = total;
+        pk.rb = rb;
+        pk.R = range ? 0u : R;
+        pk.first = td.first;
+        pk.ooff = my_ooff;
+        {
+            uint32_t *sc = g.stage_col + (size_t)blockIdx.x * BT_PMAX;
+            double *sv = g.stage_val + (size_t)blockIdx.x * BT_PMAX;
+            for (uint32_t i = tid; i < total; i += BW) {
+                sc[i] = cols[i] & colmask;
+                sv[i] = vals[i];
+            }
+        }
+        next();   // (starts with a barrier: the outputs are read, the next task may clear the table)
+    } else {
     // Where the next ticket is taken and the next task's prologue runs.  Without a chain (NUMERIC): here, under the stores.  With
-    // it (FUSED): only after the stores -- a ticket taken while this task still waits for its position puts a task into the chain
-    // that cannot publish its count before this wait is over, and every task behind it waits for that (measured: web 0.82 ->
-    // 0.95 ms, R-MAT 16 4.9 -> 5.6 ms with the prologue under the wait)
+    // it (FUSED, SPADA_PARK = 0): only after the stores -- a ticket taken while this task still waits for its position puts a task
+    // into the chain that cannot publish its count before this wait is over, and every task behind it waits for that (measured:
+    // web 0.82 -> 0.95 ms, R-MAT 16 4.9 -> 5.6 ms with the prologue under the wait)
     constexpr bool NEXT_EARLY = SPADA_NEXT_EARLY >= 0 ? SPADA_NEXT_EARLY != 0 : MODE == MODE_NUMERIC;
     if constexpr (NEXT_EARLY) next();   // (starts with a barrier: the task's outputs are complete in LDS)
     else __syncthreads();
@@ -655,8 +821,10 @@ __device__ inline void batch_main(const ARGS &g, const TaskDesc &td, uint32_t t,
     }
     if constexpr (!NEXT_EARLY) next();   // (starts with a barrier)
     else __syncthreads();                // (the outputs are read: the next task may clear the table)
+    }
     BMARK(8);
 #undef BMARK
+#undef BSTOP
 }
 
 }  // namespace spada

@@ -216,20 +216,23 @@ __device__ inline uint32_t scan_part(uint32_t v, uint32_t *slot, uint32_t tid)
     if ((tid & 63u) == 63u) slot[tid >> 6] = inc;
     return inc;
 }
+// (`nw`: only the first nw waves have called scan_part -- the others hold zeros and have left their slots alone)
 template <int NW>
-__device__ inline uint32_t scan_done(uint32_t inc, uint32_t v, const uint32_t *slot, uint32_t *total, uint32_t tid)
+__device__ inline uint32_t scan_done(uint32_t inc, uint32_t v, const uint32_t *slot, uint32_t *total, uint32_t tid, uint32_t nw = NW)
 {
-    static_assert(NW % 4 == 0, "whole uint4 reads");
-    const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
-    uint32_t add = 0, tot = 0;
-#pragma unroll
-    for (int k = 0; k < NW; k += 4) {
-        const uint4 t = *(const uint4 *)(slot + k);
-        add += ((uint32_t)k + 0u < w ? t.x : 0u) + ((uint32_t)k + 1u < w ? t.y : 0u) + ((uint32_t)k + 2u < w ? t.z : 0u) + ((uint32_t)k + 3u < w ? t.w : 0u);
-        tot += t.x + t.y + t.z + t.w;
-    }
-    *total = tot;
-    return inc - v + add;
+    static_assert(NW <= 16, "the waves' totals fit one row of 16 lanes");
+    // the waves' totals scanned once more, by every wave for itself: lane k < NW takes total k, four DPP steps inside the row of 16
+    // lanes, and the two numbers a wave needs -- the totals before it, the total of all -- are scalar reads of that register
+    // (every thread adding up NW words with compares and selects took 30 vector instructions per scan, five scans per task)
+    const uint32_t lane = tid & 63u, w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    uint32_t p = lane < nw ? slot[lane] : 0u;
+    p += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)p, 0x111, 0xf, 0xf, false);
+    p += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)p, 0x112, 0xf, 0xf, false);
+    p += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)p, 0x114, 0xf, 0xf, false);
+    if (NW > 8) p += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)p, 0x118, 0xf, 0xf, false);
+    *total = (uint32_t)__builtin_amdgcn_readlane((int)p, NW - 1);
+    const uint32_t before = w ? (uint32_t)__builtin_amdgcn_readlane((int)p, (int)(w - 1u)) : 0u;
+    return inc - v + before;
 }
 template <int NW>
 __device__ inline uint32_t block_scan_excl_dpp_n(uint32_t v, uint32_t *slot, uint32_t *total, uint32_t tid)

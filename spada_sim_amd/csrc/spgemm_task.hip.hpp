@@ -77,13 +77,22 @@ struct TaskDesc {
     uint32_t first;     // RANGE: bit 0 = first range of its row (writes C.indptr[row]); DIRECT: the row's A entries above it
     uint64_t src;       // RANGE: first product of the slice in the scratch arrays | BATCH, DIRECT: first A entry
     uint32_t col_lo, col_hi;
+    uint64_t cut;       // DIRECT (rows with at most BT_EMAX entries): the range's two rows of the cut table (k_big_cuts): for entry e of
+                        // the row, cuts[cut + e] / cuts[cut + E + e] = first position of the selected B row with a column >= col_lo /
+                        // of the next range (the B row's length behind the last range)
+    uint32_t ri, m;     // DIRECT: number of the range in its row, ranges of the row
 };
+static_assert(sizeof(TaskDesc) == 48, "three 16-byte words (load_task)");
 constexpr uint32_t TASK_BATCH = 1, TASK_RANGE = 2, TASK_RANGE_DIRECT = 3;   // (DIRECT: the products are taken from B, not from the scratch)
 
 // device counters of one pipeline run (zeroed at its start)
 struct TaskCounters {   // (a multiple of 8 bytes: k_init clears it in 8-byte words)
     unsigned long long nprod, a_nnz, nprod_big;       // of the row range
     unsigned long long scratch_cursor;                // products handed out in the scratch arrays
+    // the cut table and the work items of k_big_cuts are handed out from BX_ARENAS arenas (row of the BIG-row list modulo BX_ARENAS), a
+    // cursor pair per 128-byte line: one hot word takes ~88 atomics per microsecond, and every direct row allocates (k_big_plan 33 ->
+    // 99 us on the web input with one cursor)
+    unsigned long long cut_arena[16][16];             // [arena][0]: words handed out, [1]: work items
     unsigned long long nnz_c;                         // written by the last task (COUNT / FUSED)
     unsigned long long cls_rows[N_CLS], cls_prod[N_CLS];
     uint32_t n_big, tmp_cursor, ntasks, n_parts;
@@ -93,7 +102,8 @@ struct TaskCounters {   // (a multiple of 8 bytes: k_init clears it in 8-byte wo
     uint32_t abort_flag;                              // a workspace was too small: results invalid, sizes below say what is needed
     uint32_t cap_overflow;                            // FUSED: nnz(C) exceeded the caller's capacity (C.indptr is complete)
     uint32_t need_tmp, need_tasks;                    // (abort_flag bits: 1 tmp / scratch, 2 tasks, 4 row too long, 8 BIG rows, 16 parts)
-    uint32_t multi_pass_tasks, pad;
+    uint32_t multi_pass_tasks;
+    uint32_t scanner_cu;                              // one-pass mode: where the chain's scanner runs (XCC, SE, SH, CU | valid bit)
     uint32_t ticket[TK_NQ * 32];  // TK_NQ ticket counters, one per 128-byte line (a single hot word sustains ~88 atomics / us)
 #if SPADA_TASK_DBG
     unsigned long long dbgh[3][24];  // per task kind: [0..19] histogram of the cycles from ticket to publish (4096-cycle bins), [20] sum, [21] tasks, [22] max
@@ -413,7 +423,7 @@ struct BigSlot {
     uint32_t ok;        // 0: a workspace was too small, nothing of the row is written
     uint32_t direct;    // 1: the row is not spilled, its range tasks walk B themselves (k_big_plan)
     uint32_t part_begin, part_count;   // records of the row: parts[part_begin .. part_begin + part_count], the last a sentinel
-    uint32_t pad[2];
+    uint64_t cut_base;  // direct rows with at most BT_EMAX entries: first word of the row's (ranges + 1) x entries cut table
 };
 
 __device__ inline uint32_t big_wshift(uint32_t kmin, uint32_t kmax)
@@ -431,6 +441,8 @@ constexpr int BP_ROWS = 16;   // rows per workgroup and round: their records are
 // -- plus, for a row whose buckets are wider than the table (`wide`), up to BX_SUB_MAX descriptors for each of its at most
 // P / lim heavy buckets (below: column sub-ranges)
 constexpr uint32_t BX_SUB_MAX = 8;
+constexpr uint32_t BX_ARENAS = 16;
+constexpr uint32_t BX_CUT_ITEM = 256;   // (range, entry) pairs -- binary searches -- per work item of k_big_cuts: one per thread
 __host__ __device__ inline uint32_t big_max_ranges(uint32_t P, uint32_t lim, bool wide)
 {
     return 2u * (P / lim) + 2u * (P / (lim + 1u)) + 3u + (wide ? (BX_SUB_MAX - 1u) * (P / lim) : 0u);
@@ -495,7 +507,7 @@ __global__ __launch_bounds__(256) void k_big_parts(const uint64_t *__restrict__ 
         const uint32_t base = s_pbase[rr], tbase = s_tbase[rr];
         const bool fits = (unsigned long long)base + ub + 1 <= part_cap;
         if (lane == 0) {
-            slots[slot] = BigSlot{0ull, 0u, 0u, base, ub, {0u, 0u}};
+            slots[slot] = BigSlot{0ull, 0u, 0u, base, ub, 0ull};
             row_tmp[row] = tbase;
             if (!fits) atomicOr(&ctr->abort_flag, 16u);
             if ((unsigned long long)tbase + big_max_ranges(P, lim, wide_row(row)) > tmp_cap) atomicOr(&ctr->abort_flag, 1u);
@@ -661,7 +673,8 @@ __global__ __launch_bounds__(TK_BLOCK) void k_big_plan(const uint64_t *__restric
                                                        const uint32_t *__restrict__ row_kmax, const BigPart *__restrict__ parts,
                                                        uint32_t *__restrict__ part_hist, uint32_t *__restrict__ row_m,
                                                        const uint32_t *__restrict__ row_tmp, TaskDesc *__restrict__ tmp, uint32_t tmp_cap,
-                                                       BigSlot *__restrict__ slots, uint64_t scr_cap, TaskCounters *__restrict__ ctr)
+                                                       BigSlot *__restrict__ slots, uint64_t scr_cap, uint64_t cut_cap,
+                                                       uint2 *__restrict__ cut_items, uint64_t cut_item_cap, TaskCounters *__restrict__ ctr)
 {
     const uint32_t lim = ctr->prod_limit;
     constexpr int NB = BX_NB, BPT = NB / TK_BLOCK;
@@ -818,23 +831,39 @@ __global__ __launch_bounds__(TK_BLOCK) void k_big_plan(const uint64_t *__restric
                                 E * steps <= BX_DIRECT_MAX_SEARCH && (!SPADA_DIRECT_BATCH_ONLY || E <= (unsigned long long)SPADA_DIRECT_EMAX || nrows_call < SPADA_DIRECT_ROWS);
             const uint32_t tb = row_tmp[row];   // big_max_ranges(P) >= m records, allocated by k_big_parts
             const unsigned long long sb = direct ? 0ull : atomicAdd(&ctr->scratch_cursor, P);
+            // the cut table of a direct row whose range tasks run through the batch stages: (ranges + 1) rows of one word per entry
+            const unsigned long long cw = direct && E <= (unsigned long long)BT_EMAX ? ((unsigned long long)m + 1ull) * E : 0ull;
+            const uint32_t arena = slot % BX_ARENAS;
+            const unsigned long long acap = cut_cap / BX_ARENAS, icap = cut_item_cap / BX_ARENAS;
+            const unsigned long long co = cw ? atomicAdd(&ctr->cut_arena[arena][0], cw) : 0ull, cb = arena * acap + co;
+            // ... and its searches as work items of BX_CUT_ITEM (range, entry) pairs each (k_big_cuts)
+            const unsigned long long ni = cw ? ((unsigned long long)m * E + BX_CUT_ITEM - 1) / BX_CUT_ITEM : 0ull;
+            const unsigned long long io = ni ? atomicAdd(&ctr->cut_arena[arena][1], ni) : 0ull, ib = arena * icap + io;
+            hdr[54] = (uint32_t)ib;
+            hdr[55] = (uint32_t)(ib >> 32);
+            hdr[56] = (uint32_t)ni;
             hdr[46] = direct ? 1u : 0u;
             hdr[42] = tb;
             hdr[43] = (uint32_t)sb;
             hdr[44] = (uint32_t)(sb >> 32);
-            const bool ok = (unsigned long long)tb + m <= tmp_cap && (direct || sb + P <= scr_cap);
+            hdr[51] = (uint32_t)cb;
+            hdr[52] = (uint32_t)(cb >> 32);
+            hdr[53] = cw ? 1u : 0u;
+            const bool ok = (unsigned long long)tb + m <= tmp_cap && (direct || sb + P <= scr_cap) && co + cw <= acap && io + ni <= icap;
             hdr[45] = ok ? 1u : 0u;
             if (!ok) atomicOr(&ctr->abort_flag, 1u);
             row_m[row] = m;
             slots[slot].scr_base = sb;
+            slots[slot].cut_base = cb;
             slots[slot].ok = ok ? 1u : 0u;
             slots[slot].direct = direct ? 1u : 0u;
             if (!direct) atomicAdd(&ctr->n_spilled, 1u);
         }
         __syncthreads();
         const uint32_t tb = hdr[42];
-        const uint64_t sb = ((uint64_t)hdr[44] << 32) | hdr[43];
-        const bool ok = hdr[45] != 0, direct = hdr[46] != 0;
+        const uint64_t sb = ((uint64_t)hdr[44] << 32) | hdr[43], cb = ((uint64_t)hdr[52] << 32) | hdr[51];
+        const bool ok = hdr[45] != 0, direct = hdr[46] != 0, has_cuts = hdr[53] != 0;
+        const uint32_t m_row = row_m[row];
         if (ok) {
 #pragma unroll
             for (int k = 0; k < BPT; ++k)
@@ -843,6 +872,9 @@ __global__ __launch_bounds__(TK_BLOCK) void k_big_plan(const uint64_t *__restric
                     TaskDesc d;
                     d.kind = direct ? TASK_RANGE_DIRECT : TASK_RANGE;
                     d.row = row;
+                    d.cut = 0;
+                    d.ri = 0;
+                    d.m = m_row;
                     d.np = pre[f1] - pre[f0];
                     d.src = direct ? ((uint64_t)hdr[50] << 32 | hdr[49]) : sb + pre[f0];
                     const uint32_t lo = kmin + (f0 << wshift);
@@ -854,9 +886,15 @@ __global__ __launch_bounds__(TK_BLOCK) void k_big_plan(const uint64_t *__restric
                         d.first = (aux[r] + j == 0 ? 1u : 0u) | (wgt[k] > 1 ? 2u : 0u) | (direct ? (uint32_t)hdr[48] << 1 : 0u);
                         d.col_lo = lo + j * (uint32_t)TK_NOUT;
                         d.col_hi = j + 1 == wgt[k] ? hi : d.col_lo + (uint32_t)TK_NOUT - 1u;
+                        d.ri = aux[r] + j;
+                        d.cut = has_cuts ? cb + (uint64_t)d.ri * hdr[48] : 0ull;   // (hdr[48]: the row's entries)
                         tmp[tb + aux[r] + j] = d;
                     }
                 }
+        }
+        if (ok && has_cuts) {
+            const uint64_t ib = ((uint64_t)hdr[55] << 32) | hdr[54];
+            for (uint32_t q = tid; q < hdr[56]; q += TK_BLOCK) cut_items[ib + q] = make_uint2(slot, q);
         }
         if (ok && !direct) {
             // spilled: the counts of every part become its cursors.  Layout of the row's slice: RANGE major (a range task reads one
@@ -911,6 +949,58 @@ __global__ __launch_bounds__(TK_BLOCK) void k_big_plan(const uint64_t *__restric
             }
         }
         __syncthreads();
+    }
+}
+
+// k_big_cuts: the cut table of the direct rows.  For every range ri and every entry e of such a row: the first position of the selected
+// B row with a column >= the range's first column (B rows are ascending: a binary search) -- word ri * E + e of the row's table; the
+// last range also writes row m, the B rows' lengths.  The (range, entry) pairs of all rows are cut into work items of BX_CUT_ITEM by
+// k_big_plan, so that a hub row with hundreds of ranges is searched by hundreds of workgroups.  A direct range task then reads its entries' narrowed B rows (rows ri and
+// ri + 1) in the same round trip as the entries themselves: the dozen dependent search steps that made the range tasks the slowest
+// to publish their counts -- and every task behind them in the chain wait -- are done here, in parallel and before the task kernel.
+__global__ __launch_bounds__(256) void k_big_cuts(const uint32_t *__restrict__ bidx, const uint64_t *__restrict__ eb0,
+                                                  const uint32_t *__restrict__ elen, const uint32_t *__restrict__ big_rows,
+                                                  const uint32_t *__restrict__ row_m, const uint32_t *__restrict__ row_tmp,
+                                                  const BigSlot *__restrict__ slots, const TaskDesc *__restrict__ tmp,
+                                                  const uint2 *__restrict__ items, uint64_t item_cap, uint32_t *__restrict__ cuts,
+                                                  const TaskCounters *__restrict__ ctr)
+{
+    if (ctr->abort_flag) return;
+    unsigned long long most = 0;
+    for (uint32_t a = 0; a < BX_ARENAS; ++a) most = max(most, ctr->cut_arena[a][1]);
+    const unsigned long long icap = item_cap / BX_ARENAS;
+    for (unsigned long long x = blockIdx.x; x < most * BX_ARENAS; x += gridDim.x) {
+        const uint32_t arena = (uint32_t)(x % BX_ARENAS);
+        const unsigned long long k = x / BX_ARENAS;
+        if (k >= ctr->cut_arena[arena][1]) continue;
+        const uint2 item = items[arena * icap + k];   // (row of the BIG-row list, number of the item in the row)
+        const BigSlot sl = slots[item.x];
+        const uint32_t row = big_rows[item.x], m = row_m[row], tb = row_tmp[row];
+        const TaskDesc d0 = tmp[tb];
+        const uint32_t E = d0.first >> 1;
+        const uint64_t pairs = (uint64_t)m * E;
+#pragma unroll
+        for (int k = 0; k < BX_CUT_ITEM / 256; ++k) {
+            const uint64_t pr = (uint64_t)item.y * BX_CUT_ITEM + (uint32_t)k * 256u + threadIdx.x;
+            if (pr < pairs) {
+                const uint32_t ri = (uint32_t)(pr / E), e = (uint32_t)(pr - (uint64_t)ri * E);
+                const uint32_t lo = tmp[tb + ri].col_lo;
+                const uint64_t b0 = eb0[d0.src + e];
+                const uint32_t len = elen[d0.src + e];
+                uint32_t l = 0, n = len;
+                while (n) {
+                    const uint32_t h = n >> 1;
+                    if (bidx[b0 + l + h] < lo) {
+                        l += h + 1;
+                        n -= h + 1;
+                    } else {
+                        n = h;
+                    }
+                }
+                cuts[sl.cut_base + pr] = l;
+                if (ri + 1 == m) cuts[sl.cut_base + pairs + e] = len;
+            }
+        }
     }
 }
 
@@ -1315,6 +1405,8 @@ __global__ __launch_bounds__(256) void k_cut3(const uint8_t *__restrict__ row_cl
             d.first = 0;
             d.src = aptr[r0 + base + j];
             d.col_lo = d.col_hi = 0;
+            d.cut = 0;
+            d.ri = d.m = 0;
             tasks[idx] = d;
         } else if (cr.kind[j] == 2 && cr.t[j]) {
             kb[j] = atomicAdd(&s_nbig, 1u);
@@ -1383,6 +1475,9 @@ struct TaskArgs {
     const uint32_t *scr_col;
     const double *scr_val;
     const uint32_t *scr_seq;        // sort-merge accumulator only: number of the product inside its row (ascending k)
+    const uint32_t *cuts;           // cut table of the direct range tasks (k_big_cuts)
+    uint32_t *stage_col;            // one-pass mode: staging slices of the parked tasks, BT_PMAX outputs per workgroup (spgemm_batch.hip.hpp)
+    double *stage_val;
     uint64_t *cptr;                 // nrows + 1: COUNT / FUSED write it, NUMERIC reads it
     uint64_t *range_out;            // per task: first output of a RANGE task (COUNT writes, NUMERIC reads)
     unsigned long long *status;     // per task: chain words, zeroed before the launch
@@ -1542,6 +1637,9 @@ __host__ __device__ constexpr size_t task_lds()
 // 654 us on the mesh input were spent waiting there.  The scanner reads every word about once and keeps 256 of them in flight.
 #ifndef SPADA_CHAIN_SCANNER
 #define SPADA_CHAIN_SCANNER 1
+#endif
+#ifndef SPADA_SCANNER_ALONE
+#define SPADA_SCANNER_ALONE 1
 #endif
 constexpr int SCAN_WIN = 4;
 // (a grid too small to spare a workgroup -- every ticket queue must keep one that takes tasks -- walks back as before)
@@ -2048,11 +2146,10 @@ static_assert(flat_walk_bytes<TKW, TKW_EPT, true>() == flat_walk_bytes<TK_BLOCK,
 // space, i.e. with one scalar load into scalar registers
 __device__ inline TaskDesc load_task(const TaskDesc *tasks, uint32_t t)
 {
-    static_assert(sizeof(TaskDesc) == 32, "two 16-byte words");
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     typedef const u32x4 __attribute__((address_space(4))) *cptr4;
     const cptr4 p = (cptr4)(unsigned long long)(tasks + t);
-    const u32x4 a = p[0], b = p[1];
+    const u32x4 a = p[0], b = p[1], c = p[2];
     TaskDesc d;
     d.kind = a.x;
     d.row = a.y;
@@ -2061,6 +2158,9 @@ __device__ inline TaskDesc load_task(const TaskDesc *tasks, uint32_t t)
     d.src = ((uint64_t)b.y << 32) | b.x;
     d.col_lo = b.z;
     d.col_hi = b.w;
+    d.cut = ((uint64_t)c.y << 32) | c.x;
+    d.ri = c.z;
+    d.m = c.w;
     return d;
 }
 // (arguments of a function that is not inlined arrive in vector registers: what is uniform is made scalar again)
@@ -2201,9 +2301,30 @@ __global__ __launch_bounds__(TKW, SPADA_TASK_WAVES) void k_task(const TaskArgs *
     const int tid = threadIdx.x;
     const uint32_t ntasks = g.ctr->ntasks, task_end = min(ntasks, g.task_hi);
     if (g.ctr->abort_flag) return;
-    if (chain_has_scanner() && MODE == MODE_FUSED && blockIdx.x == 0) {   // the chain's scanner: this workgroup takes no tasks
-        chain_scanner(g.status, g.task_lo, task_end);
-        return;
+    if (chain_has_scanner() && MODE == MODE_FUSED) {
+        // The chain's scanner: workgroup 0 takes no tasks.  It gets its CU for itself (SPADA_SCANNER_ALONE): the other workgroups that
+        // land there leave at once (three of 1024).  Every link of the chain -- a task's count to the scanner, the prefix back -- is a
+        // hand-off whose price sits in the memory queue of the CU that reads: 1.1 us on a CU with nothing else in flight, 3 - 5 us on
+        // one that streams (MI355X_MICROARCH.md, handoff-1to1), and every task of the kernel waits on both links
+        const uint32_t me = ((uint32_t)__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xFF00u)            /* HW_ID: CU, SH, SE */
+                            | ((uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 16) | 1u;      /* XCC_ID */
+        if (blockIdx.x == 0) {
+            if (SPADA_SCANNER_ALONE && tid == 0) __hip_atomic_store(&g.ctr->scanner_cu, me, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#if SPADA_PRIO
+            __builtin_amdgcn_s_setprio(3);
+#endif
+            chain_scanner(g.status, g.task_lo, task_end);
+            return;
+        }
+        if (SPADA_SCANNER_ALONE) {
+            if (tid == 0) {
+                uint32_t sc;
+                while (!((sc = __hip_atomic_load(&g.ctr->scanner_cu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & 1u)) __builtin_amdgcn_s_sleep(8);
+                hdr[51] = sc == me ? 1u : 0u;
+            }
+            __syncthreads();
+            if (hdr[51]) return;
+        }
     }
 
     // Tasks are taken by ticket, in (almost) chain order: queue q hands out tasks q, q + NQ, q + 2 NQ, ...  The smallest task that
@@ -2217,9 +2338,12 @@ __global__ __launch_bounds__(TKW, SPADA_TASK_WAVES) void k_task(const TaskArgs *
     // (t is uniform: the descriptor is a scalar load, what is derived from it lives in scalar registers)
     uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)hdr[50]);
     uint32_t *dbg_ph = (uint32_t *)(smem + task_dbg_off());   // SPADA_TASK_DBG builds
+    if (SPADA_TASK_DBG && tid == 0) dbg_ph[16] = (uint32_t)__builtin_amdgcn_s_memtime();
     TaskDesc td{};
     BatchHead hd{0u, 0u, 0u, 0u};
     bool bt = false;
+    Parked pk;   // one-pass mode: the task whose outputs wait in registers for their position (spgemm_batch.hip.hpp)
+    pk.valid = 0u;
     auto uniform_head = [](const BatchHead &h) {   // (what a function returns arrives in vector registers)
         return BatchHead{(uint32_t)__builtin_amdgcn_readfirstlane((int)h.P), (uint32_t)__builtin_amdgcn_readfirstlane((int)h.nent),
                          (uint32_t)__builtin_amdgcn_readfirstlane((int)h.NBK), (uint32_t)__builtin_amdgcn_readfirstlane((int)h.ncopy)};
@@ -2250,6 +2374,7 @@ __global__ __launch_bounds__(TKW, SPADA_TASK_WAVES) void k_task(const TaskArgs *
             if (threadIdx.x == 0) hdr[50] = g.task_lo + atomicAdd(my_ticket, 1u) * TK_NQ + blockIdx.x % TK_NQ;
             __syncthreads();
             t2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)hdr[50]);
+            if (SPADA_TASK_DBG && threadIdx.x == 0) dbg_ph[16] = (uint32_t)__builtin_amdgcn_s_memtime();
             if (t2 < task_end) {
                 td2 = load_task(g.tasks, t2);
                 bt2 = task_is_batch(td2);
@@ -2258,10 +2383,11 @@ __global__ __launch_bounds__(TKW, SPADA_TASK_WAVES) void k_task(const TaskArgs *
         };
         if (bt) {
             const int v = task_variant(td);
-            if (v == 2) batch_main<MODE, true, true>(g, td, t, ntasks, smem, dbg_ph, hd, next);
-            else if (v == 1) batch_main<MODE, true>(g, td, t, ntasks, smem, dbg_ph, hd, next);
-            else batch_main<MODE, false>(g, td, t, ntasks, smem, dbg_ph, hd, next);
+            if (v == 2) batch_main<MODE, true, true>(g, td, t, ntasks, smem, dbg_ph, hd, pk, next);
+            else if (v == 1) batch_main<MODE, true>(g, td, t, ntasks, smem, dbg_ph, hd, pk, next);
+            else batch_main<MODE, false>(g, td, t, ntasks, smem, dbg_ph, hd, pk, next);
         } else {
+            if constexpr (MODE == MODE_FUSED) batch_unpark_now<MODE>(g, pk, ntasks, hdr);   // (the older path waits for its position itself)
             range_task<MODE, NOUT>(gp_, t, ntasks);
             next();
         }
@@ -2270,12 +2396,20 @@ __global__ __launch_bounds__(TKW, SPADA_TASK_WAVES) void k_task(const TaskArgs *
         hd = hd2;
         bt = bt2;
     }
+    if constexpr (MODE == MODE_FUSED) batch_unpark_now<MODE>(g, pk, ntasks, hdr);
     if (SPADA_TASK_DBG && tid == 0) {
         const uint32_t *d = (const uint32_t *)(smem + task_dbg_off());
         for (int k = 0; k < 8; ++k) atomicAdd(&g.ctr->dbg[8 + k], (unsigned long long)d[k]);
         atomicAdd(&g.ctr->dbg[6], (unsigned long long)d[8]);
         if (d[8]) atomicAdd(&g.ctr->dbg[7], 1ull);   // workgroups that took a task: the resident ones
         for (int k = 0; k < 6; ++k) atomicAdd(&g.ctr->dbg[k], (unsigned long long)d[9 + k]);   // shapes (spgemm_batch.hip.hpp)
+#if SPADA_TASK_DBG
+        for (int k = 0; k < 2; ++k) {   // ticket -> publication per kind (batch, range): sum / 16, tasks, maximum
+            atomicAdd(&g.ctr->dbgh[k][0], (unsigned long long)d[17 + 3 * k]);
+            atomicAdd(&g.ctr->dbgh[k][1], (unsigned long long)d[18 + 3 * k]);
+            atomicMax(&g.ctr->dbgh[k][2], (unsigned long long)d[19 + 3 * k]);
+        }
+#endif
     }
 }
 

@@ -14,6 +14,12 @@ struct Call {
     uint64_t op, root, count, dtype, offset;   // op: 1 group start, 2 group end, 3 broadcast, 4 allgather; offset: bytes from the registered base
 };
 std::vector<Call> g_log;
+// The ranks of a test run one after the other in one process, so a broadcast cannot move data when it is posted.  The test runs every
+// rank TWICE: in the first pass a root's broadcast deposits what it sends (keyed by the number of the call in the rank's sequence --
+// all ranks post the same sequence, which is what the test asserts first), in the second pass the other ranks' broadcasts pick it up.
+std::vector<std::vector<char>> g_store;
+int g_pass = 1, g_rank = 0;
+uint64_t g_bcast_no = 0;
 std::vector<uint64_t> g_gathered;            // what ncclAllGather delivers: the words of all ranks, rank-major
 const char *g_base_idx = nullptr, *g_base_val = nullptr, *g_base_ptr = nullptr;   // the rank's C buffers (offsets in the log are relative to them)
 uint64_t g_my_nnz = 0;
@@ -39,7 +45,12 @@ extern "C" {
 
 const char *ncclGetErrorString(ncclResult_t) { return "mock rccl error"; }
 ncclResult_t ncclGetUniqueId(ncclUniqueId *id) { std::memset(id, 7, sizeof *id); return ncclSuccess; }
-ncclResult_t ncclCommInitRank(ncclComm_t *c, int, ncclUniqueId, int) { *c = (ncclComm_t)std::malloc(1); return ncclSuccess; }
+ncclResult_t ncclCommInitRank(ncclComm_t *c, int, ncclUniqueId, int rank)
+{
+    *c = (ncclComm_t)std::malloc(1);
+    g_rank = rank;
+    return ncclSuccess;
+}
 ncclResult_t ncclCommDestroy(ncclComm_t c) { std::free(c); return ncclSuccess; }
 ncclResult_t ncclGroupStart() { g_log.push_back({1, 0, 0, 0, 0}); return ncclSuccess; }
 ncclResult_t ncclGroupEnd() { g_log.push_back({2, 0, 0, 0, 0}); return ncclSuccess; }
@@ -48,6 +59,15 @@ ncclResult_t ncclBroadcast(const void *send, void *recv, size_t count, ncclDataT
     uint64_t which = 0;
     const uint64_t off = offset_of(recv, &which);
     g_log.push_back({3, (uint64_t)root, (uint64_t)count, (uint64_t)t | (which << 8) | ((uint64_t)(send == recv ? 1 : 0) << 16), off});
+    const size_t bytes = count * (t == ncclUint32 ? 4u : 8u);
+    const uint64_t no = g_bcast_no++;
+    if (g_pass == 1 && root == g_rank) {
+        if (g_store.size() <= no) g_store.resize(no + 1);
+        g_store[no].assign((const char *)send, (const char *)send + bytes);
+    } else if (g_pass == 2 && root != g_rank) {
+        if (no >= g_store.size() || g_store[no].size() != bytes) return 1;   // (no root has posted this call: the sequences differ)
+        std::memcpy(recv, g_store[no].data(), bytes);
+    }
     return ncclSuccess;
 }
 ncclResult_t ncclAllGather(const void *, void *recv, size_t count, ncclDataType_t t, ncclComm_t, hipStream_t)
@@ -88,9 +108,15 @@ int spada_dev_spgemm_indptr(spada_ctx *, void *d_c_indptr)
 int spada_dev_synchronize(spada_ctx *) { return SPADA_OK; }
 
 // ---- what the test calls -------------------------------------------------------------------------------------------------
-void spada_mock_reset(void)
+void spada_mock_begin(int pass)   // 1: roots deposit what they send (clears the deposits), 2: the other ranks receive it
+{
+    g_pass = pass;
+    if (pass == 1) g_store.clear();
+}
+void spada_mock_reset(void)   // before every rank
 {
     g_log.clear();
+    g_bcast_no = 0;
     g_gathered.clear();
     g_pos.clear();
     g_indptr.clear();

@@ -404,3 +404,110 @@ def test_cli_usage_and_exit_codes(matrices_dir):
     if S.device_count() == 0:      # no GPU: the run itself must fail loudly, not fall back to anything
         r = _run_cli(["accuratesimu", "spada", "ss", "cari", CFG], cwd)
         assert r.returncode == 101 and "no HIP device" in r.stderr and "-----Result-----" not in r.stdout
+
+
+def _mock_lib():
+    """lib/libspada_comm_mock.so: the host half of spada_comm.hip compiled against test doubles of HIP, RCCL and the engine (csrc/mock/)."""
+    path = os.environ.get("SPADA_COMM_MOCK_LIB_PATH") or os.path.join(os.path.dirname(_ffi.LIB_PATH), "libspada_comm_mock.so")
+    _ffi.lib()                                       # (libspada_spgemm.so first: spada_last_error / fail live there)
+    L = ctypes.CDLL(path)
+    u64p, vp = ctypes.POINTER(ctypes.c_uint64), ctypes.c_void_p
+    L.spada_comm_create.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(vp)]
+    L.spada_comm_destroy.argtypes = [vp]
+    L.spada_comm_destroy.restype = None
+    L.spada_comm_allgatherv_c.argtypes = [vp, vp, vp, vp, u64p, u64p, vp, vp, vp]
+    L.spada_dist_spgemm_symbolic.argtypes = [vp, vp, vp, vp, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32, u64p, u64p]
+    L.spada_dist_spgemm_numeric.argtypes = [vp, vp, vp, vp, vp]
+    L.spada_mock_begin.argtypes = [ctypes.c_int]
+    L.spada_mock_set_gathered.argtypes = [u64p, ctypes.c_uint64]
+    L.spada_mock_set_block.argtypes = [ctypes.c_uint64, u64p, ctypes.c_uint32, u64p, ctypes.c_uint64, ctypes.c_uint32]
+    L.spada_mock_set_bases.argtypes = [vp, vp, vp]
+    L.spada_mock_log_size.restype = ctypes.c_uint64
+    L.spada_mock_log_get.argtypes = [ctypes.c_uint64, u64p]
+    for f in (L.spada_mock_begin, L.spada_mock_reset, L.spada_mock_set_gathered, L.spada_mock_set_block, L.spada_mock_set_bases, L.spada_mock_log_get):
+        f.restype = None
+    return L
+
+
+@pytest.mark.parametrize("form", ["after", "overlap"])
+@pytest.mark.parametrize("nranks", [2, 8])
+def test_exchange_call_sequence_on_mock_ranks(form, nranks):
+    """Both native exchange forms (spada_comm_allgatherv_c after a one-pass product; spada_dist_spgemm_symbolic / _numeric with the
+    pieces broadcast while the next is computed) for N = 2 and 8 ranks -- with empty row blocks, blocks without entries and empty
+    pieces -- on lib/libspada_comm_mock.so: spada_comm.hip's own host code against test doubles of the HIP / RCCL / engine calls it
+    makes (csrc/mock/).  Checked: EVERY RANK POSTS THE SAME COLLECTIVES IN THE SAME ORDER (operation, root, count, type, offset in
+    the whole C, group boundaries) -- the condition under which RCCL's grouped broadcasts match, including ranks whose own piece is
+    empty -- and, with the broadcasts replayed between the ranks' buffers, every rank ends with the whole C and its indptr.
+    No N > 1 RCCL run exists (one GPU per box); this is the host logic of that run, on the CPU."""
+    L = _mock_lib()
+    u64p = ctypes.POINTER(ctypes.c_uint64)
+    rng = np.random.default_rng(7 * nranks + len(form))
+    chunks = 4
+    for trial in range(6):
+        rows = rng.integers(1, 30, nranks).astype(np.uint64)
+        empty = rng.choice(nranks, 2 if nranks > 2 else 1, replace=False)
+        rows[empty[0]] = 0                                        # an empty row block
+        lens = [rng.integers(0, 7, int(r)) for r in rows]
+        if len(empty) > 1:
+            lens[int(empty[1])][:] = 0                            # a block whose rows are all empty
+        nnz = np.array([int(l.sum()) for l in lens], np.uint64)
+        ptrs = [np.concatenate([[0], np.cumsum(l)]).astype(np.uint64) for l in lens]
+        pos = np.zeros((nranks, chunks + 1), np.uint64)
+        for r in range(nranks):
+            cuts = np.sort(rng.integers(0, int(nnz[r]) + 1, chunks - 1))
+            if trial % 2 == 0:
+                cuts[0] = 0                                       # an empty first piece
+            pos[r] = np.concatenate([[0], cuts, [int(nnz[r])]])
+        fill = [100000 * (r + 1) for r in range(nranks)]
+        # what the mock engine writes for rank r's entry i: index fill + i, value (fill + i) / 2 (comm_mock.cpp)
+        blocks = [((fill[r] + np.arange(int(nnz[r]))).astype(np.uint32), (fill[r] + np.arange(int(nnz[r]))) * 0.5) for r in range(nranks)]
+        tot_rows, tot_nnz = int(rows.sum()), int(nnz.sum())
+        exp_idx = np.concatenate([b[0] for b in blocks]) if tot_nnz else np.zeros(0, np.uint32)
+        exp_val = np.concatenate([b[1] for b in blocks]) if tot_nnz else np.zeros(0)
+        exp_ptr = np.concatenate([[0], np.cumsum(np.concatenate(lens))]).astype(np.uint64)
+        gathered = np.concatenate([np.concatenate([[rows[r], nnz[r]], pos[r]]) for r in range(nranks)]).astype(np.uint64)
+        logs, finals = None, []
+        for pas in (1, 2):
+            L.spada_mock_begin(pas)
+            logs, finals = [], []
+            for me in range(nranks):
+                L.spada_mock_reset()
+                ci = np.full(tot_nnz + 1, 0xFFFFFFFF, np.uint32)
+                cv = np.full(tot_nnz + 1, np.nan)
+                cp = np.full(tot_rows + 1, 0xFFFFFFFFFFFFFFFF, np.uint64)
+                L.spada_mock_set_bases(ci.ctypes.data, cv.ctypes.data, cp.ctypes.data)
+                comm = ctypes.c_void_p()
+                ident = (ctypes.c_char * 128)()
+                assert L.spada_comm_create(ident, me, nranks, 0, ctypes.byref(comm)) == 0
+                if form == "after":
+                    my_i, my_v = blocks[me][0].copy(), blocks[me][1].copy()
+                    assert L.spada_comm_allgatherv_c(comm, ptrs[me].ctypes.data, my_i.ctypes.data, my_v.ctypes.data, rows.ctypes.data_as(u64p),
+                                                     nnz.ctypes.data_as(u64p), cp.ctypes.data, ci.ctypes.data, cv.ctypes.data) == 0, S.last_error()
+                else:
+                    L.spada_mock_set_block(int(nnz[me]), pos[me].ctypes.data_as(u64p), chunks, ptrs[me].ctypes.data_as(u64p), int(rows[me]), fill[me])
+                    L.spada_mock_set_gathered(gathered.ctypes.data_as(u64p), len(gathered))
+                    r_out, n_out = np.zeros(nranks, np.uint64), np.zeros(nranks, np.uint64)
+                    assert L.spada_dist_spgemm_symbolic(ctypes.c_void_p(1), comm, None, None, 0, int(rows[me]), chunks, r_out.ctypes.data_as(u64p),
+                                                        n_out.ctypes.data_as(u64p)) == 0, S.last_error()
+                    assert np.array_equal(r_out, rows) and np.array_equal(n_out, nnz)
+                    assert L.spada_dist_spgemm_numeric(ctypes.c_void_p(1), comm, cp.ctypes.data, ci.ctypes.data, cv.ctypes.data) == 0, S.last_error()
+                L.spada_comm_destroy(comm)
+                log = []
+                rec = (ctypes.c_uint64 * 5)()
+                for i in range(L.spada_mock_log_size()):
+                    L.spada_mock_log_get(i, rec)
+                    log.append(tuple(rec))
+                logs.append(log)
+                finals.append((ci[:tot_nnz].copy(), cv[:tot_nnz].copy(), cp.copy()))
+            # every rank posts the same sequence: operations, roots, counts, types, places, group boundaries
+            for me in range(1, nranks):
+                assert logs[me] == logs[0], (form, nranks, trial, me)
+        ops = [c[0] for c in logs[0]]
+        assert ops.count(1) == ops.count(2) and ops.count(3) > 0
+        assert all(c[4] != 0xFFFFFFFFFFFFFFFF for c in logs[0] if c[0] == 3)           # every broadcast lies inside the whole C
+        assert all((c[3] >> 16) & 1 for c in logs[0] if c[0] == 3)                     # ... and is in place
+        assert all(c[2] > 0 for c in logs[0] if c[0] == 3)                             # no empty collective is posted
+        for me in range(nranks):
+            fi, fv, fp = finals[me]
+            assert np.array_equal(fi, exp_idx) and np.array_equal(fv, exp_val), (form, nranks, trial, me)
+            assert np.array_equal(fp, exp_ptr), (form, nranks, trial, me)

@@ -1,4 +1,4 @@
-"""CPU, world_size 2 and 3 over gloo: the N > 1 path of bench.py -- product-balanced A-row blocks
+"""CPU, world_size 2, 3 and 8 over gloo: the N > 1 path of bench.py -- product-balanced A-row blocks
 (one per rank, B replicated) and the allgatherv that concatenates the C row blocks on every rank
 (spada_sim_amd/parallel.py).  On the GPU box the per-rank block is computed by the HIP engine; here,
 without a GPU, each rank's block is produced by the oracle so that the exchange logic is what is tested."""
@@ -33,7 +33,10 @@ def _worker(rank, world, port, ragged, q):
         from spada_sim_amd import parallel
         from oracle import oracle
         m = S.generate(S.GEN_RMAT, 10, 8, 17)
-        if ragged:   # one rank ends up with an empty row block
+        if ragged and world == 8:   # two ranks end up with an empty row block (the first and one in the middle)
+            q8 = m.shape[0] // 6
+            bounds = [0, 0, q8, 2 * q8, 2 * q8, 3 * q8, 4 * q8, 5 * q8, m.shape[0]]
+        elif ragged:   # one rank ends up with an empty row block
             bounds = [0, 0, m.shape[0]] if world == 2 else [0, 0, m.shape[0] // 2, m.shape[0]]
         else:
             bounds = S.partition_rows(m, m, world)
@@ -55,7 +58,7 @@ def _worker(rank, world, port, ragged, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,ragged", [(2, False), (3, False), (2, True)])
+@pytest.mark.parametrize("world,ragged", [(2, False), (3, False), (2, True), (8, True)])
 def test_row_blocks_allgatherv_reassembles_c(world, ragged):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

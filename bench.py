@@ -501,7 +501,7 @@ def main():
         cls_names = ["empty", "copy (one A entry)", "small", "solo", "big (column-range tasks)"]
         kernels = [
             {"kernel": "k_entry_stats + k_row_class (B-row descriptors, products per row, row classes)", "ms": ms["ms_row_stats"]},
-            {"kernel": "k_big_parts/hist/plan/scatter (big rows: column histograms, ranges; spilled rows scattered into HBM scratch)",
+            {"kernel": "k_big_parts/hist/plan/cuts/scatter (big rows: column histograms, ranges, cut table of the direct rows; spilled rows scattered into HBM scratch)",
              "ms": ms["ms_big_expand"], "products": st["cls_prod"][4] if "cls_prod" in st else None,
              "spilled_products": st.get("scratch_products"), "spilled_rows": st.get("spill_rows")},
             {"kernel": "k_cut1/2/3 (task list; where the scatter of spilled rows runs next to them on the side stream: what they add behind it)",
@@ -548,6 +548,9 @@ def main():
                 "allgatherv_ms_per_step": gather_max_s / K * 1e3 if exchange != "overlap" else None,   # max over ranks
                 "compute_ms_per_step": compute_max_s / K * 1e3,            # max over ranks: the block SpGEMM alone, timed separately
                 "value_compute_only": nnz_total / (compute_max_s / K),     # nnz(C)/s with C left sharded by row block
+                # what the replicated C costs at best: every GPU takes in (N - 1) / N of 12 B x nnz(C) over its seven xGMI links
+                # (~100 GB/s each in practice) -- to be read next to compute_ms_per_step
+                "predicted_ingest_ms": (world - 1) / world * 12.0 * nnz_total / (7 * 100e9) * 1e3,
                 "note": "value includes the allgatherv that replicates C on every rank (north_star); every GPU must take in "
                         "(N-1)/N of 12 B x nnz(C) over xGMI, which bounds strong scaling once that exceeds the compute time"},
             "config": {"workload": f"{args.workload} A*A", "rows": rows, "nnz_a": a.nnz(), "products": nprod_total,
@@ -557,12 +560,17 @@ def main():
                                       "spada_dev_spgemm_fused (one pass, C buffers sized by the product count)"
                                       if one_pass
                                       else "spada_dev_spgemm_symbolic + spada_dev_spgemm_numeric",
+                       # the headline runs on the additive one-pass entry point; the contract of SURVEY 8(b) is symbolic + numeric
+                       # (`--two-phase` times it: profiles/r04_bench_webbase-1M_two_phase.json)
+                       "entry_point_contract": ("additive one-pass entry point (spada_dev_spgemm_fused); the two-phase contract of SURVEY 8(b) "
+                                                "-- spada_dev_spgemm_symbolic + _numeric -- is what --two-phase times") if one_pass and exchange != "overlap"
+                                               else "two-phase contract of SURVEY 8(b): symbolic + numeric",
                        "parallelism": f"row-block x{world}, B replicated" +
                                       (f", C streamed in {len(chunk_bounds) - 1} row chunks per rank and not gathered"
                                        if chunk_bounds is not None else (", allgatherv of C" if world > 1 else ""))},
             "roofline": {
                 "bound": "hbm",
-                "kernel": ("k_task (persistent task kernel: expand - scale - LDS-hash accumulate - ordered emission of every row of C); "
+                "kernel": ("k_task (persistent task kernel: expand - scale - accumulate in an ordered LDS block table - emission of every row of C); "
                            "average duration per step by HIP events on its stream, rank 0") if not two_phase else
                           ("whole device time of the symbolic + numeric calls (k_task<COUNT>, k_task<NUMERIC> and the kernels around "
                            "them) against the algorithmic bytes of ONE pass over the products; HIP events on the engine stream, rank 0"),

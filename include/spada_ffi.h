@@ -109,8 +109,7 @@ typedef struct spada_stats {
     uint64_t spill_rows;      /* BIG rows that took the HBM spill path */
     uint64_t pipeline_runs;   /* > 1 when a workspace had to grow and the pipeline was run again (first call of a context) */
     uint64_t workspace_bytes; /* device scratch owned by the context */
-    uint64_t task_product_limit; /* products one task hashes at most: 1920, or 2040 where the sampled products / outputs ratio of the
-                                    input is high (fuller tables, fewer tasks); rows with more products are BIG */
+    uint64_t task_product_limit; /* products one task hashes at most: 2040 (lds_hash) / 1536 (sort_merge) */
 } spada_stats;
 
 typedef struct spada_ctx spada_ctx;          /* engine context: one GPU, one stream, scratch */

@@ -6,7 +6,7 @@ lines = open(sys.argv[1]).read().split("\n")
 name = sys.argv[2]
 i = next(k for k, l in enumerate(lines) if l.startswith(name + ":"))
 cur, order, cnt = "(before)", [], collections.defaultdict(collections.Counter)
-while "s_endpgm" not in lines[i]:
+while not lines[i].startswith(".Lfunc_end"):
     l = lines[i].strip()
     i += 1
     if "BT_MARK" in l:

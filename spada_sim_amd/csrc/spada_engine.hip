@@ -103,7 +103,7 @@ struct spada_ctx {
     DevBuf row_nprod, row_bin, row_kmin, row_kmax, cptr, t_rowP, t_rowm, t_rowt, t_rowtmp, t_big, t_tiles;
     DevBuf row_cl, row_rec, row_binfo;   // per row: class | length; RowRec; batch_info of the batch that starts at the row
     DevBuf eb0, elen;
-    DevBuf t_tmp, t_tasks, t_status, t_rangeout, t_scrcol, t_scrval, t_scrseq, t_ctr, t_args, t_cuts, t_cutitems, t_stagecol, t_stageval;
+    DevBuf t_tmp, t_tasks, t_status, t_rangeout, t_scrcol, t_scrval, t_scrseq, t_ctr, t_args, t_cuts, t_cutitems, t_stagecol, t_stageval, t_legacy;
     DevBuf t_possum;                                          // COUNT mode: sums of the tasks' counts per tile
     DevBuf t_parts, t_parthist, t_slots;                      // BIG rows: parts, bucket counts (then cursors) per part, row records
     DevBuf own_idx, own_val, own_ptr, wide_idx;
@@ -253,6 +253,10 @@ void launch_task(spada_ctx *c, const TaskArgs &g)
         hipLaunchKernelGGL(k_task_args, dim3(1), dim3(64), 0, c->stream, g, c->t_args.as<TaskArgs>());
         hipLaunchKernelGGL((k_task<MODE, TK_NOUT>), dim3(c->n_cu * (SPADA_TASK_WAVES / 2)), dim3(TKW), task_kernel_lds(), c->stream,
                            (const TaskArgs *)c->t_args.as<TaskArgs>());
+        // the modes without a chain: the tasks of the older range path in their own kernel (256-thread workgroups)
+        if constexpr (MODE != MODE_FUSED)
+            hipLaunchKernelGGL((k_task_range<MODE, TK_NOUT>), dim3(c->n_cu * 4), dim3(TK_BLOCK), task_lds(), c->stream,
+                               (const TaskArgs *)c->t_args.as<TaskArgs>());
     }
 }
 
@@ -278,6 +282,8 @@ TaskArgs task_args(spada_ctx *c, uint64_t *cptr, uint32_t *d_idx, double *d_val,
     g.scr_col = c->t_scrcol.as<uint32_t>();
     g.scr_val = c->t_scrval.as<double>();
     g.scr_seq = c->accumulator == SPADA_ACC_SORT_MERGE ? c->t_scrseq.as<uint32_t>() : nullptr;
+    g.legacy = c->t_legacy.as<uint32_t>();
+    g.b_off32 = c->B->nnz < (1ull << 29) ? 1u : 0u;
     g.cuts = c->t_cuts.as<uint32_t>();
     g.stage_col = c->t_stagecol.as<uint32_t>();
     g.stage_val = c->t_stageval.as<double>();
@@ -351,6 +357,7 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
         if ((rc = c->t_tasks.ensure(c->t_cap_tasks * sizeof(TaskDesc), false, s, &c->ws_bytes))) return rc;
         if ((rc = c->t_status.ensure(c->t_cap_tasks * 8 * ST_STRIDE, false, s, &c->ws_bytes))) return rc;
         if ((rc = c->t_rangeout.ensure(c->t_cap_tasks * 8, false, s, &c->ws_bytes))) return rc;
+        if ((rc = c->t_legacy.ensure(c->t_cap_tasks * 4, false, s, &c->ws_bytes))) return rc;
         if ((rc = c->t_possum.ensure((c->t_cap_tasks / POS_TILE + 2) * 8, false, s, &c->ws_bytes))) return rc;
         if ((rc = c->t_tmp.ensure(c->t_cap_tmp * sizeof(TaskDesc), false, s, &c->ws_bytes))) return rc;
         if ((rc = c->t_scrcol.ensure(c->t_cap_scr * 4, false, s, &c->ws_bytes))) return rc;
@@ -373,13 +380,12 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
                            c->row_kmax.as<uint32_t>(), n, c->t_status.as<unsigned long long>(), (uint64_t)cap_tasks * ST_STRIDE);
         if (n) {
             const uint32_t gent = (uint32_t)std::min<uint64_t>((a->nnz + 255) / 256 + 1, (uint64_t)c->n_cu * 8 * 4);
-            hipLaunchKernelGGL(k_entry_stats, dim3(gent + EST_ROWS), dim3(256), 0, s, a->ptr, a->idx, a->rowid, b->ptr, b->idx, c->r0, n,
+            // (products a task hashes at most: since the table of the batch tasks is keyed by BLOCKS of columns it never gets full, and
+            // the fullest tasks win on every input: 2040 / 1920 / 1792 / 1536 -> web 0.826 / 0.844 / 0.882 / 0.965 ms, R-MAT 16 4.81 /
+            // 5.00 / 5.22 / 5.98 ms in round 3; rounds 1 - 2 sampled the products / outputs ratio to choose between 1920 and 2040)
+            hipLaunchKernelGGL(k_entry_stats, dim3(gent), dim3(256), 0, s, a->ptr, a->idx, a->rowid, b->ptr, b->idx, c->r0, n,
                                c->eb0.as<uint64_t>(), c->elen.as<uint32_t>(), c->t_rowP.as<unsigned long long>(),
-                               c->row_kmin.as<uint32_t>(), c->row_kmax.as<uint32_t>(), gent,
-                               // products a task hashes at most.  Since the table of the batch tasks is keyed by BLOCKS of columns it
-                               // never gets full (a third of its slots on the web surrogate), and the fullest tasks win on every input:
-                               // 2040 / 1920 / 1792 / 1536 -> web 0.826 / 0.844 / 0.882 / 0.965 ms, R-MAT 16 4.81 / 5.00 / 5.22 / 5.98 ms
-                               // (round 2 sampled the products / outputs ratio to choose between 1920 and 2040: estimate_block)
+                               c->row_kmin.as<uint32_t>(), c->row_kmax.as<uint32_t>(),
                                c->accumulator == SPADA_ACC_SORT_MERGE ? (uint32_t)TK_SOLO_MAX : TK_LIMIT_HI, dc);
             hipLaunchKernelGGL(k_row_class, dim3(std::min<uint32_t>((n + 255) / 256, c->n_cu * 8)), dim3(256), 0, s, a->ptr, c->r0,
                                n, rmax, c->t_rowP.as<unsigned long long>(), c->row_kmin.as<uint32_t>(), c->row_kmax.as<uint32_t>(),
@@ -436,7 +442,7 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
             hipLaunchKernelGGL(k_cut3, dim3(ntiles), dim3(256), 0, s, c->row_bin.as<uint8_t>(), c->t_rowt.as<uint32_t>(),
                                c->row_binfo.as<uint32_t>(), a->ptr, c->r0, c->t_rowtmp.as<uint32_t>(), n, c->t_tiles.as<uint32_t>(),
                                c->t_tmp.as<TaskDesc>(), c->t_tasks.as<TaskDesc>(), cap_tasks, fold ? 1u : 0u,
-                               c->t_tiles.as<uint32_t>() + ntiles + 2, dc);
+                               c->t_tiles.as<uint32_t>() + ntiles + 2, c->t_legacy.as<uint32_t>(), dc);
             HIP_TRY(hipGetLastError());
             if (c->scatter_on_side) {
                 HIP_TRY(hipStreamWaitEvent(s, c->ev_join, 0));
@@ -656,6 +662,8 @@ int spada_create(const spada_options *opts, spada_ctx **out)
     if ((rc = allow_lds(k_task<MODE_COUNT, TK_NOUT>, task_kernel_lds()))) return rc;
     if ((rc = allow_lds(k_task<MODE_NUMERIC, TK_NOUT>, task_kernel_lds()))) return rc;
     if ((rc = allow_lds(k_task<MODE_FUSED, TK_NOUT>, task_kernel_lds()))) return rc;
+    if ((rc = allow_lds(k_task_range<MODE_COUNT, TK_NOUT>, task_lds()))) return rc;
+    if ((rc = allow_lds(k_task_range<MODE_NUMERIC, TK_NOUT>, task_lds()))) return rc;
     if ((rc = allow_lds(k_task_sm<MODE_COUNT>, task_sm_lds()))) return rc;
     if ((rc = allow_lds(k_task_sm<MODE_NUMERIC>, task_sm_lds()))) return rc;
     if ((rc = allow_lds(k_task_sm<MODE_FUSED>, task_sm_lds()))) return rc;
@@ -679,7 +687,7 @@ void spada_destroy(spada_ctx *c)
     c->un_val.release();
     for (DevBuf *b : {&c->row_cl, &c->row_rec, &c->row_binfo, &c->row_nprod, &c->row_bin, &c->row_kmin, &c->row_kmax, &c->cptr, &c->t_rowP, &c->t_rowm, &c->t_rowt, &c->t_rowtmp,
                       &c->t_big, &c->t_tiles, &c->eb0, &c->elen, &c->t_tmp, &c->t_tasks, &c->t_status, &c->t_rangeout, &c->t_possum, &c->t_scrcol,
-                      &c->t_scrval, &c->t_scrseq, &c->t_ctr, &c->t_args, &c->t_cuts, &c->t_cutitems, &c->t_stagecol, &c->t_stageval, &c->t_parts, &c->t_parthist, &c->t_slots, &c->own_idx, &c->own_val, &c->own_ptr, &c->wide_idx})
+                      &c->t_scrval, &c->t_scrseq, &c->t_ctr, &c->t_args, &c->t_cuts, &c->t_cutitems, &c->t_stagecol, &c->t_stageval, &c->t_legacy, &c->t_parts, &c->t_parthist, &c->t_slots, &c->own_idx, &c->own_val, &c->own_ptr, &c->wide_idx})
         b->release();
     if (c->h_tctr) (void)hipHostFree(c->h_tctr);
     for (auto &e : c->tev)

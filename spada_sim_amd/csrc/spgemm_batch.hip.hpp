@@ -62,7 +62,15 @@ struct __attribute__((aligned(16))) BtRow {   // region of a row in the table: f
     uint32_t s, g, bmin;
     float scale;
 };
-constexpr size_t BT_OFF_LIST = BT_OFF_ROWS + (size_t)TK_RMAX * (sizeof(BtRow) + 4 + 4 + 4 + 4);   // the displaced blocks of the task
+#ifndef SPADA_RESTART
+#define SPADA_RESTART 1   /* 0: no second attempt -- a task whose blocks cluster probes as far as it takes (measurements) */
+#endif
+constexpr uint32_t BT_BINS = 256;   // equalised home slots (second attempt of a task whose blocks cluster): bins of the rows' column spans
+#ifndef SPADA_PROBE_MAX
+#define SPADA_PROBE_MAX 24   /* slots a block may be displaced in the first attempt before the task starts over with equalised home slots */
+#endif
+constexpr size_t BT_OFF_BINS = BT_OFF_ROWS + (size_t)TK_RMAX * (sizeof(BtRow) + 4 + 4 + 4 + 4 + 4 + 4);
+constexpr size_t BT_OFF_LIST = BT_OFF_BINS + (size_t)BT_BINS * 4;   // the displaced blocks of the task
 constexpr uint32_t BT_LIST_CAP = (40960 - 128 - BT_OFF_LIST) / 4;   // (the last 128 bytes: the counters of SPADA_TASK_DBG builds)
 __host__ __device__ constexpr size_t batch_lds() { return BT_OFF_LIST + (size_t)BT_LIST_CAP * 4; }
 static_assert(batch_lds() <= 40960, "four workgroups per CU");
@@ -176,12 +184,15 @@ struct BatchHead {
     uint32_t *s_cpo = (uint32_t *)(s_delta + TK_RMAX);          /* COPY rows: number of the row's first product */                    \
     uint32_t *s_hoff = s_cpo + TK_RMAX;                         /* hashed outputs before the row (COUNT: outputs of the row) */       \
     uint32_t *s_info = s_hoff + TK_RMAX;                        /* class | products << 3 of the row */                                \
+    uint32_t *s_bin = s_info + TK_RMAX;                         /* equalised mapping: first bin | bins << 16 of the row */            \
+    uint32_t *s_span = s_bin + TK_RMAX;                         /* ... blocks between its first and last possible block */            \
+    uint32_t *bins = (uint32_t *)((smem) + BT_OFF_BINS);        /* equalised mapping: products per bin, then first slot | slots << 16 */ \
     uint32_t *dlist = (uint32_t *)((smem) + BT_OFF_LIST);       /* displaced blocks: slot | slots above the home << 12; hdr[41] of them */ \
     /* scan slots (eight words each) in the header; hdr[40] = a probe sequence reached the end of the table; hdr[48 .. 50] belong  \
        to the chain and the ticket, hdr[52 .. 53] to the numeric base */                                                             \
     uint32_t *slot_rows = hdr, *slot_ent = hdr + 8, *slot_sp = hdr + 16, *slot_cnt = hdr + 24, *slot_pc = hdr + 32;                  \
     (void)keys; (void)masks; (void)w_ent; (void)fo; (void)fo32; (void)bm32; (void)bm64; (void)vals; (void)cols; (void)s_emit;        \
-    (void)s_delta; (void)s_cpo; (void)s_hoff; (void)s_info; (void)dlist; (void)slot_rows; (void)slot_ent; (void)slot_sp; (void)slot_cnt; (void)slot_pc
+    (void)s_delta; (void)s_cpo; (void)s_hoff; (void)s_info; (void)dlist; (void)bins; (void)s_bin; (void)s_span; (void)slot_rows; (void)slot_ent; (void)slot_sp; (void)slot_cnt; (void)slot_pc
 
 template <int MODE, bool DENSE, bool SPILL = false, class ARGS>
 __device__ inline BatchHead batch_prologue(const ARGS &g, const TaskDesc &td, uint32_t t, unsigned char *smem)
@@ -213,28 +224,29 @@ __device__ inline BatchHead batch_prologue(const ARGS &g, const TaskDesc &td, ui
     if (range) {
         if (tid == 0) rr = RowRec{td.col_lo, td.col_hi, td.np, (uint32_t)CLS_SOLO};
     } else if ((uint32_t)tid < R) {
-        rr = g.row_rec[rb + tid];
+        rr = (g.row_rec + rb)[(uint32_t)tid];   // (uniform base + 32-bit thread offset: one shift per address)
     }
     uint64_t b0 = 0;
     uint32_t len = 0, elr = 0;
     double av = 0.0;
     bool ecopy = false;
     if (busy && PT && (uint32_t)tid < E) {
-        const uint64_t q = td.src + (uint32_t)tid;
-        b0 = g.eb0[q];
-        len = g.elen[q];
-        if constexpr (VALUES) av = g.aval[q];
+        const uint32_t ti = (uint32_t)tid;   // (the entries of a task are contiguous: uniform base + 32-bit thread offset)
+        b0 = (g.eb0 + td.src)[ti];
+        len = (g.elen + td.src)[ti];
+        if constexpr (VALUES) av = (g.aval + td.src)[ti];
         if (range) {
             // DIRECT RANGE: every selected B row narrowed to the range's columns -- B rows are ascending, and k_big_cuts has left
             // the positions of the range's bounds in every one of them: the same round trip as the entry itself
-            const uint32_t c_lo = g.cuts[td.cut + (uint32_t)tid], c_hi = g.cuts[td.cut + E + (uint32_t)tid];
+            const uint32_t c_lo = (g.cuts + td.cut)[ti], c_hi = (g.cuts + td.cut + E)[ti];
             b0 += c_lo;
             len = c_hi - c_lo;
         }
         if (!range) {
             // a COPY row is a row with ONE entry (row_class): the entry's neighbours belong to other rows (batches hold whole rows)
-            const uint32_t row = g.arow[q];
-            const uint32_t prev = tid > 0 ? g.arow[q - 1] : 0xFFFFFFFFu, nxt = (uint32_t)tid + 1u < E ? g.arow[q + 1] : 0xFFFFFFFFu;
+            const uint32_t *ar = g.arow + td.src;
+            const uint32_t row = ar[ti];
+            const uint32_t prev = tid > 0 ? ar[ti - 1u] : 0xFFFFFFFFu, nxt = ti + 1u < E ? ar[ti + 1u] : 0xFFFFFFFFu;
             elr = row - (uint32_t)g.r0 - rb;
             ecopy = prev != row && nxt != row;
         }
@@ -248,6 +260,7 @@ __device__ inline BatchHead batch_prologue(const ARGS &g, const TaskDesc &td, ui
     if (tid == 0) {
         hdr[40] = 0u;
         hdr[41] = 0u;
+        hdr[42] = 0u;
     }
     asm volatile("; BT_MARK p1" ::: "memory");
     // rows: the hashed products before every row (the table's slots are laid out over the rows in proportion to them) and the
@@ -284,6 +297,7 @@ __device__ inline BatchHead batch_prologue(const ARGS &g, const TaskDesc &td, ui
             if (spanb > G) scale = (float)G / (float)spanb;
         }
         s_emit[tid] = BtRow{S, G, bmin, scale};
+        if constexpr (!DENSE) s_span[tid] = max(spanb, 1u);   // (for the second attempt of a task whose blocks cluster, batch_main)
         s_delta[tid] = (int32_t)cpre;
         s_hoff[tid] = 0u;
         s_info[tid] = rr.cls | (min(rr.nprod, 0xFFFFFFu) << 3);
@@ -381,6 +395,7 @@ __device__ inline void batch_main(const ARGS &g, const TaskDesc &td, uint32_t t,
     uint32_t r_ck[4], r_st[4];   // the products of this thread: composite key (local row << colbits | column), state (above)
     double r_v[4];
     uint32_t mynew = 0, mykeys = 0;   // mask bits this lane has set | blocks (table keys) this lane has created
+    uint32_t NO = 0, NBt = 0, total = 0;   // hashed outputs, blocks, outputs of the task
     {
         // lane l of a segment holds product seg + l, i.e. bit l of one bitmap word: the word and its prefix are wave-uniform
         // reads; the entry of a product = the entries that END before it = tails before the word + tails below the lane (a
@@ -422,23 +437,127 @@ __device__ inline void batch_main(const ARGS &g, const TaskDesc &td, uint32_t t,
                 const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(bits >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bits, 0u));
                 j[u] = min(bp + below, nent - 1u);
             }
-            uint64_t q[4];
             double a_[4];
+            if (g.b_off32) {
+                // nnz(B) < 2^29: the byte offsets of both gathers fit 32 bits -- one shift per address on top of the scalar base
+                // instead of 64-bit adds and shifts (eight vector instructions per product less)
+                uint32_t q[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const EntryRecNum er = w_ent[j[u]];
-                q[u] = ((er.pack & M48) + pp[u]) & M48;
-                lrc[u] = (uint32_t)(er.pack >> 48);
-                a_[u] = er.av;
-            }
+                for (int u = 0; u < 4; ++u) {
+                    const EntryRecNum er = w_ent[j[u]];
+                    q[u] = (uint32_t)er.pack + pp[u];
+                    lrc[u] = (uint32_t)(er.pack >> 48);
+                    a_[u] = er.av;
+                }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) col[u] = g.bidx[q[u]];
+                for (int u = 0; u < 4; ++u) col[u] = *(const uint32_t *)((const char *)g.bidx + (uint32_t)(q[u] << 2));
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                r_v[u] = 0.0;
-                if constexpr (VALUES) r_v[u] = a_[u] * g.bval[q[u]];   // simulator.rs:100-101
+                for (int u = 0; u < 4; ++u) {
+                    r_v[u] = 0.0;
+                    if constexpr (VALUES) r_v[u] = a_[u] * *(const double *)((const char *)g.bval + (uint32_t)(q[u] << 3));   // simulator.rs:100-101
+                }
+            } else {
+                uint64_t q[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const EntryRecNum er = w_ent[j[u]];
+                    q[u] = ((er.pack & M48) + pp[u]) & M48;
+                    lrc[u] = (uint32_t)(er.pack >> 48);
+                    a_[u] = er.av;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) col[u] = g.bidx[q[u]];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    r_v[u] = 0.0;
+                    if constexpr (VALUES) r_v[u] = a_[u] * g.bval[q[u]];   // simulator.rs:100-101
+                }
             }
         }
+        // The home slot of a block is a LINEAR function of its column inside the row's span: when the columns cluster -- the rows of
+        // an R-MAT graph: a third of a row's blocks on a twentieth of its span -- the blocks of a cluster share a few home slots and
+        // linear probing pays for it quadratically (such tasks took 60 - 100 us to count their outputs, and a thousand tasks of the
+        // chain waited for each of them).  So the first attempt gives up where a block is displaced by SPADA_PROBE_MAX slots, and the
+        // task starts over with EQUALISED home slots: it counts its products in BT_BINS bins of the rows' spans (every row its own
+        // bins, s_bin), gives every bin slots in proportion to its products -- at least as many: a bin cannot overflow by itself --
+        // and interpolates inside the bin.  Still monotone in (row, column), and as even as the task's own histogram makes it.
+        // (the insertion of the hashed products: EQ = the second attempt, with equalised home slots)
+        auto insert_hashed = [&](auto EQ) {
+            constexpr bool equalised = decltype(EQ)::value;
+            mynew = mykeys = 0u;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t lr = lrc[u] & 127u;
+                const bool copy = (lrc[u] & 128u) != 0u, hashed = act[u] && !copy;
+                const uint32_t ck = compose_key(lr, col[u], colbits);
+                r_ck[u] = ck;
+                r_st[u] = act[u] ? BT_H_COPY : BT_H_NONE;
+                if (hashed) {
+                    const BtRow e = s_emit[lr];
+                    const uint32_t d = (col[u] >> BT_BSHIFT) - e.bmin;
+                    const uint32_t hk = ck >> BT_BSHIFT;
+                    uint32_t home = e.s + min((uint32_t)((float)d * e.scale), e.g - 1u);
+                    if (equalised) {
+                        const uint32_t rb_ = s_bin[lr], nb = rb_ >> 16;
+                        const float x = (float)d * ((float)nb / (float)s_span[lr]);
+                        const uint32_t k = min((uint32_t)x, nb - 1u), bw = bins[(rb_ & 0xFFFFu) + k], bg = bw >> 16;
+                        home = (bw & 0xFFFFu) + min((uint32_t)((x - (float)k) * (float)bg), bg - 1u);
+                    }
+                    uint32_t h = home, st = 0;
+                    uint32_t old = atomicCAS(&keys[h], EMPTY_KEY, hk);
+                    if (old != EMPTY_KEY && old != hk) {
+                        // upwards; at the end of the table the free slot BELOW the home takes the block (the order stage then looks at
+                        // whole clusters).  First attempt: SPADA_PROBE_MAX slots above its home the lane gives up -- the blocks cluster,
+                        // the task starts over with equalised home slots -- and leaves the loop by "finding" the key of its home slot
+                        // (no exit of its own: the common iteration is the one of a loop without a budget)
+                        uint32_t hkx = hk;
+                        const uint32_t hlim = SPADA_RESTART && !equalised ? min(home + (uint32_t)SPADA_PROBE_MAX, T) : T;
+                        do {
+                            if (h >= home) {
+                                if (++h == hlim) {
+                                    if (hlim == T) {
+                                        h = home - 1u;
+                                        hdr[40] = 1u;
+                                    } else {
+                                        hdr[42] = 1u;
+                                        h = home;
+                                        hkx = keys[home];
+                                    }
+                                }
+                            } else {
+                                --h;
+                            }
+                            old = atomicCAS(&keys[h], EMPTY_KEY, hkx);
+                        } while (old != EMPTY_KEY && old != hkx);
+                        if (old == EMPTY_KEY && h > home) {   // displaced: the order stage looks at the slots between its home and its place
+                            const uint32_t li = atomicAdd(&hdr[41], 1u);
+                            if (li < BT_LIST_CAP) dlist[li] = h | ((h - home) << 12);
+                        }
+                    }
+                    if (old == EMPTY_KEY) {
+                        ++mykeys;
+                        st = BT_ST_CREATOR;
+                    }
+                    const uint32_t bit = 1u << (col[u] & 31u);
+                    const uint32_t was = atomicOr(&masks[h], bit);
+                    if (!(was & bit)) {
+                        ++mynew;
+                        st |= BT_ST_OWNER;
+                    }
+                    r_st[u] = h | st;
+                }
+            }
+        };
+        auto count_outputs = [&]() {
+            // ---- the count of the task: new mask bits + copied products (known from the rows) -----------------------------------------
+        {
+            uint32_t tot;
+            (void)block_scan_excl_dpp_n<BT_NWAVE>(mynew | (mykeys << 16), slot_cnt, &tot, tid);   // (its barrier: the table is complete)
+            NO = tot & 0xFFFFu;
+            NBt = tot >> 16;
+            total = NO + hd.ncopy;   // + the products of the COPY rows
+        }
+        };
         if constexpr (DENSE) {
             // no keys: the slot is the block's place in the row.  The four products of a thread go through the two steps -- row
             // parameters, mask -- together, so that the four LDS operations of a step are in flight at once
@@ -466,63 +585,87 @@ __device__ inline void batch_main(const ARGS &g, const TaskDesc &td, uint32_t t,
                 if (hashed[u]) r_st[u] = h[u] | (fresh ? BT_ST_OWNER : 0u);
             }
         } else {
+            insert_hashed(std::false_type{});
+        }
+        count_outputs();
+        if constexpr (!DENSE) {
+            if (SPADA_RESTART && hdr[42] != 0u) {   // (uniform, rare: a block of the first attempt was displaced too far)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {   // (the products again from their keys and states: nothing else stays live across the count)
+                const uint32_t st = r_st[u], ck = r_ck[u];
+                act[u] = st != BT_H_NONE;
+                col[u] = colbits >= 32 ? ck : ck & ((1u << colbits) - 1u);
+                lrc[u] = (colbits >= 32 ? 0u : ck >> colbits) | (st == BT_H_COPY ? 128u : 0u);
+            }
+            {   // the rows' bins: every hashed row at least one, the rest in proportion to the products -- disjoint, ascending with the rows
+                const uint32_t R = td.kind != TASK_BATCH ? 1u : (td.np & 0xFFu);
+                uint32_t row_pr = 0;
+                if ((uint32_t)tid < R) {
+                    const uint32_t info = s_info[tid], cls = info & 7u;
+                    if (cls == CLS_SMALL || cls == CLS_SOLO) row_pr = info >> 3;
+                }
+                uint32_t rtot;
+                const uint32_t rex = block_scan_excl_dpp_n<BT_NWAVE>(row_pr | ((row_pr ? 1u : 0u) << 16), slot_rows, &rtot, tid);
+                if ((uint32_t)tid < R) {
+                    const uint32_t nh = rtot >> 16, hrb = rex >> 16, boff = rex & 0xFFFFu;
+                    const float fb = (float)(BT_BINS - nh) / (float)max(rtot & 0xFFFFu, 1u);
+                    const uint32_t b0 = hrb + (uint32_t)((float)boff * fb), b1 = hrb + (row_pr ? 1u : 0u) + (uint32_t)((float)(boff + row_pr) * fb);
+                    s_bin[tid] = min(b0, BT_BINS - 1u) | (max(min(b1, BT_BINS) - min(b0, BT_BINS - 1u), 1u) << 16);
+                }
+            }
+            {   // the table again, and the marks of the first attempt
+                uint4 *k4 = (uint4 *)keys;
+                uint32_t zero = 0u;
+                asm volatile("" : "+v"(zero));
+#pragma unroll
+                for (int s2 = 0; s2 < 3; ++s2) {
+                    const uint32_t i = (uint32_t)tid + (uint32_t)s2 * BW;
+                    const uint32_t fill = i < T / 4 ? ~zero : zero;
+                    k4[i] = make_uint4(fill, fill, fill, fill);
+                }
+                if (tid < (int)BT_BINS) bins[tid] = 0u;
+                if (tid == 0) {
+                    hdr[40] = 0u;
+                    hdr[41] = 0u;
+                }
+            }
+            __syncthreads();
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const uint32_t lr = lrc[u] & 127u;
-                const bool copy = (lrc[u] & 128u) != 0u, hashed = act[u] && !copy;
-                const uint32_t ck = compose_key(lr, col[u], colbits);
-                r_ck[u] = ck;
-                r_st[u] = act[u] ? BT_H_COPY : BT_H_NONE;
-                if (hashed) {
-                    const BtRow e = s_emit[lr];
-                    const uint32_t d = (col[u] >> BT_BSHIFT) - e.bmin;
-                    const uint32_t hk = ck >> BT_BSHIFT;
-                    const uint32_t home = e.s + min((uint32_t)((float)d * e.scale), e.g - 1u);
-                    uint32_t h = home, st = 0;
-                    uint32_t old = atomicCAS(&keys[h], EMPTY_KEY, hk);
-                    if (old != EMPTY_KEY && old != hk) {
-                        do {   // upwards; at the end of the table the free slot BELOW the home takes the block (the order stage then looks at whole clusters)
-                            if (h >= home) {
-                                if (++h == T) {
-                                    h = home - 1u;
-                                    hdr[40] = 1u;
-                                }
-                            } else {
-                                --h;
-                            }
-                            old = atomicCAS(&keys[h], EMPTY_KEY, hk);
-                        } while (old != EMPTY_KEY && old != hk);
-                        if (old == EMPTY_KEY && h > home) {   // displaced: the order stage looks at the slots between its home and its place
-                            const uint32_t li = atomicAdd(&hdr[41], 1u);
-                            if (li < BT_LIST_CAP) dlist[li] = h | ((h - home) << 12);
-                        }
-                    }
-                    if (old == EMPTY_KEY) {
-                        ++mykeys;
-                        st = BT_ST_CREATOR;
-                    }
-                    const uint32_t bit = 1u << (col[u] & 31u);
-                    const uint32_t was = atomicOr(&masks[h], bit);
-                    if (!(was & bit)) {
-                        ++mynew;
-                        st |= BT_ST_OWNER;
-                    }
-                    r_st[u] = h | st;
+                // (the lanes of a wave hold consecutive products of ascending columns: runs of lanes share a bin, one atomic per run)
+                const bool on = act[u] && !(lrc[u] & 128u);
+                uint32_t b = 0xFFFFFFFFu;
+                if (on) {
+                    const uint32_t lr = lrc[u] & 127u, rb_ = s_bin[lr], nb = rb_ >> 16;
+                    const float x = (float)((col[u] >> BT_BSHIFT) - s_emit[lr].bmin) * ((float)nb / (float)s_span[lr]);
+                    b = (rb_ & 0xFFFFu) + min((uint32_t)x, nb - 1u);
                 }
+                const uint32_t prev = (uint32_t)__shfl_up((int)b, 1);
+                const bool head = lane == 0 || prev != b;
+                const unsigned long long heads = __ballot(head), above = (heads >> lane) >> 1;
+                const uint32_t len = above ? (uint32_t)__ffsll((long long)above) : 64u - (uint32_t)lane;
+                if (head && on) atomicAdd(&bins[b], len);
+            }
+            __syncthreads();
+            if (tid < 64) {   // first slot of every bin: floor(products before it * slots / products), four bins per lane
+                const uint4 c = ((const uint4 *)bins)[lane];
+                const uint32_t sum = c.x + c.y + c.z + c.w, inc = wave_scan_incl_u32(sum), ex = inc - sum;
+                const float f = (float)BT_LAYOUT / (float)max(NBK, 1u);
+                const uint32_t p0 = ex, p1 = p0 + c.x, p2 = p1 + c.y, p3 = p2 + c.z, p4 = p3 + c.w;
+                const uint32_t s0 = min((uint32_t)((float)p0 * f), BT_LAYOUT), s1 = min((uint32_t)((float)p1 * f), BT_LAYOUT),
+                               s2 = min((uint32_t)((float)p2 * f), BT_LAYOUT), s3 = min((uint32_t)((float)p3 * f), BT_LAYOUT),
+                               s4 = min((uint32_t)((float)p4 * f), BT_LAYOUT);
+                ((uint4 *)bins)[lane] = make_uint4(s0 | (max(s1 - s0, 1u) << 16), s1 | (max(s2 - s1, 1u) << 16), s2 | (max(s3 - s2, 1u) << 16),
+                                                   s3 | (max(s4 - s3, 1u) << 16));
+            }
+            __syncthreads();
+                insert_hashed(std::true_type{});
+                count_outputs();
             }
         }
     }
     BSTOP(4);
     BMARK(3);
-    // ---- the count of the task: new mask bits + copied products (known from the rows); published as soon as it is known ----------
-    uint32_t NO, NBt, total;   // hashed outputs, blocks, outputs of the task
-    {
-        uint32_t tot;
-        (void)block_scan_excl_dpp_n<BT_NWAVE>(mynew | (mykeys << 16), slot_cnt, &tot, tid);   // (its barrier: the table is complete)
-        NO = tot & 0xFFFFu;
-        NBt = tot >> 16;
-        total = NO + hd.ncopy;   // + the products of the COPY rows
-    }
     (void)NBt;
     if constexpr (MODE != MODE_NUMERIC) task_publish<MODE>(g, t, total);
     BSTOP(5);
@@ -809,15 +952,23 @@ __device__ inline void batch_main(const ARGS &g, const TaskDesc &td, uint32_t t,
         }
     }
     BMARK(7);
-    // the slice as it is: neighbouring lanes, neighbouring addresses
-    for (uint32_t i = tid; i < total; i += BW) {
+    // the slice as it is: neighbouring lanes, neighbouring addresses -- shifted so that every wave's 64 outputs START on a 128-byte
+    // line of C.indices (and on a 256-byte boundary of C.data): a non-temporal store does not wait in the L2 for its neighbours, and a
+    // piece that straddles one more line than it fills wrote 1.18 x the bytes of C (WRITE_SIZE, round 3)
+    {
+        const uint32_t shift = (uint32_t)base & 31u;
+        for (uint32_t j = tid; j < total + shift; j += BW) {
+            if (j >= shift) {
+                const uint32_t i = j - shift;
 #if SPADA_NT_STORE
-        __builtin_nontemporal_store(cols[i] & colmask, &g.c_idx[base + i]);
-        __builtin_nontemporal_store(vals[i], &g.c_val[base + i]);
+                __builtin_nontemporal_store(cols[i] & colmask, &g.c_idx[base + i]);
+                __builtin_nontemporal_store(vals[i], &g.c_val[base + i]);
 #else
-        g.c_idx[base + i] = cols[i] & colmask;
-        g.c_val[base + i] = vals[i];
+                g.c_idx[base + i] = cols[i] & colmask;
+                g.c_val[base + i] = vals[i];
 #endif
+            }
+        }
     }
     if constexpr (!NEXT_EARLY) next();   // (starts with a barrier)
     else __syncthreads();                // (the outputs are read: the next task may clear the table)

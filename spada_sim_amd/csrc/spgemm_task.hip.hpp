@@ -5,8 +5,8 @@
 // (simulator.rs:86-230) and the partial-fiber merging (scheduler.rs:381-480, adder_tree.rs:145-188) become one LDS
 // accumulator per task; psum write-back and result assembly (simulator.rs:955-1062) become the chained output offsets.
 //
-//   table fill           ->  `limit` = products a task hashes at most: 1920 or 2040 of the 2048 slots, chosen on the device from a
-//                            sampled products / outputs ratio of the input (estimate_block, inside the statistics launch)
+//   table fill           ->  `limit` = products a task hashes at most: 2040 (the registers of a task hold 2048 products; the block table
+//                            of the batch tasks -- 3072 slots -- is then two thirds full at worst)
 //   rows of C            ->  classes by products P_i: EMPTY | COPY (one A entry: C_i = a * B_k) | SMALL (P <= 512) | SOLO
 //                            (P <= limit), both packed into batches with their neighbours | BIG (larger)
 //   BIG rows             ->  k_big_parts / k_big_hist / k_big_plan: histogram of the row's products over <= 1024 column buckets
@@ -53,22 +53,16 @@ constexpr int TK_BLOCK = 256, TK_EPT = 2, TK_LOG_T = 11, TK_T = 1 << TK_LOG_T, T
 // task passes through its stages in half the time, which is what the tasks behind it in the chain wait for.  The BIG-row kernels
 // and the sort-merge variant keep TK_BLOCK = 256.
 constexpr int TKW = 512, TKW_EPT = 1;
-// Products a task hashes at most (`limit`): the table has TK_T = 2048 slots and is probed by double hashing, which stays cheap up to
-// high fills, so fuller tables win -- fewer tasks, fewer chain hops -- until the probe sequences of a table that REALLY fills up
-// get long: inputs whose products collapse onto few outputs (cop20k_A 4.3-fold, cage12 2.2) are fastest at 2040 products per
-// task, inputs whose products mostly stay distinct (web 1.4, R-MAT) at 1920 (measured sweep in DESIGN.md).  estimate_block samples
-// the products / outputs ratio of the input and picks the limit on the device (TaskCounters::prod_limit); classification, ranges
-// and batches follow it.  At most TK_T - 8 products per task: the table keeps empty slots, so every probe sequence ends.
+// Products a task hashes at most (`limit`): TK_LIMIT_HI = 2040 on every input (rounds 1 - 2 sampled the products / outputs ratio of the
+// input to choose between 1920 and 2040 for a table keyed by columns; keyed by blocks of columns the table never fills, and the sweep
+// is monotone: the fullest tasks are fastest everywhere -- DESIGN.md).  The sort-merge accumulator's limit is TK_SOLO_MAX.
 constexpr int TK_NOUT = TK_T;                          // outputs the emission's LDS arrays are sized for
-#ifndef SPADA_LIMIT_LO
-#define SPADA_LIMIT_LO 1920
-#endif
-constexpr uint32_t TK_LIMIT_LO = SPADA_LIMIT_LO, TK_LIMIT_HI = 2040;
+constexpr uint32_t TK_LIMIT_HI = 2040;
 constexpr uint32_t TK_SMALL_MAX = 512;   // class boundary SMALL | SOLO (statistics only: both are packed into batches)
 constexpr uint32_t TK_SOLO_MAX = 1536;   // the sort-merge accumulator's limit (its network holds 2048 pairs)
 constexpr int TK_NQ = 16;                // ticket queues: task t belongs to queue t % TK_NQ, workgroup b serves queue b % TK_NQ
 constexpr int BX_NB = 1024;              // column buckets of the big-row histogram
-static_assert(TK_LIMIT_LO <= TK_LIMIT_HI && TK_LIMIT_HI + 8 <= (uint32_t)TK_T && TK_NOUT % TK_BLOCK == 0, "the table must keep empty slots");
+static_assert(TK_LIMIT_HI + 8 <= (uint32_t)TK_T && TK_NOUT % TK_BLOCK == 0, "the table must keep empty slots");
 
 struct TaskDesc {
     uint32_t kind;      // TASK_BATCH: rows [row, row of the next task) | TASK_RANGE: columns [col_lo, col_hi] of BIG row `row`
@@ -97,14 +91,14 @@ struct TaskCounters {   // (a multiple of 8 bytes: k_init clears it in 8-byte wo
     unsigned long long cls_rows[N_CLS], cls_prod[N_CLS];
     uint32_t n_big, tmp_cursor, ntasks, n_parts;
     uint32_t n_spilled, pad_spilled;                  // BIG rows whose products go through the scratch arrays
-    unsigned long long est_products, est_outputs;     // k_estimate: products and distinct outputs of the sampled rows
-    uint32_t est_done, prod_limit;                    // workgroups of k_estimate that have finished | products a task hashes at most
+    uint32_t prod_limit, pad_limit;                   // products a task hashes at most (set by k_entry_stats from its argument)
     uint32_t abort_flag;                              // a workspace was too small: results invalid, sizes below say what is needed
     uint32_t cap_overflow;                            // FUSED: nnz(C) exceeded the caller's capacity (C.indptr is complete)
     uint32_t need_tmp, need_tasks;                    // (abort_flag bits: 1 tmp / scratch, 2 tasks, 4 row too long, 8 BIG rows, 16 parts)
     uint32_t multi_pass_tasks;
     uint32_t scanner_cu;                              // one-pass mode: where the chain's scanner runs (XCC, SE, SH, CU | valid bit)
-    uint32_t ticket[TK_NQ * 32];  // TK_NQ ticket counters, one per 128-byte line (a single hot word sustains ~88 atomics / us)
+    uint32_t ticket[2 * TK_NQ * 32];  // TK_NQ ticket counters, one per 128-byte line (a single hot word sustains ~88 atomics / us); the second half: k_task_range
+    uint32_t n_legacy, pad_legacy;    // tasks of the older range path (their numbers: TaskArgs::legacy)
 #if SPADA_TASK_DBG
     unsigned long long dbgh[3][24];  // per task kind: [0..19] histogram of the cycles from ticket to publish (4096-cycle bins), [20] sum, [21] tasks, [22] max
 #endif
@@ -141,6 +135,23 @@ constexpr int BT_DSHIFT = BT_BSHIFT;   // columns per slot of a dense batch / di
 #define SPADA_BT_DENSE 1       // batches / ranges whose blocks fit the table slot for slot skip hashing and sorting (spgemm_batch.hip.hpp)
 #endif
 static_assert(BT_EMAX == (uint32_t)TKW * TKW_EPT && BT_PMAX == 4u * TKW && TK_LIMIT_HI <= BT_PMAX, "one entry and four products per thread");
+
+// Which tasks run through the batch stages (spgemm_batch.hip.hpp): consecutive non-BIG rows, a column range of a BIG row with at
+// most one chunk of entries and at most as many products as the registers hold (a heavy histogram bucket -- many products on few
+// columns -- may have more), or (SPADA_SPILL_DENSE) a single-pass spilled range that fits the registers and whose blocks fit the
+// table slot for slot
+__device__ inline bool task_spill_dense(const TaskDesc &td)
+{
+    return SPADA_BT_DENSE && SPADA_SPILL_DENSE && td.kind == TASK_RANGE && !(td.first & 2u) && td.np <= BT_PMAX &&
+           (td.col_hi >> BT_DSHIFT) - (td.col_lo >> BT_DSHIFT) < BT_T;   // (slots of 32 columns)
+}
+__device__ inline bool task_is_batch(const TaskDesc &td)
+{
+#ifdef SPADA_DEV_NO_LEGACY   /* development: resource usage of the batch stages alone */
+    return true;
+#endif
+    return td.kind == TASK_BATCH || (td.kind == TASK_RANGE_DIRECT && (td.first >> 1) <= BT_EMAX && td.np <= BT_PMAX) || task_spill_dense(td);
+}
 
 // what a task needs to know about a row, in one 16-byte load (written by k_row_class)
 struct __attribute__((aligned(16))) RowRec {
@@ -181,108 +192,17 @@ __global__ __launch_bounds__(256) void k_init(TaskCounters *__restrict__ ctr, un
     for (uint64_t i = i0; i < status_words; i += stride) status[i] = 0ull;
 }
 
-// How strongly do the products of this input collapse onto outputs?  EST_ROWS extra workgroups of k_entry_stats (they run next to
-// the statistics and need nothing from them); workgroup w looks at the first row at or behind row w * n / EST_ROWS (within EST_SCAN
-// rows) that has 2 .. 64 entries, and -- if it has 8 .. TK_LIMIT_LO products -- counts its distinct output columns in an LDS hash
-// set.  The last one to finish sets TaskCounters::prod_limit: the larger table fill where the sampled products / outputs ratio is
-// at least EST_RATIO (cop20k_A 4.3, cage12 2.2 against mc2depi 1.6, web 1.4, and the short rows of R-MAT around 1), the default
-// otherwise, or when nothing could be sampled.  `fixed_limit` != 0 (sort-merge accumulator) skips the sampling.
-constexpr int EST_ROWS = 96, EST_SCAN = 64;
-constexpr unsigned long long EST_RATIO_NUM = 9, EST_RATIO_DEN = 5;   // 1.8
-__device__ inline void estimate_block(uint32_t w, uint32_t nw, const uint64_t *__restrict__ aptr, const uint32_t *__restrict__ aidx,
-                                      const uint64_t *__restrict__ bptr, const uint32_t *__restrict__ bidx, uint64_t r0,
-                                      uint32_t nrows, uint32_t fixed_limit, TaskCounters *__restrict__ ctr)
-{
-    __shared__ uint32_t s_keys[TK_T];
-    __shared__ uint32_t s_row, s_new, s_prod;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (fixed_limit) {
-        if (w == 0 && tid == 0) ctr->prod_limit = fixed_limit;
-        return;
-    }
-    if (wave == 0) {
-        // EST_SCAN candidate rows at once; then the products of the chosen one (one entry per lane)
-        const uint32_t start = (uint32_t)((uint64_t)w * nrows / nw), r = start + lane;
-        bool ok = false;
-        if (r < nrows) {
-            const uint64_t L = aptr[r0 + r + 1] - aptr[r0 + r];
-            ok = L >= 2 && L <= 64;
-        }
-        const unsigned long long m = __ballot(ok);
-        uint32_t row = 0xFFFFFFFFu, P = 0;
-        if (m) {
-            row = start + (uint32_t)(__ffsll((long long)m) - 1);
-            const uint64_t a0 = aptr[r0 + row], a1 = aptr[r0 + row + 1];
-            unsigned long long len = 0;
-            if (a0 + lane < a1) {
-                const uint32_t k = aidx[a0 + lane];
-                len = bptr[k + 1] - bptr[k];
-            }
-            len = wave_sum_u64(len);
-            P = len > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)len;
-            if (P < 8 || P > TK_LIMIT_LO) row = 0xFFFFFFFFu;
-        }
-        if (lane == 0) {
-            s_row = row;
-            s_prod = P;
-            s_new = 0;
-        }
-    }
-    for (int k = tid; k < TK_T; k += 256) s_keys[k] = EMPTY_KEY;
-    __syncthreads();
-    const uint32_t row = s_row;
-    if (row != 0xFFFFFFFFu) {
-        uint32_t fresh = 0;
-        for (uint64_t e = aptr[r0 + row] + wave; e < aptr[r0 + row + 1]; e += 4) {   // one wave per entry, lanes over its B row
-            const uint32_t k = aidx[e];
-            const uint64_t b0 = bptr[k];
-            const uint32_t len = (uint32_t)(bptr[k + 1] - b0);
-            for (uint32_t p = lane; p < len; p += 64) {
-                const uint32_t key = bidx[b0 + p];
-                uint32_t h = hash_slot<TK_LOG_T>(key);
-                for (;;) {
-                    const uint32_t o = atomicCAS(&s_keys[h], EMPTY_KEY, key);
-                    if (o == EMPTY_KEY) {
-                        ++fresh;
-                        break;
-                    }
-                    if (o == key) break;
-                    h = (h + 1) & (TK_T - 1);
-                }
-            }
-        }
-        if (fresh) atomicAdd(&s_new, fresh);
-    }
-    __syncthreads();
-    if (tid == 0) {
-        if (row != 0xFFFFFFFFu) {
-            atomicAdd(&ctr->est_products, (unsigned long long)s_prod);
-            atomicAdd(&ctr->est_outputs, (unsigned long long)s_new);
-        }
-        __threadfence();
-        if (atomicAdd(&ctr->est_done, 1u) == nw - 1) {   // the last workgroup decides
-            const unsigned long long prods = atomicAdd(&ctr->est_products, 0ull), outs = atomicAdd(&ctr->est_outputs, 0ull);
-            ctr->prod_limit = (outs && prods * EST_RATIO_DEN >= outs * EST_RATIO_NUM) ? TK_LIMIT_HI : TK_LIMIT_LO;
-        }
-    }
-}
-
 __global__ __launch_bounds__(256) void k_entry_stats(const uint64_t *__restrict__ aptr, const uint32_t *__restrict__ aidx,
                                                      const uint32_t *__restrict__ arow, const uint64_t *__restrict__ bptr,
                                                      const uint32_t *__restrict__ bidx, uint64_t r0, uint32_t nrows,
                                                      uint64_t *__restrict__ eb0, uint32_t *__restrict__ elen,
                                                      unsigned long long *__restrict__ row_P, uint32_t *__restrict__ row_kmin,
-                                                     uint32_t *__restrict__ row_kmax, uint32_t stat_blocks, uint32_t fixed_limit,
-                                                     TaskCounters *__restrict__ ctr)
+                                                     uint32_t *__restrict__ row_kmax, uint32_t limit, TaskCounters *__restrict__ ctr)
 {
-    const uint32_t est_blocks = gridDim.x - stat_blocks;
-    if (blockIdx.x < est_blocks) {   // the sampling workgroups (above) come first: their chain of dependent loads overlaps the rest
-        estimate_block(blockIdx.x, est_blocks, aptr, aidx, bptr, bidx, r0, nrows, fixed_limit, ctr);
-        return;
-    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) ctr->prod_limit = limit;   // (products a task hashes at most: read by the kernels behind this one)
     const uint64_t e0 = aptr[r0], e1 = aptr[r0 + nrows];
     const int lane = threadIdx.x & 63;
-    for (uint64_t q0 = e0 + (uint64_t)(blockIdx.x - est_blocks) * 256 + (threadIdx.x & ~63); q0 < e1; q0 += (uint64_t)stat_blocks * 256) {
+    for (uint64_t q0 = e0 + (uint64_t)blockIdx.x * 256 + (threadIdx.x & ~63); q0 < e1; q0 += (uint64_t)gridDim.x * 256) {
         const uint64_t q = q0 + lane;
         uint32_t row = 0xFFFFFFFFu, mn = 0xFFFFFFFFu, mx = 0;
         unsigned long long len = 0;
@@ -392,7 +312,7 @@ __global__ __launch_bounds__(256) void k_row_class(const uint64_t *__restrict__ 
 //                 2^wshift over [kmin, kmax] of the row (LDS), stored per part
 //   k_big_plan    one workgroup per row: bucket counts of the row = sum over its parts; buckets grouped into column RANGES -- a
 //                 bucket with more products than the limit is a range of its own, the others are packed greedily into ranges
-//                 of at most `limit` (1920 or 2040) products, i.e. a light range fits one task's table whatever its outputs
+//                 of at most `limit` (2040) products, i.e. a light range fits one task's table whatever its outputs
 //                 are; a heavy range holds at most 2^wshift distinct columns and is split further by the task itself if
 //                 both exceed the table (k_task, multi-pass).  Range descriptors go to `tmp` (bump allocated),
 //                 their number to row_m[row].  Then the row is either left to DIRECT range tasks, which find their products
@@ -1348,7 +1268,7 @@ __global__ __launch_bounds__(256) void k_cut3(const uint8_t *__restrict__ row_cl
                                               const uint32_t *__restrict__ row_tmp, uint32_t n,
                                               uint32_t *__restrict__ tile_tasks, const TaskDesc *__restrict__ tmp,
                                               TaskDesc *__restrict__ tasks, uint32_t task_cap, uint32_t fold /* no k_cut2 has run */,
-                                              uint32_t *__restrict__ tile_first, TaskCounters *__restrict__ ctr)
+                                              uint32_t *__restrict__ tile_first, uint32_t *__restrict__ legacy, TaskCounters *__restrict__ ctr)
 {
     __shared__ CutLds L;
     __shared__ uint32_t s_nbig;
@@ -1445,7 +1365,22 @@ __global__ __launch_bounds__(256) void k_cut3(const uint8_t *__restrict__ row_cl
             else hi = mid - 1;
         }
         const uint32_t off = q - b_pre[lo];
-        if (b_first[lo] + off < task_cap) tasks[b_first[lo] + off] = tmp[b_tb[lo] + off];
+        bool leg = false;
+        if (b_first[lo] + off < task_cap) {
+            const TaskDesc d = tmp[b_tb[lo] + off];
+            tasks[b_first[lo] + off] = d;
+            leg = !task_is_batch(d);
+        }
+        // the numbers of the tasks that take the older range path (spilled multi-pass / heavy ranges, rows with many entries): one
+        // device atomic per wave
+        const unsigned long long lm = __ballot(leg);
+        if (lm) {
+            const int lead = __ffsll((long long)lm) - 1, ln = (int)(threadIdx.x & 63);
+            uint32_t lb = 0;
+            if (ln == lead) lb = atomicAdd(&ctr->n_legacy, (uint32_t)__popcll(lm));
+            lb = (uint32_t)__shfl((int)lb, lead);
+            if (leg) legacy[lb + (uint32_t)__popcll(lm & ((1ull << ln) - 1ull))] = b_first[lo] + off;
+        }
     }
 }
 
@@ -1475,6 +1410,8 @@ struct TaskArgs {
     const uint32_t *scr_col;
     const double *scr_val;
     const uint32_t *scr_seq;        // sort-merge accumulator only: number of the product inside its row (ascending k)
+    const uint32_t *legacy;         // numbers of the tasks that take the older range path (k_cut3; the modes without a chain: k_task_range)
+    uint32_t b_off32;               // nnz(B) < 2^29: byte offsets into B's index and value arrays fit 32 bits
     const uint32_t *cuts;           // cut table of the direct range tasks (k_big_cuts)
     uint32_t *stage_col;            // one-pass mode: staging slices of the parked tasks, BT_PMAX outputs per workgroup (spgemm_batch.hip.hpp)
     double *stage_val;
@@ -2171,15 +2108,11 @@ __device__ inline TaskArgsC &uniform_args(const TaskArgs *p)
     const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
     return *(TaskArgsC *)(((unsigned long long)hi << 32) | lo);
 }
-template <int MODE, int NOUT>
-__device__ __attribute__((noinline)) void range_task(const TaskArgs *gp_, uint32_t t_, uint32_t ntasks_)
+template <int BLOCK, int EPT, int MODE, int NOUT, class ARGS>
+__device__ __forceinline__ void range_task_body(const ARGS &g, const TaskDesc &td, uint32_t t, uint32_t ntasks, unsigned char *smem)
 {
-    constexpr int RMAX = TK_RMAX, BLOCK = TKW;
+    constexpr int RMAX = TK_RMAX;
     constexpr bool VALUES = MODE != MODE_COUNT;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    TaskArgsC &g = uniform_args(gp_);
-    const uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t_), ntasks = (uint32_t)__builtin_amdgcn_readfirstlane((int)ntasks_);
-    const TaskDesc td = load_task(g.tasks, t);
     uint32_t *hdr = (uint32_t *)smem;
     unsigned char *region2 = smem + 256 + ((size_t)12 << TK_LOG_T);
     unsigned char *rows = region2 + ((task_region2() + 15) & ~(size_t)15);
@@ -2192,7 +2125,7 @@ __device__ __attribute__((noinline)) void range_task(const TaskArgs *gp_, uint32
     const bool single = direct || td.np <= (uint32_t)NOUT || td.col_hi - td.col_lo < (uint32_t)NOUT;
     uint32_t total;
     if (direct) {
-        total = direct_accumulate<BLOCK, TKW_EPT, VALUES>(smem, region2, s_re, s_a0, g, td);
+        total = direct_accumulate<BLOCK, EPT, VALUES>(smem, region2, s_re, s_a0, g, td);
     } else if (single) {
         total = range_accumulate<BLOCK, VALUES>(smem, g.scr_col, g.scr_val, td.src, td.np, td.col_lo, td.col_hi, (td.first & 2u) != 0);
     } else {
@@ -2239,21 +2172,15 @@ __device__ __attribute__((noinline)) void range_task(const TaskArgs *gp_, uint32
     }
 }
 
-// Which tasks run through the batch stages (spgemm_batch.hip.hpp): consecutive non-BIG rows, a column range of a BIG row with at
-// most one chunk of entries and at most as many products as the registers hold (a heavy histogram bucket -- many products on few
-// columns -- may have more), or (SPADA_SPILL_DENSE) a single-pass spilled range that fits the registers and whose blocks fit the
-// table slot for slot
-__device__ inline bool task_spill_dense(const TaskDesc &td)
+// ... as a function of its own inside the 512-thread task kernel (one-pass mode: every task of the chain runs there)
+template <int MODE, int NOUT>
+__device__ __attribute__((noinline)) void range_task(const TaskArgs *gp_, uint32_t t_, uint32_t ntasks_)
 {
-    return SPADA_BT_DENSE && SPADA_SPILL_DENSE && td.kind == TASK_RANGE && !(td.first & 2u) && td.np <= BT_PMAX &&
-           (td.col_hi >> BT_DSHIFT) - (td.col_lo >> BT_DSHIFT) < BT_T;   // (slots of 32 columns)
-}
-__device__ inline bool task_is_batch(const TaskDesc &td)
-{
-#ifdef SPADA_DEV_NO_LEGACY   /* development: resource usage of the batch stages alone */
-    return true;
-#endif
-    return td.kind == TASK_BATCH || (td.kind == TASK_RANGE_DIRECT && (td.first >> 1) <= BT_EMAX && td.np <= BT_PMAX) || task_spill_dense(td);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    TaskArgsC &g = uniform_args(gp_);
+    const uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t_), ntasks = (uint32_t)__builtin_amdgcn_readfirstlane((int)ntasks_);
+    const TaskDesc td = load_task(g.tasks, t);
+    range_task_body<TKW, TKW_EPT, MODE, NOUT>(g, td, t, ntasks, smem);
 }
 
 // which instantiation of the batch stages a descriptor takes.  DENSE: the blocks between the first and the last column of every
@@ -2387,8 +2314,10 @@ __global__ __launch_bounds__(TKW, SPADA_TASK_WAVES) void k_task(const TaskArgs *
             else if (v == 1) batch_main<MODE, true>(g, td, t, ntasks, smem, dbg_ph, hd, pk, next);
             else batch_main<MODE, false>(g, td, t, ntasks, smem, dbg_ph, hd, pk, next);
         } else {
-            if constexpr (MODE == MODE_FUSED) batch_unpark_now<MODE>(g, pk, ntasks, hdr);   // (the older path waits for its position itself)
-            range_task<MODE, NOUT>(gp_, t, ntasks);
+            if constexpr (MODE == MODE_FUSED) {
+                batch_unpark_now<MODE>(g, pk, ntasks, hdr);   // (the older path waits for its position itself)
+                range_task<MODE, NOUT>(gp_, t, ntasks);
+            }   // (the modes without a chain: k_task_range takes these tasks)
             next();
         }
         t = t2;
@@ -2410,6 +2339,33 @@ __global__ __launch_bounds__(TKW, SPADA_TASK_WAVES) void k_task(const TaskArgs *
             atomicMax(&g.ctr->dbgh[k][2], (unsigned long long)d[19 + 3 * k]);
         }
 #endif
+    }
+}
+
+// The modes WITHOUT a chain (COUNT, NUMERIC) run the tasks of the older range path in a kernel of their own, in the shape that path was
+// written for: workgroups of 256 threads with 128 registers (inside the 512-thread kernel it is compiled for 64 and spills: the
+// chunks of R-MAT 22 whose hub rows are spilled took 2.5 x as long).  k_cut3 leaves the numbers of those tasks in `legacy`; tasks are
+// independent in these modes, so the two kernels simply follow each other on the stream.
+template <int MODE, int NOUT>
+__global__ __launch_bounds__(TK_BLOCK, 4) void k_task_range(const TaskArgs *__restrict__ gp_)
+{
+    TaskArgsC &g = *(TaskArgsC *)gp_;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t *hdr = (uint32_t *)smem;
+    const int tid = threadIdx.x;
+    if (g.ctr->abort_flag) return;
+    const uint32_t nl = g.ctr->n_legacy, ntasks = g.ctr->ntasks, task_end = min(ntasks, g.task_hi);
+    uint32_t *my_ticket = &g.ctr->ticket[(TK_NQ + blockIdx.x % TK_NQ) * 32];
+    for (;;) {
+        __syncthreads();
+        if (tid == 0) hdr[50] = atomicAdd(my_ticket, 1u) * TK_NQ + blockIdx.x % TK_NQ;
+        __syncthreads();
+        const uint32_t k = (uint32_t)__builtin_amdgcn_readfirstlane((int)hdr[50]);
+        if (k >= nl) break;
+        const uint32_t t = g.legacy[k];
+        if (t < g.task_lo || t >= task_end) continue;   // (a numeric phase in pieces)
+        const TaskDesc td = load_task(g.tasks, t);
+        range_task_body<TK_BLOCK, TK_EPT, MODE, NOUT>(g, td, t, ntasks, smem);
     }
 }
 

@@ -344,7 +344,8 @@ def test_engine_first_then_torch_in_one_process():
     import sys
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = (
-        "import sys; sys.path.insert(0, %r)\n"
+        "import sys, faulthandler; sys.path.insert(0, %r)\n"
+        "faulthandler.dump_traceback_later(150, exit=True)\n"   # (a hang says where)
         "import spada_sim_amd as S\n"
         "assert 'torch' not in sys.modules\n"
         "eng = S.Engine(); m = S.generate(S.GEN_RMAT, 8, 4, 3); c = eng.spgemm(m, m); n = c.nnz()\n"
@@ -353,7 +354,7 @@ def test_engine_first_then_torch_in_one_process():
         "c2 = eng.spgemm(m, m)\n"
         "assert x == 28 and c2.nnz() == n and n > 0\n"
         "print('ok', n)\n" % repo)
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=400)
     assert r.returncode == 0 and r.stdout.strip().startswith("ok"), r.stdout + r.stderr
 
 

@@ -83,7 +83,7 @@ constexpr uint32_t TASK_BATCH = 1, TASK_RANGE = 2, TASK_RANGE_DIRECT = 3;   // (
 struct TaskCounters {   // (a multiple of 8 bytes: k_init clears it in 8-byte words)
     unsigned long long nprod, a_nnz, nprod_big;       // of the row range
     unsigned long long scratch_cursor;                // products handed out in the scratch arrays
-    // the cut table and the work items of k_big_cuts are handed out from BX_ARENAS arenas (row of the BIG-row list modulo BX_ARENAS), a
+    // the cut table and the work items of k_big_cuts are handed out from BX_ARENAS arenas (row number modulo BX_ARENAS: the same arena in every run), a
     // cursor pair per 128-byte line: one hot word takes ~88 atomics per microsecond, and every direct row allocates (k_big_plan 33 ->
     // 99 us on the web input with one cursor)
     unsigned long long cut_arena[16][16];             // [arena][0]: words handed out, [1]: work items
@@ -753,7 +753,7 @@ __global__ __launch_bounds__(TK_BLOCK) void k_big_plan(const uint64_t *__restric
             const unsigned long long sb = direct ? 0ull : atomicAdd(&ctr->scratch_cursor, P);
             // the cut table of a direct row whose range tasks run through the batch stages: (ranges + 1) rows of one word per entry
             const unsigned long long cw = direct && E <= (unsigned long long)BT_EMAX ? ((unsigned long long)m + 1ull) * E : 0ull;
-            const uint32_t arena = slot % BX_ARENAS;
+            const uint32_t arena = row % BX_ARENAS;   // (by ROW: the list of BIG rows is in the order of its atomics, and a retry must find the arenas it has sized)
             const unsigned long long acap = cut_cap / BX_ARENAS, icap = cut_item_cap / BX_ARENAS;
             const unsigned long long co = cw ? atomicAdd(&ctr->cut_arena[arena][0], cw) : 0ull, cb = arena * acap + co;
             // ... and its searches as work items of BX_CUT_ITEM (range, entry) pairs each (k_big_cuts)

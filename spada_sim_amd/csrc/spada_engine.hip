@@ -82,6 +82,7 @@ struct spada_ctx {
     hipStream_t stream = nullptr;     // everything of one SpGEMM is queued on this stream, in order
     int accumulator = SPADA_ACC_LDS_HASH;
     uint32_t n_cu = 256;
+    int scanner_ok = -1;              // one-pass mode: enough resident workgroups for the chain's scanner (decided at the first task launch)
     hipStream_t stream2 = nullptr;    // k_big_scatter runs next to the cut kernels (neither needs the other): fork / join events below
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipStream_t stream3 = nullptr;    // ... and so does k_big_cuts, next to both
@@ -284,6 +285,19 @@ TaskArgs task_args(spada_ctx *c, uint64_t *cptr, uint32_t *d_idx, double *d_val,
     g.scr_seq = c->accumulator == SPADA_ACC_SORT_MERGE ? c->t_scrseq.as<uint32_t>() : nullptr;
     g.legacy = c->t_legacy.as<uint32_t>();
     g.b_off32 = c->B->nnz < (1ull << 29) ? 1u : 0u;
+    if (c->scanner_ok < 0) {
+        // the scanner workgroup takes no tasks: every ticket queue needs another resident workgroup (spgemm_task.hip.hpp,
+        // chain_has_scanner).  What the device can hold of the one-pass kernel, with a margin for CUs that other kernels hold
+        int occ = 0;
+        if (c->accumulator == SPADA_ACC_SORT_MERGE) {
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_task_sm<MODE_FUSED>, TK_BLOCK, task_sm_lds()) != hipSuccess) occ = 0;
+        } else {
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_task<MODE_FUSED, TK_NOUT>, TKW, task_kernel_lds()) != hipSuccess) occ = 0;
+        }
+        c->scanner_ok = (uint64_t)occ * c->n_cu >= 4u * (uint64_t)TK_NQ ? 1 : 0;
+        trace(2, "  chain scanner: %d resident workgroups per CU x %u CUs -> %s", occ, c->n_cu, c->scanner_ok ? "scanner" : "look-back per task");
+    }
+    g.scanner = (uint32_t)c->scanner_ok;
     g.cuts = c->t_cuts.as<uint32_t>();
     g.stage_col = c->t_stagecol.as<uint32_t>();
     g.stage_val = c->t_stageval.as<double>();
@@ -439,7 +453,9 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
                                c->row_binfo.as<uint32_t>());
             const bool fold = ntiles <= CUT_FOLD_TILES;
             if (!fold) hipLaunchKernelGGL(k_cut2, dim3(1), dim3(256), 0, s, c->t_tiles.as<uint32_t>(), ntiles, cap_tasks, dc);
-            hipLaunchKernelGGL(k_cut3, dim3(ntiles), dim3(256), 0, s, c->row_bin.as<uint8_t>(), c->t_rowt.as<uint32_t>(),
+            // (few tiles -- a row chunk of a streamed product: several workgroups per tile copy its range descriptors)
+            const uint32_t cut_sub = std::min<uint32_t>(16u, std::max<uint32_t>(1u, 1024u / std::max<uint32_t>(ntiles, 1u)));
+            hipLaunchKernelGGL(k_cut3, dim3(ntiles, cut_sub), dim3(256), 0, s, c->row_bin.as<uint8_t>(), c->t_rowt.as<uint32_t>(),
                                c->row_binfo.as<uint32_t>(), a->ptr, c->r0, c->t_rowtmp.as<uint32_t>(), n, c->t_tiles.as<uint32_t>(),
                                c->t_tmp.as<TaskDesc>(), c->t_tasks.as<TaskDesc>(), cap_tasks, fold ? 1u : 0u,
                                c->t_tiles.as<uint32_t>() + ntiles + 2, c->t_legacy.as<uint32_t>(), dc);
@@ -649,6 +665,7 @@ int spada_create(const spada_options *opts, spada_ctx **out)
     std::unique_ptr<spada_ctx, void (*)(spada_ctx *)> c(new spada_ctx, spada_destroy);
     c->device = dev;
     c->accumulator = o.accumulator;
+    c->scanner_ok = -1;   // (the one-pass kernel of the other accumulator has its own occupancy)
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
     HIP_TRY(hipEventCreate(&c->ev_fork));   // (with timing: the pair brackets the scatter on the side stream)

@@ -30,14 +30,19 @@
 //              to right, here the order is arbitrary: 1e-9)
 //   emit       once the task's position is known (the chain): the dense arrays are stored as they are (neighbouring lanes,
 //              neighbouring addresses), the retained products of COPY rows go straight to their place
+//   second     a task whose blocks CLUSTER (R-MAT rows: a third of a row's blocks on a twentieth of its span) would probe
+//   attempt    quadratically with a linear home-slot mapping: a lane that is displaced by SPADA_PROBE_MAX slots gives up, the task
+//              counts its products in 256 bins of the rows' spans and starts over with home slots in proportion to the bins'
+//              products (still monotone in (row, column))
 // DENSE (k_cut1 / the range's bounds decide): the blocks between the first and the last column of every hashed row, added up over
 // the rows, fit the table one slot per block: no keys at all (meshes, banded matrices, narrow column ranges).
-// The DIRECT RANGE tasks of BIG rows (columns [col_lo, col_hi] of one row; the row's entries are narrowed to the range by two
-// binary searches each: B rows are ascending) and the single-pass SPILLED ranges whose blocks fit (products read from the scratch
-// slice) run through the same stages: one row, no COPY entries, the range as the row's column bounds.
-// LDS (36 864 bytes; regions are reused by the stages):
+// The DIRECT RANGE tasks of BIG rows (columns [col_lo, col_hi] of one row; the row's entries are narrowed to the range by the cut
+// table k_big_cuts has left: B rows are ascending) and the single-pass SPILLED ranges whose blocks fit (products read from the
+// scratch slice) run through the same stages: one row, no COPY entries, the range as the row's column bounds.
+// LDS (40 832 bytes: four workgroups per CU; regions are reused by the stages):
 //   hdr 256 | keys u32[3072] | masks u32[3072] (together later: values f64[2048] + composite keys u32[2048] in output order)
-//   | entry records 8 KB (later: first outputs u16[3072]) | tail bits 256 | rows 3.5 KB
+//   | entry records 8 KB (later: first outputs u16[3072]) | tail bits 256 | rows 5 KB (BtRow + six words per row) | bins 1 KB
+//   | displaced blocks u32[352]
 #pragma once
 
 namespace spada {

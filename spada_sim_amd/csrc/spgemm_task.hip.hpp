@@ -60,7 +60,13 @@ constexpr int TK_NOUT = TK_T;                          // outputs the emission's
 constexpr uint32_t TK_LIMIT_HI = 2040;
 constexpr uint32_t TK_SMALL_MAX = 512;   // class boundary SMALL | SOLO (statistics only: both are packed into batches)
 constexpr uint32_t TK_SOLO_MAX = 1536;   // the sort-merge accumulator's limit (its network holds 2048 pairs)
-constexpr int TK_NQ = 16;                // ticket queues: task t belongs to queue t % TK_NQ, workgroup b serves queue b % TK_NQ
+#ifndef SPADA_TK_NQ
+#define SPADA_TK_NQ 16
+#endif
+#ifndef SPADA_Q_SHIFT
+#define SPADA_Q_SHIFT 0   /* workgroup b serves queue (b >> SPADA_Q_SHIFT) % TK_NQ (3: the workgroups of a queue are spread over the eight XCDs) */
+#endif
+constexpr int TK_NQ = SPADA_TK_NQ;        // ticket queues: task t belongs to queue t % TK_NQ, workgroup b serves queue task_queue()
 constexpr int BX_NB = 1024;              // column buckets of the big-row histogram
 static_assert(TK_LIMIT_HI + 8 <= (uint32_t)TK_T && TK_NOUT % TK_BLOCK == 0, "the table must keep empty slots");
 
@@ -83,7 +89,7 @@ constexpr uint32_t TASK_BATCH = 1, TASK_RANGE = 2, TASK_RANGE_DIRECT = 3;   // (
 struct TaskCounters {   // (a multiple of 8 bytes: k_init clears it in 8-byte words)
     unsigned long long nprod, a_nnz, nprod_big;       // of the row range
     unsigned long long scratch_cursor;                // products handed out in the scratch arrays
-    // the cut table and the work items of k_big_cuts are handed out from BX_ARENAS arenas (row number modulo BX_ARENAS: the same arena in every run), a
+    // the cut table and the work items of k_big_cuts are handed out from BX_ARENAS arenas (a hash of the row number: the same arena in every run), a
     // cursor pair per 128-byte line: one hot word takes ~88 atomics per microsecond, and every direct row allocates (k_big_plan 33 ->
     // 99 us on the web input with one cursor)
     unsigned long long cut_arena[16][16];             // [arena][0]: words handed out, [1]: work items
@@ -753,7 +759,10 @@ __global__ __launch_bounds__(TK_BLOCK) void k_big_plan(const uint64_t *__restric
             const unsigned long long sb = direct ? 0ull : atomicAdd(&ctr->scratch_cursor, P);
             // the cut table of a direct row whose range tasks run through the batch stages: (ranges + 1) rows of one word per entry
             const unsigned long long cw = direct && E <= (unsigned long long)BT_EMAX ? ((unsigned long long)m + 1ull) * E : 0ull;
-            const uint32_t arena = row % BX_ARENAS;   // (by ROW: the list of BIG rows is in the order of its atomics, and a retry must find the arenas it has sized)
+            // (by ROW -- the list of BIG rows is in the order of its atomics, and a retry must find the arenas it has sized -- and
+            // hashed: the heavy rows of an R-MAT matrix are the ones with few bits set, row % 16 put most of them into arena 0)
+            const uint32_t arena = (row * 0x9E3779B1u) >> 28;
+            static_assert(BX_ARENAS == 16, "the arena of a row is the top four bits of its hash");
             const unsigned long long acap = cut_cap / BX_ARENAS, icap = cut_item_cap / BX_ARENAS;
             const unsigned long long co = cw ? atomicAdd(&ctr->cut_arena[arena][0], cw) : 0ull, cb = arena * acap + co;
             // ... and its searches as work items of BX_CUT_ITEM (range, entry) pairs each (k_big_cuts)
@@ -1262,7 +1271,9 @@ __global__ __launch_bounds__(256) void k_cut2(uint32_t *__restrict__ tile_tasks,
     }
 }
 
-// k_cut3: task descriptors at their final place: tile offset + prefix of row_t inside the tile
+// k_cut3: task descriptors at their final place: tile offset + prefix of row_t inside the tile.  gridDim.y workgroups share a tile:
+// each works out the tile's layout, workgroup y = 0 writes the batch tasks, and the range descriptors of the tile's BIG rows are
+// copied by all of them (a chunk of R-MAT 22: 95 tiles with 11 000 descriptors each -- 4.5 ms on 95 workgroups)
 __global__ __launch_bounds__(256) void k_cut3(const uint8_t *__restrict__ row_cls, const uint32_t *__restrict__ row_t,
                                               const uint32_t *__restrict__ row_binfo, const uint64_t *__restrict__ aptr, uint64_t r0,
                                               const uint32_t *__restrict__ row_tmp, uint32_t n,
@@ -1271,8 +1282,7 @@ __global__ __launch_bounds__(256) void k_cut3(const uint8_t *__restrict__ row_cl
                                               uint32_t *__restrict__ tile_first, uint32_t *__restrict__ legacy, TaskCounters *__restrict__ ctr)
 {
     __shared__ CutLds L;
-    __shared__ uint32_t s_nbig;
-    if (threadIdx.x == 0) s_nbig = 0;
+    const bool lead_wg = blockIdx.y == 0;
     // first task of the tile.  Up to CUT_FOLD_TILES tiles every workgroup adds up the counts of the tiles before its own itself (a
     // few KB of L2-resident words) and the one-workgroup scan kernel between k_cut1 and k_cut3 is not launched: one launch and its
     // gap less on the critical path of every call (~7 us; what matters once a GPU holds an eighth of the rows).  tile_first keeps the
@@ -1285,7 +1295,7 @@ __global__ __launch_bounds__(256) void k_cut3(const uint8_t *__restrict__ row_cl
         (void)block_scan_excl_u32(mine, L.s_w, &before);
         first = before;
         __syncthreads();
-        if (threadIdx.x == 0) {
+        if (threadIdx.x == 0 && lead_wg) {
             tile_first[blockIdx.x] = first;
             if (blockIdx.x == gridDim.x - 1) {
                 const uint32_t all = first + tile_tasks[blockIdx.x];
@@ -1296,7 +1306,7 @@ __global__ __launch_bounds__(256) void k_cut3(const uint8_t *__restrict__ row_cl
         }
     } else {
         first = tile_tasks[blockIdx.x];
-        if (threadIdx.x == 0) tile_first[blockIdx.x] = first;
+        if (threadIdx.x == 0 && lead_wg) tile_first[blockIdx.x] = first;
     }
     CutRow cr;
     uint32_t tot, local = 0;
@@ -1310,6 +1320,13 @@ __global__ __launch_bounds__(256) void k_cut3(const uint8_t *__restrict__ row_cl
         }
     }
     uint32_t idx = block_scan_excl_u32(local, L.s_w, &tot) + first;
+    // (the tile's BIG rows numbered in row order: the same numbers in every workgroup of the tile)
+    uint32_t mybig = 0;
+#pragma unroll
+    for (int j = 0; j < CUT_ITEMS; ++j) mybig += (cr.kind[j] == 2 && cr.t[j]) ? 1u : 0u;
+    uint32_t nb;
+    __syncthreads();
+    uint32_t kbn = block_scan_excl_u32(mybig, L.s_w, &nb);
     if (ctr->abort_flag & ~2u) return;   // a workspace overflowed upstream: nothing below may be trusted (every write is bounded by task_cap)
     const uint32_t base = blockIdx.x * CUT_TILE + threadIdx.x * CUT_ITEMS;
     uint32_t kb[CUT_ITEMS], idxb[CUT_ITEMS];
@@ -1318,6 +1335,7 @@ __global__ __launch_bounds__(256) void k_cut3(const uint8_t *__restrict__ row_cl
         kb[j] = 0xFFFFFFFFu;
         idxb[j] = 0;
         if (cr.kind[j] == 1 && idx < task_cap) {
+            if (lead_wg) {
             TaskDesc d;      // everything the task needs to start its loads: rows, entries, products, first A entry
             d.kind = TASK_BATCH;
             d.row = base + j;
@@ -1328,8 +1346,9 @@ __global__ __launch_bounds__(256) void k_cut3(const uint8_t *__restrict__ row_cl
             d.cut = 0;
             d.ri = d.m = 0;
             tasks[idx] = d;
+            }
         } else if (cr.kind[j] == 2 && cr.t[j]) {
-            kb[j] = atomicAdd(&s_nbig, 1u);
+            kb[j] = kbn++;
             idxb[j] = idx;
         }
         idx += cr.t[j];
@@ -1346,7 +1365,6 @@ __global__ __launch_bounds__(256) void k_cut3(const uint8_t *__restrict__ row_cl
     __syncthreads();
     // the range descriptors of the tile's BIG rows, copied by the whole workgroup: descriptor q of the concatenation belongs
     // to the BIG row k with pre[k] <= q < pre[k + 1]
-    const uint32_t nb = s_nbig;
     uint32_t M = 0;
     for (uint32_t b0 = 0; b0 < nb; b0 += 256) {
         const uint32_t k = b0 + threadIdx.x;
@@ -1357,7 +1375,7 @@ __global__ __launch_bounds__(256) void k_cut3(const uint8_t *__restrict__ row_cl
         M += tot2;
         __syncthreads();
     }
-    for (uint32_t q = threadIdx.x; q < M; q += 256) {
+    for (uint32_t q = blockIdx.y * 256u + threadIdx.x; q < M; q += 256u * gridDim.y) {
         uint32_t lo = 0, hi = nb - 1;
         while (lo < hi) {
             const uint32_t mid = (lo + hi + 1) >> 1;
@@ -1412,6 +1430,7 @@ struct TaskArgs {
     const uint32_t *scr_seq;        // sort-merge accumulator only: number of the product inside its row (ascending k)
     const uint32_t *legacy;         // numbers of the tasks that take the older range path (k_cut3; the modes without a chain: k_task_range)
     uint32_t b_off32;               // nnz(B) < 2^29: byte offsets into B's index and value arrays fit 32 bits
+    uint32_t scanner;               // one-pass mode: enough workgroups are resident to spare one for the chain's scanner (launch_task)
     const uint32_t *cuts;           // cut table of the direct range tasks (k_big_cuts)
     uint32_t *stage_col;            // one-pass mode: staging slices of the parked tasks, BT_PMAX outputs per workgroup (spgemm_batch.hip.hpp)
     double *stage_val;
@@ -1580,11 +1599,16 @@ __host__ __device__ constexpr size_t task_lds()
 #endif
 constexpr int SCAN_WIN = 4;
 // (a grid too small to spare a workgroup -- every ticket queue must keep one that takes tasks -- walks back as before)
-__device__ inline bool chain_has_scanner() { return SPADA_CHAIN_SCANNER != 0 && gridDim.x >= 2u * (uint32_t)TK_NQ; }
-__device__ inline void chain_publish(unsigned long long *status, uint32_t t, unsigned long long count)
+__device__ inline uint32_t task_queue() { return (blockIdx.x >> SPADA_Q_SHIFT) % (uint32_t)TK_NQ; }
+// RESIDENCY: workgroup 0 takes no tasks, so every ticket queue needs ANOTHER workgroup that is resident while the others wait for
+// their positions -- queue 0's is workgroup TK_NQ -- i.e. more than TK_NQ workgroups of the grid must run at the same time.  The
+// host decides (launch_task: occupancy x CUs must be at least 4 TK_NQ, TaskArgs::scanner); a device whose CUs are masked or held by
+// other kernels below that walks back per task as before.
+__device__ inline bool chain_has_scanner(uint32_t host_says) { return SPADA_CHAIN_SCANNER != 0 && host_says != 0u && gridDim.x >= 2u * (uint32_t)TK_NQ; }
+__device__ inline void chain_publish(unsigned long long *status, uint32_t t, unsigned long long count, uint32_t scanner)
 {
     if (threadIdx.x == 0)
-        __hip_atomic_store(&status[(size_t)t * ST_STRIDE], ((t == 0 && !chain_has_scanner()) ? ST_INC : ST_AGG) | count, __ATOMIC_RELAXED,
+        __hip_atomic_store(&status[(size_t)t * ST_STRIDE], ((t == 0 && !chain_has_scanner(scanner)) ? ST_INC : ST_AGG) | count, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
 }
 
@@ -1634,11 +1658,11 @@ __device__ inline void chain_scanner(unsigned long long *status, uint32_t t_lo, 
 }
 
 __device__ inline unsigned long long chain_lookback(unsigned long long *status, uint32_t t, unsigned long long count, uint32_t *hdr,
-                                                    TaskCounters *ctr)
+                                                    TaskCounters *ctr, uint32_t scanner)
 {
     const int tid = threadIdx.x, lane = tid & 63;
     unsigned long long dbg_win = 0, dbg_spin = 0;
-    if (chain_has_scanner()) {
+    if (chain_has_scanner(scanner)) {
     // wait for the scanner to turn this task's own count into the inclusive prefix (one lane, one word)
     if (tid == 0) {
         unsigned long long s;
@@ -1736,14 +1760,14 @@ __device__ inline void task_publish(const G &g, uint32_t t, unsigned long long c
     if constexpr (MODE == MODE_COUNT) {
         if (threadIdx.x == 0) g.range_out[t] = count;
     } else {
-        chain_publish(g.status, t, count);
+        chain_publish(g.status, t, count, g.scanner);
     }
 }
 template <int MODE, class G>
 __device__ inline unsigned long long task_position(const G &g, uint32_t t, unsigned long long count, uint32_t *hdr)
 {
     if constexpr (MODE == MODE_COUNT) return 0ull;
-    else return chain_lookback(g.status, t, count, hdr, g.ctr);
+    else return chain_lookback(g.status, t, count, hdr, g.ctr, g.scanner);
 }
 
 // Ordered emission of the table (all waves): every occupied slot -> bucket = boff[lr] + floor((col - kmin) * n / span), monotone
@@ -2228,7 +2252,7 @@ __global__ __launch_bounds__(TKW, SPADA_TASK_WAVES) void k_task(const TaskArgs *
     const int tid = threadIdx.x;
     const uint32_t ntasks = g.ctr->ntasks, task_end = min(ntasks, g.task_hi);
     if (g.ctr->abort_flag) return;
-    if (chain_has_scanner() && MODE == MODE_FUSED) {
+    if (chain_has_scanner(g.scanner) && MODE == MODE_FUSED) {
         // The chain's scanner: workgroup 0 takes no tasks.  It gets its CU for itself (SPADA_SCANNER_ALONE): the other workgroups that
         // land there leave at once (three of 1024).  Every link of the chain -- a task's count to the scanner, the prefix back -- is a
         // hand-off whose price sits in the memory queue of the CU that reads: 1.1 us on a CU with nothing else in flight, 3 - 5 us on
@@ -2258,8 +2282,8 @@ __global__ __launch_bounds__(TKW, SPADA_TASK_WAVES) void k_task(const TaskArgs *
     // is not finished is either running -- it waits for finished tasks only -- or the next one of its queue, whose workgroups
     // all hold smaller, hence finished, tasks and are free to take it: no cycle of waiting workgroups can form as long as
     // every queue has a resident workgroup, which a grid of at least TK_NQ workgroups dispatched in order guarantees.
-    uint32_t *my_ticket = &g.ctr->ticket[(blockIdx.x % TK_NQ) * 32];
-    if (tid == 0) hdr[50] = g.task_lo + atomicAdd(my_ticket, 1u) * TK_NQ + blockIdx.x % TK_NQ;
+    uint32_t *my_ticket = &g.ctr->ticket[(task_queue()) * 32];
+    if (tid == 0) hdr[50] = g.task_lo + atomicAdd(my_ticket, 1u) * TK_NQ + task_queue();
     if (SPADA_TASK_DBG && tid < 32) ((uint32_t *)(smem + task_dbg_off()))[tid] = 0u;
     __syncthreads();
     // (t is uniform: the descriptor is a scalar load, what is derived from it lives in scalar registers)
@@ -2298,7 +2322,7 @@ __global__ __launch_bounds__(TKW, SPADA_TASK_WAVES) void k_task(const TaskArgs *
         bool bt2 = false;
         auto next = [&]() {
             __syncthreads();   // (the ticket word of the task before has been read by everyone; this task's outputs are complete in LDS)
-            if (threadIdx.x == 0) hdr[50] = g.task_lo + atomicAdd(my_ticket, 1u) * TK_NQ + blockIdx.x % TK_NQ;
+            if (threadIdx.x == 0) hdr[50] = g.task_lo + atomicAdd(my_ticket, 1u) * TK_NQ + task_queue();
             __syncthreads();
             t2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)hdr[50]);
             if (SPADA_TASK_DBG && threadIdx.x == 0) dbg_ph[16] = (uint32_t)__builtin_amdgcn_s_memtime();
@@ -2355,10 +2379,10 @@ __global__ __launch_bounds__(TK_BLOCK, 4) void k_task_range(const TaskArgs *__re
     const int tid = threadIdx.x;
     if (g.ctr->abort_flag) return;
     const uint32_t nl = g.ctr->n_legacy, ntasks = g.ctr->ntasks, task_end = min(ntasks, g.task_hi);
-    uint32_t *my_ticket = &g.ctr->ticket[(TK_NQ + blockIdx.x % TK_NQ) * 32];
+    uint32_t *my_ticket = &g.ctr->ticket[(TK_NQ + task_queue()) * 32];
     for (;;) {
         __syncthreads();
-        if (tid == 0) hdr[50] = atomicAdd(my_ticket, 1u) * TK_NQ + blockIdx.x % TK_NQ;
+        if (tid == 0) hdr[50] = atomicAdd(my_ticket, 1u) * TK_NQ + task_queue();
         __syncthreads();
         const uint32_t k = (uint32_t)__builtin_amdgcn_readfirstlane((int)hdr[50]);
         if (k >= nl) break;
@@ -2458,13 +2482,13 @@ __global__ __launch_bounds__(TK_BLOCK, 3) void k_task_sm(const TaskArgs g)
     const int tid = threadIdx.x;
     const uint32_t ntasks = g.ctr->ntasks, task_end = min(ntasks, g.task_hi);
     if (g.ctr->abort_flag) return;
-    if (chain_has_scanner() && MODE == MODE_FUSED && blockIdx.x == 0) {   // the chain's scanner (see k_task)
+    if (chain_has_scanner(g.scanner) && MODE == MODE_FUSED && blockIdx.x == 0) {   // the chain's scanner (see k_task)
         chain_scanner(g.status, g.task_lo, task_end);
         return;
     }
     const uint32_t colmask = g.colbits >= 32 ? 0xFFFFFFFFu : ((1u << g.colbits) - 1u);
-    uint32_t *my_ticket = &g.ctr->ticket[(blockIdx.x % TK_NQ) * 32];
-    if (tid == 0) hdr[50] = g.task_lo + atomicAdd(my_ticket, 1u) * TK_NQ + blockIdx.x % TK_NQ;
+    uint32_t *my_ticket = &g.ctr->ticket[(task_queue()) * 32];
+    if (tid == 0) hdr[50] = g.task_lo + atomicAdd(my_ticket, 1u) * TK_NQ + task_queue();
     __syncthreads();
     uint32_t t = hdr[50];
     __syncthreads();
@@ -2786,7 +2810,7 @@ __global__ __launch_bounds__(TK_BLOCK, 3) void k_task_sm(const TaskArgs g)
             }
         }
         __syncthreads();
-        if (tid == 0) hdr[50] = g.task_lo + atomicAdd(my_ticket, 1u) * TK_NQ + blockIdx.x % TK_NQ;
+        if (tid == 0) hdr[50] = g.task_lo + atomicAdd(my_ticket, 1u) * TK_NQ + task_queue();
         __syncthreads();
         t = hdr[50];
         __syncthreads();

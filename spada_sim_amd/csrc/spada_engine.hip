@@ -82,6 +82,12 @@ struct spada_ctx {
     hipStream_t stream = nullptr;     // everything of one SpGEMM is queued on this stream, in order
     int accumulator = SPADA_ACC_LDS_HASH;
     uint32_t n_cu = 256;
+    // one-pass mode: rows with at most this / 16 search steps per product get a cut table (SPADA_CUT_FACTOR16).  Measured (one pass,
+    // ms per step: web / cop20k_A / R-MAT 16 / R-MAT 18): none 1.085 / 0.784 / 6.16 / 51.9, 0.5 steps 1.058 / 0.804 / 6.17 / 50.7,
+    // **1 step 1.029 / 0.793 / 6.28 / 51.7**, 2 steps 1.045 / 0.782 / 6.56 / 55.0, every direct row 1.05 / 0.797 / 6.55 / 55.0.
+    // The two-phase contract reads the table in both phases and takes every direct row (R-MAT 18: 43.2 against 50.5 ms without)
+    uint32_t cut_factor16 = 16u;
+    bool cut_table = true;            // direct range tasks read their bounds from the cut table (k_big_cuts) instead of searching (SPADA_CUT_TABLE=0)
     int scanner_ok = -1;              // one-pass mode: enough resident workgroups for the chain's scanner (decided at the first task launch)
     hipStream_t stream2 = nullptr;    // k_big_scatter runs next to the cut kernels (neither needs the other): fork / join events below
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -298,7 +304,7 @@ TaskArgs task_args(spada_ctx *c, uint64_t *cptr, uint32_t *d_idx, double *d_val,
         trace(2, "  chain scanner: %d resident workgroups per CU x %u CUs -> %s", occ, c->n_cu, c->scanner_ok ? "scanner" : "look-back per task");
     }
     g.scanner = (uint32_t)c->scanner_ok;
-    g.cuts = c->t_cuts.as<uint32_t>();
+    g.cuts = c->cut_table ? c->t_cuts.as<uint32_t>() : nullptr;
     g.stage_col = c->t_stagecol.as<uint32_t>();
     g.stage_val = c->t_stageval.as<double>();
     g.cptr = cptr;
@@ -421,7 +427,8 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
                                c->accumulator == SPADA_ACC_SORT_MERGE ? 0u : 1u, c->t_big.as<uint32_t>(),
                                c->row_kmin.as<uint32_t>(), c->row_kmax.as<uint32_t>(), c->t_parts.as<BigPart>(),
                                c->t_parthist.as<uint32_t>(), c->t_rowm.as<uint32_t>(), c->t_rowtmp.as<uint32_t>(),
-                               c->t_tmp.as<TaskDesc>(), cap_tmp, c->t_slots.as<BigSlot>(), c->t_cap_scr, c->t_cap_cuts,
+                               c->t_tmp.as<TaskDesc>(), cap_tmp, c->t_slots.as<BigSlot>(), c->t_cap_scr, c->cut_table ? c->t_cap_cuts : 0ull,
+                               mode == MODE_FUSED ? c->cut_factor16 : 16u * (uint32_t)BX_DIRECT_FACTOR,
                                c->t_cutitems.as<uint2>(), cap_cut_items, dc);
             // the scatter of the spilled rows runs NEXT to the cut (second stream): the cut needs the range descriptors k_big_plan
             // wrote, not the scratch; the task kernel waits for both
@@ -438,6 +445,7 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
                                c->t_slots.as<BigSlot>(), c->t_scrcol.as<uint32_t>(), c->t_scrval.as<double>(), seq, dc);
             // ... and so does the cut table of the direct rows (the cut needs the number of range tasks of a row, not their cuts)
             if (side) HIP_TRY(hipEventRecord(c->ev_join, c->stream2));
+            if (c->cut_table)
             hipLaunchKernelGGL(k_big_cuts, dim3(c->n_cu * 8), dim3(256), 0, side ? c->stream3 : s, b->idx, c->eb0.as<uint64_t>(),
                                c->elen.as<uint32_t>(), c->t_big.as<uint32_t>(), c->t_rowm.as<uint32_t>(), c->t_rowtmp.as<uint32_t>(),
                                c->t_slots.as<BigSlot>(), c->t_tmp.as<TaskDesc>(), c->t_cutitems.as<uint2>(), cap_cut_items,
@@ -666,6 +674,8 @@ int spada_create(const spada_options *opts, spada_ctx **out)
     c->device = dev;
     c->accumulator = o.accumulator;
     c->scanner_ok = -1;   // (the one-pass kernel of the other accumulator has its own occupancy)
+    if (const char *e = getenv("SPADA_CUT_TABLE")) c->cut_table = atoi(e) != 0;
+    if (const char *e = getenv("SPADA_CUT_FACTOR16")) c->cut_factor16 = (uint32_t)atoi(e);
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
     HIP_TRY(hipEventCreate(&c->ev_fork));   // (with timing: the pair brackets the scatter on the side stream)

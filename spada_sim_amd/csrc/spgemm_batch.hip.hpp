@@ -243,9 +243,40 @@ __device__ inline BatchHead batch_prologue(const ARGS &g, const TaskDesc &td, ui
         if (range) {
             // DIRECT RANGE: every selected B row narrowed to the range's columns -- B rows are ascending, and k_big_cuts has left
             // the positions of the range's bounds in every one of them: the same round trip as the entry itself
-            const uint32_t c_lo = (g.cuts + td.cut)[ti], c_hi = (g.cuts + td.cut + E)[ti];
-            b0 += c_lo;
-            len = c_hi - c_lo;
+            if (g.cuts && td.cut != ~0ull) {
+                const uint32_t c_lo = (g.cuts + td.cut)[ti], c_hi = (g.cuts + td.cut + E)[ti];
+                b0 += c_lo;
+                len = c_hi - c_lo;
+            } else {
+                // (a row without a cut table -- k_big_plan -- or SPADA_CUT_TABLE=0: the searches inside the task -- l1 = first position with column >= lo, l2 = first with column
+                // > hi, all searches of the wave in lock step)
+                const uint32_t lo = td.col_lo, hi = td.col_hi;
+                const uint32_t *__restrict__ bidx = g.bidx;
+                uint32_t l1 = 0, l2 = 0, n1 = len, n2 = len;
+                while (n1 | n2) {
+                    const uint32_t c1 = n1 ? bidx[b0 + l1 + (n1 >> 1)] : 0u, c2 = n2 ? bidx[b0 + l2 + (n2 >> 1)] : 0u;
+                    if (n1) {
+                        const uint32_t hh = n1 >> 1;
+                        if (c1 < lo) {
+                            l1 += hh + 1;
+                            n1 -= hh + 1;
+                        } else {
+                            n1 = hh;
+                        }
+                    }
+                    if (n2) {
+                        const uint32_t hh = n2 >> 1;
+                        if (c2 <= hi) {
+                            l2 += hh + 1;
+                            n2 -= hh + 1;
+                        } else {
+                            n2 = hh;
+                        }
+                    }
+                }
+                b0 += l1;
+                len = l2 - l1;
+            }
         }
         if (!range) {
             // a COPY row is a row with ONE entry (row_class): the entry's neighbours belong to other rows (batches hold whole rows)

@@ -599,7 +599,7 @@ __global__ __launch_bounds__(TK_BLOCK) void k_big_plan(const uint64_t *__restric
                                                        const uint32_t *__restrict__ row_kmax, const BigPart *__restrict__ parts,
                                                        uint32_t *__restrict__ part_hist, uint32_t *__restrict__ row_m,
                                                        const uint32_t *__restrict__ row_tmp, TaskDesc *__restrict__ tmp, uint32_t tmp_cap,
-                                                       BigSlot *__restrict__ slots, uint64_t scr_cap, uint64_t cut_cap,
+                                                       BigSlot *__restrict__ slots, uint64_t scr_cap, uint64_t cut_cap, uint32_t cut_factor16,
                                                        uint2 *__restrict__ cut_items, uint64_t cut_item_cap, TaskCounters *__restrict__ ctr)
 {
     const uint32_t lim = ctr->prod_limit;
@@ -758,7 +758,13 @@ __global__ __launch_bounds__(TK_BLOCK) void k_big_plan(const uint64_t *__restric
             const uint32_t tb = row_tmp[row];   // big_max_ranges(P) >= m records, allocated by k_big_parts
             const unsigned long long sb = direct ? 0ull : atomicAdd(&ctr->scratch_cursor, P);
             // the cut table of a direct row whose range tasks run through the batch stages: (ranges + 1) rows of one word per entry
-            const unsigned long long cw = direct && E <= (unsigned long long)BT_EMAX ? ((unsigned long long)m + 1ull) * E : 0ull;
+            // -- if the row's searches are few enough for its products (cut_factor16 / 16 searches steps per product: the host's
+            // choice per mode).  One search per (range, entry) in a kernel of its own replaces two per pair inside the tasks, where
+            // they hide behind other workgroups' work: the table pays when BOTH phases of the two-phase contract read it, and in the
+            // one-pass mode for rows whose tasks would otherwise be late for the chain (few searches per product: the web input);
+            // the rows of an R-MAT graph -- hundreds of entries, dozens of ranges -- search for themselves there
+            const bool few = (unsigned long long)m * E * steps * 16ull <= (unsigned long long)cut_factor16 * P;
+            const unsigned long long cw = direct && few && cut_cap != 0ull && E <= (unsigned long long)BT_EMAX ? ((unsigned long long)m + 1ull) * E : 0ull;
             // (by ROW -- the list of BIG rows is in the order of its atomics, and a retry must find the arenas it has sized -- and
             // hashed: the heavy rows of an R-MAT matrix are the ones with few bits set, row % 16 put most of them into arena 0)
             const uint32_t arena = (row * 0x9E3779B1u) >> 28;
@@ -801,7 +807,7 @@ __global__ __launch_bounds__(TK_BLOCK) void k_big_plan(const uint64_t *__restric
                     TaskDesc d;
                     d.kind = direct ? TASK_RANGE_DIRECT : TASK_RANGE;
                     d.row = row;
-                    d.cut = 0;
+                    d.cut = ~0ull;
                     d.ri = 0;
                     d.m = m_row;
                     d.np = pre[f1] - pre[f0];
@@ -816,7 +822,7 @@ __global__ __launch_bounds__(TK_BLOCK) void k_big_plan(const uint64_t *__restric
                         d.col_lo = lo + j * (uint32_t)TK_NOUT;
                         d.col_hi = j + 1 == wgt[k] ? hi : d.col_lo + (uint32_t)TK_NOUT - 1u;
                         d.ri = aux[r] + j;
-                        d.cut = has_cuts ? cb + (uint64_t)d.ri * hdr[48] : 0ull;   // (hdr[48]: the row's entries)
+                        d.cut = has_cuts ? cb + (uint64_t)d.ri * hdr[48] : ~0ull;   // (hdr[48]: the row's entries; none: the task searches)
                         tmp[tb + aux[r] + j] = d;
                     }
                 }

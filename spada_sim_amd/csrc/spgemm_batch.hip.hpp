@@ -67,6 +67,12 @@ struct __attribute__((aligned(16))) BtRow {   // region of a row in the table: f
     uint32_t s, g, bmin;
     float scale;
 };
+#ifndef SPADA_EQ_FIRST
+#define SPADA_EQ_FIRST 0
+#endif
+#ifndef SPADA_COUNT_HASHED
+#define SPADA_COUNT_HASHED 1   /* counting mode: hashed instead of monotone home slots (nothing is ordered there) */
+#endif
 #ifndef SPADA_RESTART
 #define SPADA_RESTART 1   /* 0: no second attempt -- a task whose blocks cluster probes as far as it takes (measurements) */
 #endif
@@ -518,8 +524,10 @@ __device__ inline void batch_main(const ARGS &g, const TaskDesc &td, uint32_t t,
         // bins, s_bin), gives every bin slots in proportion to its products -- at least as many: a bin cannot overflow by itself --
         // and interpolates inside the bin.  Still monotone in (row, column), and as even as the task's own histogram makes it.
         // (the insertion of the hashed products: EQ = the second attempt, with equalised home slots)
+        constexpr bool EQF = SPADA_EQ_FIRST != 0 && MODE != MODE_COUNT && !DENSE;   // (development: every hashed task with equalised home slots)
         auto insert_hashed = [&](auto EQ) {
             constexpr bool equalised = decltype(EQ)::value;
+            constexpr bool COUNT_HASHED = MODE == MODE_COUNT && SPADA_COUNT_HASHED != 0;
             mynew = mykeys = 0u;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -529,15 +537,22 @@ __device__ inline void batch_main(const ARGS &g, const TaskDesc &td, uint32_t t,
                 r_ck[u] = ck;
                 r_st[u] = act[u] ? BT_H_COPY : BT_H_NONE;
                 if (hashed) {
+                    const uint32_t hk = ck >> BT_BSHIFT;
+                    uint32_t home;
+                    if constexpr (COUNT_HASHED) {
+                        // the counting mode orders nothing: a hashed home slot -- no clusters whatever the columns are, no second
+                        // attempt, no list of displaced blocks, no row record to read
+                        home = __umulhi(hk * 0x9E3779B1u, T);
+                    } else {
                     const BtRow e = s_emit[lr];
                     const uint32_t d = (col[u] >> BT_BSHIFT) - e.bmin;
-                    const uint32_t hk = ck >> BT_BSHIFT;
-                    uint32_t home = e.s + min((uint32_t)((float)d * e.scale), e.g - 1u);
+                    home = e.s + min((uint32_t)((float)d * e.scale), e.g - 1u);
                     if (equalised) {
                         const uint32_t rb_ = s_bin[lr], nb = rb_ >> 16;
                         const float x = (float)d * ((float)nb / (float)s_span[lr]);
                         const uint32_t k = min((uint32_t)x, nb - 1u), bw = bins[(rb_ & 0xFFFFu) + k], bg = bw >> 16;
                         home = (bw & 0xFFFFu) + min((uint32_t)((x - (float)k) * (float)bg), bg - 1u);
+                    }
                     }
                     uint32_t h = home, st = 0;
                     uint32_t old = atomicCAS(&keys[h], EMPTY_KEY, hk);
@@ -547,7 +562,7 @@ __device__ inline void batch_main(const ARGS &g, const TaskDesc &td, uint32_t t,
                         // the task starts over with equalised home slots -- and leaves the loop by "finding" the key of its home slot
                         // (no exit of its own: the common iteration is the one of a loop without a budget)
                         uint32_t hkx = hk;
-                        const uint32_t hlim = SPADA_RESTART && !equalised ? min(home + (uint32_t)SPADA_PROBE_MAX, T) : T;
+                        const uint32_t hlim = SPADA_RESTART && !equalised && !COUNT_HASHED ? min(home + (uint32_t)SPADA_PROBE_MAX, T) : T;
                         do {
                             if (h >= home) {
                                 if (++h == hlim) {
@@ -565,7 +580,7 @@ __device__ inline void batch_main(const ARGS &g, const TaskDesc &td, uint32_t t,
                             }
                             old = atomicCAS(&keys[h], EMPTY_KEY, hkx);
                         } while (old != EMPTY_KEY && old != hkx);
-                        if (old == EMPTY_KEY && h > home) {   // displaced: the order stage looks at the slots between its home and its place
+                        if (!COUNT_HASHED && old == EMPTY_KEY && h > home) {   // displaced: the order stage looks at the slots between its home and its place
                             const uint32_t li = atomicAdd(&hdr[41], 1u);
                             if (li < BT_LIST_CAP) dlist[li] = h | ((h - home) << 12);
                         }
@@ -621,11 +636,12 @@ __device__ inline void batch_main(const ARGS &g, const TaskDesc &td, uint32_t t,
                 if (hashed[u]) r_st[u] = h[u] | (fresh ? BT_ST_OWNER : 0u);
             }
         } else {
-            insert_hashed(std::false_type{});
+            if constexpr (!EQF) insert_hashed(std::false_type{});
         }
-        count_outputs();
+        if constexpr (DENSE || !EQF) count_outputs();
         if constexpr (!DENSE) {
-            if (SPADA_RESTART && hdr[42] != 0u) {   // (uniform, rare: a block of the first attempt was displaced too far)
+            if (EQF || (SPADA_RESTART && !(MODE == MODE_COUNT && SPADA_COUNT_HASHED) && hdr[42] != 0u)) {   // (uniform, rare: a block of the first attempt was displaced too far)
+            if constexpr (!EQF)
 #pragma unroll
             for (int u = 0; u < 4; ++u) {   // (the products again from their keys and states: nothing else stays live across the count)
                 const uint32_t st = r_st[u], ck = r_ck[u];

@@ -249,6 +249,12 @@ float tev_ms(spada_ctx *c, int a, int b)
     return ms;
 }
 
+// (the arguments of k_task go through device memory: see k_task.  Queued ahead of the event that opens the task kernel's interval,
+// so that the interval holds that kernel alone -- what roofline.kernel_ms of bench.py is compared with in the rocprofv3 summary)
+void launch_task_args(spada_ctx *c, const TaskArgs &g)
+{
+    if (c->accumulator != SPADA_ACC_SORT_MERGE) hipLaunchKernelGGL(k_task_args, dim3(1), dim3(64), 0, c->stream, g, c->t_args.as<TaskArgs>());
+}
 template <int MODE>
 void launch_task(spada_ctx *c, const TaskArgs &g)
 {
@@ -256,8 +262,6 @@ void launch_task(spada_ctx *c, const TaskArgs &g)
         hipLaunchKernelGGL(k_task_sm<MODE>, dim3(c->n_cu * 3), dim3(TK_BLOCK), task_sm_lds(), c->stream, g);
     else
     {
-        // (the arguments go through device memory: see k_task)
-        hipLaunchKernelGGL(k_task_args, dim3(1), dim3(64), 0, c->stream, g, c->t_args.as<TaskArgs>());
         hipLaunchKernelGGL((k_task<MODE, TK_NOUT>), dim3(c->n_cu * (SPADA_TASK_WAVES / 2)), dim3(TKW), task_kernel_lds(), c->stream,
                            (const TaskArgs *)c->t_args.as<TaskArgs>());
         // the modes without a chain: the tasks of the older range path in their own kernel (256-thread workgroups)
@@ -473,9 +477,13 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
                 HIP_TRY(hipStreamWaitEvent(s, c->ev_join3, 0));
             }
         }
+        TaskArgs g{};
+        if (n) {
+            g = task_args(c, cptr, d_idx, d_val, capacity);
+            launch_task_args(c, g);
+        }
         HIP_TRY(hipEventRecord(c->tev[3], s));
         if (n) {
-            const TaskArgs g = task_args(c, cptr, d_idx, d_val, capacity);
             if (mode == MODE_COUNT) {
                 // no chain in the counting mode: the tasks leave their counts, three small kernels turn them into positions
                 launch_task<MODE_COUNT>(c, g);
@@ -616,6 +624,7 @@ int task_numeric(spada_ctx *c, uint64_t *d_ptr, uint32_t *d_idx, double *d_val)
     HIP_TRY(hipMemsetAsync(c->t_ctr.as<TaskCounters>()->ticket, 0, sizeof(TaskCounters::ticket), s));
     if (c->nrows) {
         const TaskArgs g = task_args(c, c->cptr.as<uint64_t>(), d_idx, d_val, c->nnz_c);
+        launch_task_args(c, g);
         launch_task<MODE_NUMERIC>(c, g);
         HIP_TRY(hipGetLastError());
     }
@@ -949,6 +958,7 @@ int spada_dev_spgemm_numeric_chunk(spada_ctx *c, uint32_t k, void *d_c_indices, 
         TaskArgs g = task_args(c, c->cptr.as<uint64_t>(), (uint32_t *)d_c_indices, (double *)d_c_data, c->nnz_c);
         g.task_lo = c->chunk_task[k];
         g.task_hi = c->chunk_task[k + 1];
+        launch_task_args(c, g);
         launch_task<MODE_NUMERIC>(c, g);
         HIP_TRY(hipGetLastError());
     }

@@ -581,6 +581,9 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
         std::fprintf(stderr, "[publish dbg] %s tasks: %llu, clock ticks from ticket to publication: mean %.0f, largest %llu\n", k ? "range" : "batch",
                      h.dbgh[k][1], 16.0 * (double)h.dbgh[k][0] / (double)h.dbgh[k][1], h.dbgh[k][2]);
     }
+    std::fprintf(stderr, "[publish dbg] second attempts %llu; ticket -> publication histogram (< 16 k, 20, 24, 28, 32, 40, 60, more):", h.dbgh[0][3]);
+    for (int k = 0; k < 8; ++k) std::fprintf(stderr, " %llu", h.dbgh[0][4 + k]);
+    std::fprintf(stderr, "\n");
 #endif
     if (SPADA_TASK_DBG && h.dbg[5])
         std::fprintf(stderr, "[shape dbg] %llu tasks through the batch path: products %.0f, hashed outputs %.0f, blocks %.0f, displaced blocks %.1f, entries %.0f per task\n",

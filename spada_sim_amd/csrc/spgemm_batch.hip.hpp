@@ -728,6 +728,11 @@ __device__ inline void batch_main(const ARGS &g, const TaskDesc &td, uint32_t t,
         dbg_ph[k] += d >> 4;
         dbg_ph[k + 1] += 1u;
         dbg_ph[k + 2] = max(dbg_ph[k + 2], d);
+        {   // histogram of that latency (bins end at 16 / 20 / 24 / 28 / 32 / 40 / 60 thousand ticks), and the tasks that took the second attempt
+            const uint32_t b = d < 16000u ? 0u : d < 20000u ? 1u : d < 24000u ? 2u : d < 28000u ? 3u : d < 32000u ? 4u : d < 40000u ? 5u : d < 60000u ? 6u : 7u;
+            dbg_ph[24 + b] += 1u;
+            if (!DENSE && hdr[42]) dbg_ph[23] += 1u;
+        }
 #if SPADA_TASK_DBG
         if (d > 60000u) {   // the slowest tasks: what they are
             const unsigned long long n = atomicAdd(&g.ctr->dbgh[2][0], 1ull);

@@ -2368,6 +2368,7 @@ __global__ __launch_bounds__(TKW, SPADA_TASK_WAVES) void k_task(const TaskArgs *
             atomicAdd(&g.ctr->dbgh[k][1], (unsigned long long)d[18 + 3 * k]);
             atomicMax(&g.ctr->dbgh[k][2], (unsigned long long)d[19 + 3 * k]);
         }
+        for (int k = 0; k < 9; ++k) atomicAdd(&g.ctr->dbgh[0][3 + k], (unsigned long long)d[23 + k]);   // second attempts, latency histogram
 #endif
     }
 }

@@ -358,12 +358,14 @@ def test_engine_first_then_torch_in_one_process():
     assert r.returncode == 0 and r.stdout.strip().startswith("ok"), r.stdout + r.stderr
 
 
-@pytest.mark.parametrize("span_blocks", [40, 81, 82, 83, 120, 163, 164, 165, 700, 2047, 2048, 2049, 4094, 4096, 4098])
+@pytest.mark.parametrize("span_blocks", [40, 81, 82, 83, 120, 163, 164, 165, 244, 245, 246, 247, 700, 2047, 2048, 2049, 4094, 4096, 4098,
+                                         6142, 6144, 6146])
 def test_dense_tasks_at_the_slot_boundary(engine, span_blocks):
-    """Batches whose rows' column spans add up to about the table's 2048 slots (a slot of the dense layout covers 32 columns, i.e.
-    two of the 16-column blocks counted here): below the bound a batch (or a single row) takes the DENSE path of the batch task
-    (slot = place of the columns in their row, no keys, no sorting), above it the hashed one; every row of C spans exactly
-    `span_blocks` blocks, ~25 rows make a batch.  Both entry points against the oracle."""
+    """Batches whose rows' column spans add up to about the table's slots -- 3072 since round 4, 2048 before (a slot of the dense
+    layout covers 32 columns, i.e. two of the 16-column blocks counted here): below the bound a batch (or a single row) takes the
+    DENSE path of the batch task (slot = place of the columns in their row, no keys), above it the monotone table with keys; every
+    row of C spans exactly `span_blocks` blocks, ~25 rows make a batch (the bound of a batch: ~246 blocks per row; of a single row:
+    6144).  Both entry points against the oracle."""
     import spada_sim_amd as S
     rng = np.random.default_rng(span_blocks)
     rows, k = 3000, 1500
@@ -394,3 +396,63 @@ def test_dense_tasks_at_the_slot_boundary(engine, span_blocks):
     assert_parity(c, ref, ao, bo, RTOL)
     c2 = engine.spgemm(a, b)
     assert_parity(c2, ref, ao, bo, RTOL)
+
+
+@pytest.mark.parametrize("cluster_blocks", [40, 300, 620])
+def test_clustered_columns_take_the_second_attempt(engine, cluster_blocks):
+    """Rows whose blocks CLUSTER: every row of C has one column near 0, one near 2 M and `cluster_blocks` x 8 columns, one per
+    32-column block, in a window around column 1 M.  The monotone table's home slots are a linear function of the column inside the
+    row's span (62 500 blocks here), so the cluster's blocks share a handful of home slots; past SPADA_PROBE_MAX = 24 slots of
+    displacement the task starts over with home slots equalised over its own histogram (spgemm_batch.hip.hpp).  40 blocks per B
+    row stay within what two or three rows of a batch may displace; 300 and 620 force the second attempt.  Both entry points
+    (the counting mode of the two-phase one hashes its home slots instead) against the oracle."""
+    import spada_sim_amd as S
+    rng = np.random.default_rng(cluster_blocks)
+    per = max(cluster_blocks // 8, 1)          # cluster columns per B row: eight B rows make a row of C
+    rows, k, n = 600, 1600, 2_100_000
+    b_ptr = np.zeros(k + 1, np.uint64)
+    b_idx, b_val = [], []
+    for j in range(k):
+        base = 1_000_000 + (j % 8) * per * 32 + int(rng.integers(0, 4)) * 8 * per * 32
+        cl = base + 32 * np.arange(per) + rng.integers(0, 32, per)
+        c = np.unique(np.concatenate([[j % 97], cl, [2_000_000 + j % 89]]))
+        b_idx.append(c.astype(np.uint64))
+        b_val.append(rng.uniform(0.5, 1.5, len(c)))
+        b_ptr[j + 1] = b_ptr[j] + len(c)
+    b = S.CsMat((k, n), b_ptr, np.concatenate(b_idx), np.concatenate(b_val))
+    # A: row i selects eight B rows with the eight residues mod 8 (disjoint cluster windows inside one row of C)
+    a_ptr = np.arange(0, 8 * rows + 1, 8, dtype=np.uint64)
+    a_idx = np.sort(8 * rng.integers(0, k // 8, (rows, 8)) + np.arange(8)[None, :], axis=1).reshape(-1).astype(np.uint64)
+    a = S.CsMat((rows, k), a_ptr, a_idx, rng.uniform(0.5, 1.5, 8 * rows))
+    ao, bo = to_oracle(a), to_oracle(b)
+    ref = oracle.spgemm_sortmerge(ao, bo)
+    c, st = fused(engine, a, b)
+    assert_parity(c, ref, ao, bo, RTOL)
+    c2 = engine.spgemm(a, b)
+    assert_parity(c2, ref, ao, bo, RTOL)
+
+
+def test_cut_table_switch_gives_the_same_product():
+    """SPADA_CUT_TABLE=0 (the direct range tasks search for their bounds themselves) and the default (k_big_cuts leaves them in a
+    table; in the one-pass mode only for rows with few searches per product) give the same C: R-MAT 13, both entry points."""
+    import os
+    import spada_sim_amd as S
+    m = S.generate(S.GEN_RMAT, 13, 16, 5)
+    a = to_oracle(m)
+    ref = oracle.spgemm_spa(a, a)
+    old = os.environ.get("SPADA_CUT_TABLE")
+    try:
+        for flag in ("0", "1"):
+            os.environ["SPADA_CUT_TABLE"] = flag
+            eng = S.Engine()
+            try:
+                c, st = fused(eng, m, m)
+                assert_parity(c, ref, a, a, RTOL)
+                assert_parity(eng.spgemm(m, m), ref, a, a, RTOL)
+            finally:
+                eng.close()
+    finally:
+        if old is None:
+            os.environ.pop("SPADA_CUT_TABLE", None)
+        else:
+            os.environ["SPADA_CUT_TABLE"] = old

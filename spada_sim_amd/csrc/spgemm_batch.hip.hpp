@@ -67,6 +67,9 @@ struct __attribute__((aligned(16))) BtRow {   // region of a row in the table: f
     uint32_t s, g, bmin;
     float scale;
 };
+#ifndef SPADA_WAIT_T0
+#define SPADA_WAIT_T0 0xFFFFFFFFu   /* one-pass mode: ticks a task waits for its position before the next prologue goes under the wait (off) */
+#endif
 #ifndef SPADA_EQ_FIRST
 #define SPADA_EQ_FIRST 0
 #endif
@@ -985,10 +988,26 @@ __device__ inline void batch_main(const ARGS &g, const TaskDesc &td, uint32_t t,
     // into the chain that cannot publish its count before this wait is over, and every task behind it waits for that (measured:
     // web 0.82 -> 0.95 ms, R-MAT 16 4.9 -> 5.6 ms with the prologue under the wait)
     constexpr bool NEXT_EARLY = SPADA_NEXT_EARLY >= 0 ? SPADA_NEXT_EARLY != 0 : MODE == MODE_NUMERIC;
+    // One-pass mode, SPADA_WAIT_T0: the task waits up to that many ticks for its position; if it has not arrived by then the wait is a
+    // long one -- a slow predecessor -- and the next ticket and prologue go under the rest of it (a ticket taken at once would put
+    // an unstarted task into the chain for the whole wait; one taken after a part of it only for about a prologue's length)
+    bool nexted = NEXT_EARLY;
     if constexpr (NEXT_EARLY) next();   // (starts with a barrier: the task's outputs are complete in LDS)
     else __syncthreads();
     if constexpr (MODE != MODE_NUMERIC) {
-        base = task_position<MODE>(g, t, total, hdr);
+        bool have = false;
+        if constexpr (MODE == MODE_FUSED && !NEXT_EARLY && SPADA_WAIT_T0 != 0xFFFFFFFFu) {
+            if (chain_has_scanner(g.scanner)) {   // (uniform)
+                unsigned long long b_;
+                have = chain_try_position(g.status, t, total, hdr, SPADA_WAIT_T0, &b_);
+                base = b_;
+                if (!have) {
+                    next();
+                    nexted = true;
+                }
+            }
+        }
+        if (!have) base = task_position<MODE>(g, t, total, hdr);
         if (range) {
             if (tid == 0) {
                 if (td.first & 1u) g.cptr[rb] = base;   // first range of its row
@@ -1003,7 +1022,7 @@ __device__ inline void batch_main(const ARGS &g, const TaskDesc &td, uint32_t t,
         }
         if (base + total > g.capacity) {
             if (tid == 0) atomicOr(&g.ctr->cap_overflow, 1u);
-            if constexpr (!NEXT_EARLY) next();
+            if (!nexted) next();
             else __syncthreads();   // (the next task clears the table behind this barrier)
             return;
         }
@@ -1027,8 +1046,8 @@ __device__ inline void batch_main(const ARGS &g, const TaskDesc &td, uint32_t t,
             }
         }
     }
-    if constexpr (!NEXT_EARLY) next();   // (starts with a barrier)
-    else __syncthreads();                // (the outputs are read: the next task may clear the table)
+    if (!nexted) next();   // (starts with a barrier)
+    else __syncthreads();  // (the outputs are read: the next task may clear the table)
     }
     BMARK(8);
 #undef BMARK

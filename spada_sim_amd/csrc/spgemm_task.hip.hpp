@@ -1663,6 +1663,36 @@ __device__ inline void chain_scanner(unsigned long long *status, uint32_t t_lo, 
     }
 }
 
+// scanner mode: has the position of task t arrived within `budget` clock ticks?  (one lane polls; all threads get the answer and,
+// if so, the position in *base)
+__device__ inline bool chain_try_position(unsigned long long *status, uint32_t t, unsigned long long count, uint32_t *hdr, uint32_t budget,
+                                          unsigned long long *base)
+{
+    if (threadIdx.x == 0) {
+        const uint32_t t0 = (uint32_t)__builtin_amdgcn_s_memtime();
+        unsigned long long s;
+        uint32_t ok = 0;
+        for (;;) {
+            s = __hip_atomic_load(&status[(size_t)t * ST_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((s & ST_MASK) == ST_INC) {
+                ok = 1;
+                break;
+            }
+            if ((uint32_t)__builtin_amdgcn_s_memtime() - t0 >= budget) break;
+            __builtin_amdgcn_s_sleep(2);
+        }
+        const unsigned long long excl = (s & ~ST_MASK) - count;
+        hdr[48] = (uint32_t)excl;
+        hdr[49] = (uint32_t)(excl >> 32);
+        hdr[46] = ok;
+    }
+    __syncthreads();
+    const bool ok = hdr[46] != 0u;
+    *base = ((unsigned long long)hdr[49] << 32) | hdr[48];
+    __syncthreads();
+    return ok;
+}
+
 __device__ inline unsigned long long chain_lookback(unsigned long long *status, uint32_t t, unsigned long long count, uint32_t *hdr,
                                                     TaskCounters *ctr, uint32_t scanner)
 {

@@ -987,7 +987,7 @@ __device__ inline void batch_main(const ARGS &g, const TaskDesc &td, uint32_t t,
     // it (FUSED, SPADA_PARK = 0): only after the stores -- a ticket taken while this task still waits for its position puts a task
     // into the chain that cannot publish its count before this wait is over, and every task behind it waits for that (measured:
     // web 0.82 -> 0.95 ms, R-MAT 16 4.9 -> 5.6 ms with the prologue under the wait)
-    constexpr bool NEXT_EARLY = SPADA_NEXT_EARLY >= 0 ? SPADA_NEXT_EARLY != 0 : MODE == MODE_NUMERIC;
+    constexpr bool NEXT_EARLY = SPADA_NEXT_EARLY >= 0 ? SPADA_NEXT_EARLY != 0 : (MODE == MODE_NUMERIC || (MODE == MODE_FUSED && SPADA_STATIC_FUSED != 0));
     // One-pass mode, SPADA_WAIT_T0: the task waits up to that many ticks for its position; if it has not arrived by then the wait is a
     // long one -- a slow predecessor -- and the next ticket and prologue go under the rest of it (a ticket taken at once would put
     // an unstarted task into the chain for the whole wait; one taken after a part of it only for about a prologue's length)

@@ -60,6 +60,9 @@ constexpr int TK_NOUT = TK_T;                          // outputs the emission's
 constexpr uint32_t TK_LIMIT_HI = 2040;
 constexpr uint32_t TK_SMALL_MAX = 512;   // class boundary SMALL | SOLO (statistics only: both are packed into batches)
 constexpr uint32_t TK_SOLO_MAX = 1536;   // the sort-merge accumulator's limit (its network holds 2048 pairs)
+#ifndef SPADA_STATIC_FUSED
+#define SPADA_STATIC_FUSED 0
+#endif
 #ifndef SPADA_TK_NQ
 #define SPADA_TK_NQ 16
 #endif
@@ -2282,6 +2285,7 @@ __global__ void k_task_args(const TaskArgs g, TaskArgs *__restrict__ dst)
 template <int MODE, int NOUT>
 __global__ __launch_bounds__(TKW, SPADA_TASK_WAVES) void k_task(const TaskArgs *__restrict__ gp_)
 {
+    constexpr bool STATIC = SPADA_STATIC_FUSED != 0 && MODE == MODE_FUSED;
     TaskArgsC &g = *(TaskArgsC *)gp_;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *hdr = (uint32_t *)smem;
@@ -2303,7 +2307,7 @@ __global__ __launch_bounds__(TKW, SPADA_TASK_WAVES) void k_task(const TaskArgs *
             chain_scanner(g.status, g.task_lo, task_end);
             return;
         }
-        if (SPADA_SCANNER_ALONE) {
+        if (SPADA_SCANNER_ALONE && !STATIC) {
             if (tid == 0) {
                 uint32_t sc;
                 while (!((sc = __hip_atomic_load(&g.ctr->scanner_cu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & 1u)) __builtin_amdgcn_s_sleep(8);
@@ -2319,7 +2323,12 @@ __global__ __launch_bounds__(TKW, SPADA_TASK_WAVES) void k_task(const TaskArgs *
     // all hold smaller, hence finished, tasks and are free to take it: no cycle of waiting workgroups can form as long as
     // every queue has a resident workgroup, which a grid of at least TK_NQ workgroups dispatched in order guarantees.
     uint32_t *my_ticket = &g.ctr->ticket[(task_queue()) * 32];
-    if (tid == 0) hdr[50] = g.task_lo + atomicAdd(my_ticket, 1u) * TK_NQ + task_queue();
+    // STATIC (one-pass mode, development switch SPADA_STATIC_FUSED): no tickets -- worker w takes tasks w, w + G, w + 2 G, ...  The
+    // in-order rule of the chain keeps the workgroups in step anyway, and a task that is known without a ticket can have its prologue
+    // run under the wait of the task before it WITHOUT sitting unstarted in the chain any longer than it does now.  Needs every
+    // workgroup of the grid resident at the same time (the host's business).
+    const uint32_t w_first = chain_has_scanner(g.scanner) && MODE == MODE_FUSED ? 1u : 0u, G_static = gridDim.x - w_first;
+    if (tid == 0) hdr[50] = STATIC ? g.task_lo + (blockIdx.x - w_first) : g.task_lo + atomicAdd(my_ticket, 1u) * TK_NQ + task_queue();
     if (SPADA_TASK_DBG && tid < 32) ((uint32_t *)(smem + task_dbg_off()))[tid] = 0u;
     __syncthreads();
     // (t is uniform: the descriptor is a scalar load, what is derived from it lives in scalar registers)
@@ -2358,9 +2367,13 @@ __global__ __launch_bounds__(TKW, SPADA_TASK_WAVES) void k_task(const TaskArgs *
         bool bt2 = false;
         auto next = [&]() {
             __syncthreads();   // (the ticket word of the task before has been read by everyone; this task's outputs are complete in LDS)
-            if (threadIdx.x == 0) hdr[50] = g.task_lo + atomicAdd(my_ticket, 1u) * TK_NQ + task_queue();
-            __syncthreads();
-            t2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)hdr[50]);
+            if constexpr (STATIC) {
+                t2 = t + G_static;
+            } else {
+                if (threadIdx.x == 0) hdr[50] = g.task_lo + atomicAdd(my_ticket, 1u) * TK_NQ + task_queue();
+                __syncthreads();
+                t2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)hdr[50]);
+            }
             if (SPADA_TASK_DBG && threadIdx.x == 0) dbg_ph[16] = (uint32_t)__builtin_amdgcn_s_memtime();
             if (t2 < task_end) {
                 td2 = load_task(g.tasks, t2);

@@ -12,22 +12,26 @@
 //   BIG rows             ->  k_big_parts / k_big_hist / k_big_plan: histogram of the row's products over <= 1024 column buckets
 //                            (the row cut into parts of ~8192 products, one workgroup each), buckets packed greedily into column
 //                            RANGES of <= limit products; every range becomes a task of its own.  A DIRECT range task finds its
-//                            products in B itself (B rows are ascending: two binary searches narrow each selected B row to
-//                            the range); rows for which that costs more than a spill (thousands of entries, hundreds of
-//                            ranges: R-MAT hubs) have their products scattered into HBM scratch range by range
-//                            (k_big_scatter, the "spill" of rows whose accumulator does not fit LDS)
+//                            products in B itself (B rows are ascending: the positions of the range's bounds in every selected B row
+//                            come from the cut table k_big_cuts has left, or from two binary searches inside the task); rows for
+//                            which that costs more than a spill (thousands of entries, hundreds of ranges: R-MAT hubs) have their
+//                            products scattered into HBM scratch range by range (k_big_scatter, the "spill" of rows whose
+//                            accumulator does not fit LDS)
 //   task list            ->  k_cut1/2/3: consecutive non-BIG rows are cut into batches of <= limit products; tasks are numbered in
 //                            output order (row, then column range)
-//   k_task               ->  persistent workgroups take tasks by ticket.  A task expands its products (flat walk over the A
-//                            entries of its rows, narrowed to a column range or not, or a stream over its scratch slice),
-//                            accumulates them in a 2048-slot LDS hash table (ds_cmpst / ds_add_f64), counts the distinct outputs per row, obtains the position
-//                            of its slice of C from the per-task status words of the chain (a scanner workgroup turns the tasks' counts into prefixes),
-//                            and emits its outputs in (row, column) order (monotone buckets + in-bucket rank).
+//   k_task               ->  persistent workgroups of 512 threads take tasks by ticket.  A task expands its products into registers,
+//                            accumulates them in the LDS block table of spgemm_batch.hip.hpp (3072 slots keyed by 32-column blocks,
+//                            monotone in (row, column): the table is its own sort), counts the distinct outputs, obtains the
+//                            position of its slice of C from the per-task status words of the chain (a scanner workgroup turns the
+//                            tasks' counts into prefixes) and stores its outputs in (row, column) order.  The range tasks that do
+//                            not fit those stages (multi-pass / heavy spilled ranges, rows with more than 512 entries) keep the
+//                            older path: flat walk, 2048-slot table keyed by column, bucket-ranked emission (range_task_body; in
+//                            the modes without a chain in a kernel of its own, k_task_range)
 //                            MODE COUNT   : symbolic phase of the two-phase ABI -- counts only, no chain: the tasks leave their
 //                                           counts and k_pos1-4 scan them into C.indptr and the positions of the range tasks
 //                            MODE NUMERIC : numeric phase after COUNT -- C.indptr known, no chain
 //                            MODE FUSED   : one pass, C written into an upper-bound buffer, C.indptr produced by the chain
-// Every workgroup uses the same 39 KiB of LDS (4 per CU): nothing needs a CU of its own.
+// Every workgroup of k_task uses the same 40 KB of LDS (4 per CU = eight waves per SIMD): nothing needs a CU of its own.
 #pragma once
 #include "spgemm_common.hip.hpp"
 
@@ -48,10 +52,10 @@ namespace spada {
 constexpr uint8_t CLS_EMPTY = 0, CLS_COPY = 1, CLS_SMALL = 2, CLS_SOLO = 3, CLS_BIG = 4;
 constexpr int N_CLS = 5, CLS_SLOTS = 64;
 constexpr int TK_BLOCK = 256, TK_EPT = 2, TK_LOG_T = 11, TK_T = 1 << TK_LOG_T, TK_RMAX = 128;
-// The task kernel itself runs workgroups of TKW = 512 threads (eight waves), four per CU: eight waves per SIMD hide the dependent
-// round trips of a task (ticket -> descriptor -> entries -> B) that four could not (66 % of the wave cycles were waits), and a
-// task passes through its stages in half the time, which is what the tasks behind it in the chain wait for.  The BIG-row kernels
-// and the sort-merge variant keep TK_BLOCK = 256.
+// The task kernel itself runs workgroups of TKW = 512 threads (eight waves), four per CU, compiled for 64 VGPRs: eight waves per
+// SIMD (round 3: four, 66 % of the wave cycles were waits).  Measured: the utilisation stayed where it was (VALU busy 50 %, waits
+// 70 %) -- the kernel is bound by the instructions of its per-wave, per-task overhead, not by latency.  The
+// BIG-row kernels, the older range path and the sort-merge variant keep TK_BLOCK = 256.
 constexpr int TKW = 512, TKW_EPT = 1;
 // Products a task hashes at most (`limit`): TK_LIMIT_HI = 2040 on every input (rounds 1 - 2 sampled the products / outputs ratio of the
 // input to choose between 1920 and 2040 for a table keyed by columns; keyed by blocks of columns the table never fills, and the sweep

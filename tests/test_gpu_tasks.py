@@ -456,3 +456,35 @@ def test_cut_table_switch_gives_the_same_product():
             os.environ.pop("SPADA_CUT_TABLE", None)
         else:
             os.environ["SPADA_CUT_TABLE"] = old
+
+
+@pytest.mark.parametrize("run", [6, 10, 11])
+def test_many_displaced_blocks_take_the_cluster_fix(engine, run):
+    """Batches of ~90 short rows, each with two runs of `run` ADJACENT 32-column blocks and a far column that stretches the row's span
+    to 2 000 blocks: the ~22 blocks of a row share one or two home slots of its ~30-slot region, so most blocks of the task are
+    displaced -- by less than SPADA_PROBE_MAX slots each, i.e. without a second attempt, but far more of them than the list of
+    displaced blocks holds (352): the order stage examines whole clusters instead (spgemm_batch.hip.hpp).  Both entry points
+    against the oracle."""
+    import spada_sim_amd as S
+    rng = np.random.default_rng(run)
+    rows, k, n = 4000, 2000, 200_000
+    b_ptr = np.zeros(k + 1, np.uint64)
+    b_idx, b_val = [], []
+    for j in range(k):
+        lo = int(rng.integers(0, 3000)) * 32
+        c = np.unique(np.concatenate([lo + 32 * np.arange(run) + rng.integers(0, 32, run), [lo + 64_000 + j % 31]]))
+        b_idx.append(c.astype(np.uint64))
+        b_val.append(rng.uniform(0.5, 1.5, len(c)))
+        b_ptr[j + 1] = b_ptr[j] + len(c)
+    b = S.CsMat((k, n), b_ptr, np.concatenate(b_idx), np.concatenate(b_val))
+    a_ptr = np.arange(0, 2 * rows + 1, 2, dtype=np.uint64)
+    a_idx = np.sort(rng.choice(k, (rows, 2)), axis=1)
+    a_idx[:, 1] = np.where(a_idx[:, 1] == a_idx[:, 0], (a_idx[:, 0] + 1) % k, a_idx[:, 1])
+    a_idx = np.sort(a_idx, axis=1).reshape(-1).astype(np.uint64)
+    a = S.CsMat((rows, k), a_ptr, a_idx, rng.uniform(0.5, 1.5, 2 * rows))
+    ao, bo = to_oracle(a), to_oracle(b)
+    ref = oracle.spgemm_sortmerge(ao, bo)
+    c, st = fused(engine, a, b)
+    assert_parity(c, ref, ao, bo, RTOL)
+    c2 = engine.spgemm(a, b)
+    assert_parity(c2, ref, ao, bo, RTOL)

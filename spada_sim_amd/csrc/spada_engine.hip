@@ -400,8 +400,15 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
         c->scatter_on_side = false;
         HIP_TRY(hipEventRecord(c->tev[0], s));
         static_assert(sizeof(TaskCounters) % 8 == 0, "k_init clears the counters in 8-byte words");
-        hipLaunchKernelGGL(k_init, dim3(c->n_cu * 4), dim3(256), 0, s, dc, c->t_rowP.as<unsigned long long>(), c->row_kmin.as<uint32_t>(),
-                           c->row_kmax.as<uint32_t>(), n, c->t_status.as<unsigned long long>(), (uint64_t)cap_tasks * ST_STRIDE);
+        // (the arguments of the task kernel -- all of them known here -- travel with the clearing kernel: see k_task_args)
+        const TaskArgs g = task_args(c, cptr, d_idx, d_val, capacity);
+        if (c->accumulator == SPADA_ACC_SORT_MERGE)
+            hipLaunchKernelGGL(k_init, dim3(c->n_cu * 4), dim3(256), 0, s, dc, c->t_rowP.as<unsigned long long>(), c->row_kmin.as<uint32_t>(),
+                               c->row_kmax.as<uint32_t>(), n, c->t_status.as<unsigned long long>(), (uint64_t)cap_tasks * ST_STRIDE);
+        else
+            hipLaunchKernelGGL(k_init_args, dim3(c->n_cu * 4), dim3(256), 0, s, dc, c->t_rowP.as<unsigned long long>(),
+                               c->row_kmin.as<uint32_t>(), c->row_kmax.as<uint32_t>(), n, c->t_status.as<unsigned long long>(),
+                               (uint64_t)cap_tasks * ST_STRIDE, g, c->t_args.as<TaskArgs>());
         if (n) {
             const uint32_t gent = (uint32_t)std::min<uint64_t>((a->nnz + 255) / 256 + 1, (uint64_t)c->n_cu * 8 * 4);
             // (products a task hashes at most: since the table of the batch tasks is keyed by BLOCKS of columns it never gets full, and
@@ -476,11 +483,6 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
                 HIP_TRY(hipStreamWaitEvent(s, c->ev_join, 0));
                 HIP_TRY(hipStreamWaitEvent(s, c->ev_join3, 0));
             }
-        }
-        TaskArgs g{};
-        if (n) {
-            g = task_args(c, cptr, d_idx, d_val, capacity);
-            launch_task_args(c, g);
         }
         HIP_TRY(hipEventRecord(c->tev[3], s));
         if (n) {

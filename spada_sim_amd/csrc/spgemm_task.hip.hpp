@@ -2136,6 +2136,23 @@ __host__ __device__ constexpr size_t task_kernel_lds() { return task_dbg_off() +
 static_assert(task_kernel_lds() <= 40960, "four workgroups per CU");
 static_assert(flat_walk_bytes<TKW, TKW_EPT, true>() == flat_walk_bytes<TK_BLOCK, TK_EPT, true>(), "one walk scratch size for both workgroup shapes");
 
+// ... or, at the head of a pipeline run, by the kernel that clears the counters, the per-row accumulators and the status words anyway
+// (k_init with one more store): the task kernel then follows the cut without a launch of its own in between
+__global__ __launch_bounds__(256) void k_init_args(TaskCounters *__restrict__ ctr, unsigned long long *__restrict__ row_P,
+                                                   uint32_t *__restrict__ row_kmin, uint32_t *__restrict__ row_kmax, uint32_t nrows,
+                                                   unsigned long long *__restrict__ status, uint64_t status_words, const TaskArgs g,
+                                                   TaskArgs *__restrict__ dst)
+{
+    const uint64_t i0 = (uint64_t)blockIdx.x * 256 + threadIdx.x, stride = (uint64_t)gridDim.x * 256;
+    if (i0 == 0) *dst = g;
+    for (uint64_t i = i0; i < sizeof(TaskCounters) / 8; i += stride) ((unsigned long long *)ctr)[i] = 0ull;
+    for (uint64_t i = i0; i < nrows; i += stride) {
+        row_P[i] = 0ull;
+        row_kmin[i] = 0xFFFFFFFFu;
+        row_kmax[i] = 0u;
+    }
+    for (uint64_t i = i0; i < status_words; i += stride) status[i] = 0ull;
+}
 #ifndef SPADA_TASK_WAVES
 #define SPADA_TASK_WAVES 8   /* waves per SIMD the task kernel is compiled for (HIP: second argument of __launch_bounds__): 8 = 64 VGPRs */
 #endif

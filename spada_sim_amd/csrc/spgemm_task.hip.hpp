@@ -1610,7 +1610,12 @@ __host__ __device__ constexpr size_t task_lds()
 #ifndef SPADA_SCANNER_ALONE
 #define SPADA_SCANNER_ALONE 1
 #endif
-constexpr int SCAN_WIN = 4;
+#ifndef SPADA_SCAN_WIN
+#define SPADA_SCAN_WIN 8   /* 64-word windows of status words the scanner has in flight per step.  Round 4 (task kernel, ms: web / cop20k_A /
+                             cage12 / R-MAT 16): 4: 0.772 - 0.787 / 0.580 / 0.226 / 4.63 - 4.68; 8: 0.766 - 0.770 / 0.564 / 0.217 / 4.59 - 4.61;
+                             6: 0.799 / 0.596 / 0.230 / 4.67; 12: 0.791 / 0.576 / 0.221 / 4.71; 16: 0.87 / 0.73 / 0.274 / 5.1 */
+#endif
+constexpr int SCAN_WIN = SPADA_SCAN_WIN;
 // (a grid too small to spare a workgroup -- every ticket queue must keep one that takes tasks -- walks back as before)
 __device__ inline uint32_t task_queue() { return (blockIdx.x >> SPADA_Q_SHIFT) % (uint32_t)TK_NQ; }
 // RESIDENCY: workgroup 0 takes no tasks, so every ticket queue needs ANOTHER workgroup that is resident while the others wait for
@@ -1648,11 +1653,19 @@ __device__ inline void chain_scanner(unsigned long long *status, uint32_t t_lo, 
             const uint32_t idx = next + (uint32_t)j * 64u + lane;
             const unsigned long long ready = __ballot((sv[j] & ST_MASK) == ST_AGG);
             const uint32_t lead = ready == ~0ull ? 64u : (uint32_t)__ffsll((long long)~ready) - 1u;   // leading lanes with a count
-            unsigned long long v = lane < lead ? (sv[j] & ~ST_MASK) : 0ull, inc = v;
+            // (a task's count fits 32 bits -- it has at most 2^32 - 1 products -- and so does the sum of 64 of them as long as they
+            // are the counts of table-sized tasks; a window whose counts are larger takes the 64-bit scan)
+            const unsigned long long v = lane < lead ? (sv[j] & ~ST_MASK) : 0ull;
+            unsigned long long inc;
+            if (__ballot(v >> 26) == 0ull) {   // (uniform)
+                inc = (unsigned long long)wave_scan_incl_u32((uint32_t)v);
+            } else {
+                inc = v;
 #pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const unsigned long long u = __shfl_up(inc, o);
-                if ((int)lane >= o) inc += u;
+                for (int o = 1; o < 64; o <<= 1) {
+                    const unsigned long long u = __shfl_up(inc, o);
+                    if ((int)lane >= o) inc += u;
+                }
             }
             if (lane < lead) __hip_atomic_store(&status[(size_t)idx * ST_STRIDE], ST_INC | (run + inc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             run += __shfl(inc, 63);

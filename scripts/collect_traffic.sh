@@ -16,6 +16,12 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o p -- $CMD > $OUT
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -o p -- $CMD > $OUT/write.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o p -- $CMD > $OUT/stats.log 2>&1
 cp $OUT/stats/p_kernel_stats.csv $OUT/${TAG}_${WL}_kernel_stats.csv
+# the launches of the one-pass task kernel one by one (the summary's average includes the aborted run of the first call)
+python3 - <<PY
+import csv
+d = sorted((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in csv.DictReader(open("$OUT/stats/p_kernel_trace.csv")) if "k_task<2" in r["Kernel_Name"])
+open("$OUT/${TAG}_${WL}_k_task_launches.txt", "w").write("# per-launch durations (us) of k_task<2, 2048> in the kernel trace behind ${TAG}_${WL}_kernel_stats.csv ($CMD)\n" + " ".join(f"{x:.2f}" for x in d) + "\n")
+PY
 python3 - <<PY
 import csv, json, collections, re
 def short(n):

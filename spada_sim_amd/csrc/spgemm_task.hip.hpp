@@ -1610,6 +1610,13 @@ __host__ __device__ constexpr size_t task_lds()
 #ifndef SPADA_SCANNER_ALONE
 #define SPADA_SCANNER_ALONE 1
 #endif
+#ifndef SPADA_SCAN_IDLE_SLEEP
+#define SPADA_SCAN_IDLE_SLEEP 1
+#endif
+#ifndef SPADA_SCAN_IDLE_MAX
+#define SPADA_SCAN_IDLE_MAX 0   /* steps the scanner's pause grows to when a step found no new count (round 3: 8; the scanner has a CU of its
+                                  own now and nothing to yield to; 0 / 2 / 8 / 32 and no pause at all are within the run-to-run noise of 1.5 %) */
+#endif
 #ifndef SPADA_SCAN_WIN
 #define SPADA_SCAN_WIN 8   /* 64-word windows of status words the scanner has in flight per step.  Round 4 (task kernel, ms: web / cop20k_A /
                              cage12 / R-MAT 16): 4: 0.772 - 0.787 / 0.580 / 0.226 / 4.63 - 4.68; 8: 0.766 - 0.770 / 0.564 / 0.217 / 4.59 - 4.61;
@@ -1676,8 +1683,8 @@ __device__ inline void chain_scanner(unsigned long long *status, uint32_t t_lo, 
         if (adv) {
             idle = 0;
         } else {
-            __builtin_amdgcn_s_sleep(2);
-            if (idle < 8) ++idle;
+            if (SPADA_SCAN_IDLE_SLEEP) __builtin_amdgcn_s_sleep(2);
+            if (idle < SPADA_SCAN_IDLE_MAX) ++idle;
             for (uint32_t z = 0; z < idle; ++z) __builtin_amdgcn_s_sleep(4);
         }
     }

@@ -1,11 +1,11 @@
 #!/bin/bash
 # usage (GPU box): scripts/collect_sq.sh <workload> <tag> [extra bench.py flags, e.g. --two-phase]
 # Two separate --pmc passes of SQ counters (8 SQ slots per pass: MI355X_MICROARCH.md, rocprofv3 PMC slots; counters only, no trace
-# domains) over `bench.py --steps 5 --warmup 2 --no-cpu-baseline`; per kernel and launch (averaged over the launches) ->
+# domains) over `bench.py --steps 5 --warmup 2 --no-cpu-baseline`; per kernel and STEADY launch (scripts/pmc_per_launch.py: median, aborted launches dropped) ->
 # gpurun_out/sq_<tag>/<tag>.json, to be copied into profiles/.
 set -e
 WL=${1:-webbase-1M}
-TAG=${2:-r03_sq_$WL}
+TAG=${2:-r05_sq_$WL}
 shift 2 || true
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/sq_$TAG
@@ -16,25 +16,4 @@ rocprofv3 --pmc SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_LDS
     --output-format csv -d $OUT/p1 -o p -- $CMD > $OUT/p1.log 2>&1
 rocprofv3 --pmc SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS \
     --output-format csv -d $OUT/p2 -o p -- $CMD > $OUT/p2.log 2>&1
-python3 - <<PY
-import csv, json, collections
-def short(n):
-    return n.replace("spada::", "").replace("void ", "").split("(")[0].strip()
-out = collections.defaultdict(dict)
-for p in ("p1", "p2"):
-    agg = collections.defaultdict(float); calls = collections.Counter()
-    for r in csv.DictReader(open("$OUT/%s/p_counter_collection.csv" % p)):
-        k = (short(r["Kernel_Name"]), r["Counter_Name"])
-        agg[k] += float(r["Counter_Value"]); calls[k] += 1
-    for (n, c), v in agg.items():
-        if n.startswith("k_"):
-            out[n][c] = v / calls[(n, c)]
-            out[n]["launches"] = calls[(n, c)]
-res = {"_command": "$CMD", "_note": "rocprofv3 --pmc, two passes, values per launch (mean over the launches).  SQ_WAVE_CYCLES, SQ_WAIT_*, "
-       "SQ_ACTIVE_INST_* count quad-cycles summed over waves; SQ_INSTS_* count wave-instructions."}
-res.update(out)
-json.dump(res, open("$OUT/$TAG.json", "w"), indent=1, sort_keys=True)
-for n, d in sorted(out.items()):
-    if n.startswith("k_task"):
-        print(n, {k: (round(v / 1e6, 2) if isinstance(v, float) else v) for k, v in sorted(d.items())}, "(millions)")
-PY
+python3 $REPO/scripts/pmc_per_launch.py $OUT/$TAG.json "rocprofv3 --pmc, two passes over: $CMD.  SQ_WAVE_CYCLES, SQ_WAIT_*, SQ_ACTIVE_INST_* count quad-cycles summed over waves; SQ_INSTS_* count wave-instructions." $OUT/p1 $OUT/p2

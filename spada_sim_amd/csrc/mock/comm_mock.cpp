@@ -3,6 +3,7 @@
 // drives them with.  Linked with -Bsymbolic so that spada_comm.hip binds to THESE spada_dev_* functions, not to the refusing ones of
 // the sanitizer build of libspada_spgemm.so.
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 

@@ -19,12 +19,8 @@
 
 using namespace spada;
 
-#ifndef SPADA_BH_GRID
-#define SPADA_BH_GRID 32   /* workgroups per CU in the grid of k_big_hist (8 -> 32: BIG-row stage -11 % web, -12 % R-MAT 16 / 18; 64, 128 the same) */
-#endif
-#ifndef SPADA_BP_GRID
-#define SPADA_BP_GRID 32   /* ... of k_big_plan */
-#endif
+// workgroups per CU in the grids of k_big_hist and k_big_plan (8 -> 32: BIG-row stage -11 % web, -12 % R-MAT 16 / 18; 64, 128 the same)
+constexpr uint32_t BH_GRID = 32, BP_GRID = 32;
 #define HIP_TRY(expr)                                                                                      \
     do {                                                                                                   \
         hipError_t e_ = (expr);                                                                            \
@@ -93,7 +89,7 @@ struct spada_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipStream_t stream3 = nullptr;    // ... and so does k_big_cuts, next to both
     hipEvent_t ev_join3 = nullptr;
-    bool scatter_on_side = false;     // the last pipeline run had its scatter on the side stream (phase times below)
+    bool join2 = false, join3 = false;   // this pipeline run has a kernel on stream2 / stream3 that the task kernel must wait for
     uint64_t last_cuts = 0;           // words of the cut table in the previous pipeline run (k_big_cuts runs next to the cut as well)
     uint32_t last_spilled = 0;        // rows the previous pipeline run spilled: the fork / join costs ~10 us and pays only if there is a scatter
     hipEvent_t tev[6] = {};           // phase boundaries of the last pipeline run
@@ -110,11 +106,11 @@ struct spada_ctx {
     DevBuf row_nprod, row_bin, row_kmin, row_kmax, cptr, t_rowP, t_rowm, t_rowt, t_rowtmp, t_big, t_tiles;
     DevBuf row_cl, row_rec, row_binfo;   // per row: class | length; RowRec; batch_info of the batch that starts at the row
     DevBuf eb0, elen;
-    DevBuf t_tmp, t_tasks, t_status, t_rangeout, t_scrcol, t_scrval, t_scrseq, t_ctr, t_args, t_cuts, t_cutitems, t_stagecol, t_stageval, t_legacy;
+    DevBuf t_tmp, t_tasks, t_status, t_rangeout, t_scrcol, t_scrval, t_scrseq, t_ctr, t_args, t_cuts, t_cutitems, t_legacy;
     DevBuf t_possum;                                          // COUNT mode: sums of the tasks' counts per tile
     DevBuf t_parts, t_parthist, t_slots;                      // BIG rows: parts, bucket counts (then cursors) per part, row records
     DevBuf own_idx, own_val, own_ptr, wide_idx;
-    uint64_t t_cap_tmp = 0, t_cap_tasks = 0, t_cap_scr = 0, t_cap_parts = 0, t_cap_cuts = 0;
+    uint64_t t_cap_tmp = 0, t_cap_tasks = 0, t_cap_scr = 0, t_cap_parts = 0, t_cap_cuts = 0, t_cap_cutitems = 0;
     uint32_t prod_limit = TK_SOLO_MAX;   // capacities the kernels may rely on
     TaskCounters *h_tctr = nullptr;   // pinned
     // numeric phase in pieces (spada_dev_spgemm_numeric_plan / _chunk): task boundaries, one event per piece
@@ -262,7 +258,7 @@ void launch_task(spada_ctx *c, const TaskArgs &g)
         hipLaunchKernelGGL(k_task_sm<MODE>, dim3(c->n_cu * 3), dim3(TK_BLOCK), task_sm_lds(), c->stream, g);
     else
     {
-        hipLaunchKernelGGL((k_task<MODE, TK_NOUT>), dim3(c->n_cu * (SPADA_TASK_WAVES / 2)), dim3(TKW), task_kernel_lds(), c->stream,
+        hipLaunchKernelGGL((k_task<MODE, TK_NOUT>), dim3(c->n_cu * (TASK_WAVES / 2)), dim3(TKW), task_kernel_lds(), c->stream,
                            (const TaskArgs *)c->t_args.as<TaskArgs>());
         // the modes without a chain: the tasks of the older range path in their own kernel (256-thread workgroups)
         if constexpr (MODE != MODE_FUSED)
@@ -309,8 +305,6 @@ TaskArgs task_args(spada_ctx *c, uint64_t *cptr, uint32_t *d_idx, double *d_val,
     }
     g.scanner = (uint32_t)c->scanner_ok;
     g.cuts = c->cut_table ? c->t_cuts.as<uint32_t>() : nullptr;
-    g.stage_col = c->t_stagecol.as<uint32_t>();
-    g.stage_val = c->t_stageval.as<double>();
     g.cptr = cptr;
     g.range_out = c->t_rangeout.as<uint64_t>();
     g.status = c->t_status.as<unsigned long long>();
@@ -352,11 +346,6 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
     if ((rc = c->cptr.ensure(n1 * 8, false, s, &c->ws_bytes))) return rc;
     if ((rc = c->t_ctr.ensure(sizeof(TaskCounters), false, s, &c->ws_bytes))) return rc;
     if ((rc = c->t_args.ensure(sizeof(TaskArgs), false, s, &c->ws_bytes))) return rc;
-    {   // staging slices of the parked tasks (one-pass mode): one per workgroup of the task kernel
-        const size_t wgs = (size_t)c->n_cu * (SPADA_TASK_WAVES / 2);
-        if ((rc = c->t_stagecol.ensure(wgs * BT_PMAX * 4, false, s, &c->ws_bytes))) return rc;
-        if ((rc = c->t_stageval.ensure(wgs * BT_PMAX * 8, false, s, &c->ws_bytes))) return rc;
-    }
     if ((rc = c->eb0.ensure(std::max<uint64_t>(a->nnz, 1) * 8, false, s, &c->ws_bytes))) return rc;
     if ((rc = c->elen.ensure(std::max<uint64_t>(a->nnz, 1) * 4, false, s, &c->ws_bytes))) return rc;
     const uint32_t ntiles = std::max<uint32_t>((n + CUT_TILE - 1) / CUT_TILE, 1);
@@ -387,7 +376,8 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
         if ((rc = c->t_scrcol.ensure(c->t_cap_scr * 4, false, s, &c->ws_bytes))) return rc;
         if ((rc = c->t_scrval.ensure(c->t_cap_scr * 8, false, s, &c->ws_bytes))) return rc;
         if ((rc = c->t_cuts.ensure(c->t_cap_cuts * 4, false, s, &c->ws_bytes))) return rc;
-        const uint64_t cap_cut_items = c->t_cap_cuts / BX_CUT_ITEM + (uint64_t)n + 16 * BX_ARENAS;   // (at most one partly filled item per row)
+        // (at most one partly filled item per row; an arena that rows of few words each crowd reports its items, and the retry takes them)
+        const uint64_t cap_cut_items = std::max<uint64_t>(c->t_cap_cuts / BX_CUT_ITEM + (uint64_t)n + 16 * BX_ARENAS, c->t_cap_cutitems);
         if ((rc = c->t_cutitems.ensure(cap_cut_items * sizeof(uint2), false, s, &c->ws_bytes))) return rc;
         if (c->accumulator == SPADA_ACC_SORT_MERGE && (rc = c->t_scrseq.ensure(c->t_cap_scr * 4, false, s, &c->ws_bytes))) return rc;
         if ((rc = c->t_parts.ensure(c->t_cap_parts * sizeof(BigPart), false, s, &c->ws_bytes))) return rc;
@@ -397,7 +387,7 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
         const uint32_t cap_tmp = (uint32_t)std::min<uint64_t>(c->t_cap_tmp, 0xFFFFFFF0u);
         const uint32_t cap_parts = (uint32_t)std::min<uint64_t>(c->t_cap_parts, 0xFFFFFFF0u);
         ++c->stats.pipeline_runs;
-        c->scatter_on_side = false;
+        c->join2 = c->join3 = false;
         HIP_TRY(hipEventRecord(c->tev[0], s));
         static_assert(sizeof(TaskCounters) % 8 == 0, "k_init clears the counters in 8-byte words");
         // (the arguments of the task kernel -- all of them known here -- travel with the clearing kernel: see k_task_args)
@@ -431,39 +421,38 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
                                c->t_big.as<uint32_t>(), c->row_nprod.as<uint32_t>(), c->row_kmin.as<uint32_t>(),
                                c->row_kmax.as<uint32_t>(), c->accumulator == SPADA_ACC_SORT_MERGE ? 0u : 1u, c->t_parts.as<BigPart>(), cap_parts,
                                c->t_rowtmp.as<uint32_t>(), cap_tmp, c->t_slots.as<BigSlot>(), dc);
-            hipLaunchKernelGGL(k_big_hist, dim3(c->n_cu * SPADA_BH_GRID), dim3(TK_BLOCK), BX_WALK_LDS, s, b->idx, c->eb0.as<uint64_t>(),
+            hipLaunchKernelGGL(k_big_hist, dim3(c->n_cu * BH_GRID), dim3(TK_BLOCK), BX_WALK_LDS, s, b->idx, c->eb0.as<uint64_t>(),
                                c->elen.as<uint32_t>(), c->t_big.as<uint32_t>(), c->row_kmin.as<uint32_t>(),
                                c->row_kmax.as<uint32_t>(), c->t_parts.as<BigPart>(), c->t_parthist.as<uint32_t>(), dc);
-            hipLaunchKernelGGL(k_big_plan, dim3(c->n_cu * SPADA_BP_GRID), dim3(TK_BLOCK), BX_PLAN_LDS, s, a->ptr, c->r0, n,
+            hipLaunchKernelGGL(k_big_plan, dim3(c->n_cu * BP_GRID), dim3(TK_BLOCK), BX_PLAN_LDS, s, a->ptr, c->r0, n,
                                c->accumulator == SPADA_ACC_SORT_MERGE ? 0u : 1u, c->t_big.as<uint32_t>(),
                                c->row_kmin.as<uint32_t>(), c->row_kmax.as<uint32_t>(), c->t_parts.as<BigPart>(),
                                c->t_parthist.as<uint32_t>(), c->t_rowm.as<uint32_t>(), c->t_rowtmp.as<uint32_t>(),
                                c->t_tmp.as<TaskDesc>(), cap_tmp, c->t_slots.as<BigSlot>(), c->t_cap_scr, c->cut_table ? c->t_cap_cuts : 0ull,
                                mode == MODE_FUSED ? c->cut_factor16 : 16u * (uint32_t)BX_DIRECT_FACTOR,
                                c->t_cutitems.as<uint2>(), cap_cut_items, dc);
-            // the scatter of the spilled rows runs NEXT to the cut (second stream): the cut needs the range descriptors k_big_plan
-            // wrote, not the scratch; the task kernel waits for both
-            // (only if the previous run of this context spilled anything: without a scatter there is nothing to hide behind the events)
-            const bool side = c->last_spilled != 0 || c->last_cuts != 0;
-            if (side) {
-                HIP_TRY(hipEventRecord(c->ev_fork, s));
-                HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
-                HIP_TRY(hipStreamWaitEvent(c->stream3, c->ev_fork, 0));
-            }
-            hipLaunchKernelGGL(k_big_scatter, dim3(c->n_cu * 8), dim3(TK_BLOCK), BX_WALK_LDS, side ? c->stream2 : s, a->val, b->idx, b->val,
+            // the scatter of the spilled rows and the cut table of the direct rows run NEXT to the cut (side streams): the cut needs the
+            // range descriptors k_big_plan wrote -- not the scratch, not the cuts; the task kernel waits for all three.  Each fork is
+            // taken only if the previous run of this context had work for it (a fork / join pair costs ~10 us and hides nothing when
+            // its kernel finds nothing to do); the two are decided separately
+            const bool side2 = c->last_spilled != 0, side3 = c->cut_table && c->last_cuts != 0;
+            if (side2 || side3) HIP_TRY(hipEventRecord(c->ev_fork, s));
+            if (side2) HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+            if (side3) HIP_TRY(hipStreamWaitEvent(c->stream3, c->ev_fork, 0));
+            hipLaunchKernelGGL(k_big_scatter, dim3(c->n_cu * 8), dim3(TK_BLOCK), BX_WALK_LDS, side2 ? c->stream2 : s, a->val, b->idx, b->val,
                                c->eb0.as<uint64_t>(), c->elen.as<uint32_t>(), c->t_big.as<uint32_t>(), c->row_kmin.as<uint32_t>(),
                                c->row_kmax.as<uint32_t>(), c->t_parts.as<BigPart>(), c->t_parthist.as<uint32_t>(),
                                c->t_slots.as<BigSlot>(), c->t_scrcol.as<uint32_t>(), c->t_scrval.as<double>(), seq, dc);
-            // ... and so does the cut table of the direct rows (the cut needs the number of range tasks of a row, not their cuts)
-            if (side) HIP_TRY(hipEventRecord(c->ev_join, c->stream2));
+            if (side2) HIP_TRY(hipEventRecord(c->ev_join, c->stream2));
             if (c->cut_table)
-            hipLaunchKernelGGL(k_big_cuts, dim3(c->n_cu * 8), dim3(256), 0, side ? c->stream3 : s, b->idx, c->eb0.as<uint64_t>(),
-                               c->elen.as<uint32_t>(), c->t_big.as<uint32_t>(), c->t_rowm.as<uint32_t>(), c->t_rowtmp.as<uint32_t>(),
-                               c->t_slots.as<BigSlot>(), c->t_tmp.as<TaskDesc>(), c->t_cutitems.as<uint2>(), cap_cut_items,
-                               c->t_cuts.as<uint32_t>(), dc);
+                hipLaunchKernelGGL(k_big_cuts, dim3(c->n_cu * 8), dim3(256), 0, side3 ? c->stream3 : s, b->idx, c->eb0.as<uint64_t>(),
+                                   c->elen.as<uint32_t>(), c->t_big.as<uint32_t>(), c->t_rowm.as<uint32_t>(), c->t_rowtmp.as<uint32_t>(),
+                                   c->t_slots.as<BigSlot>(), c->t_tmp.as<TaskDesc>(), c->t_cutitems.as<uint2>(), cap_cut_items,
+                                   c->t_cuts.as<uint32_t>(), dc);
             HIP_TRY(hipGetLastError());
-            if (side) HIP_TRY(hipEventRecord(c->ev_join3, c->stream3));
-            c->scatter_on_side = side;
+            if (side3) HIP_TRY(hipEventRecord(c->ev_join3, c->stream3));
+            c->join2 = side2;
+            c->join3 = side3;
         }
         if (c->phase_timing) HIP_TRY(hipEventRecord(c->tev[2], s));
         if (n) {
@@ -479,10 +468,8 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
                                c->t_tmp.as<TaskDesc>(), c->t_tasks.as<TaskDesc>(), cap_tasks, fold ? 1u : 0u,
                                c->t_tiles.as<uint32_t>() + ntiles + 2, c->t_legacy.as<uint32_t>(), dc);
             HIP_TRY(hipGetLastError());
-            if (c->scatter_on_side) {
-                HIP_TRY(hipStreamWaitEvent(s, c->ev_join, 0));
-                HIP_TRY(hipStreamWaitEvent(s, c->ev_join3, 0));
-            }
+            if (c->join2) HIP_TRY(hipStreamWaitEvent(s, c->ev_join, 0));
+            if (c->join3) HIP_TRY(hipStreamWaitEvent(s, c->ev_join3, 0));
         }
         HIP_TRY(hipEventRecord(c->tev[3], s));
         if (n) {
@@ -521,7 +508,11 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
         h.nprod_big = h.cls_prod[CLS_BIG];
         c->last_spilled = h.n_spilled;
         uint64_t cut_most = 0;   // (the fullest arena sets the size)
-        for (uint32_t a2 = 0; a2 < BX_ARENAS; ++a2) cut_most = std::max<uint64_t>(cut_most, h.cut_arena[a2][0]);
+        uint64_t items_most = 0;
+        for (uint32_t a2 = 0; a2 < BX_ARENAS; ++a2) {
+            cut_most = std::max<uint64_t>(cut_most, h.cut_arena[a2][0]);
+            items_most = std::max<uint64_t>(items_most, h.cut_arena[a2][1]);
+        }
         c->last_cuts = cut_most;
         if (!h.abort_flag) break;
         if (attempt == 3) return fail(SPADA_ERR_HIP, "task pipeline: workspaces still too small after three retries (flag %u)", h.abort_flag);
@@ -532,6 +523,7 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
                         h.dbg[2], h.dbg[1] & 0xFFFF, h.dbg[1] >> 16);
         c->t_cap_scr = std::max<uint64_t>(c->t_cap_scr, h.scratch_cursor + h.scratch_cursor / 16 + 1024);
         c->t_cap_cuts = std::max<uint64_t>(c->t_cap_cuts, BX_ARENAS * (cut_most + cut_most / 8 + 1024));
+        c->t_cap_cutitems = std::max<uint64_t>(c->t_cap_cutitems, BX_ARENAS * (items_most + items_most / 8 + 64));
         c->t_cap_tmp = std::max<uint64_t>(c->t_cap_tmp, (uint64_t)h.tmp_cursor + h.tmp_cursor / 16 + 1024);
         c->t_cap_parts = std::max<uint64_t>(c->t_cap_parts, (uint64_t)h.n_parts + h.n_parts / 16 + 256);
         if ((h.abort_flag & 16u) && !h.scratch_cursor)   // the plan has not run: a guess, replaced by the exact size if it is too small
@@ -554,15 +546,9 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
     st.ms_row_stats = c->phase_timing ? tev_ms(c, 0, 1) : 0.f;
     st.ms_big_expand = c->phase_timing ? tev_ms(c, 1, 2) : 0.f;
     st.ms_cut = c->phase_timing ? tev_ms(c, 2, 3) : 0.f;
-    if (c->phase_timing && c->scatter_on_side) {
-        // the scatter ran on the side stream, under the cut: it belongs to the BIG-row stage; what is left for the cut is the time
-        // its kernels ADD behind the scatter (nothing, where the scatter is the longer of the two)
-        float sc = 0.f;
-        if (hipEventElapsedTime(&sc, c->ev_fork, c->ev_join) == hipSuccess && sc > 0.f) {
-            st.ms_big_expand += sc;
-            st.ms_cut = std::max(0.0, (double)st.ms_cut - (double)sc);
-        }
-    }
+    // (ms_big_expand = the BIG-row kernels on the engine stream: parts, histograms, plan; ms_cut = from the plan's end to the task kernel's
+    // start: the cut kernels and whatever the scatter / the cut table on the side streams add behind them.  Plain intervals of the engine
+    // stream: nothing is subtracted, so none of them depends on which of the overlapped kernels happened to be the longer one)
     st.ms_task = tev_ms(c, 3, 4);
     for (int k = 0; k < N_CLS; ++k) {
         st.cls_rows[k] = h.cls_rows[k];
@@ -728,7 +714,7 @@ void spada_destroy(spada_ctx *c)
     c->un_val.release();
     for (DevBuf *b : {&c->row_cl, &c->row_rec, &c->row_binfo, &c->row_nprod, &c->row_bin, &c->row_kmin, &c->row_kmax, &c->cptr, &c->t_rowP, &c->t_rowm, &c->t_rowt, &c->t_rowtmp,
                       &c->t_big, &c->t_tiles, &c->eb0, &c->elen, &c->t_tmp, &c->t_tasks, &c->t_status, &c->t_rangeout, &c->t_possum, &c->t_scrcol,
-                      &c->t_scrval, &c->t_scrseq, &c->t_ctr, &c->t_args, &c->t_cuts, &c->t_cutitems, &c->t_stagecol, &c->t_stageval, &c->t_legacy, &c->t_parts, &c->t_parthist, &c->t_slots, &c->own_idx, &c->own_val, &c->own_ptr, &c->wide_idx})
+                      &c->t_scrval, &c->t_scrseq, &c->t_ctr, &c->t_args, &c->t_cuts, &c->t_cutitems, &c->t_legacy, &c->t_parts, &c->t_parthist, &c->t_slots, &c->own_idx, &c->own_val, &c->own_ptr, &c->wide_idx})
         b->release();
     if (c->h_tctr) (void)hipHostFree(c->h_tctr);
     for (auto &e : c->tev)

@@ -31,7 +31,7 @@
 //   emit       once the task's position is known (the chain): the dense arrays are stored as they are (neighbouring lanes,
 //              neighbouring addresses), the retained products of COPY rows go straight to their place
 //   second     a task whose blocks CLUSTER (R-MAT rows: a third of a row's blocks on a twentieth of its span) would probe
-//   attempt    quadratically with a linear home-slot mapping: a lane that is displaced by SPADA_PROBE_MAX slots gives up, the task
+//   attempt    quadratically with a linear home-slot mapping: a lane that is displaced by BT_PROBE_MAX slots gives up, the task
 //              counts its products in 256 bins of the rows' spans and starts over with home slots in proportion to the bins'
 //              products (still monotone in (row, column))
 // DENSE (k_cut1 / the range's bounds decide): the blocks between the first and the last column of every hashed row, added up over
@@ -47,15 +47,6 @@
 
 namespace spada {
 
-#ifndef SPADA_BT_STOP
-#define SPADA_BT_STOP 0   /* development: the counting mode cut short behind stage k of the batch task (instruction counts per stage) */
-#endif
-#ifndef SPADA_PARK
-#define SPADA_PARK 0   /* one-pass mode: a finished task is parked in registers and stored one task later instead of waiting for its position */
-#endif
-#ifndef SPADA_NEXT_EARLY
-#define SPADA_NEXT_EARLY (-1)   /* development: 1 / 0 = the next task's prologue under the stores / behind them in every mode */
-#endif
 constexpr int BW = TKW, BT_NWAVE = BW / 64;
 constexpr uint32_t BT_LAYOUT = BT_T - 32u;   // slots the rows' regions are laid out over; the rest takes the overflow of the last cluster
 constexpr uint32_t BT_H_NONE = 0xFFFFFFFFu, BT_H_COPY = 0xFFFFFFFEu;   // `state` of a lane without a product / of a copied product
@@ -67,22 +58,8 @@ struct __attribute__((aligned(16))) BtRow {   // region of a row in the table: f
     uint32_t s, g, bmin;
     float scale;
 };
-#ifndef SPADA_WAIT_T0
-#define SPADA_WAIT_T0 0xFFFFFFFFu   /* one-pass mode: ticks a task waits for its position before the next prologue goes under the wait (off) */
-#endif
-#ifndef SPADA_EQ_FIRST
-#define SPADA_EQ_FIRST 0
-#endif
-#ifndef SPADA_COUNT_HASHED
-#define SPADA_COUNT_HASHED 1   /* counting mode: hashed instead of monotone home slots (nothing is ordered there) */
-#endif
-#ifndef SPADA_RESTART
-#define SPADA_RESTART 1   /* 0: no second attempt -- a task whose blocks cluster probes as far as it takes (measurements) */
-#endif
 constexpr uint32_t BT_BINS = 256;   // equalised home slots (second attempt of a task whose blocks cluster): bins of the rows' column spans
-#ifndef SPADA_PROBE_MAX
-#define SPADA_PROBE_MAX 24   /* slots a block may be displaced in the first attempt before the task starts over with equalised home slots */
-#endif
+constexpr uint32_t BT_PROBE_MAX = 24;   // slots a block may be displaced in the first attempt before the task starts over with equalised home slots (16 / 32: within noise; 64 / 128: R-MAT 18 + 40 ... 75 %)
 constexpr size_t BT_OFF_BINS = BT_OFF_ROWS + (size_t)TK_RMAX * (sizeof(BtRow) + 4 + 4 + 4 + 4 + 4 + 4);
 constexpr size_t BT_OFF_LIST = BT_OFF_BINS + (size_t)BT_BINS * 4;   // the displaced blocks of the task
 constexpr uint32_t BT_LIST_CAP = (40960 - 128 - BT_OFF_LIST) / 4;   // (the last 128 bytes: the counters of SPADA_TASK_DBG builds)
@@ -91,86 +68,6 @@ static_assert(batch_lds() <= 40960, "four workgroups per CU");
 static_assert(BT_T == 6 * BW && BT_PMAX == 4u * BW && BT_EMAX == (uint32_t)BW && BT_T * 8 == BT_PMAX * 12,
               "the LDS map and the per-thread arrays are written for these sizes");
 static_assert(TK_RMAX <= 128 && BT_T <= 4096 && BT_PMAX <= 4096, "field widths of the product state");
-
-// One-pass mode: a task that has assembled its slice of C in LDS does not WAIT for its position (the sum of the counts of all tasks
-// before it arrives some ten microseconds after its own count was published: two hand-offs between loaded CUs, and the publication
-// of the slowest task before it).  It is PARKED instead: its at most 2048 outputs go from LDS to the workgroup's staging slice in
-// global memory (24 KB; the slices of all workgroups stay in the L2 / Infinity Cache), and the NEXT task of the workgroup takes
-// them from there -- the loads are issued right after its own count is published and land under its order stages -- and stores
-// them to C where it would itself start to wait: by then the parked task's position has long arrived.  Tickets are still taken only
-// where a task really starts, so nothing sits unstarted in the chain; a workgroup has at most one parked task.
-// (Parked in registers -- twelve per thread -- the register allocator spilled them: web 0.76 -> 1.06 ms.)
-struct Parked {
-    uint32_t valid, t, total;      // the task, its outputs
-    uint32_t rb, R, first;         // rows [rb, rb + R) get their C.indptr from it (R = 0: a range task; first & 1: the first range of row rb)
-    uint32_t ooff;                 // thread tid < R: outputs of the task before row rb + tid
-};
-struct ParkedRegs {                // thread i: outputs i, i + 512, ... of the parked task, on their way from the staging slice
-    uint32_t col[BT_PMAX / BW];
-    double val[BT_PMAX / BW];
-};
-template <class ARGS>
-__device__ inline void batch_park_load(const ARGS &g, const Parked &pk, ParkedRegs &pr, uint32_t tid)
-{
-    const uint32_t *sc = g.stage_col + (size_t)blockIdx.x * BT_PMAX;
-    const double *sv = g.stage_val + (size_t)blockIdx.x * BT_PMAX;
-#pragma unroll
-    for (int k = 0; k < (int)(BT_PMAX / BW); ++k) {
-        const uint32_t i = tid + (uint32_t)k * BW;
-        pr.col[k] = 0u;
-        pr.val[k] = 0.0;
-        if (pk.valid && i < pk.total) {
-            pr.col[k] = sc[i];
-            pr.val[k] = sv[i];
-        }
-    }
-}
-template <int MODE, class ARGS>
-__device__ inline void batch_unpark(const ARGS &g, Parked &pk, const ParkedRegs &pr, uint32_t ntasks, uint32_t *hdr, uint32_t tid)
-{
-    if (!pk.valid) return;   // (uniform)
-    pk.valid = 0u;
-    const unsigned long long base = task_position<MODE>(g, pk.t, pk.total, hdr);
-    if (pk.R == 0u) {
-        if (tid == 0) {
-            if (pk.first & 1u) g.cptr[pk.rb] = base;   // first range of its row
-            g.range_out[pk.t] = base;
-        }
-    } else if (tid < pk.R) {
-        g.cptr[pk.rb + tid] = base + pk.ooff;
-    }
-    if (pk.t == ntasks - 1 && tid == 0) {
-        g.cptr[g.nrows] = base + pk.total;
-        g.ctr->nnz_c = base + pk.total;
-    }
-    if (base + pk.total > g.capacity) {
-        if (tid == 0) atomicOr(&g.ctr->cap_overflow, 1u);
-        return;
-    }
-    // the slice as it is: neighbouring lanes, neighbouring addresses
-#pragma unroll
-    for (int k = 0; k < (int)(BT_PMAX / BW); ++k) {
-        const uint32_t i = tid + (uint32_t)k * BW;
-        if (i < pk.total) {
-#if SPADA_NT_STORE
-            __builtin_nontemporal_store(pr.col[k], &g.c_idx[base + i]);
-            __builtin_nontemporal_store(pr.val[k], &g.c_val[base + i]);
-#else
-            g.c_idx[base + i] = pr.col[k];
-            g.c_val[base + i] = pr.val[k];
-#endif
-        }
-    }
-}
-// (where no task follows that could take the parked one along: before a task of the older range path, and at the end of the kernel)
-template <int MODE, class ARGS>
-__device__ inline void batch_unpark_now(const ARGS &g, Parked &pk, uint32_t ntasks, uint32_t *hdr)
-{
-    if (!pk.valid) return;
-    ParkedRegs pr;
-    batch_park_load(g, pk, pr, threadIdx.x);
-    batch_unpark<MODE>(g, pk, pr, ntasks, hdr, threadIdx.x);
-}
 
 // The task loop runs every batch task in two parts.  batch_prologue -- descriptor -> row records / A entries -> (range: narrowing
 // searches) -> scans -> entry records, tail bits and row regions in LDS -- touches neither the table nor the outputs of the task
@@ -371,7 +268,7 @@ __device__ inline BatchHead batch_prologue(const ARGS &g, const TaskDesc &td, ui
 // next ticket and runs the next task's prologue
 template <int MODE, bool DENSE, bool SPILL = false, class ARGS, class NEXT>
 __device__ inline void batch_main(const ARGS &g, const TaskDesc &td, uint32_t t, uint32_t ntasks, unsigned char *smem,
-                                  uint32_t *dbg_ph /* LDS: SPADA_TASK_DBG builds */, const BatchHead hd, Parked &pk, NEXT &&next)
+                                  uint32_t *dbg_ph /* LDS: SPADA_TASK_DBG builds */, const BatchHead hd, NEXT &&next)
 {
     constexpr bool VALUES = MODE != MODE_COUNT;
     constexpr uint32_t T = BT_T;
@@ -394,14 +291,6 @@ __device__ inline void batch_main(const ARGS &g, const TaskDesc &td, uint32_t t,
     } while (0)
     if (SPADA_TASK_DBG && tid == 0) dbg_ph[8] += 1;
     BMARK(0);
-#define BSTOP(i)                                                \
-    do {                                                        \
-        if (MODE == MODE_COUNT && SPADA_BT_STOP == (i)) {       \
-            next();                                             \
-            return;                                             \
-        }                                                       \
-    } while (0)
-    BSTOP(1);
     constexpr bool spill = SPILL;
     const bool range = td.kind != TASK_BATCH;
     const uint32_t rb = td.row, R = range ? 1u : (td.np & 0xFFu), E = spill ? 0u : range ? (td.first >> 1) : ((td.np >> 8) & 0x3FFu);
@@ -423,7 +312,6 @@ __device__ inline void batch_main(const ARGS &g, const TaskDesc &td, uint32_t t,
         }
     }
     BMARK(1);
-    BSTOP(2);
     __syncthreads();   // the table is cleared; the prologue's records, tail bits and row regions are written
     // tails before every 64-bit word of the bitmap (32 words): every wave scans them for itself and keeps the prefixes in the
     // lanes of one register (word w in lane w): the per-segment values are then scalar reads, and no further barrier is needed
@@ -434,7 +322,6 @@ __device__ inline void batch_main(const ARGS &g, const TaskDesc &td, uint32_t t,
         tail_pre = inc - c;
     }
 
-    BSTOP(3);
     BMARK(2);
     // ---- expand - scale - accumulate blocks (scheduler.rs:482-606, simulator.rs:892-953, :86-111) ---------------------------
     uint32_t r_ck[4], r_st[4];   // the products of this thread: composite key (local row << colbits | column), state (above)
@@ -522,15 +409,14 @@ __device__ inline void batch_main(const ARGS &g, const TaskDesc &td, uint32_t t,
         // The home slot of a block is a LINEAR function of its column inside the row's span: when the columns cluster -- the rows of
         // an R-MAT graph: a third of a row's blocks on a twentieth of its span -- the blocks of a cluster share a few home slots and
         // linear probing pays for it quadratically (such tasks took 60 - 100 us to count their outputs, and a thousand tasks of the
-        // chain waited for each of them).  So the first attempt gives up where a block is displaced by SPADA_PROBE_MAX slots, and the
+        // chain waited for each of them).  So the first attempt gives up where a block is displaced by BT_PROBE_MAX slots, and the
         // task starts over with EQUALISED home slots: it counts its products in BT_BINS bins of the rows' spans (every row its own
         // bins, s_bin), gives every bin slots in proportion to its products -- at least as many: a bin cannot overflow by itself --
         // and interpolates inside the bin.  Still monotone in (row, column), and as even as the task's own histogram makes it.
         // (the insertion of the hashed products: EQ = the second attempt, with equalised home slots)
-        constexpr bool EQF = SPADA_EQ_FIRST != 0 && MODE != MODE_COUNT && !DENSE;   // (development: every hashed task with equalised home slots)
         auto insert_hashed = [&](auto EQ) {
             constexpr bool equalised = decltype(EQ)::value;
-            constexpr bool COUNT_HASHED = MODE == MODE_COUNT && SPADA_COUNT_HASHED != 0;
+            constexpr bool COUNT_HASHED = MODE == MODE_COUNT;   // (web count kernel 0.52 -> 0.42 ms against monotone home slots)
             mynew = mykeys = 0u;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -561,11 +447,11 @@ __device__ inline void batch_main(const ARGS &g, const TaskDesc &td, uint32_t t,
                     uint32_t old = atomicCAS(&keys[h], EMPTY_KEY, hk);
                     if (old != EMPTY_KEY && old != hk) {
                         // upwards; at the end of the table the free slot BELOW the home takes the block (the order stage then looks at
-                        // whole clusters).  First attempt: SPADA_PROBE_MAX slots above its home the lane gives up -- the blocks cluster,
+                        // whole clusters).  First attempt: BT_PROBE_MAX slots above its home the lane gives up -- the blocks cluster,
                         // the task starts over with equalised home slots -- and leaves the loop by "finding" the key of its home slot
                         // (no exit of its own: the common iteration is the one of a loop without a budget)
                         uint32_t hkx = hk;
-                        const uint32_t hlim = SPADA_RESTART && !equalised && !COUNT_HASHED ? min(home + (uint32_t)SPADA_PROBE_MAX, T) : T;
+                        const uint32_t hlim = !equalised && !COUNT_HASHED ? min(home + BT_PROBE_MAX, T) : T;
                         do {
                             if (h >= home) {
                                 if (++h == hlim) {
@@ -639,12 +525,11 @@ __device__ inline void batch_main(const ARGS &g, const TaskDesc &td, uint32_t t,
                 if (hashed[u]) r_st[u] = h[u] | (fresh ? BT_ST_OWNER : 0u);
             }
         } else {
-            if constexpr (!EQF) insert_hashed(std::false_type{});
+            insert_hashed(std::false_type{});
         }
-        if constexpr (DENSE || !EQF) count_outputs();
+        count_outputs();
         if constexpr (!DENSE) {
-            if (EQF || (SPADA_RESTART && !(MODE == MODE_COUNT && SPADA_COUNT_HASHED) && hdr[42] != 0u)) {   // (uniform, rare: a block of the first attempt was displaced too far)
-            if constexpr (!EQF)
+            if (MODE != MODE_COUNT && hdr[42] != 0u) {   // (uniform, rare: a block of the first attempt was displaced too far)
 #pragma unroll
             for (int u = 0; u < 4; ++u) {   // (the products again from their keys and states: nothing else stays live across the count)
                 const uint32_t st = r_st[u], ck = r_ck[u];
@@ -719,13 +604,9 @@ __device__ inline void batch_main(const ARGS &g, const TaskDesc &td, uint32_t t,
             }
         }
     }
-    BSTOP(4);
     BMARK(3);
     (void)NBt;
     if constexpr (MODE != MODE_NUMERIC) task_publish<MODE>(g, t, total);
-    BSTOP(5);
-    ParkedRegs pr;
-    if constexpr (MODE == MODE_FUSED && SPADA_PARK) batch_park_load(g, pk, pr, (uint32_t)tid);   // (the task parked before this one: on its way back)
     if (SPADA_TASK_DBG && tid == 0) {   // ticks from the task's ticket (dbg_ph[16], k_task) to its publication, per kind: sum, tasks, maximum
         const uint32_t d = (uint32_t)__builtin_amdgcn_s_memtime() - dbg_ph[16], k = range ? 20u : 17u;
         dbg_ph[k] += d >> 4;
@@ -757,9 +638,7 @@ __device__ inline void batch_main(const ARGS &g, const TaskDesc &td, uint32_t t,
             dbg_ph[9 + 5] += 1u;
         }
     }
-#if SPADA_PRIO
     if constexpr (MODE == MODE_FUSED) __builtin_amdgcn_s_setprio(0);
-#endif
     if constexpr (MODE == MODE_COUNT) {
         if (range) {   // (the count of a range task is all the position kernels need)
             next();
@@ -961,53 +840,17 @@ __device__ inline void batch_main(const ARGS &g, const TaskDesc &td, uint32_t t,
     const uint32_t my_ooff = ooff;
 
     // ---- position of the task's slice of C, then the stores --------------------------------------------------------------------
-    if constexpr (MODE == MODE_FUSED && SPADA_PARK) {
-        // the chain: the task parked before this one is stored (its position is there by now), this one is parked in its place
-        __syncthreads();   // (the task's outputs are complete in LDS)
-        batch_unpark<MODE>(g, pk, pr, ntasks, hdr, (uint32_t)tid);
-        BMARK(7);
-        pk.valid = 1u;
-        pk.t = t;
-        pk.total = total;
-        pk.rb = rb;
-        pk.R = range ? 0u : R;
-        pk.first = td.first;
-        pk.ooff = my_ooff;
-        {
-            uint32_t *sc = g.stage_col + (size_t)blockIdx.x * BT_PMAX;
-            double *sv = g.stage_val + (size_t)blockIdx.x * BT_PMAX;
-            for (uint32_t i = tid; i < total; i += BW) {
-                sc[i] = cols[i] & colmask;
-                sv[i] = vals[i];
-            }
-        }
-        next();   // (starts with a barrier: the outputs are read, the next task may clear the table)
-    } else {
     // Where the next ticket is taken and the next task's prologue runs.  Without a chain (NUMERIC): here, under the stores.  With
-    // it (FUSED, SPADA_PARK = 0): only after the stores -- a ticket taken while this task still waits for its position puts a task
-    // into the chain that cannot publish its count before this wait is over, and every task behind it waits for that (measured:
-    // web 0.82 -> 0.95 ms, R-MAT 16 4.9 -> 5.6 ms with the prologue under the wait)
-    constexpr bool NEXT_EARLY = SPADA_NEXT_EARLY >= 0 ? SPADA_NEXT_EARLY != 0 : (MODE == MODE_NUMERIC || (MODE == MODE_FUSED && SPADA_STATIC_FUSED != 0));
-    // One-pass mode, SPADA_WAIT_T0: the task waits up to that many ticks for its position; if it has not arrived by then the wait is a
-    // long one -- a slow predecessor -- and the next ticket and prologue go under the rest of it (a ticket taken at once would put
-    // an unstarted task into the chain for the whole wait; one taken after a part of it only for about a prologue's length)
-    bool nexted = NEXT_EARLY;
+    // it (FUSED): only after the stores -- a ticket taken while this task still waits for its position puts a task into the chain that
+    // cannot publish its count before this wait is over, and every task behind it waits for that (measured: web 0.82 -> 0.95 ms,
+    // R-MAT 16 4.9 -> 5.6 ms with the prologue under the wait; a wait of 2 - 12 thousand ticks before the early ticket: web 1.16 ... 0.81
+    // against 0.77 ms; parking the finished task in registers or in a global staging slice instead of waiting: no gain either --
+    // profiles/r04_experiments.txt)
+    constexpr bool NEXT_EARLY = MODE == MODE_NUMERIC;
     if constexpr (NEXT_EARLY) next();   // (starts with a barrier: the task's outputs are complete in LDS)
     else __syncthreads();
     if constexpr (MODE != MODE_NUMERIC) {
-        bool have = false;
-        if constexpr (MODE == MODE_FUSED && !NEXT_EARLY && SPADA_WAIT_T0 != 0xFFFFFFFFu) {
-            if (chain_has_scanner(g.scanner)) {   // (uniform)
-                unsigned long long b_;
-                have = chain_try_position(g.status, t, total, hdr, SPADA_WAIT_T0, &b_);
-                base = b_;
-                if (!have) {
-                    next();
-                    nexted = true;
-                }
-            }
-        }
-        if (!have) base = task_position<MODE>(g, t, total, hdr);
+        base = task_position<MODE>(g, t, total, hdr);
         if (range) {
             if (tid == 0) {
                 if (td.first & 1u) g.cptr[rb] = base;   // first range of its row
@@ -1022,8 +865,7 @@ __device__ inline void batch_main(const ARGS &g, const TaskDesc &td, uint32_t t,
         }
         if (base + total > g.capacity) {
             if (tid == 0) atomicOr(&g.ctr->cap_overflow, 1u);
-            if (!nexted) next();
-            else __syncthreads();   // (the next task clears the table behind this barrier)
+            next();
             return;
         }
     }
@@ -1036,22 +878,15 @@ __device__ inline void batch_main(const ARGS &g, const TaskDesc &td, uint32_t t,
         for (uint32_t j = tid; j < total + shift; j += BW) {
             if (j >= shift) {
                 const uint32_t i = j - shift;
-#if SPADA_NT_STORE
                 __builtin_nontemporal_store(cols[i] & colmask, &g.c_idx[base + i]);
                 __builtin_nontemporal_store(vals[i], &g.c_val[base + i]);
-#else
-                g.c_idx[base + i] = cols[i] & colmask;
-                g.c_val[base + i] = vals[i];
-#endif
             }
         }
     }
-    if (!nexted) next();   // (starts with a barrier)
-    else __syncthreads();  // (the outputs are read: the next task may clear the table)
-    }
+    if constexpr (NEXT_EARLY) __syncthreads();   // (the outputs are read: the next task may clear the table)
+    else next();                                 // (starts with a barrier)
     BMARK(8);
 #undef BMARK
-#undef BSTOP
 }
 
 }  // namespace spada

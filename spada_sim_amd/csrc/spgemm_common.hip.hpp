@@ -271,9 +271,7 @@ constexpr uint32_t LR_NONE = 0xFFFFFFFFu;
 // LDS scratch: entry records {pack = (begin - offset) mod 2^48 | local row << 48, a value} | bm u64[PWIN / 64] |
 // bpre u32[PWIN / 64]
 constexpr int FLAT_PWIN = 8192;
-#ifndef SPADA_FLAT_U
-#define SPADA_FLAT_U 4
-#endif
+constexpr int FLAT_U = 4;   // segments of 64 products per thread and round (2: +0 ... 2 %, 8: +3 ... 6 %)
 constexpr unsigned long long M48 = 0xFFFFFFFFFFFFull;
 
 struct __attribute__((aligned(16))) EntryRecNum {

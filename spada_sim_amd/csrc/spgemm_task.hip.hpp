@@ -35,14 +35,11 @@
 #pragma once
 #include "spgemm_common.hip.hpp"
 
-#ifndef SPADA_NT_STORE
-#define SPADA_NT_STORE 1   /* C is written once and not read again by the pipeline: non-temporal stores keep A, B and the descriptors
-                            in the caches (web -3 %, cop20k_A -1.3 %, R-MAT 16 -1 % per step) */
-#endif
-#ifndef SPADA_PRIO
-#define SPADA_PRIO 3   /* wave priority from a task's start until its count is published (one-pass mode): what the tasks behind it wait
-                         for wins the arbitration against emissions and stores; measured -1.4 % (web), -1.1 % (R-MAT 16), 0 elsewhere */
-#endif
+// (C is written once and not read again by the pipeline: its stores are non-temporal, which keeps A, B and the descriptors in the caches:
+// web -3 %, cop20k_A -1.3 %, R-MAT 16 -1 % per step)
+// wave priority from a task's start until its count is published (one-pass mode): what the tasks behind it wait for wins the
+// arbitration against emissions and stores; measured -1.4 % (web), -1.1 % (R-MAT 16), 0 elsewhere
+constexpr int TASK_PRIO = 3;
 #ifndef SPADA_TASK_DBG
 #define SPADA_TASK_DBG 0   /* 1 (scripts/build_dbg.sh): phase cycle counters of k_task, printed to stderr */
 #endif
@@ -64,16 +61,8 @@ constexpr int TK_NOUT = TK_T;                          // outputs the emission's
 constexpr uint32_t TK_LIMIT_HI = 2040;
 constexpr uint32_t TK_SMALL_MAX = 512;   // class boundary SMALL | SOLO (statistics only: both are packed into batches)
 constexpr uint32_t TK_SOLO_MAX = 1536;   // the sort-merge accumulator's limit (its network holds 2048 pairs)
-#ifndef SPADA_STATIC_FUSED
-#define SPADA_STATIC_FUSED 0
-#endif
-#ifndef SPADA_TK_NQ
-#define SPADA_TK_NQ 16
-#endif
-#ifndef SPADA_Q_SHIFT
-#define SPADA_Q_SHIFT 0   /* workgroup b serves queue (b >> SPADA_Q_SHIFT) % TK_NQ (3: the workgroups of a queue are spread over the eight XCDs) */
-#endif
-constexpr int TK_NQ = SPADA_TK_NQ;        // ticket queues: task t belongs to queue t % TK_NQ, workgroup b serves queue task_queue()
+constexpr int TK_NQ = 16;                // ticket queues: task t belongs to queue t % TK_NQ, workgroup b serves queue b % TK_NQ (1 / 4 / 8 queues, queues
+                                         // spread over the XCDs: within 1 % on web / R-MAT 16, one queue 5 - 10 % slower on cop20k_A: profiles/r04_experiments.txt)
 constexpr int BX_NB = 1024;              // column buckets of the big-row histogram
 static_assert(TK_LIMIT_HI + 8 <= (uint32_t)TK_T && TK_NOUT % TK_BLOCK == 0, "the table must keep empty slots");
 
@@ -111,7 +100,8 @@ struct TaskCounters {   // (a multiple of 8 bytes: k_init clears it in 8-byte wo
     uint32_t multi_pass_tasks;
     uint32_t scanner_cu;                              // one-pass mode: where the chain's scanner runs (XCC, SE, SH, CU | valid bit)
     uint32_t ticket[2 * TK_NQ * 32];  // TK_NQ ticket counters, one per 128-byte line (a single hot word sustains ~88 atomics / us); the second half: k_task_range
-    uint32_t n_legacy, pad_legacy;    // tasks of the older range path (their numbers: TaskArgs::legacy)
+    uint32_t n_legacy;                // tasks of the older range path (their numbers: TaskArgs::legacy)
+    uint32_t scanner_leavers;         // one-pass mode: workgroups that left the scanner's CU to it (at most SCANNER_LEAVERS_MAX)
 #if SPADA_TASK_DBG
     unsigned long long dbgh[3][24];  // per task kind: [0..19] histogram of the cycles from ticket to publish (4096-cycle bins), [20] sum, [21] tasks, [22] max
 #endif
@@ -130,39 +120,27 @@ struct TaskCounters {   // (a multiple of 8 bytes: k_init clears it in 8-byte wo
 constexpr uint32_t BT_EMAX = 512, BT_PMAX = 2048;
 constexpr int BT_BSHIFT = 5;   // a block = 32 consecutive columns of one row of C (the batch tasks key their table by blocks)
 constexpr uint32_t BT_T = 3072;   // slots of the batch tasks' block table (at most `limit` = 2040 blocks: two thirds full at worst)
-#ifndef SPADA_SPILL_DENSE
-#define SPADA_SPILL_DENSE 1
-#endif
-#ifndef SPADA_DIRECT_BATCH_ONLY
-#define SPADA_DIRECT_BATCH_ONLY 1   // a BIG row goes direct only if its range tasks fit the batch stages (one chunk of entries); 0: up to BX_DIRECT_MAX_SEARCH
-#endif
-#ifndef SPADA_DIRECT_ROWS
-#define SPADA_DIRECT_ROWS 400000u   // ... in calls over at least this many rows: on a small row block (an eighth of the web input) the scatter of
-                                    // the few spilled rows costs 20 us and the chain, with a few thousand tasks in all, gains nothing
-#endif
-#ifndef SPADA_DIRECT_EMAX
-#define SPADA_DIRECT_EMAX 512       // (= BT_EMAX; 384 / 256 measured: see profiles/r03_experiments.txt)
-#endif
+// a BIG row goes direct only if its range tasks fit the batch stages (one chunk of entries: BX_DIRECT_EMAX = BT_EMAX; 384 / 256 measured:
+// profiles/r03_experiments.txt) ...
+// ... in calls over at least this many rows: on a small row block (an eighth of the web input) the scatter of the few spilled rows costs
+// 20 us and the chain, with a few thousand tasks in all, gains nothing
+constexpr uint32_t BX_DIRECT_ROWS = 400000u;
+constexpr unsigned long long BX_DIRECT_EMAX = 512;
 constexpr int BT_DSHIFT = BT_BSHIFT;   // columns per slot of a dense batch / direct range: 2^BT_DSHIFT
-#ifndef SPADA_BT_DENSE
-#define SPADA_BT_DENSE 1       // batches / ranges whose blocks fit the table slot for slot skip hashing and sorting (spgemm_batch.hip.hpp)
-#endif
+// (batches / ranges whose blocks fit the table slot for slot skip hashing and sorting: DENSE, spgemm_batch.hip.hpp)
 static_assert(BT_EMAX == (uint32_t)TKW * TKW_EPT && BT_PMAX == 4u * TKW && TK_LIMIT_HI <= BT_PMAX, "one entry and four products per thread");
 
 // Which tasks run through the batch stages (spgemm_batch.hip.hpp): consecutive non-BIG rows, a column range of a BIG row with at
 // most one chunk of entries and at most as many products as the registers hold (a heavy histogram bucket -- many products on few
-// columns -- may have more), or (SPADA_SPILL_DENSE) a single-pass spilled range that fits the registers and whose blocks fit the
+// columns -- may have more), or a single-pass spilled range that fits the registers and whose blocks fit the
 // table slot for slot
 __device__ inline bool task_spill_dense(const TaskDesc &td)
 {
-    return SPADA_BT_DENSE && SPADA_SPILL_DENSE && td.kind == TASK_RANGE && !(td.first & 2u) && td.np <= BT_PMAX &&
+    return td.kind == TASK_RANGE && !(td.first & 2u) && td.np <= BT_PMAX &&
            (td.col_hi >> BT_DSHIFT) - (td.col_lo >> BT_DSHIFT) < BT_T;   // (slots of 32 columns)
 }
 __device__ inline bool task_is_batch(const TaskDesc &td)
 {
-#ifdef SPADA_DEV_NO_LEGACY   /* development: resource usage of the batch stages alone */
-    return true;
-#endif
     return td.kind == TASK_BATCH || (td.kind == TASK_RANGE_DIRECT && (td.first >> 1) <= BT_EMAX && td.np <= BT_PMAX) || task_spill_dense(td);
 }
 
@@ -334,18 +312,10 @@ __global__ __launch_bounds__(256) void k_row_class(const uint64_t *__restrict__ 
 //   k_big_scatter one workgroup per part of a spilled row: walks its products again and stores (column, a * b) at the bucket's
 //                 cursor: afterwards the scratch slice of every range is contiguous
 // k_cut3 copies the range descriptors into the task list in row order.
-#ifndef SPADA_LB_PAUSE_MAX
-#define SPADA_LB_PAUSE_MAX 2   // a task polls its status word with a pause that grows by this many steps (0 .. 12: within 1 %)
-#endif
-#ifndef SPADA_BX_PART
-#define SPADA_BX_PART 8192
-#endif
-#ifndef SPADA_BX_RUN
-#define SPADA_BX_RUN 8
-#endif
-constexpr uint32_t BX_PART = SPADA_BX_PART;
+constexpr uint32_t LB_PAUSE_MAX = 2;   // a task polls its status word with a pause that grows by this many steps (0 .. 12: within 1 %)
+constexpr uint32_t BX_PART = 8192;   // products per part of a BIG row (4 K / 16 K / 32 K: within 3 % on web and R-MAT 16 / 18)
 constexpr uint32_t BX_NOPART = 0xFFFFFFFFu;
-constexpr uint32_t BX_RUN = SPADA_BX_RUN;   // consecutive part records per workgroup (k_big_scatter)
+constexpr uint32_t BX_RUN = 8;   // consecutive part records per workgroup (k_big_scatter)
 struct BigPart {
     uint32_t slot;      // position of the row in big_rows; BX_NOPART: sentinel / unused record
     uint32_t p_begin;   // products of the row before the part (sort-merge: product numbers)
@@ -512,9 +482,6 @@ __global__ __launch_bounds__(256) void k_big_parts(const uint64_t *__restrict__ 
 // row: on a skewed input -- the popular columns of an R-MAT graph -- dozens of neighbouring lanes fall into the same bucket and an
 // LDS atomic per lane serialises on one address.  The first lane of every run speaks for the run: `head`, the run's length, and
 // for every lane the lane of its head.  key = 0xFFFFFFFF marks a lane without a product (such lanes form runs that add nothing).
-#ifndef SPADA_BX_RUNS
-#define SPADA_BX_RUNS 1
-#endif
 // Returns false -- and nothing else -- when no two neighbouring lanes share a bucket (meshes: the check costs three instructions,
 // the run bookkeeping a dozen and a cross-lane read).
 __device__ inline bool wave_runs(uint32_t key, bool &head, uint32_t &len, uint32_t &head_lane)
@@ -539,7 +506,7 @@ __global__ __launch_bounds__(TK_BLOCK) void k_big_hist(const uint32_t *__restric
                                                        const BigPart *__restrict__ parts, uint32_t *__restrict__ part_hist,
                                                        const TaskCounters *__restrict__ ctr)
 {
-    constexpr int NB = BX_NB, U = SPADA_FLAT_U;
+    constexpr int NB = BX_NB, U = FLAT_U;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *hdr = (uint32_t *)smem;
     uint32_t *cnt = (uint32_t *)(smem + 256);
@@ -566,15 +533,11 @@ __global__ __launch_bounds__(TK_BLOCK) void k_big_hist(const uint32_t *__restric
                                                  [&](uint32_t(&col)[U], uint32_t(&plr)[U], double(&)[U], uint32_t(&)[U]) {
 #pragma unroll
                                                      for (int u = 0; u < U; ++u) {
-#if SPADA_BX_RUNS
                                                          const uint32_t bk = plr[u] != LR_NONE ? (col[u] - kmin) >> wshift : 0xFFFFFFFFu;
                                                          bool head;
                                                          uint32_t len, hl;
                                                          if (!wave_runs(bk, head, len, hl)) len = 1u;   // (every lane its own run)
                                                          if (head && bk != 0xFFFFFFFFu) atomicAdd(&cnt[bk], len);
-#else
-                                                         if (plr[u] != LR_NONE) atomicAdd(&cnt[(col[u] - kmin) >> wshift], 1u);
-#endif
                                                      }
                                                  });
         __syncthreads();
@@ -761,7 +724,7 @@ __global__ __launch_bounds__(TK_BLOCK) void k_big_plan(const uint64_t *__restric
             const uint32_t avg_len = (uint32_t)min(P / max(E, 1ull), 0xFFFFFFFFull);
             const unsigned long long steps = 1ull + (avg_len ? 31u - (uint32_t)__clz((int)avg_len) : 0u);   // of one binary search
             const bool direct = allow_direct && hdr[47] == 0 && (unsigned long long)m * E * steps <= (unsigned long long)BX_DIRECT_FACTOR * P &&
-                                E * steps <= BX_DIRECT_MAX_SEARCH && (!SPADA_DIRECT_BATCH_ONLY || E <= (unsigned long long)SPADA_DIRECT_EMAX || nrows_call < SPADA_DIRECT_ROWS);
+                                E * steps <= BX_DIRECT_MAX_SEARCH && (E <= BX_DIRECT_EMAX || nrows_call < BX_DIRECT_ROWS);
             const uint32_t tb = row_tmp[row];   // big_max_ranges(P) >= m records, allocated by k_big_parts
             const unsigned long long sb = direct ? 0ull : atomicAdd(&ctr->scratch_cursor, P);
             // the cut table of a direct row whose range tasks run through the batch stages: (ranges + 1) rows of one word per entry
@@ -955,7 +918,7 @@ __global__ __launch_bounds__(TK_BLOCK) void k_big_scatter(const double *__restri
                                                           double *__restrict__ scr_val, uint32_t *__restrict__ scr_seq /* may be null */,
                                                           const TaskCounters *__restrict__ ctr)
 {
-    constexpr int NB = BX_NB, U = SPADA_FLAT_U;
+    constexpr int NB = BX_NB, U = FLAT_U;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *hdr = (uint32_t *)smem;
     uint32_t *cur = (uint32_t *)(smem + 256);
@@ -992,7 +955,6 @@ __global__ __launch_bounds__(TK_BLOCK) void k_big_scatter(const double *__restri
                                                 [&](uint32_t(&col)[U], uint32_t(&plr)[U], double(&v)[U], uint32_t(&pp)[U]) {
 #pragma unroll
                                                     for (int u = 0; u < U; ++u) {
-#if SPADA_BX_RUNS
                                                         const uint32_t bk = plr[u] != LR_NONE ? (col[u] - kmin) >> wshift : 0xFFFFFFFFu;
                                                         bool head;
                                                         uint32_t len, hl;
@@ -1004,13 +966,8 @@ __global__ __launch_bounds__(TK_BLOCK) void k_big_scatter(const double *__restri
                                                         uint32_t pbase = 0;
                                                         if (head && bk != 0xFFFFFFFFu) pbase = atomicAdd(&cur[bk], len);
                                                         if (runs) pbase = (uint32_t)__shfl((int)pbase, (int)hl);
-#endif
                                                         if (plr[u] != LR_NONE) {
-#if SPADA_BX_RUNS
                                                             const uint32_t p = pbase + ((threadIdx.x & 63) - hl);
-#else
-                                                            const uint32_t p = atomicAdd(&cur[(col[u] - kmin) >> wshift], 1u);
-#endif
                                                             // (plain stores: the runs of a range are completed in the caches;
                                                             // non-temporal ones made the stage 1.4 - 2 x slower)
                                                             scr_col[sb + p] = col[u];
@@ -1114,7 +1071,7 @@ __device__ inline uint32_t cut_tile(const uint32_t *__restrict__ row_cl, const u
         const uint32_t i = base + j;
         const uint32_t cl = i < n ? row_cl[i] : (uint32_t)CLS_EMPTY;
         RowRec rr{0u, 0u, 0u, (uint32_t)CLS_EMPTY};
-        if (SPADA_BT_DENSE && i < n) rr = row_rec[i];   // (issued with the other loads of the row, not behind its class)
+        if (i < n) rr = row_rec[i];   // (issued with the other loads of the row, not behind its class)
         cls[j] = (uint8_t)(cl & 7u);
         const uint32_t len = cl >> 3;
         const uint32_t P = i < n ? row_nprod[i] : 0u;
@@ -1123,7 +1080,7 @@ __device__ inline uint32_t cut_tile(const uint32_t *__restrict__ row_cl, const u
         w[j] = cls[j] == CLS_COPY ? P : 0u;
         e[j] = (cls[j] == CLS_BIG || fat[j]) ? 0u : len;
         sp[j] = 0;
-        if (SPADA_BT_DENSE && (cls[j] == CLS_SMALL || cls[j] == CLS_SOLO))   // blocks a table addressed by column would need for the row
+        if ((cls[j] == CLS_SMALL || cls[j] == CLS_SOLO))   // blocks a table addressed by column would need for the row
             sp[j] = min((rr.kmax >> BT_DSHIFT) - (rr.kmin >> BT_DSHIFT) + 1u, 2u * BT_T);
         L.mark[threadIdx.x * CUT_ITEMS + j] = 0;
         sc += c[j];
@@ -1231,7 +1188,7 @@ __device__ inline uint32_t cut_tile(const uint32_t *__restrict__ row_cl, const u
                 const uint32_t end = nm[j];
                 binfo[j] = fat[j] ? batch_info(1u, 0u, 0u)
                                   : batch_info(end - li, L.pe[end] - L.pe[li], (L.pc[end] - L.pc[li]) + (L.pw[end] - L.pw[li]));
-                if (SPADA_BT_DENSE && !fat[j] && L.pc[end] > L.pc[li] && L.ps[end] - L.ps[li] <= BT_T) binfo[j] |= BINFO_DENSE;
+                if (!fat[j] && L.pc[end] > L.pc[li] && L.ps[end] - L.ps[li] <= BT_T) binfo[j] |= BINFO_DENSE;
             }
         }
         local += cr.t[j];
@@ -1417,10 +1374,7 @@ __global__ __launch_bounds__(256) void k_cut3(const uint8_t *__restrict__ row_cl
 
 // ---- 4. the task kernel ------------------------------------------------------------------------------------------------
 constexpr int MODE_COUNT = 0, MODE_NUMERIC = 1, MODE_FUSED = 2;
-#ifndef SPADA_ST_STRIDE
-#define SPADA_ST_STRIDE 2   /* 16 bytes per task: measured 3 % faster than adjacent words (fewer writers per line) */
-#endif
-constexpr long long ST_STRIDE = SPADA_ST_STRIDE;   // words between the status words of consecutive tasks
+constexpr long long ST_STRIDE = 2;   // words between the status words of consecutive tasks: 16 bytes per task, measured 3 % faster than adjacent words (fewer writers per line)
 constexpr unsigned long long ST_AGG = 1ull << 62, ST_INC = 2ull << 62, ST_MASK = 3ull << 62;
 
 struct TaskArgs {
@@ -1445,8 +1399,6 @@ struct TaskArgs {
     uint32_t b_off32;               // nnz(B) < 2^29: byte offsets into B's index and value arrays fit 32 bits
     uint32_t scanner;               // one-pass mode: enough workgroups are resident to spare one for the chain's scanner (launch_task)
     const uint32_t *cuts;           // cut table of the direct range tasks (k_big_cuts)
-    uint32_t *stage_col;            // one-pass mode: staging slices of the parked tasks, BT_PMAX outputs per workgroup (spgemm_batch.hip.hpp)
-    double *stage_val;
     uint64_t *cptr;                 // nrows + 1: COUNT / FUSED write it, NUMERIC reads it
     uint64_t *range_out;            // per task: first output of a RANGE task (COUNT writes, NUMERIC reads)
     unsigned long long *status;     // per task: chain words, zeroed before the launch
@@ -1597,39 +1549,25 @@ __host__ __device__ constexpr size_t task_lds()
 // needed (all threads) -- the LDS half of the emission sits between the two, so the wait for predecessors that are still
 // accumulating is mostly over by the time the look-back starts.
 //
-// SPADA_CHAIN_SCANNER (default): the walking is taken away from the tasks.  Workgroup 0 of the kernel takes no tasks; its first
+// The scanner: the walking is taken away from the tasks.  Workgroup 0 of the kernel takes no tasks; its first
 // wave reads the status words in task order, SCAN_WIN windows of 64 per step with all loads in flight together, and turns every
 // count it finds (AGG) into the inclusive prefix (INC) in place.  A task then waits for ITS OWN word with one lane.  Why: a status
 // word is an agent-scope access that no L2 serves (about a microsecond), and with tasks walking back 64 predecessors per round
 // trip the front of known prefixes cannot advance faster than 64 tasks per round trip, while a thousand workgroups re-read the
 // windows in front of it -- measured (development build with a look-back that costs nothing): 85 of 818 us on the web input, 150 of
 // 654 us on the mesh input were spent waiting there.  The scanner reads every word about once and keeps 256 of them in flight.
-#ifndef SPADA_CHAIN_SCANNER
-#define SPADA_CHAIN_SCANNER 1
-#endif
-#ifndef SPADA_SCANNER_ALONE
-#define SPADA_SCANNER_ALONE 1
-#endif
-#ifndef SPADA_SCAN_IDLE_SLEEP
-#define SPADA_SCAN_IDLE_SLEEP 1
-#endif
-#ifndef SPADA_SCAN_IDLE_MAX
-#define SPADA_SCAN_IDLE_MAX 0   /* steps the scanner's pause grows to when a step found no new count (round 3: 8; the scanner has a CU of its
-                                  own now and nothing to yield to; 0 / 2 / 8 / 32 and no pause at all are within the run-to-run noise of 1.5 %) */
-#endif
-#ifndef SPADA_SCAN_WIN
-#define SPADA_SCAN_WIN 8   /* 64-word windows of status words the scanner has in flight per step.  Round 4 (task kernel, ms: web / cop20k_A /
-                             cage12 / R-MAT 16): 4: 0.772 - 0.787 / 0.580 / 0.226 / 4.63 - 4.68; 8: 0.766 - 0.770 / 0.564 / 0.217 / 4.59 - 4.61;
-                             6: 0.799 / 0.596 / 0.230 / 4.67; 12: 0.791 / 0.576 / 0.221 / 4.71; 16: 0.87 / 0.73 / 0.274 / 5.1 */
-#endif
-constexpr int SCAN_WIN = SPADA_SCAN_WIN;
+// 64-word windows of status words the scanner has in flight per step.  Round 4 (task kernel, ms: web / cop20k_A / cage12 / R-MAT 16):
+// 4: 0.772 - 0.787 / 0.580 / 0.226 / 4.63 - 4.68; 8: 0.766 - 0.770 / 0.564 / 0.217 / 4.59 - 4.61; 6: 0.799 / 0.596 / 0.230 / 4.67; 12: 0.791 /
+// 0.576 / 0.221 / 4.71; 16: 0.87 / 0.73 / 0.274 / 5.1
+constexpr int SCAN_WIN = 8;
+constexpr uint32_t SCANNER_LEAVERS_MAX = 3;   // (four workgroups per CU: the scanner and three others)
 // (a grid too small to spare a workgroup -- every ticket queue must keep one that takes tasks -- walks back as before)
-__device__ inline uint32_t task_queue() { return (blockIdx.x >> SPADA_Q_SHIFT) % (uint32_t)TK_NQ; }
+__device__ inline uint32_t task_queue() { return blockIdx.x % (uint32_t)TK_NQ; }
 // RESIDENCY: workgroup 0 takes no tasks, so every ticket queue needs ANOTHER workgroup that is resident while the others wait for
 // their positions -- queue 0's is workgroup TK_NQ -- i.e. more than TK_NQ workgroups of the grid must run at the same time.  The
 // host decides (launch_task: occupancy x CUs must be at least 4 TK_NQ, TaskArgs::scanner); a device whose CUs are masked or held by
 // other kernels below that walks back per task as before.
-__device__ inline bool chain_has_scanner(uint32_t host_says) { return SPADA_CHAIN_SCANNER != 0 && host_says != 0u && gridDim.x >= 2u * (uint32_t)TK_NQ; }
+__device__ inline bool chain_has_scanner(uint32_t host_says) { return host_says != 0u && gridDim.x >= 2u * (uint32_t)TK_NQ; }
 __device__ inline void chain_publish(unsigned long long *status, uint32_t t, unsigned long long count, uint32_t scanner)
 {
     if (threadIdx.x == 0)
@@ -1643,7 +1581,7 @@ __device__ inline void chain_scanner(unsigned long long *status, uint32_t t_lo, 
     if (threadIdx.x >= 64) return;
     const uint32_t lane = threadIdx.x;
     unsigned long long run = 0;   // counts of the tasks before `next`
-    uint32_t next = t_lo, idle = 0;
+    uint32_t next = t_lo;
     while (next < t_end) {
         unsigned long long sv[SCAN_WIN];
 #pragma unroll
@@ -1680,44 +1618,8 @@ __device__ inline void chain_scanner(unsigned long long *status, uint32_t t_lo, 
             open = lead == 64u;
         }
         next += adv;
-        if (adv) {
-            idle = 0;
-        } else {
-            if (SPADA_SCAN_IDLE_SLEEP) __builtin_amdgcn_s_sleep(2);
-            if (idle < SPADA_SCAN_IDLE_MAX) ++idle;
-            for (uint32_t z = 0; z < idle; ++z) __builtin_amdgcn_s_sleep(4);
-        }
+        if (!adv) __builtin_amdgcn_s_sleep(2);   // (a pause that grows to 2 / 8 / 32 steps, or none at all: within the run-to-run noise)
     }
-}
-
-// scanner mode: has the position of task t arrived within `budget` clock ticks?  (one lane polls; all threads get the answer and,
-// if so, the position in *base)
-__device__ inline bool chain_try_position(unsigned long long *status, uint32_t t, unsigned long long count, uint32_t *hdr, uint32_t budget,
-                                          unsigned long long *base)
-{
-    if (threadIdx.x == 0) {
-        const uint32_t t0 = (uint32_t)__builtin_amdgcn_s_memtime();
-        unsigned long long s;
-        uint32_t ok = 0;
-        for (;;) {
-            s = __hip_atomic_load(&status[(size_t)t * ST_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if ((s & ST_MASK) == ST_INC) {
-                ok = 1;
-                break;
-            }
-            if ((uint32_t)__builtin_amdgcn_s_memtime() - t0 >= budget) break;
-            __builtin_amdgcn_s_sleep(2);
-        }
-        const unsigned long long excl = (s & ~ST_MASK) - count;
-        hdr[48] = (uint32_t)excl;
-        hdr[49] = (uint32_t)(excl >> 32);
-        hdr[46] = ok;
-    }
-    __syncthreads();
-    const bool ok = hdr[46] != 0u;
-    *base = ((unsigned long long)hdr[49] << 32) | hdr[48];
-    __syncthreads();
-    return ok;
 }
 
 __device__ inline unsigned long long chain_lookback(unsigned long long *status, uint32_t t, unsigned long long count, uint32_t *hdr,
@@ -1734,7 +1636,7 @@ __device__ inline unsigned long long chain_lookback(unsigned long long *status, 
             s = __hip_atomic_load(&status[(size_t)t * ST_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if ((s & ST_MASK) == ST_INC) break;
             __builtin_amdgcn_s_sleep(2);
-            if (pause < SPADA_LB_PAUSE_MAX) ++pause;
+            if (pause < LB_PAUSE_MAX) ++pause;
             for (uint32_t z = 0; z < pause; ++z) __builtin_amdgcn_s_sleep(4);
         }
         const unsigned long long excl = (s & ~ST_MASK) - count;
@@ -1748,14 +1650,6 @@ __device__ inline unsigned long long chain_lookback(unsigned long long *status, 
         return base_;
     }
     }
-#ifdef SPADA_FAKE_CHAIN   /* development: what the one-pass mode would take if the look-back cost nothing (WRONG positions) */
-    if (tid == 0) {
-        hdr[48] = 0;
-        hdr[49] = 0;
-    }
-    __syncthreads();
-    return 0ull;
-#endif
     if (tid < 64) {
         if (t == 0) {
             if (lane == 0) {
@@ -1783,7 +1677,7 @@ __device__ inline unsigned long long chain_lookback(unsigned long long *status, 
                         while ((__hip_atomic_load(&status[idx * ST_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & ST_MASK) == 0) {
                             ++spins;
                             __builtin_amdgcn_s_sleep(8);
-                            if (pause < SPADA_LB_PAUSE_MAX) ++pause;
+                            if (pause < LB_PAUSE_MAX) ++pause;
                             for (uint32_t z = 0; z < pause; ++z) __builtin_amdgcn_s_sleep(16);
                         }
                     }
@@ -1917,13 +1811,8 @@ __device__ inline unsigned long long emit_table(unsigned char *smem, uint32_t NO
 #pragma unroll
         for (int w = 0; w < OPT; ++w)
             if (tid + w * BLOCK < NO) {
-#if SPADA_NT_STORE
                 __builtin_nontemporal_store(ecol[w], &c_idx[base + epos[w]]);
                 __builtin_nontemporal_store(evl[w], &c_val[base + epos[w]]);
-#else
-                c_idx[base + epos[w]] = ecol[w];
-                c_val[base + epos[w]] = evl[w];
-#endif
             }
     }
     __syncthreads();
@@ -2068,7 +1957,7 @@ template <int BLOCK, int EPT, bool VALUES, class G>
 __device__ inline uint32_t direct_accumulate(unsigned char *smem, unsigned char *region2, uint32_t *s_re, uint64_t *s_a0,
                                              const G &g, const TaskDesc &td)
 {
-    constexpr int U = SPADA_FLAT_U;
+    constexpr int U = FLAT_U;
     uint32_t *hdr = (uint32_t *)smem;
     uint32_t *keys = (uint32_t *)(smem + 256);
     double *vals = (double *)(keys + TK_T);
@@ -2173,9 +2062,6 @@ __global__ __launch_bounds__(256) void k_init_args(TaskCounters *__restrict__ ct
     }
     for (uint64_t i = i0; i < status_words; i += stride) status[i] = 0ull;
 }
-#ifndef SPADA_TASK_WAVES
-#define SPADA_TASK_WAVES 8   /* waves per SIMD the task kernel is compiled for (HIP: second argument of __launch_bounds__): 8 = 64 VGPRs */
-#endif
 // ---- RANGE task of the older kind: columns [col_lo, col_hi] of a BIG row -- the products of a spilled row's scratch slice that do not
 // fit the batch stages (more products than the registers hold, sub-ranges of a heavy bucket, multi-pass ranges), or a direct range
 // of a row with more than BT_EMAX entries: table keyed by column, monotone buckets + in-bucket rank (emit_table).
@@ -2237,9 +2123,7 @@ __device__ __forceinline__ void range_task_body(const ARGS &g, const TaskDesc &t
         total = range_dfs<BLOCK, false, NOUT>(smem, s_re, s_row, s_out, td, g.scr_col, g.scr_val, 0ull, nullptr, nullptr);
     }
     if constexpr (MODE != MODE_NUMERIC) task_publish<MODE>(g, t, total);
-#if SPADA_PRIO
     if constexpr (MODE == MODE_FUSED) __builtin_amdgcn_s_setprio(0);
-#endif
     auto resolve = [&]() -> unsigned long long {
         if constexpr (MODE == MODE_NUMERIC) {
             return g.range_out[t];
@@ -2292,7 +2176,7 @@ __device__ __attribute__((noinline)) void range_task(const TaskArgs *gp_, uint32
 __device__ inline int task_variant(const TaskDesc &d)
 {
     if (task_spill_dense(d)) return 2;
-    const bool dense = SPADA_BT_DENSE && (d.kind == TASK_BATCH ? (d.np & BINFO_DENSE) != 0
+    const bool dense = (d.kind == TASK_BATCH ? (d.np & BINFO_DENSE) != 0
                                                                 : (d.col_hi >> BT_DSHIFT) - (d.col_lo >> BT_DSHIFT) < BT_T);
     return dense ? 1 : 0;
 }
@@ -2320,13 +2204,10 @@ __global__ void k_task_args(const TaskArgs g, TaskArgs *__restrict__ dst)
 {
     if (threadIdx.x == 0) *dst = g;
 }
-#ifndef SPADA_TASK_WAVES
-#define SPADA_TASK_WAVES 8   /* waves per SIMD the task kernel is compiled for (HIP: second argument of __launch_bounds__): 8 = 64 VGPRs */
-#endif
+constexpr int TASK_WAVES = 8;   // waves per SIMD the task kernel is compiled for (HIP: second argument of __launch_bounds__): 8 = 64 VGPRs
 template <int MODE, int NOUT>
-__global__ __launch_bounds__(TKW, SPADA_TASK_WAVES) void k_task(const TaskArgs *__restrict__ gp_)
+__global__ __launch_bounds__(TKW, TASK_WAVES) void k_task(const TaskArgs *__restrict__ gp_)
 {
-    constexpr bool STATIC = SPADA_STATIC_FUSED != 0 && MODE == MODE_FUSED;
     TaskArgsC &g = *(TaskArgsC *)gp_;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *hdr = (uint32_t *)smem;
@@ -2334,25 +2215,27 @@ __global__ __launch_bounds__(TKW, SPADA_TASK_WAVES) void k_task(const TaskArgs *
     const uint32_t ntasks = g.ctr->ntasks, task_end = min(ntasks, g.task_hi);
     if (g.ctr->abort_flag) return;
     if (chain_has_scanner(g.scanner) && MODE == MODE_FUSED) {
-        // The chain's scanner: workgroup 0 takes no tasks.  It gets its CU for itself (SPADA_SCANNER_ALONE): the other workgroups that
+        // The chain's scanner: workgroup 0 takes no tasks.  It gets its CU for itself: the other workgroups that
         // land there leave at once (three of 1024).  Every link of the chain -- a task's count to the scanner, the prefix back -- is a
         // hand-off whose price sits in the memory queue of the CU that reads: 1.1 us on a CU with nothing else in flight, 3 - 5 us on
         // one that streams (MI355X_MICROARCH.md, handoff-1to1), and every task of the kernel waits on both links
         const uint32_t me = ((uint32_t)__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xFF00u)            /* HW_ID: CU, SH, SE */
                             | ((uint32_t)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 16) | 1u;      /* XCC_ID */
         if (blockIdx.x == 0) {
-            if (SPADA_SCANNER_ALONE && tid == 0) __hip_atomic_store(&g.ctr->scanner_cu, me, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#if SPADA_PRIO
+            if (tid == 0) __hip_atomic_store(&g.ctr->scanner_cu, me, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __builtin_amdgcn_s_setprio(3);
-#endif
             chain_scanner(g.status, g.task_lo, task_end);
             return;
         }
-        if (SPADA_SCANNER_ALONE && !STATIC) {
+        {
             if (tid == 0) {
                 uint32_t sc;
                 while (!((sc = __hip_atomic_load(&g.ctr->scanner_cu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & 1u)) __builtin_amdgcn_s_sleep(8);
-                hdr[51] = sc == me ? 1u : 0u;
+                // At most SCANNER_LEAVERS_MAX workgroups leave -- the ones that share the CU with the scanner when the kernel starts -- and
+                // never one of the first 2 TK_NQ: the chain is live as long as every ticket queue keeps a resident worker, and a slot that
+                // every later arrival left again would let a grid that is held back (CUs masked, or busy with another kernel) drain
+                // through the scanner's CU without ever serving its queues
+                hdr[51] = sc == me && blockIdx.x >= 2u * (uint32_t)TK_NQ && atomicAdd(&g.ctr->scanner_leavers, 1u) < SCANNER_LEAVERS_MAX ? 1u : 0u;
             }
             __syncthreads();
             if (hdr[51]) return;
@@ -2364,12 +2247,9 @@ __global__ __launch_bounds__(TKW, SPADA_TASK_WAVES) void k_task(const TaskArgs *
     // all hold smaller, hence finished, tasks and are free to take it: no cycle of waiting workgroups can form as long as
     // every queue has a resident workgroup, which a grid of at least TK_NQ workgroups dispatched in order guarantees.
     uint32_t *my_ticket = &g.ctr->ticket[(task_queue()) * 32];
-    // STATIC (one-pass mode, development switch SPADA_STATIC_FUSED): no tickets -- worker w takes tasks w, w + G, w + 2 G, ...  The
-    // in-order rule of the chain keeps the workgroups in step anyway, and a task that is known without a ticket can have its prologue
-    // run under the wait of the task before it WITHOUT sitting unstarted in the chain any longer than it does now.  Needs every
-    // workgroup of the grid resident at the same time (the host's business).
-    const uint32_t w_first = chain_has_scanner(g.scanner) && MODE == MODE_FUSED ? 1u : 0u, G_static = gridDim.x - w_first;
-    if (tid == 0) hdr[50] = STATIC ? g.task_lo + (blockIdx.x - w_first) : g.task_lo + atomicAdd(my_ticket, 1u) * TK_NQ + task_queue();
+    // (a static round-robin assignment instead of tickets: web -1 %, R-MAT 16 -6.5 %, and it needs every workgroup of the grid resident at
+    // once -- two one-pass kernels of two contexts on one GPU would deadlock each other; not adopted: profiles/r04_experiments.txt)
+    if (tid == 0) hdr[50] = g.task_lo + atomicAdd(my_ticket, 1u) * TK_NQ + task_queue();
     if (SPADA_TASK_DBG && tid < 32) ((uint32_t *)(smem + task_dbg_off()))[tid] = 0u;
     __syncthreads();
     // (t is uniform: the descriptor is a scalar load, what is derived from it lives in scalar registers)
@@ -2379,8 +2259,6 @@ __global__ __launch_bounds__(TKW, SPADA_TASK_WAVES) void k_task(const TaskArgs *
     TaskDesc td{};
     BatchHead hd{0u, 0u, 0u, 0u};
     bool bt = false;
-    Parked pk;   // one-pass mode: the task whose outputs wait in registers for their position (spgemm_batch.hip.hpp)
-    pk.valid = 0u;
     auto uniform_head = [](const BatchHead &h) {   // (what a function returns arrives in vector registers)
         return BatchHead{(uint32_t)__builtin_amdgcn_readfirstlane((int)h.P), (uint32_t)__builtin_amdgcn_readfirstlane((int)h.nent),
                          (uint32_t)__builtin_amdgcn_readfirstlane((int)h.NBK), (uint32_t)__builtin_amdgcn_readfirstlane((int)h.ncopy)};
@@ -2399,22 +2277,16 @@ __global__ __launch_bounds__(TKW, SPADA_TASK_WAVES) void k_task(const TaskArgs *
         // position and store (`next`, called by the task).  Tickets taken earlier than that cost more than they hide: a task that
         // sits unstarted in the chain holds up every task behind it (measured in rounds 2 and 3: +6 % on the web surrogate, +30 % on
         // R-MAT 16 for a ticket taken across the stores); taken HERE the workgroup would otherwise idle.
-#if SPADA_PRIO
-        if constexpr (MODE == MODE_FUSED) __builtin_amdgcn_s_setprio(SPADA_PRIO);
-#endif
+        if constexpr (MODE == MODE_FUSED) __builtin_amdgcn_s_setprio(TASK_PRIO);
         uint32_t t2 = 0xFFFFFFFFu;
         TaskDesc td2{};
         BatchHead hd2{0u, 0u, 0u, 0u};
         bool bt2 = false;
         auto next = [&]() {
             __syncthreads();   // (the ticket word of the task before has been read by everyone; this task's outputs are complete in LDS)
-            if constexpr (STATIC) {
-                t2 = t + G_static;
-            } else {
-                if (threadIdx.x == 0) hdr[50] = g.task_lo + atomicAdd(my_ticket, 1u) * TK_NQ + task_queue();
-                __syncthreads();
-                t2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)hdr[50]);
-            }
+            if (threadIdx.x == 0) hdr[50] = g.task_lo + atomicAdd(my_ticket, 1u) * TK_NQ + task_queue();
+            __syncthreads();
+            t2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)hdr[50]);
             if (SPADA_TASK_DBG && threadIdx.x == 0) dbg_ph[16] = (uint32_t)__builtin_amdgcn_s_memtime();
             if (t2 < task_end) {
                 td2 = load_task(g.tasks, t2);
@@ -2424,12 +2296,11 @@ __global__ __launch_bounds__(TKW, SPADA_TASK_WAVES) void k_task(const TaskArgs *
         };
         if (bt) {
             const int v = task_variant(td);
-            if (v == 2) batch_main<MODE, true, true>(g, td, t, ntasks, smem, dbg_ph, hd, pk, next);
-            else if (v == 1) batch_main<MODE, true>(g, td, t, ntasks, smem, dbg_ph, hd, pk, next);
-            else batch_main<MODE, false>(g, td, t, ntasks, smem, dbg_ph, hd, pk, next);
+            if (v == 2) batch_main<MODE, true, true>(g, td, t, ntasks, smem, dbg_ph, hd, next);
+            else if (v == 1) batch_main<MODE, true>(g, td, t, ntasks, smem, dbg_ph, hd, next);
+            else batch_main<MODE, false>(g, td, t, ntasks, smem, dbg_ph, hd, next);
         } else {
             if constexpr (MODE == MODE_FUSED) {
-                batch_unpark_now<MODE>(g, pk, ntasks, hdr);   // (the older path waits for its position itself)
                 range_task<MODE, NOUT>(gp_, t, ntasks);
             }   // (the modes without a chain: k_task_range takes these tasks)
             next();
@@ -2439,7 +2310,6 @@ __global__ __launch_bounds__(TKW, SPADA_TASK_WAVES) void k_task(const TaskArgs *
         hd = hd2;
         bt = bt2;
     }
-    if constexpr (MODE == MODE_FUSED) batch_unpark_now<MODE>(g, pk, ntasks, hdr);
     if (SPADA_TASK_DBG && tid == 0) {
         const uint32_t *d = (const uint32_t *)(smem + task_dbg_off());
         for (int k = 0; k < 8; ++k) atomicAdd(&g.ctr->dbg[8 + k], (unsigned long long)d[k]);
@@ -2555,7 +2425,7 @@ __device__ inline uint32_t sm_heads(const unsigned long long *sk, uint32_t N, un
 template <int MODE>
 __global__ __launch_bounds__(TK_BLOCK, 3) void k_task_sm(const TaskArgs g)
 {
-    constexpr int BLOCK = TK_BLOCK, EPT = TK_EPT, RMAX = TK_RMAX, U = SPADA_FLAT_U;
+    constexpr int BLOCK = TK_BLOCK, EPT = TK_EPT, RMAX = TK_RMAX, U = FLAT_U;
     constexpr bool VALUES = MODE != MODE_COUNT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *hdr = (uint32_t *)smem;

@@ -118,3 +118,16 @@ def test_reorder_api_leaves_c_unchanged(engine):
     sim.execute()
     assert_parity(sim.result_matrix(), ref, ao, ao, RTOL)
     assert dram_a.remapped and [dram_a.row_remap[i] for i in range(5)] == list(np.argsort(lens, kind="stable")[:5])
+
+
+def test_bench_exercises_the_native_exchange_on_one_rank():
+    """`bench.py --exercise-exchange`: both forms of libspada_comm.so's RCCL exchange on a one-rank communicator, checked against the
+    plain one-pass product -- the code path the driver's multi-GPU runs take.  In the file that runs first, as a process of its own:
+    the native exchange is exercised on the box even when a later test file stops the run."""
+    import json
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--exercise-exchange", "--workload", "mc2depi", "--no-cpu-baseline"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["exercise_exchange"] == "ok" and line["nnz_c"] > 0 and line["modes"] == ["overlap", "after"]

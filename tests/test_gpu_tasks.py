@@ -198,21 +198,28 @@ def test_counting_mode_positions_across_tiles(engine, engine_sm):
     assert np.all(np.abs(c3.data - c1.data[lo:hi]) <= RTOL * np.abs(c1.data[lo:hi]))
 
 
-def test_phase_timing_switch(engine):
+def test_phase_timing_switch():
     """spada_set_phase_timing(0): the event records between the small kernels are left out (their three times read 0), the call
-    and the task kernel are still timed and the product is the same."""
+    and the task kernel are still timed and the product is the same.  On a context of its own: which of the small kernels run on
+    the side streams depends on the context's previous call, and a phase may legitimately read 0.0 (intervals of the engine
+    stream between back-to-back event records) -- what must hold is that the phases are not negative, that together they are a
+    part of the call, and that the switch turns them off."""
     import spada_sim_amd as S
     m = S.generate(S.GEN_RMAT, 12, 8, 31)
+    eng = S.Engine()
     try:
-        c1, st1 = fused(engine, m, m)
-        assert st1["ms_row_stats"] > 0 and st1["ms_cut"] > 0 and st1["ms_task"] > 0
-        engine.set_phase_timing(False)
-        c2, st2 = fused(engine, m, m)
+        for _ in range(2):   # (the second call forks the side streams the first call found work for)
+            c1, st1 = fused(eng, m, m)
+            phases = [st1["ms_row_stats"], st1["ms_big_expand"], st1["ms_cut"]]
+            assert all(p >= 0 for p in phases) and sum(phases) > 0 and st1["ms_task"] > 0
+            assert st1["ms_fused_call"] >= sum(phases) + st1["ms_task"] - 1e-3
+        eng.set_phase_timing(False)
+        c2, st2 = fused(eng, m, m)
         assert st2["ms_row_stats"] == 0 and st2["ms_big_expand"] == 0 and st2["ms_cut"] == 0
         assert st2["ms_task"] > 0 and st2["ms_fused_call"] >= st2["ms_task"]
         assert np.array_equal(c1.indptr, c2.indptr) and np.array_equal(c1.indices, c2.indices)
     finally:
-        engine.set_phase_timing(True)
+        eng.close()
 
 
 def test_workspace_growth_reruns(engine):

@@ -409,6 +409,8 @@ def test_cli_usage_and_exit_codes(matrices_dir):
 def _mock_lib():
     """lib/libspada_comm_mock.so: the host half of spada_comm.hip compiled against test doubles of HIP, RCCL and the engine (csrc/mock/)."""
     path = os.environ.get("SPADA_COMM_MOCK_LIB_PATH") or os.path.join(os.path.dirname(_ffi.LIB_PATH), "libspada_comm_mock.so")
+    if not os.path.exists(path):
+        pytest.skip(f"{os.path.basename(path)} not built (make -C spada_sim_amd/csrc all)")
     _ffi.lib()                                       # (libspada_spgemm.so first: spada_last_error / fail live there)
     L = ctypes.CDLL(path)
     u64p, vp = ctypes.POINTER(ctypes.c_uint64), ctypes.c_void_p

@@ -1,35 +1,23 @@
 #!/bin/bash
-# development aid (GPU box): SQ instruction counts and time of k_task<NUMERIC> for the early-stop variants libspada_stopK.so
-# (scripts/build_variant.sh stopK -DSPADA_BT_STOP=K): the difference between consecutive cut points is what a stage of the batch
-# task costs.   usage: scripts/dev/stage_counts.sh <probe workload name> <out dir> [variants ...]
-WL=${1:-webbase}
-REPO=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=$REPO/gpurun_out/${2:-stages}
-shift 2
-VARS=${*:-stop10 stop1 stop11 stop12 stop13 stop2 stop14 stop3 stop15 stop16 stop17 stop18 stop19 stop5 stop20 stop6 stop21 spgemm}
+# GPU box: SQ instruction counts of the NUMERIC task kernel cut short behind successive stages of the batch task (libspada_stop<k>.so built by
+# `scripts/dev/ablate.sh` with masks 256 512 768 1280 1536 -> stop 1 2 3 5 6) next to the full kernel; one --pmc pass each
+cd "$(dirname "$0")/../.."
+REPO=$PWD
+OUT=$REPO/gpurun_out/r05/stages
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-for v in $VARS; do
-  export SPADA_LIB_PATH=$REPO/spada_sim_amd/lib/libspada_$v.so
-  [ -f $SPADA_LIB_PATH ] || continue
-  rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD \
-      --output-format csv -d $OUT/$v -o p -- python3 $REPO/scripts/probe_tasks.py $WL > $OUT/$v.log 2>&1
-done
-python3 - <<PY
-import csv, collections, os
-prev = None
-for v in "$VARS".split():
-    p = "$OUT/%s/p_counter_collection.csv" % v
-    if not os.path.exists(p): continue
-    agg = collections.defaultdict(float); n = collections.Counter(); t = []
-    for r in csv.DictReader(open(p)):
-        if "k_task<1" in r["Kernel_Name"]:
-            agg[r["Counter_Name"]] += float(r["Counter_Value"]); n[r["Counter_Name"]] += 1
-            if r["Counter_Name"] == "SQ_INSTS_VALU": t.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
-    d = {k: agg[k] / n[k] / 1e6 for k in agg}
-    us = sorted(t)[len(t) // 2] if t else 0
-    line = f"{v:8s} us {us:7.1f} valu {d.get('SQ_INSTS_VALU',0):6.1f} salu {d.get('SQ_INSTS_SALU',0):6.1f} lds {d.get('SQ_INSTS_LDS',0):5.1f} vmem_rd {d.get('SQ_INSTS_VMEM_RD',0):4.1f}"
-    if prev: line += f"   | delta us {us - prev[0]:6.1f} valu {d.get('SQ_INSTS_VALU',0) - prev[1]:6.1f} lds {d.get('SQ_INSTS_LDS',0) - prev[2]:5.1f}"
-    prev = (us, d.get('SQ_INSTS_VALU',0), d.get('SQ_INSTS_LDS',0))
-    print(line)
+for l in $REPO/spada_sim_amd/lib/libspada_abl256.so $REPO/spada_sim_amd/lib/libspada_abl512.so $REPO/spada_sim_amd/lib/libspada_abl768.so $REPO/spada_sim_amd/lib/libspada_abl1280.so $REPO/spada_sim_amd/lib/libspada_abl1536.so $REPO/spada_sim_amd/lib/libspada_spgemm.so; do
+  n=$(basename $l .so)
+  SPADA_LIB_PATH=$l rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $OUT/$n -o p -- python3 $REPO/scripts/dev/run_two_phase.py webbase > $OUT/$n.log 2>&1
+  python3 - <<PY
+import csv, collections
+agg = collections.defaultdict(float); dur = {}
+for r in csv.DictReader(open("$OUT/$n/p_counter_collection.csv")):
+    if "k_task<1" not in r["Kernel_Name"]: continue
+    agg[(r["Dispatch_Id"], r["Counter_Name"])] += float(r["Counter_Value"])
+    dur[r["Dispatch_Id"]] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+ids = sorted(dur, key=lambda d: dur[d])
+d = ids[len(ids) // 2] if ids else None
+print("$n", {c: round(v / 1e6, 1) for (i, c), v in sorted(agg.items()) if i == d}, "us", dur.get(d, 0) / 1e3, "launches", len(ids))
 PY
+done

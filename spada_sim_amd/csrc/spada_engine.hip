@@ -35,6 +35,8 @@ struct spada_dev_csr {
     uint32_t *idx = nullptr;
     double *val = nullptr;
     uint32_t *rowid = nullptr;   // row of every entry: lets the row statistics run entry-parallel whatever the row lengths are
+    uint2 *rext = nullptr;       // first / last column of every row (0xFFFFFFFF / 0 for an empty one): what a product row can reach at most
+                                 // is known from ONE 8-byte gather per A entry instead of two gathers from random lines of B.indices
     uint32_t *rowmap = nullptr;  // reordered matrices (-p): row i holds original row rowmap[i] (storage.rs:156-157 row_remap)
 };
 
@@ -84,6 +86,7 @@ struct spada_ctx {
     // The two-phase contract reads the table in both phases and takes every direct row (R-MAT 18: 43.2 against 50.5 ms without)
     uint32_t cut_factor16 = 16u;
     bool cut_table = true;            // direct range tasks read their bounds from the cut table (k_big_cuts) instead of searching (SPADA_CUT_TABLE=0)
+    uint32_t task_wgs = TASK_WAVES / 2; // workgroups of the task kernel per CU (SPADA_TASK_WGS: measurements with fewer)
     int scanner_ok = -1;              // one-pass mode: enough resident workgroups for the chain's scanner (decided at the first task launch)
     hipStream_t stream2 = nullptr;    // k_big_scatter runs next to the cut kernels (neither needs the other): fork / join events below
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -113,6 +116,13 @@ struct spada_ctx {
     uint64_t t_cap_tmp = 0, t_cap_tasks = 0, t_cap_scr = 0, t_cap_parts = 0, t_cap_cuts = 0, t_cap_cutitems = 0;
     uint32_t prod_limit = TK_SOLO_MAX;   // capacities the kernels may rely on
     TaskCounters *h_tctr = nullptr;   // pinned
+    // The device counters exist twice.  A pipeline run finds its set cleared: the set of the run BEFORE the last one is cleared behind
+    // the end of every run, where nobody waits for it (the last run's set stays as it is: the numeric call reads its task count)
+    int ctr_idx = 0;
+    int side_mode = 2;                // (SPADA_SIDE: 0 no side streams, 1 scatter and cut table on one, 2 on one each -- measurements)
+    bool shadow = true;               // (SPADA_SHADOW=0: the clearing at the head of every run instead of behind the one before -- measurements)
+    uint64_t rows_preset = 0;         // rows whose accumulators (row_P, row_kmin, row_kmax) hold their presets: every run puts back what it used
+    hipEvent_t ev_done = nullptr;     // the counters of a run have reached the host
     // numeric phase in pieces (spada_dev_spgemm_numeric_plan / _chunk): task boundaries, one event per piece
     std::vector<uint32_t> chunk_task;
     std::vector<hipEvent_t> chunk_ev;
@@ -140,8 +150,25 @@ void dev_free(spada_dev_csr *m)
     if (m->idx) (void)hipFree(m->idx);
     if (m->val) (void)hipFree(m->val);
     if (m->rowid) (void)hipFree(m->rowid);
+    if (m->rext) (void)hipFree(m->rext);
     if (m->rowmap) (void)hipFree(m->rowmap);
     delete m;
+}
+
+// first / last column of every row of a device CSR (rows are ascending: its first and last entry)
+__global__ void k_row_extents(const uint64_t *__restrict__ ptr, const uint32_t *__restrict__ idx, uint64_t rows, uint2 *__restrict__ ext)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < rows; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t b0 = ptr[i], b1 = ptr[i + 1];
+        ext[i] = b1 > b0 ? make_uint2(idx[b0], idx[b1 - 1]) : make_uint2(0xFFFFFFFFu, 0u);
+    }
+}
+int dev_row_extents(spada_ctx *c, spada_dev_csr *d)
+{
+    HIP_TRY(hipMalloc((void **)&d->rext, std::max<uint64_t>(d->rows, 1) * sizeof(uint2)));
+    if (d->rows) hipLaunchKernelGGL(k_row_extents, dim3((unsigned)std::min<uint64_t>((d->rows + 255) / 256, 4096)), dim3(256), 0, c->stream, d->ptr, d->idx, d->rows, d->rext);
+    HIP_TRY(hipGetLastError());
+    return SPADA_OK;
 }
 
 int dev_upload(spada_ctx *c, const spada_csr_view *m, spada_dev_csr **out)
@@ -172,6 +199,7 @@ int dev_upload(spada_ctx *c, const spada_csr_view *m, spada_dev_csr **out)
             HIP_TRY(hipMemcpyAsync(d->val, m->data, m->nnz * 8, hipMemcpyHostToDevice, c->stream));
             HIP_TRY(hipMemcpyAsync(d->rowid, rid32.data(), m->nnz * 4, hipMemcpyHostToDevice, c->stream));
         }
+        if (int rc2 = dev_row_extents(c, d.get())) return rc2;
         HIP_TRY(hipStreamSynchronize(c->stream));
         return SPADA_OK;
     };
@@ -258,7 +286,7 @@ void launch_task(spada_ctx *c, const TaskArgs &g)
         hipLaunchKernelGGL(k_task_sm<MODE>, dim3(c->n_cu * 3), dim3(TK_BLOCK), task_sm_lds(), c->stream, g);
     else
     {
-        hipLaunchKernelGGL((k_task<MODE, TK_NOUT>), dim3(c->n_cu * (TASK_WAVES / 2)), dim3(TKW), task_kernel_lds(), c->stream,
+        hipLaunchKernelGGL((k_task<MODE, TK_NOUT>), dim3(c->n_cu * c->task_wgs), dim3(TKW), task_kernel_lds(), c->stream,
                            (const TaskArgs *)c->t_args.as<TaskArgs>());
         // the modes without a chain: the tasks of the older range path in their own kernel (256-thread workgroups)
         if constexpr (MODE != MODE_FUSED)
@@ -266,6 +294,8 @@ void launch_task(spada_ctx *c, const TaskArgs &g)
                                (const TaskArgs *)c->t_args.as<TaskArgs>());
     }
 }
+
+TaskCounters *dev_counters(spada_ctx *c) { return c->t_ctr.as<TaskCounters>() + c->ctr_idx; }
 
 TaskArgs task_args(spada_ctx *c, uint64_t *cptr, uint32_t *d_idx, double *d_val, uint64_t capacity)
 {
@@ -308,7 +338,7 @@ TaskArgs task_args(spada_ctx *c, uint64_t *cptr, uint32_t *d_idx, double *d_val,
     g.cptr = cptr;
     g.range_out = c->t_rangeout.as<uint64_t>();
     g.status = c->t_status.as<unsigned long long>();
-    g.ctr = c->t_ctr.as<TaskCounters>();
+    g.ctr = dev_counters(c);
     g.c_idx = d_idx;
     g.c_val = d_val;
     g.capacity = capacity;
@@ -332,19 +362,21 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
     const size_t n1 = (size_t)n + 1;
     if ((rc = c->row_nprod.ensure(n1 * 4, false, s, &c->ws_bytes))) return rc;
     if ((rc = c->row_bin.ensure(n1, false, s, &c->ws_bytes))) return rc;
+    const void *acc_before[3] = {c->row_kmin.p, c->row_kmax.p, c->t_rowP.p};
     if ((rc = c->row_kmin.ensure(n1 * 4, false, s, &c->ws_bytes))) return rc;
     if ((rc = c->row_kmax.ensure(n1 * 4, false, s, &c->ws_bytes))) return rc;
     if ((rc = c->row_cl.ensure(n1 * 4, false, s, &c->ws_bytes))) return rc;
     if ((rc = c->row_rec.ensure(n1 * sizeof(RowRec), false, s, &c->ws_bytes))) return rc;
     if ((rc = c->row_binfo.ensure(n1 * 4, false, s, &c->ws_bytes))) return rc;
     if ((rc = c->t_rowP.ensure(n1 * 8, false, s, &c->ws_bytes))) return rc;
+    if (acc_before[0] != c->row_kmin.p || acc_before[1] != c->row_kmax.p || acc_before[2] != c->t_rowP.p) c->rows_preset = 0;   // (new memory)
     if ((rc = c->t_rowm.ensure(n1 * 4, false, s, &c->ws_bytes))) return rc;
     if ((rc = c->t_rowt.ensure(n1 * 4, false, s, &c->ws_bytes))) return rc;
     if ((rc = c->t_rowtmp.ensure(n1 * 4, false, s, &c->ws_bytes))) return rc;
     if ((rc = c->t_big.ensure(n1 * 4, false, s, &c->ws_bytes))) return rc;
     if ((rc = c->t_slots.ensure(n1 * sizeof(BigSlot), false, s, &c->ws_bytes))) return rc;
     if ((rc = c->cptr.ensure(n1 * 8, false, s, &c->ws_bytes))) return rc;
-    if ((rc = c->t_ctr.ensure(sizeof(TaskCounters), false, s, &c->ws_bytes))) return rc;
+    if ((rc = c->t_ctr.ensure(2 * sizeof(TaskCounters), true, s, &c->ws_bytes))) return rc;
     if ((rc = c->t_args.ensure(sizeof(TaskArgs), false, s, &c->ws_bytes))) return rc;
     if ((rc = c->eb0.ensure(std::max<uint64_t>(a->nnz, 1) * 8, false, s, &c->ws_bytes))) return rc;
     if ((rc = c->elen.ensure(std::max<uint64_t>(a->nnz, 1) * 4, false, s, &c->ws_bytes))) return rc;
@@ -356,7 +388,6 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
     c->colbits = cb;
     const uint32_t rmax = cb >= 32 ? 1u : (uint32_t)std::min<uint64_t>((1ull << (32 - cb)) - 1, TK_RMAX);
     if (cptr == nullptr) cptr = c->cptr.as<uint64_t>();
-    TaskCounters *dc = c->t_ctr.as<TaskCounters>();
     if (!c->t_cap_tasks) {
         c->t_cap_tasks = n / 4 + 4096;
         c->t_cap_tmp = std::min<uint64_t>(std::max<uint64_t>(a->nnz / 16, 4096), 1u << 20);
@@ -389,25 +420,32 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
         ++c->stats.pipeline_runs;
         c->join2 = c->join3 = false;
         HIP_TRY(hipEventRecord(c->tev[0], s));
-        static_assert(sizeof(TaskCounters) % 8 == 0, "k_init clears the counters in 8-byte words");
-        // (the arguments of the task kernel -- all of them known here -- travel with the clearing kernel: see k_task_args)
+        static_assert(sizeof(TaskCounters) % 8 == 0, "k_clear_counters clears the counters in 8-byte words");
+        c->ctr_idx ^= 1;   // (the set the run before the last one used: cleared behind the last run)
+        TaskCounters *dc = dev_counters(c);
+        if (!c->shadow) {
+            hipLaunchKernelGGL(k_clear_counters, dim3(8), dim3(256), 0, s, dc);
+            c->rows_preset = 0;
+        }
+        if (c->rows_preset < n) {   // (the first run of a context, or one over more rows than any before it; else the run before has seen to it)
+            hipLaunchKernelGGL(k_preset_rows, dim3(c->n_cu * 4), dim3(256), 0, s, c->t_rowP.as<unsigned long long>(), c->row_kmin.as<uint32_t>(),
+                               c->row_kmax.as<uint32_t>(), (uint64_t)n);
+            c->rows_preset = n;
+        }
+        const uint64_t preset_before = c->rows_preset;
+        c->rows_preset = 0;   // (in use from here on; put back behind the run, below -- an error in between leaves them marked as unknown)
+        // (the arguments of the task kernel -- all of them known here -- travel with the first kernel of the run: see k_task_args)
         const TaskArgs g = task_args(c, cptr, d_idx, d_val, capacity);
-        if (c->accumulator == SPADA_ACC_SORT_MERGE)
-            hipLaunchKernelGGL(k_init, dim3(c->n_cu * 4), dim3(256), 0, s, dc, c->t_rowP.as<unsigned long long>(), c->row_kmin.as<uint32_t>(),
-                               c->row_kmax.as<uint32_t>(), n, c->t_status.as<unsigned long long>(), (uint64_t)cap_tasks * ST_STRIDE);
-        else
-            hipLaunchKernelGGL(k_init_args, dim3(c->n_cu * 4), dim3(256), 0, s, dc, c->t_rowP.as<unsigned long long>(),
-                               c->row_kmin.as<uint32_t>(), c->row_kmax.as<uint32_t>(), n, c->t_status.as<unsigned long long>(),
-                               (uint64_t)cap_tasks * ST_STRIDE, g, c->t_args.as<TaskArgs>());
         if (n) {
-            const uint32_t gent = (uint32_t)std::min<uint64_t>((a->nnz + 255) / 256 + 1, (uint64_t)c->n_cu * 8 * 4);
             // (products a task hashes at most: since the table of the batch tasks is keyed by BLOCKS of columns it never gets full, and
             // the fullest tasks win on every input: 2040 / 1920 / 1792 / 1536 -> web 0.826 / 0.844 / 0.882 / 0.965 ms, R-MAT 16 4.81 /
             // 5.00 / 5.22 / 5.98 ms in round 3; rounds 1 - 2 sampled the products / outputs ratio to choose between 1920 and 2040)
-            hipLaunchKernelGGL(k_entry_stats, dim3(gent), dim3(256), 0, s, a->ptr, a->idx, a->rowid, b->ptr, b->idx, c->r0, n,
+            const uint32_t gent = (uint32_t)std::min<uint64_t>((a->nnz + 255) / 256 + 1, (uint64_t)c->n_cu * 8 * 4);
+            hipLaunchKernelGGL(k_entry_stats<TaskArgs>, dim3(gent), dim3(256), 0, s, a->ptr, a->idx, a->rowid, b->ptr, b->rext, c->r0, n,
                                c->eb0.as<uint64_t>(), c->elen.as<uint32_t>(), c->t_rowP.as<unsigned long long>(),
                                c->row_kmin.as<uint32_t>(), c->row_kmax.as<uint32_t>(),
-                               c->accumulator == SPADA_ACC_SORT_MERGE ? (uint32_t)TK_SOLO_MAX : TK_LIMIT_HI, dc);
+                               c->accumulator == SPADA_ACC_SORT_MERGE ? (uint32_t)TK_SOLO_MAX : TK_LIMIT_HI, dc, g,
+                               c->accumulator == SPADA_ACC_SORT_MERGE ? (TaskArgs *)nullptr : c->t_args.as<TaskArgs>());
             hipLaunchKernelGGL(k_row_class, dim3(std::min<uint32_t>((n + 255) / 256, c->n_cu * 8)), dim3(256), 0, s, a->ptr, c->r0,
                                n, rmax, c->t_rowP.as<unsigned long long>(), c->row_kmin.as<uint32_t>(), c->row_kmax.as<uint32_t>(),
                                c->row_nprod.as<uint32_t>(), c->row_bin.as<uint8_t>(), c->row_cl.as<uint32_t>(),
@@ -435,7 +473,14 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
             // range descriptors k_big_plan wrote -- not the scratch, not the cuts; the task kernel waits for all three.  Each fork is
             // taken only if the previous run of this context had work for it (a fork / join pair costs ~10 us and hides nothing when
             // its kernel finds nothing to do); the two are decided separately
-            const bool side2 = c->last_spilled != 0, side3 = c->cut_table && c->last_cuts != 0;
+            bool side2 = c->last_spilled != 0, side3 = c->cut_table && c->last_cuts != 0;
+            hipStream_t s3 = c->stream3;
+            if (c->side_mode == 0) side2 = side3 = false;
+            if (c->side_mode == 1) {   // (one side stream for both: one fork, one join)
+                side2 = side2 || side3;
+                side3 = false;
+                s3 = side2 ? c->stream2 : s;
+            }
             if (side2 || side3) HIP_TRY(hipEventRecord(c->ev_fork, s));
             if (side2) HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
             if (side3) HIP_TRY(hipStreamWaitEvent(c->stream3, c->ev_fork, 0));
@@ -445,12 +490,13 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
                                c->t_slots.as<BigSlot>(), c->t_scrcol.as<uint32_t>(), c->t_scrval.as<double>(), seq, dc);
             if (side2) HIP_TRY(hipEventRecord(c->ev_join, c->stream2));
             if (c->cut_table)
-                hipLaunchKernelGGL(k_big_cuts, dim3(c->n_cu * 8), dim3(256), 0, side3 ? c->stream3 : s, b->idx, c->eb0.as<uint64_t>(),
+                hipLaunchKernelGGL(k_big_cuts, dim3(c->n_cu * 8), dim3(256), 0, side3 ? c->stream3 : (c->side_mode == 1 ? s3 : s), b->idx, c->eb0.as<uint64_t>(),
                                    c->elen.as<uint32_t>(), c->t_big.as<uint32_t>(), c->t_rowm.as<uint32_t>(), c->t_rowtmp.as<uint32_t>(),
                                    c->t_slots.as<BigSlot>(), c->t_tmp.as<TaskDesc>(), c->t_cutitems.as<uint2>(), cap_cut_items,
                                    c->t_cuts.as<uint32_t>(), dc);
             HIP_TRY(hipGetLastError());
             if (side3) HIP_TRY(hipEventRecord(c->ev_join3, c->stream3));
+            if (c->side_mode == 1 && side2) HIP_TRY(hipEventRecord(c->ev_join, c->stream2));   // (behind the cut table as well)
             c->join2 = side2;
             c->join3 = side3;
         }
@@ -466,7 +512,7 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
             hipLaunchKernelGGL(k_cut3, dim3(ntiles, cut_sub), dim3(256), 0, s, c->row_bin.as<uint8_t>(), c->t_rowt.as<uint32_t>(),
                                c->row_binfo.as<uint32_t>(), a->ptr, c->r0, c->t_rowtmp.as<uint32_t>(), n, c->t_tiles.as<uint32_t>(),
                                c->t_tmp.as<TaskDesc>(), c->t_tasks.as<TaskDesc>(), cap_tasks, fold ? 1u : 0u,
-                               c->t_tiles.as<uint32_t>() + ntiles + 2, c->t_legacy.as<uint32_t>(), dc);
+                               c->t_tiles.as<uint32_t>() + ntiles + 2, c->t_legacy.as<uint32_t>(), c->t_status.as<unsigned long long>(), dc);
             HIP_TRY(hipGetLastError());
             if (c->join2) HIP_TRY(hipStreamWaitEvent(s, c->ev_join, 0));
             if (c->join3) HIP_TRY(hipStreamWaitEvent(s, c->ev_join3, 0));
@@ -492,7 +538,13 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
         }
         HIP_TRY(hipEventRecord(c->tev[4], s));
         HIP_TRY(hipMemcpyAsync(c->h_tctr, dc, sizeof(TaskCounters), hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
+        HIP_TRY(hipEventRecord(c->ev_done, s));
+        // behind the end of the run, where nobody waits: the other set of counters and the per-row accumulators for the run after this one
+        if (c->shadow) hipLaunchKernelGGL(k_clear_counters, dim3(8), dim3(256), 0, s, c->t_ctr.as<TaskCounters>() + (c->ctr_idx ^ 1));
+        if (n && c->shadow) hipLaunchKernelGGL(k_preset_rows, dim3(c->n_cu * 4), dim3(256), 0, s, c->t_rowP.as<unsigned long long>(), c->row_kmin.as<uint32_t>(),
+                                  c->row_kmax.as<uint32_t>(), (uint64_t)n);
+        c->rows_preset = c->shadow ? preset_before : 0;
+        HIP_TRY(hipEventSynchronize(c->ev_done));
         TaskCounters &h = *c->h_tctr;
         h.a_nnz = 0;
         for (int k = 0; k < N_CLS; ++k) h.cls_rows[k] = h.cls_prod[k] = 0;
@@ -612,7 +664,7 @@ int task_numeric(spada_ctx *c, uint64_t *d_ptr, uint32_t *d_idx, double *d_val)
     hipStream_t s = c->stream;
     HIP_TRY(hipEventRecord(c->tev[0], s));
     HIP_TRY(hipMemcpyAsync(d_ptr, c->cptr.p, ((size_t)c->nrows + 1) * 8, hipMemcpyDeviceToDevice, s));
-    HIP_TRY(hipMemsetAsync(c->t_ctr.as<TaskCounters>()->ticket, 0, sizeof(TaskCounters::ticket), s));
+    HIP_TRY(hipMemsetAsync(dev_counters(c)->ticket, 0, sizeof(TaskCounters::ticket), s));
     if (c->nrows) {
         const TaskArgs g = task_args(c, c->cptr.as<uint64_t>(), d_idx, d_val, c->nnz_c);
         launch_task_args(c, g);
@@ -674,10 +726,14 @@ int spada_create(const spada_options *opts, spada_ctx **out)
     c->device = dev;
     c->accumulator = o.accumulator;
     c->scanner_ok = -1;   // (the one-pass kernel of the other accumulator has its own occupancy)
+    if (const char *e = getenv("SPADA_SIDE")) c->side_mode = atoi(e);
+    if (const char *e = getenv("SPADA_SHADOW")) c->shadow = atoi(e) != 0;
+    if (const char *e = getenv("SPADA_TASK_WGS")) c->task_wgs = (uint32_t)std::min(std::max(atoi(e), 1), TASK_WAVES / 2);
     if (const char *e = getenv("SPADA_CUT_TABLE")) c->cut_table = atoi(e) != 0;
     if (const char *e = getenv("SPADA_CUT_FACTOR16")) c->cut_factor16 = (uint32_t)atoi(e);
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
     HIP_TRY(hipEventCreate(&c->ev_fork));   // (with timing: the pair brackets the scatter on the side stream)
     HIP_TRY(hipEventCreate(&c->ev_join));
     HIP_TRY(hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking));
@@ -722,6 +778,7 @@ void spada_destroy(spada_ctx *c)
     for (auto &e : c->chunk_ev)
         if (e) (void)hipEventDestroy(e);
     c->t_chunk.release();
+    if (c->ev_done) (void)hipEventDestroy(c->ev_done);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
@@ -783,7 +840,7 @@ int spada_dev_csr_reorder(spada_ctx *c, const spada_dev_csr *a, const spada_dev_
         HIP_TRY(hipMalloc((void **)&id_in, std::max<size_t>(rows, 1) * 4));
         if (!rows) {
             HIP_TRY(hipMemsetAsync(d->ptr, 0, 8, s));
-            return SPADA_OK;
+            return dev_row_extents(c, d.get());
         }
         const uint32_t grid = std::min<uint32_t>((rows + 255) / 256, c->n_cu * 8);
         hipLaunchKernelGGL(k_reorder_keys, dim3(grid), dim3(256), 0, s, a->ptr, a->idx, b ? b->ptr : nullptr, rows,
@@ -803,7 +860,7 @@ int spada_dev_csr_reorder(spada_ctx *c, const spada_dev_csr *a, const spada_dev_
         hipLaunchKernelGGL((k_move_rows<true, true>), dim3(std::min<uint32_t>((rows + 3) / 4, c->n_cu * 16)), dim3(256), 0, s, a->ptr,
                            a->idx, a->val, d->ptr, d->idx, d->val, d->rowid, d->rowmap, rows);
         HIP_TRY(hipGetLastError());
-        return SPADA_OK;
+        return dev_row_extents(c, d.get());
     };
     int rc = body();
     if (rc == SPADA_OK && hipStreamSynchronize(s) != hipSuccess) rc = fail(SPADA_ERR_HIP, "row reordering failed on the device");
@@ -924,7 +981,7 @@ int spada_dev_spgemm_numeric_plan(spada_ctx *c, uint32_t chunks, uint64_t *chunk
     uint32_t *d_t = (uint32_t *)(d_pos + chunks + 1);
     HIP_TRY(hipMemcpyAsync(d_t, c->chunk_task.data(), (size_t)(chunks + 1) * 4, hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(k_task_positions, dim3((chunks + 256) / 256), dim3(256), 0, c->stream, c->t_tasks.as<TaskDesc>(),
-                       c->cptr.as<uint64_t>(), c->t_rangeout.as<uint64_t>(), c->t_ctr.as<TaskCounters>(), c->nrows, d_t, chunks + 1,
+                       c->cptr.as<uint64_t>(), c->t_rangeout.as<uint64_t>(), dev_counters(c), c->nrows, d_t, chunks + 1,
                        d_pos);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(chunk_pos, d_pos, (size_t)(chunks + 1) * 8, hipMemcpyDeviceToHost, c->stream));
@@ -945,7 +1002,7 @@ int spada_dev_spgemm_numeric_chunk(spada_ctx *c, uint32_t k, void *d_c_indices, 
         c->chunk_timing_open = true;
     }
     if (c->nrows && c->chunk_task[k + 1] > c->chunk_task[k]) {
-        HIP_TRY(hipMemsetAsync(c->t_ctr.as<TaskCounters>()->ticket, 0, sizeof(TaskCounters::ticket), s));
+        HIP_TRY(hipMemsetAsync(dev_counters(c)->ticket, 0, sizeof(TaskCounters::ticket), s));
         TaskArgs g = task_args(c, c->cptr.as<uint64_t>(), (uint32_t *)d_c_indices, (double *)d_c_data, c->nnz_c);
         g.task_lo = c->chunk_task[k];
         g.task_hi = c->chunk_task[k + 1];

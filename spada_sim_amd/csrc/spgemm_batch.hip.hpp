@@ -47,6 +47,11 @@
 
 namespace spada {
 
+#ifndef SPADA_ABLATE
+#define SPADA_ABLATE 0   /* development (scripts/dev/ablate.sh): WRONG RESULTS -- stages of the batch task left out, to see what the kernel's time is sensitive
+                            to: 1 displaced-block fix | 2 popcount sweep + ranks | 4 scale-add into LDS | 8 stores to C | 16 table atomics | 32 B gathers;
+                            bits 8 .. 11: the NUMERIC mode cut short behind stage k (instruction counts per stage: scripts/dev/stage_counts.sh) */
+#endif
 constexpr int BW = TKW, BT_NWAVE = BW / 64;
 constexpr uint32_t BT_LAYOUT = BT_T - 32u;   // slots the rows' regions are laid out over; the rest takes the overflow of the last cluster
 constexpr uint32_t BT_H_NONE = 0xFFFFFFFFu, BT_H_COPY = 0xFFFFFFFEu;   // `state` of a lane without a product / of a copied product
@@ -68,6 +73,7 @@ static_assert(batch_lds() <= 40960, "four workgroups per CU");
 static_assert(BT_T == 6 * BW && BT_PMAX == 4u * BW && BT_EMAX == (uint32_t)BW && BT_T * 8 == BT_PMAX * 12,
               "the LDS map and the per-thread arrays are written for these sizes");
 static_assert(TK_RMAX <= 128 && BT_T <= 4096 && BT_PMAX <= 4096, "field widths of the product state");
+static_assert(BT_LAYOUT + BT_PROBE_MAX < BT_T, "the first attempt's walk stays inside the table");
 
 // The task loop runs every batch task in two parts.  batch_prologue -- descriptor -> row records / A entries -> (range: narrowing
 // searches) -> scans -> entry records, tail bits and row regions in LDS -- touches neither the table nor the outputs of the task
@@ -104,6 +110,21 @@ struct BatchHead {
     uint32_t *slot_rows = hdr, *slot_ent = hdr + 8, *slot_sp = hdr + 16, *slot_cnt = hdr + 24, *slot_pc = hdr + 32;                  \
     (void)keys; (void)masks; (void)w_ent; (void)fo; (void)fo32; (void)bm32; (void)bm64; (void)vals; (void)cols; (void)s_emit;        \
     (void)s_delta; (void)s_cpo; (void)s_hoff; (void)s_info; (void)dlist; (void)bins; (void)s_bin; (void)s_span; (void)slot_rows; (void)slot_ent; (void)slot_sp; (void)slot_cnt; (void)slot_pc
+
+// keys (EMPTY), then masks (0): 1536 uint4, three per thread (a dense task has no keys)
+template <bool DENSE>
+__device__ inline void batch_clear_table(uint32_t *keys, int tid)
+{
+    uint4 *k4 = (uint4 *)keys;
+    uint32_t zero = 0u;   // (opaque: a constant vector would be built before the task loop and kept -- spilled -- across it)
+    asm volatile("" : "+v"(zero));
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        const uint32_t i = (uint32_t)tid + (uint32_t)s * BW;
+        const uint32_t fill = i < BT_T / 4 ? ~zero : zero;
+        if (!DENSE || i >= BT_T / 4) k4[i] = make_uint4(fill, fill, fill, fill);
+    }
+}
 
 template <int MODE, bool DENSE, bool SPILL = false, class ARGS>
 __device__ inline BatchHead batch_prologue(const ARGS &g, const TaskDesc &td, uint32_t t, unsigned char *smem)
@@ -204,6 +225,8 @@ __device__ inline BatchHead batch_prologue(const ARGS &g, const TaskDesc &td, ui
         hdr[41] = 0u;
         hdr[42] = 0u;
     }
+    // one-pass mode: the table of the task before is free by now (its stores are done): cleared here, under the loads above
+    if constexpr (MODE == MODE_FUSED) batch_clear_table<DENSE>(keys, tid);
     asm volatile("; BT_MARK p1" ::: "memory");
     // rows: the hashed products before every row (the table's slots are laid out over the rows in proportion to them) and the
     // outputs of COPY rows before it -- both known before anything is expanded.  Entries: numbered densely, and their products
@@ -290,6 +313,16 @@ __device__ inline void batch_main(const ARGS &g, const TaskDesc &td, uint32_t t,
         }                                                                       \
     } while (0)
     if (SPADA_TASK_DBG && tid == 0) dbg_ph[8] += 1;
+    // (development: the numeric mode cut short behind stage k; `sink` keeps what the stage computed alive)
+#define BSTOP(k, sink)                                                              \
+    do {                                                                            \
+        if (MODE == MODE_NUMERIC && ((SPADA_ABLATE >> 8) & 15) == (k)) {            \
+            if ((sink) == 0x9E3779B1u) hdr[60] = 1u;                                \
+            next();                                                                 \
+            __syncthreads();                                                        \
+            return;                                                                 \
+        }                                                                           \
+    } while (0)
     BMARK(0);
     constexpr bool spill = SPILL;
     const bool range = td.kind != TASK_BATCH;
@@ -300,17 +333,9 @@ __device__ inline void batch_main(const ARGS &g, const TaskDesc &td, uint32_t t,
     const uint32_t hshift = colbits >= 32 ? 0u : colbits - BT_BSHIFT;   // block key = composite key >> 5 = local row << hshift | block
     auto lr_of_ck = [&](uint32_t ck) { return colbits >= 32 ? 0u : ck >> colbits; };
     const uint32_t P = hd.P, nent = hd.nent, NBK = hd.NBK;
-    {
-        uint4 *k4 = (uint4 *)keys;   // keys (EMPTY), then masks (0): 1536 uint4, three per thread
-        uint32_t zero = 0u;   // (opaque: a constant vector would be built before the task loop and kept -- spilled -- across it)
-        asm volatile("" : "+v"(zero));
-#pragma unroll
-        for (int s = 0; s < 3; ++s) {
-            const uint32_t i = (uint32_t)tid + (uint32_t)s * BW;
-            const uint32_t fill = i < T / 4 ? ~zero : zero;
-            if (!DENSE || i >= T / 4) k4[i] = make_uint4(fill, fill, fill, fill);
-        }
-    }
+    // (one-pass mode: the prologue has cleared the table under its loads -- it runs behind the stores of the task before, when the table
+    // is free; in the other modes it runs UNDER those stores, and the table is cleared here)
+    if constexpr (MODE != MODE_FUSED) batch_clear_table<DENSE>(keys, tid);
     BMARK(1);
     __syncthreads();   // the table is cleared; the prologue's records, tail bits and row regions are written
     // tails before every 64-bit word of the bitmap (32 words): every wave scans them for itself and keeps the prefixes in the
@@ -321,6 +346,7 @@ __device__ inline void batch_main(const ARGS &g, const TaskDesc &td, uint32_t t,
         const uint32_t inc = wave_scan_incl_u32(lane < 32 ? c : 0u);
         tail_pre = inc - c;
     }
+    BSTOP(1, tail_pre);
 
     BMARK(2);
     // ---- expand - scale - accumulate blocks (scheduler.rs:482-606, simulator.rs:892-953, :86-111) ---------------------------
@@ -341,10 +367,11 @@ __device__ inline void batch_main(const ARGS &g, const TaskDesc &td, uint32_t t,
             pp[u] = min(p, P ? P - 1u : 0u);
         }
         uint32_t col[4], lrc[4];   // column | local row, copy << 7
-        if (P == 0) {
+        if (P == 0 || (SPADA_ABLATE & 32)) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                col[u] = lrc[u] = 0u;
+                col[u] = (SPADA_ABLATE & 32) ? pp[u] * 7u : 0u;
+                lrc[u] = 0u;
                 r_v[u] = 0.0;
             }
         } else if (spill) {
@@ -406,6 +433,7 @@ __device__ inline void batch_main(const ARGS &g, const TaskDesc &td, uint32_t t,
                 }
             }
         }
+        BSTOP(2, col[0] ^ col[1] ^ col[2] ^ col[3] ^ lrc[0] ^ lrc[1] ^ lrc[2] ^ lrc[3] ^ (uint32_t)__double2loint(r_v[0] + r_v[1] + r_v[2] + r_v[3]));
         // The home slot of a block is a LINEAR function of its column inside the row's span: when the columns cluster -- the rows of
         // an R-MAT graph: a third of a row's blocks on a twentieth of its span -- the blocks of a cluster share a few home slots and
         // linear probing pays for it quadratically (such tasks took 60 - 100 us to count their outputs, and a thousand tasks of the
@@ -418,6 +446,10 @@ __device__ inline void batch_main(const ARGS &g, const TaskDesc &td, uint32_t t,
             constexpr bool equalised = decltype(EQ)::value;
             constexpr bool COUNT_HASHED = MODE == MODE_COUNT;   // (web count kernel 0.52 -> 0.42 ms against monotone home slots)
             mynew = mykeys = 0u;
+            // the home slots of the thread's four products first -- their row parameters are four independent LDS reads, in flight together --
+            // then the four insertions: a step's chain of dependent LDS round trips is the CAS (and its probes) and the OR, not the row read
+            // in front of them (the insertions are what a task's count, i.e. everything behind it in the chain, waits for)
+            uint32_t homes[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const uint32_t lr = lrc[u] & 127u;
@@ -425,9 +457,9 @@ __device__ inline void batch_main(const ARGS &g, const TaskDesc &td, uint32_t t,
                 const uint32_t ck = compose_key(lr, col[u], colbits);
                 r_ck[u] = ck;
                 r_st[u] = act[u] ? BT_H_COPY : BT_H_NONE;
+                uint32_t home = 0u;
                 if (hashed) {
                     const uint32_t hk = ck >> BT_BSHIFT;
-                    uint32_t home;
                     if constexpr (COUNT_HASHED) {
                         // the counting mode orders nothing: a hashed home slot -- no clusters whatever the columns are, no second
                         // attempt, no list of displaced blocks, no row record to read
@@ -443,32 +475,47 @@ __device__ inline void batch_main(const ARGS &g, const TaskDesc &td, uint32_t t,
                         home = (bw & 0xFFFFu) + min((uint32_t)((x - (float)k) * (float)bg), bg - 1u);
                     }
                     }
+                }
+                homes[u] = home;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool hashed = r_st[u] == BT_H_COPY && !(lrc[u] & 128u);
+                if (hashed) {
+                    const uint32_t hk = r_ck[u] >> BT_BSHIFT, home = homes[u];
                     uint32_t h = home, st = 0;
-                    uint32_t old = atomicCAS(&keys[h], EMPTY_KEY, hk);
+                    uint32_t old = (SPADA_ABLATE & 16) ? EMPTY_KEY : atomicCAS(&keys[h], EMPTY_KEY, hk);
                     if (old != EMPTY_KEY && old != hk) {
                         // upwards; at the end of the table the free slot BELOW the home takes the block (the order stage then looks at
                         // whole clusters).  First attempt: BT_PROBE_MAX slots above its home the lane gives up -- the blocks cluster,
                         // the task starts over with equalised home slots -- and leaves the loop by "finding" the key of its home slot
                         // (no exit of its own: the common iteration is the one of a loop without a budget)
                         uint32_t hkx = hk;
-                        const uint32_t hlim = !equalised && !COUNT_HASHED ? min(home + BT_PROBE_MAX, T) : T;
-                        do {
-                            if (h >= home) {
+                        if constexpr (!equalised && !COUNT_HASHED) {
+                            // (first attempt: home + BT_PROBE_MAX lies inside the table -- the rows' regions end BT_T - BT_LAYOUT slots before
+                            // its end -- so the walk never wraps and needs no direction: one compare per step besides the CAS)
+                            const uint32_t hlim = home + BT_PROBE_MAX;
+                            do {
                                 if (++h == hlim) {
-                                    if (hlim == T) {
+                                    hdr[42] = 1u;
+                                    h = home;
+                                    hkx = keys[home];
+                                }
+                                old = atomicCAS(&keys[h], EMPTY_KEY, hkx);
+                            } while (old != EMPTY_KEY && old != hkx);
+                        } else {
+                            do {
+                                if (h >= home) {
+                                    if (++h == T) {
                                         h = home - 1u;
                                         hdr[40] = 1u;
-                                    } else {
-                                        hdr[42] = 1u;
-                                        h = home;
-                                        hkx = keys[home];
                                     }
+                                } else {
+                                    --h;
                                 }
-                            } else {
-                                --h;
-                            }
-                            old = atomicCAS(&keys[h], EMPTY_KEY, hkx);
-                        } while (old != EMPTY_KEY && old != hkx);
+                                old = atomicCAS(&keys[h], EMPTY_KEY, hkx);
+                            } while (old != EMPTY_KEY && old != hkx);
+                        }
                         if (!COUNT_HASHED && old == EMPTY_KEY && h > home) {   // displaced: the order stage looks at the slots between its home and its place
                             const uint32_t li = atomicAdd(&hdr[41], 1u);
                             if (li < BT_LIST_CAP) dlist[li] = h | ((h - home) << 12);
@@ -479,7 +526,7 @@ __device__ inline void batch_main(const ARGS &g, const TaskDesc &td, uint32_t t,
                         st = BT_ST_CREATOR;
                     }
                     const uint32_t bit = 1u << (col[u] & 31u);
-                    const uint32_t was = atomicOr(&masks[h], bit);
+                    const uint32_t was = (SPADA_ABLATE & 16) ? 0u : atomicOr(&masks[h], bit);
                     if (!(was & bit)) {
                         ++mynew;
                         st |= BT_ST_OWNER;
@@ -605,6 +652,7 @@ __device__ inline void batch_main(const ARGS &g, const TaskDesc &td, uint32_t t,
         }
     }
     BMARK(3);
+    BSTOP(3, r_st[0] ^ r_st[1] ^ r_st[2] ^ r_st[3] ^ r_ck[0] ^ r_ck[1] ^ r_ck[2] ^ r_ck[3] ^ total ^ (uint32_t)__double2loint(r_v[0] + r_v[1] + r_v[2] + r_v[3]));
     (void)NBt;
     if constexpr (MODE != MODE_NUMERIC) task_publish<MODE>(g, t, total);
     if (SPADA_TASK_DBG && tid == 0) {   // ticks from the task's ticket (dbg_ph[16], k_task) to its publication, per kind: sum, tasks, maximum
@@ -701,7 +749,7 @@ __device__ inline void batch_main(const ARGS &g, const TaskDesc &td, uint32_t t,
     // ---- order: first output of every block = outputs of the blocks before it in (row, block) order ----------------------------
     uint32_t hoff = 0;   // hashed outputs of the batch before this thread's row
     uint32_t rank[4] = {0u, 0u, 0u, 0u};
-    if (NO) {
+    if (NO && !(SPADA_ABLATE & 2)) {
         {
             // the slots are in (row, block) order up to the clusters: one prefix sum over the popcounts of the masks, six consecutive
             // slots per thread
@@ -727,7 +775,8 @@ __device__ inline void batch_main(const ARGS &g, const TaskDesc &td, uint32_t t,
             // long as the final values fit, whatever the intermediate carries are.
             const uint32_t ndisp = hdr[41];
             const bool whole_clusters = hdr[40] != 0u || ndisp > BT_LIST_CAP;   // (uniform) a block was placed BELOW its home, or the list is full
-            if (!whole_clusters) {
+            if (SPADA_ABLATE & 1) {
+            } else if (!whole_clusters) {
                 // (the list spread over the waves: entry e to lane e / 8 of wave e % 8 -- a wave waits for the longest walk among its lanes)
                 for (uint32_t e = (uint32_t)lane * BT_NWAVE + wave_u; e < ndisp; e += BW) {
                     const uint32_t ent = dlist[e], h = ent & 0xFFFu, k = keys[h], mine = (uint32_t)__popc(masks[h]);
@@ -764,6 +813,7 @@ __device__ inline void batch_main(const ARGS &g, const TaskDesc &td, uint32_t t,
             __syncthreads();
         }
         BMARK(5);
+        BSTOP(5, r_st[0] ^ r_st[1] ^ r_st[2] ^ r_st[3] ^ r_ck[0] ^ r_ck[1] ^ r_ck[2] ^ r_ck[3] ^ (uint32_t)fo[tid] ^ (uint32_t)__double2loint(r_v[0] + r_v[1] + r_v[2] + r_v[3]));
         // output of a product = first output of its block + mask bits below its own
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -812,12 +862,12 @@ __device__ inline void batch_main(const ARGS &g, const TaskDesc &td, uint32_t t,
     // mask bit first stores its value, the others of the same output add theirs afterwards.
 #pragma unroll
     for (int u = 0; u < 4; ++u)
-        if (r_st[u] < BT_ST_HASHED_MAX && (r_st[u] & BT_ST_OWNER)) {
+        if (!(SPADA_ABLATE & 4) && r_st[u] < BT_ST_HASHED_MAX && (r_st[u] & BT_ST_OWNER)) {
             const uint32_t i = rank[u] + (uint32_t)s_delta[lr_of_ck(r_ck[u])];   // (a hashed row's delta is final since the prologue)
             if constexpr (VALUES) vals[i] = r_v[u];
             cols[i] = r_ck[u];
         }
-    if (NO != NBK || total > NO) {   // (uniform) some products share their output with another one, or some are copied
+    if (!(SPADA_ABLATE & 4) && (NO != NBK || total > NO)) {   // (uniform) some products share their output with another one, or some are copied
         __syncthreads();
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -835,6 +885,7 @@ __device__ inline void batch_main(const ARGS &g, const TaskDesc &td, uint32_t t,
         }
     }
     BMARK(6);
+    BSTOP(6, ooff ^ cols[tid]);
     unsigned long long base = 0;
     if constexpr (MODE == MODE_NUMERIC) base = ((unsigned long long)hdr[53] << 32) | hdr[52];   // (before the next task's prologue writes its own)
     const uint32_t my_ooff = ooff;
@@ -875,7 +926,7 @@ __device__ inline void batch_main(const ARGS &g, const TaskDesc &td, uint32_t t,
     // piece that straddles one more line than it fills wrote 1.18 x the bytes of C (WRITE_SIZE, round 3)
     {
         const uint32_t shift = (uint32_t)base & 31u;
-        for (uint32_t j = tid; j < total + shift; j += BW) {
+        for (uint32_t j = tid; j < ((SPADA_ABLATE & 8) ? 0u : total + shift); j += BW) {
             if (j >= shift) {
                 const uint32_t i = j - shift;
                 __builtin_nontemporal_store(cols[i] & colmask, &g.c_idx[base + i]);
@@ -887,6 +938,7 @@ __device__ inline void batch_main(const ARGS &g, const TaskDesc &td, uint32_t t,
     else next();                                 // (starts with a barrier)
     BMARK(8);
 #undef BMARK
+#undef BSTOP
 }
 
 }  // namespace spada

@@ -63,6 +63,7 @@ constexpr uint32_t TK_SMALL_MAX = 512;   // class boundary SMALL | SOLO (statist
 constexpr uint32_t TK_SOLO_MAX = 1536;   // the sort-merge accumulator's limit (its network holds 2048 pairs)
 constexpr int TK_NQ = 16;                // ticket queues: task t belongs to queue t % TK_NQ, workgroup b serves queue b % TK_NQ (1 / 4 / 8 queues, queues
                                          // spread over the XCDs: within 1 % on web / R-MAT 16, one queue 5 - 10 % slower on cop20k_A: profiles/r04_experiments.txt)
+constexpr long long ST_STRIDE = 2;   // words between the chain's status words of consecutive tasks: 16 bytes per task, measured 3 % faster than adjacent words (fewer writers per line)
 constexpr int BX_NB = 1024;              // column buckets of the big-row histogram
 static_assert(TK_LIMIT_HI + 8 <= (uint32_t)TK_T && TK_NOUT % TK_BLOCK == 0, "the table must keep empty slots");
 
@@ -162,35 +163,45 @@ __device__ inline uint8_t row_class(uint64_t P, uint32_t L, uint32_t rmax, uint3
 }
 // ---- 1. entry descriptors + row statistics ---------------------------------------------------------------------------------
 // k_entry_stats: one lane per A entry, 64 consecutive entries per wave and round, whatever the row lengths are (the row of an
-// entry comes from A.rowid).  Per entry: the irregular 16-byte B.indptr gather of the path, done exactly once -> eb0 / elen
-// (begin, length of the selected B row), and the row's first / last column.  Entries of one row are adjacent lanes: a
-// segmented wave scan adds them up, and the last lane of every run adds the run to the row's totals (row_P, row_kmin,
-// row_kmax, preset to 0 / max / 0) with one device atomic each -- ~1 atomic triple per row, none of them contended.
-// k_row_class: one lane per row: class, statistics, the list of BIG rows.
-// k_init: everything the pipeline wants cleared before it starts, in one launch instead of five fills: the counters, the per-row
-// accumulators of k_entry_stats (products 0, first column 0xFFFFFFFF, last column 0) and the chain's status words.
-__global__ __launch_bounds__(256) void k_init(TaskCounters *__restrict__ ctr, unsigned long long *__restrict__ row_P,
-                                              uint32_t *__restrict__ row_kmin, uint32_t *__restrict__ row_kmax, uint32_t nrows,
-                                              unsigned long long *__restrict__ status, uint64_t status_words)
+// entry comes from A.rowid).  Per entry: the irregular gathers of the path, done exactly once -- the 16-byte B.indptr pair -> eb0 /
+// elen (begin, length of the selected B row) and the 8-byte extent of that row (first / last column: spada_dev_csr::rext, kept with
+// the matrix).  Entries of one row are adjacent lanes: a segmented wave scan adds them up, and the last lane of every run adds the
+// run to the row's totals (row_P, row_kmin, row_kmax, preset to 0 / max / 0) with one device atomic each -- ~1 atomic triple per
+// row, none of them contended.
+// k_row_class: one lane per row: class, statistics, the list of BIG rows -- and the row's accumulators put back to their presets
+// for the next run (nobody reads them after this kernel), so that no clearing kernel stands at the head of a run.
+// (Measured and not kept, round 5: both kernels as ONE, a workgroup per tile of 1024 rows walking the tile's entries with the row
+// totals in LDS -- no device atomics, no accumulators in HBM: correct, and 4.5 x SLOWER on the web input (0.297 against 0.066 ms): the
+// entries of a tile range from 600 to 67 000, and a matrix with few rows (R-MAT 16: 64 tiles) does not fill the GPU at all.  The
+// walk has to be balanced over ENTRIES.)
+__global__ __launch_bounds__(256) void k_clear_counters(TaskCounters *__restrict__ ctr)
 {
-    const uint64_t i0 = (uint64_t)blockIdx.x * 256 + threadIdx.x, stride = (uint64_t)gridDim.x * 256;
-    for (uint64_t i = i0; i < sizeof(TaskCounters) / 8; i += stride) ((unsigned long long *)ctr)[i] = 0ull;
-    for (uint64_t i = i0; i < nrows; i += stride) {
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < sizeof(TaskCounters) / 8; i += gridDim.x * 256) ((unsigned long long *)ctr)[i] = 0ull;
+}
+// (the first run of a context, and a run over more rows than any before it)
+__global__ __launch_bounds__(256) void k_preset_rows(unsigned long long *__restrict__ row_P, uint32_t *__restrict__ row_kmin,
+                                                     uint32_t *__restrict__ row_kmax, uint64_t n)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
         row_P[i] = 0ull;
         row_kmin[i] = 0xFFFFFFFFu;
         row_kmax[i] = 0u;
     }
-    for (uint64_t i = i0; i < status_words; i += stride) status[i] = 0ull;
 }
 
+template <class ARGS>
 __global__ __launch_bounds__(256) void k_entry_stats(const uint64_t *__restrict__ aptr, const uint32_t *__restrict__ aidx,
                                                      const uint32_t *__restrict__ arow, const uint64_t *__restrict__ bptr,
-                                                     const uint32_t *__restrict__ bidx, uint64_t r0, uint32_t nrows,
+                                                     const uint2 *__restrict__ bext, uint64_t r0, uint32_t nrows,
                                                      uint64_t *__restrict__ eb0, uint32_t *__restrict__ elen,
                                                      unsigned long long *__restrict__ row_P, uint32_t *__restrict__ row_kmin,
-                                                     uint32_t *__restrict__ row_kmax, uint32_t limit, TaskCounters *__restrict__ ctr)
+                                                     uint32_t *__restrict__ row_kmax, uint32_t limit, TaskCounters *__restrict__ ctr,
+                                                     const ARGS g, ARGS *__restrict__ g_dst)
 {
-    if (blockIdx.x == 0 && threadIdx.x == 0) ctr->prod_limit = limit;   // (products a task hashes at most: read by the kernels behind this one)
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        ctr->prod_limit = limit;   // (products a task hashes at most: read by the kernels behind this one)
+        if (g_dst) *g_dst = g;     // (the arguments of the task kernel travel with the first kernel of the run: see k_task_args)
+    }
     const uint64_t e0 = aptr[r0], e1 = aptr[r0 + nrows];
     const int lane = threadIdx.x & 63;
     for (uint64_t q0 = e0 + (uint64_t)blockIdx.x * 256 + (threadIdx.x & ~63); q0 < e1; q0 += (uint64_t)gridDim.x * 256) {
@@ -204,9 +215,10 @@ __global__ __launch_bounds__(256) void k_entry_stats(const uint64_t *__restrict_
             eb0[q] = b0;
             len = b1 - b0;
             elen[q] = (uint32_t)len;
-            if (b1 > b0) {
-                mn = bidx[b0];
-                mx = bidx[b1 - 1];
+            if (b1 > b0) {   // (first / last column of the selected B row: one 8-byte gather, spada_dev_csr::rext)
+                const uint2 ex = bext[k];
+                mn = ex.x;
+                mx = ex.y;
             }
         }
         // segmented inclusive scan over runs of equal row
@@ -1249,7 +1261,9 @@ __global__ __launch_bounds__(256) void k_cut3(const uint8_t *__restrict__ row_cl
                                               const uint32_t *__restrict__ row_tmp, uint32_t n,
                                               uint32_t *__restrict__ tile_tasks, const TaskDesc *__restrict__ tmp,
                                               TaskDesc *__restrict__ tasks, uint32_t task_cap, uint32_t fold /* no k_cut2 has run */,
-                                              uint32_t *__restrict__ tile_first, uint32_t *__restrict__ legacy, TaskCounters *__restrict__ ctr)
+                                              uint32_t *__restrict__ tile_first, uint32_t *__restrict__ legacy,
+                                              unsigned long long *__restrict__ status /* the chain's status words: cleared with the task they belong to */,
+                                              TaskCounters *__restrict__ ctr)
 {
     __shared__ CutLds L;
     const bool lead_wg = blockIdx.y == 0;
@@ -1316,6 +1330,7 @@ __global__ __launch_bounds__(256) void k_cut3(const uint8_t *__restrict__ row_cl
             d.cut = 0;
             d.ri = d.m = 0;
             tasks[idx] = d;
+            status[(size_t)idx * ST_STRIDE] = 0ull;
             }
         } else if (cr.kind[j] == 2 && cr.t[j]) {
             kb[j] = kbn++;
@@ -1357,6 +1372,7 @@ __global__ __launch_bounds__(256) void k_cut3(const uint8_t *__restrict__ row_cl
         if (b_first[lo] + off < task_cap) {
             const TaskDesc d = tmp[b_tb[lo] + off];
             tasks[b_first[lo] + off] = d;
+            status[(size_t)(b_first[lo] + off) * ST_STRIDE] = 0ull;
             leg = !task_is_batch(d);
         }
         // the numbers of the tasks that take the older range path (spilled multi-pass / heavy ranges, rows with many entries): one
@@ -1374,7 +1390,6 @@ __global__ __launch_bounds__(256) void k_cut3(const uint8_t *__restrict__ row_cl
 
 // ---- 4. the task kernel ------------------------------------------------------------------------------------------------
 constexpr int MODE_COUNT = 0, MODE_NUMERIC = 1, MODE_FUSED = 2;
-constexpr long long ST_STRIDE = 2;   // words between the status words of consecutive tasks: 16 bytes per task, measured 3 % faster than adjacent words (fewer writers per line)
 constexpr unsigned long long ST_AGG = 1ull << 62, ST_INC = 2ull << 62, ST_MASK = 3ull << 62;
 
 struct TaskArgs {
@@ -2045,23 +2060,6 @@ __host__ __device__ constexpr size_t task_kernel_lds() { return task_dbg_off() +
 static_assert(task_kernel_lds() <= 40960, "four workgroups per CU");
 static_assert(flat_walk_bytes<TKW, TKW_EPT, true>() == flat_walk_bytes<TK_BLOCK, TK_EPT, true>(), "one walk scratch size for both workgroup shapes");
 
-// ... or, at the head of a pipeline run, by the kernel that clears the counters, the per-row accumulators and the status words anyway
-// (k_init with one more store): the task kernel then follows the cut without a launch of its own in between
-__global__ __launch_bounds__(256) void k_init_args(TaskCounters *__restrict__ ctr, unsigned long long *__restrict__ row_P,
-                                                   uint32_t *__restrict__ row_kmin, uint32_t *__restrict__ row_kmax, uint32_t nrows,
-                                                   unsigned long long *__restrict__ status, uint64_t status_words, const TaskArgs g,
-                                                   TaskArgs *__restrict__ dst)
-{
-    const uint64_t i0 = (uint64_t)blockIdx.x * 256 + threadIdx.x, stride = (uint64_t)gridDim.x * 256;
-    if (i0 == 0) *dst = g;
-    for (uint64_t i = i0; i < sizeof(TaskCounters) / 8; i += stride) ((unsigned long long *)ctr)[i] = 0ull;
-    for (uint64_t i = i0; i < nrows; i += stride) {
-        row_P[i] = 0ull;
-        row_kmin[i] = 0xFFFFFFFFu;
-        row_kmax[i] = 0u;
-    }
-    for (uint64_t i = i0; i < status_words; i += stride) status[i] = 0ull;
-}
 // ---- RANGE task of the older kind: columns [col_lo, col_hi] of a BIG row -- the products of a spilled row's scratch slice that do not
 // fit the batch stages (more products than the registers hold, sub-ranges of a heavy bucket, multi-pass ranges), or a direct range
 // of a row with more than BT_EMAX entries: table keyed by column, monotone buckets + in-bucket rank (emit_table).

@@ -383,6 +383,13 @@ class Engine:
         check(self._L.spada_get_stats(self._ctx, ctypes.byref(st)))
         return st.as_dict()
 
+    def stats_raw(self, st=None):
+        """The statistics of the last call as the C structure itself (spada_stats; fields as in stats()): no conversion -- for loops
+        that time calls (bench.py), where building the dictionary of stats() costs as much host time as a small call takes."""
+        st = st if st is not None else _ffi.Stats()
+        check(self._L.spada_get_stats(self._ctx, ctypes.byref(st)))
+        return st
+
 
 class Comm:
     """One RCCL communicator per process / GPU (libspada_comm.so, include/spada_comm.h): the allgatherv of the C row blocks.

@@ -129,5 +129,7 @@ def test_bench_exercises_the_native_exchange_on_one_rank():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--exercise-exchange", "--workload", "mc2depi", "--no-cpu-baseline"],
                        cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
-    line = json.loads(r.stdout.strip().splitlines()[-1])
+    found = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and "exercise_exchange" in ln]
+    assert found, (r.stdout[-1000:], r.stderr[-1000:])
+    line = json.loads(found[-1])
     assert line["exercise_exchange"] == "ok" and line["nnz_c"] > 0 and line["modes"] == ["overlap", "after"]

@@ -119,6 +119,7 @@ struct spada_ctx {
     // The device counters exist twice.  A pipeline run finds its set cleared: the set of the run BEFORE the last one is cleared behind
     // the end of every run, where nobody waits for it (the last run's set stays as it is: the numeric call reads its task count)
     int ctr_idx = 0;
+    uint32_t scatter_wgs = 8;         // workgroups of k_big_scatter per CU (SPADA_SCATTER_WGS: measurements)
     int side_mode = 2;                // (SPADA_SIDE: 0 no side streams, 1 scatter and cut table on one, 2 on one each -- measurements)
     bool shadow = true;               // (SPADA_SHADOW=0: the clearing at the head of every run instead of behind the one before -- measurements)
     uint64_t rows_preset = 0;         // rows whose accumulators (row_P, row_kmin, row_kmax) hold their presets: every run puts back what it used
@@ -484,7 +485,7 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
             if (side2 || side3) HIP_TRY(hipEventRecord(c->ev_fork, s));
             if (side2) HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
             if (side3) HIP_TRY(hipStreamWaitEvent(c->stream3, c->ev_fork, 0));
-            hipLaunchKernelGGL(k_big_scatter, dim3(c->n_cu * 8), dim3(TK_BLOCK), BX_WALK_LDS, side2 ? c->stream2 : s, a->val, b->idx, b->val,
+            hipLaunchKernelGGL(k_big_scatter, dim3(c->n_cu * c->scatter_wgs), dim3(TK_BLOCK), BX_WALK_LDS, side2 ? c->stream2 : s, a->val, b->idx, b->val,
                                c->eb0.as<uint64_t>(), c->elen.as<uint32_t>(), c->t_big.as<uint32_t>(), c->row_kmin.as<uint32_t>(),
                                c->row_kmax.as<uint32_t>(), c->t_parts.as<BigPart>(), c->t_parthist.as<uint32_t>(),
                                c->t_slots.as<BigSlot>(), c->t_scrcol.as<uint32_t>(), c->t_scrval.as<double>(), seq, dc);
@@ -726,6 +727,7 @@ int spada_create(const spada_options *opts, spada_ctx **out)
     c->device = dev;
     c->accumulator = o.accumulator;
     c->scanner_ok = -1;   // (the one-pass kernel of the other accumulator has its own occupancy)
+    if (const char *e = getenv("SPADA_SCATTER_WGS")) c->scatter_wgs = (uint32_t)std::max(atoi(e), 1);
     if (const char *e = getenv("SPADA_SIDE")) c->side_mode = atoi(e);
     if (const char *e = getenv("SPADA_SHADOW")) c->shadow = atoi(e) != 0;
     if (const char *e = getenv("SPADA_TASK_WGS")) c->task_wgs = (uint32_t)std::min(std::max(atoi(e), 1), TASK_WAVES / 2);

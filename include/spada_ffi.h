@@ -98,8 +98,10 @@ typedef struct spada_stats {
     double ms_numeric_call;   /* whole spada_dev_spgemm_numeric call */
     double ms_fused_call;     /* whole one-pass call (spada_dev_spgemm_fused) */
     double ms_row_stats;      /* B-row descriptors, products per row, row classes */
-    double ms_big_expand;     /* BIG rows: parts, column histograms, ranges; scatter of the spilled rows' products into HBM scratch */
-    double ms_cut;            /* task list (scan kernels); when the scatter runs next to them on the side stream: what they add behind it */
+    double ms_big_expand;     /* BIG rows, the kernels on the engine stream: parts, column histograms, ranges (and the scatter of the spilled rows /
+                                 the cut table of the direct rows when they are not forked to the side streams) */
+    double ms_cut;            /* from the end of the plan to the start of the task kernel: the task list (scan kernels) and, next to them on the
+                                 side streams, scatter and cut table.  The three phases are consecutive intervals of the engine stream */
     double ms_task;           /* the task kernel of the last call (count, numeric or one-pass) */
     uint64_t cls_rows[8];     /* rows per class: 0 EMPTY, 1 COPY (one A entry), 2 SMALL, 3 SOLO, 4 BIG (column-range tasks) */
     uint64_t cls_prod[8];     /* products per class */

@@ -12,7 +12,9 @@
 // already ascending and needs no accumulator).  Stages:
 //   prologue   the descriptor carries R, E, P and the first A entry: the entry loads (B-row begin / length, A value, row of the
 //              entry: ONE entry per thread) and the row records (one 16-byte RowRec per row) are issued together, the table is
-//              cleared under them; the scans over the rows and over the entries share one barrier
+//              cleared under them (one-pass mode, where the prologue runs behind the stores of the task before; in the other modes it
+//              runs under those stores and the table is cleared at the start of the task); the scans over the rows and over the entries
+//              share one barrier
 //   expand     four products per thread, 64 consecutive products per wave and step (coalesced gathers from B); the entry of a
 //              product comes from the tail bits of the entries (2048 bits) with a v_mbcnt pair.  The products STAY IN REGISTERS
 //   accumulate the table is keyed by BLOCK -- (local row, column / 32) -- and holds a 32-bit mask of the columns seen in the block.
@@ -29,7 +31,7 @@
 //              a mask bit first stores its value at that rank, the others add theirs (ds_add_f64; simulator.rs:213-218 adds left
 //              to right, here the order is arbitrary: 1e-9)
 //   emit       once the task's position is known (the chain): the dense arrays are stored as they are (neighbouring lanes,
-//              neighbouring addresses), the retained products of COPY rows go straight to their place
+//              neighbouring addresses); the retained products of COPY rows were put into the same arrays at their place in the slice
 //   second     a task whose blocks CLUSTER (R-MAT rows: a third of a row's blocks on a twentieth of its span) would probe
 //   attempt    quadratically with a linear home-slot mapping: a lane that is displaced by BT_PROBE_MAX slots gives up, the task
 //              counts its products in 256 bins of the rows' spans and starts over with home slots in proportion to the bins'

@@ -618,6 +618,16 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
         std::fprintf(stderr, "\n");
     }
     for (int k = 0; k < 2; ++k) {
+        unsigned long long q[16] = {};
+        for (int w = 0; w < 2048; ++w)
+            for (int i = 0; i < 16; ++i) q[i] += h.dbgs[w][k][i];
+        if (!q[0]) continue;
+        const double n_ = (double)q[0];
+        std::fprintf(stderr, "[late dbg] %s: %llu tasks; per task: products %.0f entries %.0f rows %.1f displaced %.1f outputs %.0f; second attempts %llu dense %llu range %llu "
+                     "in the last 1000 tasks %llu; ticks from the ticket: task start %.0f, gathers arrived %.0f, publication %.0f\n", k ? "all tasks" : "published > 30000 ticks after their ticket",
+                     q[0], q[1] / n_, q[2] / n_, q[3] / n_, q[4] / n_, q[5] / n_, q[6], q[7], q[8], q[12], q[9] / n_, q[10] / n_, q[11] / n_);
+    }
+    for (int k = 0; k < 2; ++k) {
         if (!h.dbgh[k][1]) continue;
         std::fprintf(stderr, "[publish dbg] %s tasks: %llu, clock ticks from ticket to publication: mean %.0f, largest %llu\n", k ? "range" : "batch",
                      h.dbgh[k][1], 16.0 * (double)h.dbgh[k][0] / (double)h.dbgh[k][1], h.dbgh[k][2]);

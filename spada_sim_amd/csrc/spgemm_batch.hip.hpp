@@ -315,6 +315,7 @@ __device__ inline void batch_main(const ARGS &g, const TaskDesc &td, uint32_t t,
         }                                                                       \
     } while (0)
     if (SPADA_TASK_DBG && tid == 0) dbg_ph[8] += 1;
+    uint32_t dbg_t_start = SPADA_TASK_DBG ? (uint32_t)__builtin_amdgcn_s_memtime() : 0u, dbg_t_gath = 0u;
     // (development: the numeric mode cut short behind stage k; `sink` keeps what the stage computed alive)
 #define BSTOP(k, sink)                                                              \
     do {                                                                            \
@@ -435,6 +436,7 @@ __device__ inline void batch_main(const ARGS &g, const TaskDesc &td, uint32_t t,
                 }
             }
         }
+        if (SPADA_TASK_DBG) dbg_t_gath = (uint32_t)__builtin_amdgcn_s_memtime() + (col[0] & 0u);
         BSTOP(2, col[0] ^ col[1] ^ col[2] ^ col[3] ^ lrc[0] ^ lrc[1] ^ lrc[2] ^ lrc[3] ^ (uint32_t)__double2loint(r_v[0] + r_v[1] + r_v[2] + r_v[3]));
         // The home slot of a block is a LINEAR function of its column inside the row's span: when the columns cluster -- the rows of
         // an R-MAT graph: a third of a row's blocks on a twentieth of its span -- the blocks of a cluster share a few home slots and
@@ -668,6 +670,22 @@ __device__ inline void batch_main(const ARGS &g, const TaskDesc &td, uint32_t t,
             if (!DENSE && hdr[42]) dbg_ph[23] += 1u;
         }
 #if SPADA_TASK_DBG
+        for (int grp = d > 30000u ? 0 : 1; grp < 2; ++grp) {   // late tasks | all tasks: what they are, and where their time went
+            unsigned long long *q = g.ctr->dbgs[blockIdx.x & 2047u][grp];
+            q[0] += 1ull;
+            q[1] += P;
+            q[2] += E;
+            q[3] += R;
+            q[4] += hdr[41];
+            q[5] += NO;
+            q[6] += !DENSE && hdr[42] ? 1u : 0u;
+            q[7] += DENSE ? 1u : 0u;
+            q[8] += range ? 1u : 0u;
+            q[9] += dbg_t_start - dbg_ph[16];
+            q[10] += dbg_t_gath - dbg_ph[16];
+            q[11] += d;
+            q[12] += t + 1000u >= ntasks ? 1u : 0u;
+        }
         if (d > 60000u) {   // the slowest tasks: what they are
             const unsigned long long n = atomicAdd(&g.ctr->dbgh[2][0], 1ull);
             if (n < 7) {

@@ -104,7 +104,8 @@ struct TaskCounters {   // (a multiple of 8 bytes: k_init clears it in 8-byte wo
     uint32_t n_legacy;                // tasks of the older range path (their numbers: TaskArgs::legacy)
     uint32_t scanner_leavers;         // one-pass mode: workgroups that left the scanner's CU to it (at most SCANNER_LEAVERS_MAX)
 #if SPADA_TASK_DBG
-    unsigned long long dbgh[3][24];  // per task kind: [0..19] histogram of the cycles from ticket to publish (4096-cycle bins), [20] sum, [21] tasks, [22] max
+    unsigned long long dbgh[3][24];
+    unsigned long long dbgs[2048][2][16];  // (per workgroup: no contended atomics in the measurement) tasks that published late (> 30 000 ticks) | all: tasks, products, entries, rows, displaced, outputs, second attempts, dense, range, ticks ticket -> task start, -> gathers arrived, -> publication, tasks in the kernel's last 1000  // per task kind: [0..19] histogram of the cycles from ticket to publish (4096-cycle bins), [20] sum, [21] tasks, [22] max
 #endif
     // statistics of k_row_class, spread over CLS_SLOTS lines (workgroup b adds to slot b % CLS_SLOTS; the host sums them): rows per
     // class [0 .. 4], products per class [5 .. 9], A entries [10].  One hot word takes ~90 atomics per microsecond: with the

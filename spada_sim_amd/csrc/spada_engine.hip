@@ -120,6 +120,7 @@ struct spada_ctx {
     // the end of every run, where nobody waits for it (the last run's set stays as it is: the numeric call reads its task count)
     int ctr_idx = 0;
     uint32_t scatter_wgs = 8;         // workgroups of k_big_scatter per CU (SPADA_SCATTER_WGS: measurements)
+    bool expect_no_big = false;       // the last pipeline run of this context found no BIG row (the next one does not launch their kernels)
     int side_mode = 2;                // (SPADA_SIDE: 0 no side streams, 1 scatter and cut table on one, 2 on one each -- measurements)
     bool shadow = true;               // (SPADA_SHADOW=0: the clearing at the head of every run instead of behind the one before -- measurements)
     uint64_t rows_preset = 0;         // rows whose accumulators (row_P, row_kmin, row_kmax) hold their presets: every run puts back what it used
@@ -454,7 +455,11 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
             HIP_TRY(hipGetLastError());
         }
         if (c->phase_timing) HIP_TRY(hipEventRecord(c->tev[1], s));
-        if (n) {
+        // A run whose predecessor on this context found no BIG row does not launch the five BIG-row kernels (each costs a launch and a
+        // drain -- together a tenth of a step of the mesh inputs -- to find an empty list).  The guess is checked at the end of the run:
+        // if the row classes did find BIG rows, the run is thrown away and repeated with the kernels (never twice in a row)
+        const bool no_big = c->expect_no_big;
+        if (n && !no_big) {
             uint32_t *seq = c->accumulator == SPADA_ACC_SORT_MERGE ? c->t_scrseq.as<uint32_t>() : (uint32_t *)nullptr;
             hipLaunchKernelGGL(k_big_parts, dim3(c->n_cu * 2), dim3(256), 0, s, a->ptr, c->elen.as<uint32_t>(), c->r0,
                                c->t_big.as<uint32_t>(), c->row_nprod.as<uint32_t>(), c->row_kmin.as<uint32_t>(),
@@ -567,6 +572,14 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
             items_most = std::max<uint64_t>(items_most, h.cut_arena[a2][1]);
         }
         c->last_cuts = cut_most;
+        if (no_big && h.n_big != 0 && !(h.abort_flag & ~2u)) {   // the guess was wrong: nothing of this run may be kept
+            c->expect_no_big = false;
+            trace(2, "  %u BIG rows in a run that expected none: running again with the BIG-row kernels", h.n_big);
+            --attempt;   // (not one of the workspace retries)
+            c->t_cap_tasks = std::max<uint64_t>(c->t_cap_tasks, (uint64_t)h.need_tasks + h.need_tasks / 16 + 1024);
+            continue;
+        }
+        c->expect_no_big = h.n_big == 0 && !h.abort_flag;
         if (!h.abort_flag) break;
         if (attempt == 3) return fail(SPADA_ERR_HIP, "task pipeline: workspaces still too small after three retries (flag %u)", h.abort_flag);
         if (h.abort_flag & 4u) return fail(SPADA_ERR_UNSUPPORTED, "a row of C has 2^32 or more products");

@@ -316,6 +316,8 @@ __device__ inline void batch_main(const ARGS &g, const TaskDesc &td, uint32_t t,
     } while (0)
     if (SPADA_TASK_DBG && tid == 0) dbg_ph[8] += 1;
     uint32_t dbg_t_start = SPADA_TASK_DBG ? (uint32_t)__builtin_amdgcn_s_memtime() : 0u, dbg_t_gath = 0u;
+    (void)dbg_t_start;
+    (void)dbg_t_gath;
     // (development: the numeric mode cut short behind stage k; `sink` keeps what the stage computed alive)
 #define BSTOP(k, sink)                                                              \
     do {                                                                            \

@@ -495,3 +495,30 @@ def test_many_displaced_blocks_take_the_cluster_fix(engine, run):
     assert_parity(c, ref, ao, bo, RTOL)
     c2 = engine.spgemm(a, b)
     assert_parity(c2, ref, ao, bo, RTOL)
+
+
+def test_a_run_that_expected_no_big_rows_is_repeated_when_there_are_some():
+    """A context whose last run found no BIG row does not launch the BIG-row kernels in the next one; when that next product does
+    have BIG rows the run is thrown away and repeated with them (stats.pipeline_runs = 2), and the product is right -- also for
+    the call after it (no second repetition) and in the two-phase contract."""
+    import spada_sim_amd as S
+    flat = S.generate(S.GEN_UNIFORM, 3000, 4, 5)            # every row 4 entries: no BIG rows
+    hubs = S.generate(S.GEN_RMAT, 12, 16, 9)                # power-law rows: BIG rows
+    eng = S.Engine()
+    try:
+        c0, st0 = fused(eng, flat, flat)
+        assert st0["cls_rows"][4] == 0
+        assert_parity(c0, oracle.spgemm_sortmerge(to_oracle(flat), to_oracle(flat)), to_oracle(flat), to_oracle(flat), RTOL)
+        ref = oracle.spgemm_sortmerge(to_oracle(hubs), to_oracle(hubs))
+        c1, st1 = fused(eng, hubs, hubs)
+        assert st1["cls_rows"][4] > 0 and st1["pipeline_runs"] >= 2
+        assert_parity(c1, ref, to_oracle(hubs), to_oracle(hubs), RTOL)
+        c2, st2 = fused(eng, hubs, hubs)
+        assert st2["pipeline_runs"] == 1
+        assert_parity(c2, ref, to_oracle(hubs), to_oracle(hubs), RTOL)
+        c3, _ = fused(eng, flat, flat)                       # ... and back: the kernels run once more, find nothing, and are left out again
+        assert np.array_equal(c3.indptr, c0.indptr) and np.array_equal(c3.indices, c0.indices)
+        c4 = eng.spgemm(hubs, hubs)                          # two-phase contract after a run without BIG rows
+        assert_parity(c4, ref, to_oracle(hubs), to_oracle(hubs), RTOL)
+    finally:
+        eng.close()

@@ -448,6 +448,12 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
                                c->row_kmin.as<uint32_t>(), c->row_kmax.as<uint32_t>(),
                                c->accumulator == SPADA_ACC_SORT_MERGE ? (uint32_t)TK_SOLO_MAX : TK_LIMIT_HI, dc, g,
                                c->accumulator == SPADA_ACC_SORT_MERGE ? (TaskArgs *)nullptr : c->t_args.as<TaskArgs>());
+            if (c->expect_no_big)   // (row classes and the tiles' cut in one kernel: nothing of the BIG-row stage is expected in between)
+                hipLaunchKernelGGL(k_row_class_cut, dim3(ntiles), dim3(256), 0, s, a->ptr, c->r0, n, rmax, c->t_rowP.as<unsigned long long>(),
+                                   c->row_kmin.as<uint32_t>(), c->row_kmax.as<uint32_t>(), c->row_nprod.as<uint32_t>(), c->row_bin.as<uint8_t>(),
+                                   c->row_cl.as<uint32_t>(), c->row_rec.as<RowRec>(), c->t_rowm.as<uint32_t>(), c->t_big.as<uint32_t>(), dc,
+                                   c->t_tiles.as<uint32_t>(), c->t_rowt.as<uint32_t>(), c->row_binfo.as<uint32_t>());
+            else
             hipLaunchKernelGGL(k_row_class, dim3(std::min<uint32_t>((n + 255) / 256, c->n_cu * 8)), dim3(256), 0, s, a->ptr, c->r0,
                                n, rmax, c->t_rowP.as<unsigned long long>(), c->row_kmin.as<uint32_t>(), c->row_kmax.as<uint32_t>(),
                                c->row_nprod.as<uint32_t>(), c->row_bin.as<uint8_t>(), c->row_cl.as<uint32_t>(),
@@ -508,6 +514,7 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
         }
         if (c->phase_timing) HIP_TRY(hipEventRecord(c->tev[2], s));
         if (n) {
+            if (!no_big)   // (else: k_row_class_cut has cut the tiles)
             hipLaunchKernelGGL(k_cut1, dim3(ntiles), dim3(256), 0, s, c->row_cl.as<uint32_t>(), c->row_nprod.as<uint32_t>(),
                                c->row_rec.as<RowRec>(), c->t_rowm.as<uint32_t>(), n, rmax, dc, c->t_tiles.as<uint32_t>(), c->t_rowt.as<uint32_t>(),
                                c->row_binfo.as<uint32_t>());

@@ -1232,6 +1232,86 @@ __global__ __launch_bounds__(256) void k_cut1(const uint32_t *__restrict__ row_c
         }
 }
 
+// k_row_class and k_cut1 as ONE kernel, a workgroup per tile of CUT_TILE rows -- for the runs that expect no BIG row (spada_engine.hip:
+// the run before on the context found none): the cut of a tile then needs nothing that the BIG-row kernels write, and a launch, its
+// drain and the re-read of the row words are a twentieth of a step of the mesh inputs.  Should the rows have BIG ones after all, they
+// are listed and counted as in k_row_class and the engine repeats the run the long way.
+__global__ __launch_bounds__(256) void k_row_class_cut(const uint64_t *__restrict__ aptr, uint64_t r0, uint32_t nrows, uint32_t rmax,
+                                                       const unsigned long long *__restrict__ row_P, const uint32_t *__restrict__ row_kmin,
+                                                       const uint32_t *__restrict__ row_kmax, uint32_t *__restrict__ row_nprod,
+                                                       uint8_t *__restrict__ row_cls, uint32_t *__restrict__ row_cl,
+                                                       RowRec *__restrict__ row_rec, uint32_t *__restrict__ row_m,
+                                                       uint32_t *__restrict__ big_rows, TaskCounters *__restrict__ ctr,
+                                                       uint32_t *__restrict__ tile_tasks, uint32_t *__restrict__ row_t,
+                                                       uint32_t *__restrict__ row_binfo)
+{
+    const uint32_t lim = ctr->prod_limit;
+    __shared__ unsigned long long s_rows[N_CLS], s_prod[N_CLS], s_tot;
+    __shared__ CutLds L;
+    if (threadIdx.x < N_CLS) s_rows[threadIdx.x] = s_prod[threadIdx.x] = 0;
+    if (threadIdx.x == 0) s_tot = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    unsigned long long c_rows[N_CLS] = {0, 0, 0, 0, 0}, c_prod[N_CLS] = {0, 0, 0, 0, 0}, tot_l = 0;
+#pragma unroll
+    for (int q = 0; q < CUT_ITEMS; ++q) {
+        const uint32_t i = blockIdx.x * CUT_TILE + (uint32_t)q * 256u + threadIdx.x;
+        uint8_t cls = CLS_EMPTY;
+        if (i < nrows) {
+            const unsigned long long P = row_P[i];
+            const uint32_t L_ = (uint32_t)(aptr[r0 + i + 1] - aptr[r0 + i]);
+            cls = row_class(P, L_, rmax, lim);
+            const uint32_t P32 = P > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)P;
+            row_nprod[i] = P32;
+            row_cls[i] = cls;
+            row_cl[i] = (uint32_t)cls | (min(L_, 0x1FFFFFFFu) << 3);
+            row_rec[i] = RowRec{row_kmin[i], row_kmax[i], P32, (uint32_t)cls};
+            row_m[i] = 0;
+#pragma unroll
+            for (int k = 0; k < N_CLS; ++k) {
+                c_rows[k] += cls == k ? 1ull : 0ull;
+                c_prod[k] += cls == k ? P : 0ull;
+            }
+            tot_l += L_;
+        }
+        const unsigned long long bm = __ballot(i < nrows && cls == CLS_BIG);
+        if (bm) {   // (not expected: listed for the count that sends the engine the long way)
+            uint32_t base = 0;
+            if (lane == __ffsll((long long)bm) - 1) base = atomicAdd(&ctr->n_big, (uint32_t)__popcll(bm));
+            base = __shfl(base, __ffsll((long long)bm) - 1);
+            if (i < nrows && cls == CLS_BIG) big_rows[base + (uint32_t)__popcll(bm & ((1ull << lane) - 1ull))] = i;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < N_CLS; ++k) {
+        const unsigned long long r = wave_sum_u64(c_rows[k]), p = wave_sum_u64(c_prod[k]);
+        if (lane == 0 && r) {
+            atomicAdd(&s_rows[k], r);
+            atomicAdd(&s_prod[k], p);
+        }
+    }
+    const unsigned long long wl = wave_sum_u64(tot_l);
+    if (lane == 0 && wl) atomicAdd(&s_tot, wl);
+    __syncthreads();   // (the tile's row words are written: the cut below reads them back)
+    unsigned long long *part = ctr->cls_part[blockIdx.x % CLS_SLOTS];
+    if (threadIdx.x < N_CLS && s_rows[threadIdx.x]) {
+        atomicAdd(&part[threadIdx.x], s_rows[threadIdx.x]);
+        atomicAdd(&part[N_CLS + threadIdx.x], s_prod[threadIdx.x]);
+    }
+    if (threadIdx.x == 0 && s_tot) atomicAdd(&part[2 * N_CLS], s_tot);
+    CutRow cr;
+    uint32_t tot, binfo[CUT_ITEMS];
+    (void)cut_tile(row_cl, row_nprod, row_rec, row_m, nrows, rmax, lim, L, cr, &tot, binfo);
+    if (threadIdx.x == 0) tile_tasks[blockIdx.x] = tot;
+    const uint32_t base = blockIdx.x * CUT_TILE + threadIdx.x * CUT_ITEMS;
+#pragma unroll
+    for (int j = 0; j < CUT_ITEMS; ++j)
+        if (base + j < nrows) {
+            row_t[base + j] = cr.t[j];
+            row_binfo[base + j] = binfo[j];
+        }
+}
+
 // single workgroup: exclusive scan of the tile totals in place; total -> ctr->ntasks
 __global__ __launch_bounds__(256) void k_cut2(uint32_t *__restrict__ tile_tasks, uint32_t ntiles, uint32_t task_cap,
                                               TaskCounters *__restrict__ ctr)

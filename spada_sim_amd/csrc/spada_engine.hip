@@ -485,7 +485,9 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
             // range descriptors k_big_plan wrote -- not the scratch, not the cuts; the task kernel waits for all three.  Each fork is
             // taken only if the previous run of this context had work for it (a fork / join pair costs ~10 us and hides nothing when
             // its kernel finds nothing to do); the two are decided separately
-            bool side2 = c->last_spilled != 0, side3 = c->cut_table && c->last_cuts != 0;
+            // (the cut table alone is not worth its fork and join -- cop20k_A, no spilled row: 0.737 ms per call with the fork, 0.723 without --
+            // next to a scatter it is: web 1.02 - 1.04 ms without side streams, 1.01 with)
+            bool side2 = c->last_spilled != 0, side3 = c->cut_table && c->last_cuts != 0 && c->last_spilled != 0;
             hipStream_t s3 = c->stream3;
             if (c->side_mode == 0) side2 = side3 = false;
             if (c->side_mode == 1) {   // (one side stream for both: one fork, one join)

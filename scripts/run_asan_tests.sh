@@ -4,10 +4,10 @@
 # under it.  The interpreter itself is not instrumented, so libasan is preloaded and leak detection (which would report
 # CPython's own allocations) is off; every other ASan / UBSan finding aborts the test.  tests/test_multi_rank_gloo.py is left out:
 # it tests spada_sim_amd/parallel.py (Python over torch.distributed), no native code of this repository.
-#   scripts/run_asan_tests.sh [log file]      (default profiles/r04_asan_cpu_tests.txt)
+#   scripts/run_asan_tests.sh [log file]      (default profiles/r05_asan_cpu_tests.txt)
 set -e
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
-LOG="${1:-$ROOT/profiles/r04_asan_cpu_tests.txt}"
+LOG="${1:-$ROOT/profiles/r05_asan_cpu_tests.txt}"
 make -s -C "$ROOT/spada_sim_amd/csrc" all asan
 make -s -C "$ROOT/oracle" liboracle_spgemm.so asan
 ASAN_SO="$(gcc -print-file-name=libasan.so)"

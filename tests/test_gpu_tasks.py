@@ -522,3 +522,32 @@ def test_a_run_that_expected_no_big_rows_is_repeated_when_there_are_some():
         assert_parity(c4, ref, to_oracle(hubs), to_oracle(hubs), RTOL)
     finally:
         eng.close()
+
+
+def test_one_context_across_row_blocks_matrices_and_failed_calls():
+    """No kernel clears anything at the head of a run: the counters of a run are cleared behind the run before it and the per-row
+    accumulators are put back behind every run.  One context through row blocks of different sizes and offsets, matrices of
+    different shapes, a call that fails for capacity and a retry of the workspaces in between: every product is the oracle's."""
+    import spada_sim_amd as S
+    mats = [S.generate(S.GEN_RMAT, 11, 8, 3), S.generate(S.GEN_UNIFORM, 5000, 3, 8), S.generate(S.GEN_RMAT, 13, 12, 4),
+            S.generate(S.GEN_UNIFORM, 700, 9, 2)]
+    refs = [oracle.spgemm_sortmerge(to_oracle(m), to_oracle(m)) for m in mats]
+    eng = S.Engine()
+    try:
+        for rnd in range(2):
+            for m, ref in zip(mats, refs):
+                n = m.shape[0]
+                for (r0, r1) in ((0, n), (n // 3, n - n // 5), (n - 7, n), (5, 6)):
+                    c, st = fused(eng, m, m, r0=r0, r1=r1)
+                    lo, hi = int(ref.indptr[r0]), int(ref.indptr[r1])
+                    assert st["c_nnz"] == hi - lo
+                    assert np.array_equal(c.indptr.astype(np.int64), ref.indptr[r0:r1 + 1].astype(np.int64) - lo)
+                    assert np.array_equal(c.indices, ref.indices[lo:hi])
+                    assert np.all(np.abs(c.data - ref.data[lo:hi]) <= RTOL * np.abs(ref.data[lo:hi]))
+                if rnd == 0:
+                    with pytest.raises(S.SpadaError):          # capacity too small: the call fails, the context stays usable
+                        fused(eng, m, m, capacity=max(ref.nnz // 2, 1))
+                c2 = eng.spgemm(m, m)                          # two-phase contract on the same context
+                assert_parity(c2, ref, to_oracle(m), to_oracle(m), RTOL)
+    finally:
+        eng.close()

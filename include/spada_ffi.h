@@ -27,9 +27,11 @@
  *   - column indices are narrowed to 32 bit on the device (cols < 2^32 is checked); the host ABI
  *     stays 64 bit to match `usize`.
  *   - STREAM ORDER (spada_dev_* entry points): the engine queues its kernels on a stream of its own (non-blocking, i.e. not
- *     ordered against the caller's default or torch stream).  Every spada_dev_* compute call returns only after that stream has
- *     drained -- EXCEPT spada_dev_spgemm_numeric_chunk and spada_dev_spgemm_indptr, which return as soon as their work is
- *     queued (wait for the event the former returns, or call spada_dev_synchronize).  So results may be read on any stream once a
+ *     ordered against the caller's default or torch stream).  Every spada_dev_* compute call returns only after its RESULT is
+ *     complete on that stream (what may still run behind it touches the engine's own workspaces only: the counters and per-row
+ *     accumulators of the symbolic / one-pass pipeline are put back for the next run there) -- EXCEPT spada_dev_spgemm_numeric_chunk
+ *     and spada_dev_spgemm_indptr, which return as soon as their work is queued (wait for the event the former returns, or call
+ *     spada_dev_synchronize).  So results may be read on any stream once a
  *     call has returned; but work the CALLER has queued on its own streams is not waited for: a caller that reads, fills or
  *     frees a buffer on its own stream must have that stream finished with the buffer before it hands it (or memory reused
  *     from it) to the next spada_dev_* call (hipStreamSynchronize / an event wait of its own).

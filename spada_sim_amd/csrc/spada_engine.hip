@@ -684,10 +684,10 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
           (unsigned long long)h.nprod, (unsigned long long)c->nnz_c, h.ntasks, tev_ms(c, 0, 4), (unsigned long long)st.pipeline_runs,
           st.pipeline_runs == 1 ? "" : "s");
     trace(2, "  rows empty / copy / small / solo / big: %llu / %llu / %llu / %llu / %llu; products per task <= %u; spilled rows %u (%llu "
-          "products); statistics %.3f, BIG-row stage %.3f, cut %.3f, task kernel %.3f ms; workspaces %.1f MB",
+          "products); statistics %.3f, BIG-row stage %.3f, cut %.3f, task kernel %.3f ms; workspaces %.1f MB; %u workgroups left the scanner's CU",
           (unsigned long long)h.cls_rows[0], (unsigned long long)h.cls_rows[1], (unsigned long long)h.cls_rows[2],
           (unsigned long long)h.cls_rows[3], (unsigned long long)h.cls_rows[4], h.prod_limit, h.n_spilled,
-          (unsigned long long)h.scratch_cursor, st.ms_row_stats, st.ms_big_expand, st.ms_cut, st.ms_task, c->ws_bytes / 1e6);
+          (unsigned long long)h.scratch_cursor, st.ms_row_stats, st.ms_big_expand, st.ms_cut, st.ms_task, c->ws_bytes / 1e6, h.scanner_leavers);
     return SPADA_OK;
 }
 

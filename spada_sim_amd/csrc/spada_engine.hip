@@ -116,6 +116,8 @@ struct spada_ctx {
     uint64_t t_cap_tmp = 0, t_cap_tasks = 0, t_cap_scr = 0, t_cap_parts = 0, t_cap_cuts = 0, t_cap_cutitems = 0;
     uint32_t prod_limit = TK_SOLO_MAX;   // capacities the kernels may rely on
     TaskCounters *h_tctr = nullptr;   // pinned
+    unsigned long long *h_seq = nullptr, seq = 0;   // pinned: the number of the last run whose counters have arrived in h_tctr (k_export_counters)
+    bool export_poll = true;          // (SPADA_EXPORT=0: copy command + event at the end of a run, as in rounds 1 - 4)
     // The device counters exist twice.  A pipeline run finds its set cleared: the set of the run BEFORE the last one is cleared behind
     // the end of every run, where nobody waits for it (the last run's set stays as it is: the numeric call reads its task count)
     int ctr_idx = 0;
@@ -552,14 +554,32 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
             HIP_TRY(hipMemsetAsync(cptr, 0, 8, s));
         }
         HIP_TRY(hipEventRecord(c->tev[4], s));
-        HIP_TRY(hipMemcpyAsync(c->h_tctr, dc, sizeof(TaskCounters), hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipEventRecord(c->ev_done, s));
+        if (c->export_poll) {
+            hipLaunchKernelGGL(k_export_counters, dim3(1), dim3(256), 0, s, (const TaskCounters *)dc, c->h_tctr, c->h_seq, ++c->seq);
+        } else {
+            HIP_TRY(hipMemcpyAsync(c->h_tctr, dc, sizeof(TaskCounters), hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipEventRecord(c->ev_done, s));
+        }
         // behind the end of the run, where nobody waits: the other set of counters and the per-row accumulators for the run after this one
         if (c->shadow) hipLaunchKernelGGL(k_clear_counters, dim3(8), dim3(256), 0, s, c->t_ctr.as<TaskCounters>() + (c->ctr_idx ^ 1));
         if (n && c->shadow) hipLaunchKernelGGL(k_preset_rows, dim3(c->n_cu * 4), dim3(256), 0, s, c->t_rowP.as<unsigned long long>(), c->row_kmin.as<uint32_t>(),
                                   c->row_kmax.as<uint32_t>(), (uint64_t)n);
         c->rows_preset = c->shadow ? preset_before : 0;
-        HIP_TRY(hipEventSynchronize(c->ev_done));
+        HIP_TRY(hipGetLastError());
+        if (c->export_poll) {
+            // (the stream is asked now and then: a kernel that faulted never writes the number)
+            for (unsigned spins = 0; __atomic_load_n(c->h_seq, __ATOMIC_ACQUIRE) != c->seq; ++spins) {
+                __builtin_ia32_pause();
+                if ((spins & 0xFFFu) == 0xFFFu) {
+                    const hipError_t q = hipStreamQuery(s);
+                    if (q == hipSuccess) break;
+                    if (q != hipErrorNotReady) return fail(SPADA_ERR_HIP, "task pipeline: %s", hipGetErrorString(q));
+                }
+            }
+            if (__atomic_load_n(c->h_seq, __ATOMIC_ACQUIRE) != c->seq) HIP_TRY(hipStreamSynchronize(s));
+        } else {
+            HIP_TRY(hipEventSynchronize(c->ev_done));
+        }
         TaskCounters &h = *c->h_tctr;
         h.a_nnz = 0;
         for (int k = 0; k < N_CLS; ++k) h.cls_rows[k] = h.cls_prod[k] = 0;
@@ -761,6 +781,7 @@ int spada_create(const spada_options *opts, spada_ctx **out)
     c->scanner_ok = -1;   // (the one-pass kernel of the other accumulator has its own occupancy)
     if (const char *e = getenv("SPADA_SCATTER_WGS")) c->scatter_wgs = (uint32_t)std::max(atoi(e), 1);
     if (const char *e = getenv("SPADA_SIDE")) c->side_mode = atoi(e);
+    if (const char *e = getenv("SPADA_EXPORT")) c->export_poll = atoi(e) != 0;
     if (const char *e = getenv("SPADA_SHADOW")) c->shadow = atoi(e) != 0;
     if (const char *e = getenv("SPADA_TASK_WGS")) c->task_wgs = (uint32_t)std::min(std::max(atoi(e), 1), TASK_WAVES / 2);
     if (const char *e = getenv("SPADA_CUT_TABLE")) c->cut_table = atoi(e) != 0;
@@ -773,6 +794,8 @@ int spada_create(const spada_options *opts, spada_ctx **out)
     HIP_TRY(hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&c->ev_join3, hipEventDisableTiming));
     HIP_TRY(hipHostMalloc((void **)&c->h_tctr, sizeof(TaskCounters), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void **)&c->h_seq, 64, hipHostMallocDefault));
+    *c->h_seq = 0;
     for (auto &e : c->tev) HIP_TRY(hipEventCreate(&e));
     c->n_cu = (uint32_t)std::max(1, prop.multiProcessorCount);
     int rc;
@@ -807,6 +830,7 @@ void spada_destroy(spada_ctx *c)
                       &c->t_scrval, &c->t_scrseq, &c->t_ctr, &c->t_args, &c->t_cuts, &c->t_cutitems, &c->t_legacy, &c->t_parts, &c->t_parthist, &c->t_slots, &c->own_idx, &c->own_val, &c->own_ptr, &c->wide_idx})
         b->release();
     if (c->h_tctr) (void)hipHostFree(c->h_tctr);
+    if (c->h_seq) (void)hipHostFree(c->h_seq);
     for (auto &e : c->tev)
         if (e) (void)hipEventDestroy(e);
     for (auto &e : c->chunk_ev)

@@ -179,6 +179,16 @@ __global__ __launch_bounds__(256) void k_clear_counters(TaskCounters *__restrict
 {
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < sizeof(TaskCounters) / 8; i += gridDim.x * 256) ((unsigned long long *)ctr)[i] = 0ull;
 }
+// The counters of a finished run written straight into pinned host memory, then a sequence number the host polls: what the host waits for at
+// the end of a call is this store becoming visible -- no copy command, no event, no wake-up through the runtime
+__global__ __launch_bounds__(256) void k_export_counters(const TaskCounters *__restrict__ src, TaskCounters *__restrict__ host_dst,
+                                                         unsigned long long *__restrict__ host_seq, unsigned long long seq)
+{
+    for (uint32_t i = threadIdx.x; i < sizeof(TaskCounters) / 8; i += 256) ((unsigned long long *)host_dst)[i] = ((const unsigned long long *)src)[i];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(host_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 // (the first run of a context, and a run over more rows than any before it)
 __global__ __launch_bounds__(256) void k_preset_rows(unsigned long long *__restrict__ row_P, uint32_t *__restrict__ row_kmin,
                                                      uint32_t *__restrict__ row_kmax, uint64_t n)

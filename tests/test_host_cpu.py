@@ -513,3 +513,31 @@ def test_exchange_call_sequence_on_mock_ranks(form, nranks):
             fi, fv, fp = finals[me]
             assert np.array_equal(fi, exp_idx) and np.array_equal(fv, exp_val), (form, nranks, trial, me)
             assert np.array_equal(fp, exp_ptr), (form, nranks, trial, me)
+
+
+def test_counter_summaries_drop_the_aborted_launch(tmp_path):
+    """scripts/pmc_per_launch.py (what collect_sq.sh / collect_traffic.sh summarise the rocprofv3 --pmc passes with): the value per
+    kernel is the MEDIAN over its steady launches; a launch far shorter than the kernel's median duration -- the aborted pipeline run
+    of a context's first call -- is dropped, and launches_used / launches_seen say so.  (Round 4's files averaged it in.)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("pmc_per_launch", os.path.join(ROOT, "scripts", "pmc_per_launch.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    d = tmp_path / "p1"
+    d.mkdir()
+    rows = ["Correlation_Id,Dispatch_Id,Agent_Id,Queue_Id,Process_Id,Thread_Id,Grid_Size,Kernel_Id,Kernel_Name,Workgroup_Size,"
+            "LDS_Block_Size,Scratch_Size,VGPR_Count,Accum_VGPR_Count,SGPR_Count,Counter_Name,Counter_Value,Start_Timestamp,End_Timestamp"]
+    def add(disp, name, counter, value, dur):
+        rows.append(f'1,{disp},"Agent 2",4,1,1,256,7,"{name}",512,0,0,64,0,80,"{counter}",{value},1000,{1000 + dur}')
+    kern = "void spada::k_task<2, 2048>(spada::TaskArgs const*)"
+    add(1, kern, "SQ_INSTS_VALU", 0.0, 1600)                       # the aborted run: 1.6 us
+    for i, v in enumerate((262.0e6, 262.4e6, 261.8e6, 262.2e6)):   # four steady launches; one counter split over two rows (XCDs)
+        add(2 + i, kern, "SQ_INSTS_VALU", v / 2, 770000 + 1000 * i)
+        add(2 + i, kern, "SQ_INSTS_VALU", v / 2, 770000 + 1000 * i)
+    add(9, "void at::native::fill(int)", "SQ_INSTS_VALU", 5.0, 3000)   # not one of ours
+    (d / "p_counter_collection.csv").write_text("\n".join(rows) + "\n")
+    res = mod.summarize([str(d)])
+    k = res["k_task<2, 2048>"]
+    assert k["launches_seen"] == 5 and k["launches_used"] == 4
+    assert abs(k["SQ_INSTS_VALU"] - 262.1e6) < 1e3 and abs(k["SQ_INSTS_VALU__mean"] - 262.1e6) < 1e3
+    assert list(res) == ["k_task<2, 2048>"]

@@ -122,6 +122,7 @@ struct spada_ctx {
     // the end of every run, where nobody waits for it (the last run's set stays as it is: the numeric call reads its task count)
     int ctr_idx = 0;
     uint32_t scatter_wgs = 8;         // workgroups of k_big_scatter per CU (SPADA_SCATTER_WGS: measurements)
+    bool expect_no_spill = false;     // ... spilled no row: k_big_scatter is left out (k_cut3 stops the run if the plan spills one after all)
     bool expect_no_big = false;       // the last pipeline run of this context found no BIG row (the next one does not launch their kernels)
     int side_mode = 2;                // (SPADA_SIDE: 0 no side streams, 1 scatter and cut table on one, 2 on one each -- measurements)
     bool shadow = true;               // (SPADA_SHADOW=0: the clearing at the head of every run instead of behind the one before -- measurements)
@@ -467,6 +468,7 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
         // drain -- together a tenth of a step of the mesh inputs -- to find an empty list).  The guess is checked at the end of the run:
         // if the row classes did find BIG rows, the run is thrown away and repeated with the kernels (never twice in a row)
         const bool no_big = c->expect_no_big;
+        bool scatter_launched = false;
         if (n && !no_big) {
             uint32_t *seq = c->accumulator == SPADA_ACC_SORT_MERGE ? c->t_scrseq.as<uint32_t>() : (uint32_t *)nullptr;
             hipLaunchKernelGGL(k_big_parts, dim3(c->n_cu * 2), dim3(256), 0, s, a->ptr, c->elen.as<uint32_t>(), c->r0,
@@ -500,7 +502,10 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
             if (side2 || side3) HIP_TRY(hipEventRecord(c->ev_fork, s));
             if (side2) HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
             if (side3) HIP_TRY(hipStreamWaitEvent(c->stream3, c->ev_fork, 0));
-            hipLaunchKernelGGL(k_big_scatter, dim3(c->n_cu * c->scatter_wgs), dim3(TK_BLOCK), BX_WALK_LDS, side2 ? c->stream2 : s, a->val, b->idx, b->val,
+            // (left out when the run before on this context spilled no row: guarded by k_cut3, verified at the end of the run)
+            scatter_launched = !c->expect_no_spill;
+            if (scatter_launched)
+    hipLaunchKernelGGL(k_big_scatter, dim3(c->n_cu * c->scatter_wgs), dim3(TK_BLOCK), BX_WALK_LDS, side2 ? c->stream2 : s, a->val, b->idx, b->val,
                                c->eb0.as<uint64_t>(), c->elen.as<uint32_t>(), c->t_big.as<uint32_t>(), c->row_kmin.as<uint32_t>(),
                                c->row_kmax.as<uint32_t>(), c->t_parts.as<BigPart>(), c->t_parthist.as<uint32_t>(),
                                c->t_slots.as<BigSlot>(), c->t_scrcol.as<uint32_t>(), c->t_scrval.as<double>(), seq, dc);
@@ -529,7 +534,7 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
             hipLaunchKernelGGL(k_cut3, dim3(ntiles, cut_sub), dim3(256), 0, s, c->row_bin.as<uint8_t>(), c->t_rowt.as<uint32_t>(),
                                c->row_binfo.as<uint32_t>(), a->ptr, c->r0, c->t_rowtmp.as<uint32_t>(), n, c->t_tiles.as<uint32_t>(),
                                c->t_tmp.as<TaskDesc>(), c->t_tasks.as<TaskDesc>(), cap_tasks, fold ? 1u : 0u,
-                               c->t_tiles.as<uint32_t>() + ntiles + 2, c->t_legacy.as<uint32_t>(), c->t_status.as<unsigned long long>(), dc);
+                               c->t_tiles.as<uint32_t>() + ntiles + 2, c->t_legacy.as<uint32_t>(), c->t_status.as<unsigned long long>(), scatter_launched ? 1u : 0u, dc);
             HIP_TRY(hipGetLastError());
             if (c->join2) HIP_TRY(hipStreamWaitEvent(s, c->ev_join, 0));
             if (c->join3) HIP_TRY(hipStreamWaitEvent(s, c->ev_join3, 0));
@@ -601,6 +606,16 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
             items_most = std::max<uint64_t>(items_most, h.cut_arena[a2][1]);
         }
         c->last_cuts = cut_most;
+        if (h.abort_flag & 64u) {   // rows were spilled in a run without the scatter kernel (stopped before the task kernel): again, with it
+            c->expect_no_spill = false;
+            h.abort_flag &= ~64u;
+            if (!(h.abort_flag & ~2u)) {
+                trace(2, "  %u spilled rows in a run that expected none: running again with the scatter", h.n_spilled);
+                --attempt;
+                c->t_cap_tasks = std::max<uint64_t>(c->t_cap_tasks, (uint64_t)h.need_tasks + h.need_tasks / 16 + 1024);
+                continue;
+            }
+        }
         if (no_big && h.n_big != 0 && !(h.abort_flag & ~2u)) {   // the guess was wrong: nothing of this run may be kept
             c->expect_no_big = false;
             trace(2, "  %u BIG rows in a run that expected none: running again with the BIG-row kernels", h.n_big);
@@ -609,6 +624,7 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
             continue;
         }
         c->expect_no_big = h.n_big == 0 && !h.abort_flag;
+        c->expect_no_spill = h.n_spilled == 0 && !h.abort_flag;
         if (!h.abort_flag) break;
         if (attempt == 3) return fail(SPADA_ERR_HIP, "task pipeline: workspaces still too small after three retries (flag %u)", h.abort_flag);
         if (h.abort_flag & 4u) return fail(SPADA_ERR_UNSUPPORTED, "a row of C has 2^32 or more products");

@@ -1354,10 +1354,13 @@ __global__ __launch_bounds__(256) void k_cut3(const uint8_t *__restrict__ row_cl
                                               TaskDesc *__restrict__ tasks, uint32_t task_cap, uint32_t fold /* no k_cut2 has run */,
                                               uint32_t *__restrict__ tile_first, uint32_t *__restrict__ legacy,
                                               unsigned long long *__restrict__ status /* the chain's status words: cleared with the task they belong to */,
-                                              TaskCounters *__restrict__ ctr)
+                                              uint32_t scatter_launched, TaskCounters *__restrict__ ctr)
 {
     __shared__ CutLds L;
     const bool lead_wg = blockIdx.y == 0;
+    // (the engine leaves k_big_scatter out when the context's previous run spilled no row; should the plan of THIS run have spilled some,
+    // the run is stopped here -- flag 64: the task kernel returns at once -- before any task can walk a scratch slice nobody filled)
+    if (!scatter_launched && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && ctr->n_spilled != 0) atomicOr(&ctr->abort_flag, 64u);
     // first task of the tile.  Up to CUT_FOLD_TILES tiles every workgroup adds up the counts of the tiles before its own itself (a
     // few KB of L2-resident words) and the one-workgroup scan kernel between k_cut1 and k_cut3 is not launched: one launch and its
     // gap less on the critical path of every call (~7 us; what matters once a GPU holds an eighth of the rows).  tile_first keeps the

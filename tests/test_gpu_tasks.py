@@ -551,3 +551,28 @@ def test_one_context_across_row_blocks_matrices_and_failed_calls():
                 assert_parity(c2, ref, to_oracle(m), to_oracle(m), RTOL)
     finally:
         eng.close()
+
+
+def test_a_run_that_expected_no_spilled_rows_is_stopped_and_repeated():
+    """The scatter kernel is left out when the context's previous run spilled no row; k_cut3 stops a run whose plan spills rows after
+    all (before any task can read an unfilled scratch slice) and the engine repeats it with the scatter."""
+    import spada_sim_amd as S
+    mild = S.generate(S.GEN_COP20K_LIKE, 20000, 0, 5)       # BIG rows, none spilled
+    hubs = S.generate(S.GEN_RMAT, 14, 16, 4)                # hub rows: spilled
+    eng = S.Engine()
+    try:
+        c0, st0 = fused(eng, mild, mild)
+        assert st0["spill_rows"] == 0
+        assert_parity(c0, oracle.spgemm_sortmerge(to_oracle(mild), to_oracle(mild)), to_oracle(mild), to_oracle(mild), RTOL)
+        c0b, st0b = fused(eng, mild, mild)                   # (this run leaves the scatter out)
+        assert np.array_equal(c0b.indices, c0.indices) and st0b["pipeline_runs"] == 1
+        ref = oracle.spgemm_sortmerge(to_oracle(hubs), to_oracle(hubs))
+        c1, st1 = fused(eng, hubs, hubs)
+        assert st1["spill_rows"] > 0 and st1["pipeline_runs"] >= 2
+        assert_parity(c1, ref, to_oracle(hubs), to_oracle(hubs), RTOL)
+        c2 = eng.spgemm(mild, mild)                          # two-phase, back on the input without spilled rows ...
+        assert np.array_equal(c2.indices, c0.indices)
+        c3 = eng.spgemm(hubs, hubs)                          # ... and the hubs again through the two-phase contract
+        assert_parity(c3, ref, to_oracle(hubs), to_oracle(hubs), RTOL)
+    finally:
+        eng.close()

@@ -536,7 +536,10 @@ def main():
                 {"kernel": "k_task<NUMERIC> (expand - scale - accumulate - order at the known positions)", "ms": ms["ms_numeric_call"],
                  "products": nprod_total if world == 1 else st["nprod"], "tasks": st.get("n_tasks")}]
         else:
-            kernels += [{"kernel": "k_task (expand - scale - accumulate - order, all rows)", "ms": ms["ms_task"],
+            inside_two = ms.get("ms_symbolic_call", 0.0) > 0   # the engine ran its count + numeric pipeline inside the one-pass entry point
+            kernels += [{"kernel": "k_task<COUNT> + k_task<NUMERIC> (the engine measured both pipelines on this input and runs the two-phase one "
+                                   "inside spada_dev_spgemm_fused: no chain)" if inside_two else
+                                   "k_task (expand - scale - accumulate - order, all rows)", "ms": ms["ms_task"],
                          "products": nprod_total if world == 1 else st["nprod"], "tasks": st.get("n_tasks")}]
         out = {
             "metric": "nnz(C)/sec on A*A SpGEMM",
@@ -573,7 +576,9 @@ def main():
                        "nnz_c": nnz_total, "accumulator": args.accumulator,
                        "entry_point": ("spada_dist_spgemm_symbolic + spada_dist_spgemm_numeric (libspada_comm.so: two-phase, numeric phase in "
                                        f"{args.exchange_chunks} pieces overlapped with their broadcast)") if exchange == "overlap" else
-                                      "spada_dev_spgemm_fused (one pass, C buffers sized by the product count)"
+                                      ("spada_dev_spgemm_fused (C buffers sized by the product count; the engine runs one pass or -- where it measured "
+                                       "that faster on this input -- count + numeric inside the call: " +
+                                       ("count + numeric" if ms.get("ms_symbolic_call", 0.0) > 0 and ms.get("ms_fused_call", 0.0) > 0 else "one pass") + ")")
                                       if one_pass
                                       else "spada_dev_spgemm_symbolic + spada_dev_spgemm_numeric",
                        # the headline runs on the additive one-pass entry point; the contract of SURVEY 8(b) is symbolic + numeric

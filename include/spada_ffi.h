@@ -98,7 +98,7 @@ typedef struct spada_stats {
     /* HIP-event times on the engine stream, milliseconds */
     double ms_symbolic_call;  /* whole spada_dev_spgemm_symbolic call (row statistics ... counting task kernel) */
     double ms_numeric_call;   /* whole spada_dev_spgemm_numeric call */
-    double ms_fused_call;     /* whole one-pass call (spada_dev_spgemm_fused) */
+    double ms_fused_call;     /* whole spada_dev_spgemm_fused call (with ms_symbolic_call > 0: its count + numeric pipeline ran, ms_task = both task kernels) */
     double ms_row_stats;      /* B-row descriptors, products per row, row classes */
     double ms_big_expand;     /* BIG rows, the kernels on the engine stream: parts, column histograms, ranges (and the scatter of the spilled rows /
                                  the cut table of the direct rows when they are not forked to the side streams) */
@@ -183,7 +183,11 @@ int spada_dev_synchronize(spada_ctx *ctx);
  * C.indptr, the first *nnz_c entries of indices / data, and *nnz_c.  SPADA_ERR_CAPACITY when capacity < nnz(C): indptr and
  * *nnz_c are complete, indices / data are not; allocate *nnz_c entries and call spada_dev_spgemm_numeric (the context then
  * holds the state of a finished symbolic phase).  Replaces Simulator::execute + get_exec_result in one call
- * (simulator.rs:509-890, :1034-1062). */
+ * (simulator.rs:509-890, :1034-1062).
+ * Inside, the engine runs either its one-pass pipeline (row counts exchanged between the tasks while the rows are computed) or
+ * count + positions + numeric into the same buffers: on an input whose products lie mostly in rows too large for one task it
+ * measures both -- first call one pass, second call two phases -- and stays with the faster (spada_stats: ms_symbolic_call > 0
+ * next to ms_fused_call says the two-phase pipeline ran; SPADA_AUTO=0 in the environment: always one pass).  C is the same. */
 int spada_dev_spgemm_fused(spada_ctx *ctx, const spada_dev_csr *a, const spada_dev_csr *b, uint64_t row_begin,
                            uint64_t row_end, void *d_c_indptr, void *d_c_indices, void *d_c_data, uint64_t capacity,
                            uint64_t *nnz_c);

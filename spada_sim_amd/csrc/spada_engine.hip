@@ -122,6 +122,11 @@ struct spada_ctx {
     // the end of every run, where nobody waits for it (the last run's set stays as it is: the numeric call reads its task count)
     int ctr_idx = 0;
     uint32_t scatter_wgs = 8;         // workgroups of k_big_scatter per CU (SPADA_SCATTER_WGS: measurements)
+    // one pass or two phases inside spada_dev_spgemm_fused: measured per input (spada_dev_spgemm_fused; SPADA_AUTO=0: always one pass)
+    bool auto_pipeline = true, at_two = false;
+    int at_phase = 0;
+    uint64_t at_sig = 0;
+    double at_ms_fused = 0;
     bool expect_no_spill = false;     // ... spilled no row: k_big_scatter is left out (k_cut3 stops the run if the plan spills one after all)
     bool expect_no_big = false;       // the last pipeline run of this context found no BIG row (the next one does not launch their kernels)
     int side_mode = 2;                // (SPADA_SIDE: 0 no side streams, 1 scatter and cut table on one, 2 on one each -- measurements)
@@ -797,6 +802,7 @@ int spada_create(const spada_options *opts, spada_ctx **out)
     c->scanner_ok = -1;   // (the one-pass kernel of the other accumulator has its own occupancy)
     if (const char *e = getenv("SPADA_SCATTER_WGS")) c->scatter_wgs = (uint32_t)std::max(atoi(e), 1);
     if (const char *e = getenv("SPADA_SIDE")) c->side_mode = atoi(e);
+    if (const char *e = getenv("SPADA_AUTO")) c->auto_pipeline = atoi(e) != 0;
     if (const char *e = getenv("SPADA_EXPORT")) c->export_poll = atoi(e) != 0;
     if (const char *e = getenv("SPADA_SHADOW")) c->shadow = atoi(e) != 0;
     if (const char *e = getenv("SPADA_TASK_WGS")) c->task_wgs = (uint32_t)std::min(std::max(atoi(e), 1), TASK_WAVES / 2);
@@ -1129,6 +1135,42 @@ int spada_dev_spgemm_fused(spada_ctx *c, const spada_dev_csr *a, const spada_dev
     c->nrows = (uint32_t)(row_end - row_begin);
     c->nnz_c = 0;
     std::memset(&c->stats, 0, sizeof c->stats);
+    // WHICH PIPELINE.  The one-pass pipeline (counts exchanged through the chain while the rows are computed) wins where the tasks are
+    // alike -- web graphs, meshes: 1.0 against 1.4 ms on the web input -- and loses where many range tasks take the older path inside the
+    // task kernel and a thousand tasks of the chain wait for each of them: R-MAT 16 6.2 against 5.7 ms, R-MAT 18 50 against 43 ms for
+    // count + positions + numeric.  So a context MEASURES: the first call on an input (operands, row range) whose products are mostly
+    // in BIG rows runs one pass, the second the two-phase pipeline into the same caller buffers, and from the third on the faster of
+    // the two runs.  The result is the same either way; spada_stats says what ran (ms_symbolic_call > 0 next to ms_fused_call).
+    const uint64_t sig = (uint64_t)(uintptr_t)a * 0x9E3779B97F4A7C15ull ^ (uint64_t)(uintptr_t)b * 0xC2B2AE3D27D4EB4Full ^ row_begin * 0x165667B19E3779F9ull ^
+                         row_end * 0x27D4EB2F165667C5ull ^ a->nnz ^ (b->nnz << 20);
+    if (sig != c->at_sig) {
+        c->at_sig = sig;
+        c->at_phase = 0;
+    }
+    const bool two = c->auto_pipeline && (c->at_phase == 1 || (c->at_phase == 2 && c->at_two));
+    if (two) {
+        int rc2 = task_pipeline(c, MODE_COUNT, nullptr, nullptr, nullptr, 0);
+        if (rc2) return rc2;
+        *nnz_c = c->nnz_c;
+        if (c->nnz_c > capacity) {
+            HIP_TRY(hipMemcpyAsync(d_c_indptr, c->cptr.p, ((size_t)c->nrows + 1) * 8, hipMemcpyDeviceToDevice, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            c->have_symbolic = true;
+            return fail(SPADA_ERR_CAPACITY, "nnz(C) = %llu exceeds the capacity of %llu entries", (unsigned long long)c->nnz_c,
+                        (unsigned long long)capacity);
+        }
+        const double ms_sym = c->stats.ms_symbolic_call, ms_count_task = c->stats.ms_task;
+        if ((rc2 = task_numeric(c, (uint64_t *)d_c_indptr, (uint32_t *)d_c_indices, (double *)d_c_data))) return rc2;
+        c->stats.ms_fused_call = ms_sym + c->stats.ms_numeric_call;
+        c->stats.ms_task = ms_count_task + c->stats.ms_numeric_call;   // (the two task kernels of the call)
+        if (c->at_phase == 1) {
+            c->at_two = c->stats.ms_fused_call < c->at_ms_fused;
+            c->at_phase = 2;
+            trace(1, "one pass %.3f ms, two-phase pipeline %.3f ms on this input: %s from here on", c->at_ms_fused, c->stats.ms_fused_call,
+                  c->at_two ? "two phases" : "one pass");
+        }
+        return SPADA_OK;
+    }
     int rc = task_pipeline(c, MODE_FUSED, (uint64_t *)d_c_indptr, (uint32_t *)d_c_indices, (double *)d_c_data, capacity);
     if (rc) return rc;
     *nnz_c = c->nnz_c;
@@ -1139,6 +1181,11 @@ int spada_dev_spgemm_fused(spada_ctx *c, const spada_dev_csr *a, const spada_dev
         c->have_symbolic = true;    // task list, scratch and range offsets are those of a finished symbolic phase
         return fail(SPADA_ERR_CAPACITY, "nnz(C) = %llu exceeds the capacity of %llu entries", (unsigned long long)c->nnz_c,
                     (unsigned long long)capacity);
+    }
+    if (c->at_phase == 0) {   // (a candidate for the comparison only if most products lie in BIG rows: the others stay with one pass)
+        c->at_ms_fused = c->stats.ms_fused_call;
+        c->at_two = false;
+        c->at_phase = c->auto_pipeline && c->stats.cls_prod[CLS_BIG] * 2 > c->stats.nprod ? 1 : 2;
     }
     return SPADA_OK;
 }

@@ -233,8 +233,14 @@ def test_workspace_growth_reruns(engine):
         a = to_oracle(m)
         assert_parity(c, oracle.spgemm_spa(a, a), a, a, RTOL)
         assert st["pipeline_runs"] in (1, 2, 3)
-        c, st = fused(eng, m, m)
-        assert st["pipeline_runs"] == 1
+        # (the second call on an input of BIG rows may run the engine's other pipeline for the first time -- count + numeric inside the
+        # one-pass entry point -- whose cut tables and task list can want room once more; from then on nothing grows)
+        runs = []
+        for _ in range(3):
+            c, st = fused(eng, m, m)
+            runs.append(st["pipeline_runs"])
+        assert runs[-1] == 1 and max(runs) <= 3
+        assert_parity(c, oracle.spgemm_spa(a, a), a, a, RTOL)
     finally:
         eng.close()
 
@@ -574,5 +580,42 @@ def test_a_run_that_expected_no_spilled_rows_is_stopped_and_repeated():
         assert np.array_equal(c2.indices, c0.indices)
         c3 = eng.spgemm(hubs, hubs)                          # ... and the hubs again through the two-phase contract
         assert_parity(c3, ref, to_oracle(hubs), to_oracle(hubs), RTOL)
+    finally:
+        eng.close()
+
+
+def test_one_pass_entry_point_measures_both_pipelines_on_big_row_inputs():
+    """spada_dev_spgemm_fused on an input whose products lie mostly in BIG rows: the first call runs one pass, the second the count +
+    numeric pipeline into the same caller buffers (stats: ms_symbolic_call > 0 next to ms_fused_call), later calls the faster of the
+    two; every call returns the oracle's product.  Inputs without that profile never leave the one-pass pipeline."""
+    import spada_sim_amd as S
+    hubs = S.generate(S.GEN_RMAT, 13, 16, 11)
+    flat = S.generate(S.GEN_UNIFORM, 4000, 5, 3)
+    eng = S.Engine()
+    try:
+        ref = oracle.spgemm_sortmerge(to_oracle(hubs), to_oracle(hubs))
+        d = eng.upload(hubs)
+        cap = S.count_products(hubs, hubs, 0, hubs.shape[0])
+        seen_two = 0
+        for call in range(4):
+            p, i, v, nnz = eng.fused_owned(d, d, 0, hubs.shape[0], cap)
+            st = eng.stats()
+            assert st["ms_fused_call"] > 0 and st["ms_fused_call"] >= st["ms_task"] > 0
+            if call == 0:
+                assert st["cls_prod"][4] * 2 > st["nprod"] and st["ms_symbolic_call"] == 0
+            if call == 1:
+                assert st["ms_symbolic_call"] > 0
+            seen_two += st["ms_symbolic_call"] > 0
+            c = eng.download(p, i, v, hubs.shape[0], nnz, hubs.shape[1])
+            assert_parity(c, ref, to_oracle(hubs), to_oracle(hubs), RTOL)
+        assert seen_two >= 1
+        with pytest.raises(S.SpadaError):                    # capacity too small, whichever pipeline runs by now
+            eng.fused_owned(d, d, 0, hubs.shape[0], max(ref.nnz // 3, 1))
+        eng.free(d)
+        d2 = eng.upload(flat)
+        for call in range(3):
+            eng.fused_owned(d2, d2, 0, flat.shape[0], S.count_products(flat, flat, 0, flat.shape[0]))
+            assert eng.stats()["ms_symbolic_call"] == 0
+        eng.free(d2)
     finally:
         eng.close()

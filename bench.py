@@ -118,6 +118,11 @@ def main():
                          "plain one-pass result and exit (the code path the driver's multi-GPU runs take, on the one GPU a builder has)")
     ap.add_argument("--chunk-one-pass", action="store_true",
                     help="chunked steps (R-MAT 22) through spada_dev_spgemm_fused with reused buffers instead of symbolic + numeric")
+    ap.add_argument("--chunk-consumer", choices=("none", "checksum"), default="none",
+                    help="chunked steps: what reads a finished chunk of C before it is dropped -- nothing (default: the engine's calls alone, "
+                         "as for the workloads whose C fits: nobody reads C there either) or a torch reduction over its values inside the "
+                         "timed step (rounds 2 - 4 and profiles/r05_bench_rmat22_1gpu_checksum.json: 8 bytes per output read once more, and "
+                         "the engine's own scatter phase runs 0.15 - 0.25 s per step slower behind it)")
     ap.add_argument("--chunk-products", type=float, default=0,
                     help="stream C in A-row chunks of about this many products (0 = automatic: chunk when the product "
                          "count of a rank exceeds 3e9, i.e. when C would not fit next to the inputs)")
@@ -160,7 +165,7 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     # chunked mode (R-MAT scale 22): the rank's row block is cut into product-balanced row chunks whose C is produced,
-    # checksummed and dropped one after the other; nothing is gathered (C of the whole job would not fit one GPU)
+    # dropped (or first read by a checksum: --chunk-consumer) one after the other; nothing is gathered (C of the whole job would not fit one GPU)
     my_products = S.count_products(a, a, r0, r1)
     chunk_products = args.chunk_products or (2.0 ** 31 if my_products > 3e9 else 0)
     chunk_bounds = None
@@ -256,10 +261,13 @@ def main():
                 return bufs["p"].data_ptr(), bufs["i"].data_ptr(), bufs["v"].data_ptr()
 
             def consume(b0, b1, nnz, st):
-                checksum.add_(bufs["v"][:nnz].sum())
-                # the sum runs on torch's stream, the next chunk is written by the engine's own (non-blocking) stream: it must
-                # have read the buffer before the buffer is dropped and its memory handed to the next chunk
-                torch.cuda.current_stream().synchronize()
+                if args.chunk_consumer == "checksum":
+                    checksum.add_(bufs["v"][:nnz].sum())
+                    # the sum runs on torch's stream, the next chunk is written by the engine's own (non-blocking) stream: it must
+                    # have read the buffer before the buffer is dropped and its memory handed to the next chunk
+                    # (letting the sum of chunk k run NEXT to the engine's work on chunk k + 1 instead was measured in round 5:
+                    # 3.12 s per step of R-MAT 22 against 2.98 s -- the reduction takes the scatter's HBM bandwidth; the wait stays)
+                    torch.cuda.current_stream().synchronize()
                 for k in ("c_nnz", "nprod", "bytes_read", "bytes_write"):
                     agg[k] += st[k]
                 for k, v in st.items():
@@ -587,7 +595,9 @@ def main():
                                                 "-- spada_dev_spgemm_symbolic + _numeric -- is what --two-phase times") if one_pass and exchange != "overlap"
                                                else "two-phase contract of SURVEY 8(b): symbolic + numeric",
                        "parallelism": f"row-block x{world}, B replicated" +
-                                      (f", C streamed in {len(chunk_bounds) - 1} row chunks per rank and not gathered"
+                                      (f", C streamed in {len(chunk_bounds) - 1} row chunks per rank and not gathered; every finished chunk "
+                                       + ("read once by a checksum of its values inside the timed step (--chunk-consumer)"
+                                          if args.chunk_consumer == "checksum" else "dropped unread (--chunk-consumer none)")
                                        if chunk_bounds is not None else (", allgatherv of C" if world > 1 else ""))},
             "roofline": {
                 "bound": "hbm",

@@ -121,6 +121,7 @@ struct spada_ctx {
     // The device counters exist twice.  A pipeline run finds its set cleared: the set of the run BEFORE the last one is cleared behind
     // the end of every run, where nobody waits for it (the last run's set stays as it is: the numeric call reads its task count)
     int ctr_idx = 0;
+    bool range_cursors = true;        // the scatter appends per (part, range), not per (part, bucket) (SPADA_RANGE_CURSORS=0: measurements)
     uint32_t scatter_wgs = 8;         // workgroups of k_big_scatter per CU (SPADA_SCATTER_WGS: measurements)
     // one pass or two phases inside spada_dev_spgemm_fused: measured per input (spada_dev_spgemm_fused; SPADA_AUTO=0: always one pass)
     bool auto_pipeline = true, at_two = false;
@@ -299,6 +300,9 @@ void launch_task(spada_ctx *c, const TaskArgs &g)
         hipLaunchKernelGGL((k_task<MODE, TK_NOUT>), dim3(c->n_cu * c->task_wgs), dim3(TKW), task_kernel_lds(), c->stream,
                            (const TaskArgs *)c->t_args.as<TaskArgs>());
         // the modes without a chain: the tasks of the older range path in their own kernel (256-thread workgroups)
+        // (NEXT to the first kernel on a side stream instead of behind it -- separate tickets, nothing shared: R-MAT 22 chunks and the
+        // two-phase R-MAT 16 / 18 within +-1 %, profiles/r05_experiments.txt section 21: the first kernel holds all the LDS of every
+        // CU while it has tasks, so only its tail could overlap, and that tail is short)
         if constexpr (MODE != MODE_FUSED)
             hipLaunchKernelGGL((k_task_range<MODE, TK_NOUT>), dim3(c->n_cu * 4), dim3(TK_BLOCK), task_lds(), c->stream,
                                (const TaskArgs *)c->t_args.as<TaskArgs>());
@@ -489,7 +493,7 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
                                c->t_parthist.as<uint32_t>(), c->t_rowm.as<uint32_t>(), c->t_rowtmp.as<uint32_t>(),
                                c->t_tmp.as<TaskDesc>(), cap_tmp, c->t_slots.as<BigSlot>(), c->t_cap_scr, c->cut_table ? c->t_cap_cuts : 0ull,
                                mode == MODE_FUSED ? c->cut_factor16 : 16u * (uint32_t)BX_DIRECT_FACTOR,
-                               c->t_cutitems.as<uint2>(), cap_cut_items, dc);
+                               c->t_cutitems.as<uint2>(), cap_cut_items, c->range_cursors ? 1u : 0u, dc);
             // the scatter of the spilled rows and the cut table of the direct rows run NEXT to the cut (side streams): the cut needs the
             // range descriptors k_big_plan wrote -- not the scratch, not the cuts; the task kernel waits for all three.  Each fork is
             // taken only if the previous run of this context had work for it (a fork / join pair costs ~10 us and hides nothing when
@@ -801,6 +805,7 @@ int spada_create(const spada_options *opts, spada_ctx **out)
     c->accumulator = o.accumulator;
     c->scanner_ok = -1;   // (the one-pass kernel of the other accumulator has its own occupancy)
     if (const char *e = getenv("SPADA_SCATTER_WGS")) c->scatter_wgs = (uint32_t)std::max(atoi(e), 1);
+    if (const char *e = getenv("SPADA_RANGE_CURSORS")) c->range_cursors = atoi(e) != 0;
     if (const char *e = getenv("SPADA_SIDE")) c->side_mode = atoi(e);
     if (const char *e = getenv("SPADA_AUTO")) c->auto_pipeline = atoi(e) != 0;
     if (const char *e = getenv("SPADA_EXPORT")) c->export_poll = atoi(e) != 0;

@@ -338,6 +338,7 @@ __global__ __launch_bounds__(256) void k_row_class(const uint64_t *__restrict__ 
 constexpr uint32_t LB_PAUSE_MAX = 2;   // a task polls its status word with a pause that grows by this many steps (0 .. 12: within 1 %)
 constexpr uint32_t BX_PART = 8192;   // products per part of a BIG row (4 K / 16 K / 32 K: within 3 % on web and R-MAT 16 / 18)
 constexpr uint32_t BX_NOPART = 0xFFFFFFFFu;
+constexpr uint32_t BX_MARK = 0x80000000u;   // a cursor word of k_big_plan that names the bucket holding the cursor instead (k_big_scatter)
 constexpr uint32_t BX_RUN = 8;   // consecutive part records per workgroup (k_big_scatter)
 struct BigPart {
     uint32_t slot;      // position of the row in big_rows; BX_NOPART: sentinel / unused record
@@ -593,7 +594,8 @@ __global__ __launch_bounds__(TK_BLOCK) void k_big_plan(const uint64_t *__restric
                                                        uint32_t *__restrict__ part_hist, uint32_t *__restrict__ row_m,
                                                        const uint32_t *__restrict__ row_tmp, TaskDesc *__restrict__ tmp, uint32_t tmp_cap,
                                                        BigSlot *__restrict__ slots, uint64_t scr_cap, uint64_t cut_cap, uint32_t cut_factor16,
-                                                       uint2 *__restrict__ cut_items, uint64_t cut_item_cap, TaskCounters *__restrict__ ctr)
+                                                       uint2 *__restrict__ cut_items, uint64_t cut_item_cap, uint32_t range_cursors,
+                                                       TaskCounters *__restrict__ ctr)
 {
     const uint32_t lim = ctr->prod_limit;
     constexpr int NB = BX_NB, BPT = NB / TK_BLOCK;
@@ -783,7 +785,8 @@ __global__ __launch_bounds__(TK_BLOCK) void k_big_plan(const uint64_t *__restric
             row_m[row] = m;
             slots[slot].scr_base = sb;
             slots[slot].cut_base = cb;
-            slots[slot].ok = ok ? 1u : 0u;
+            // (bit 1: ONE cursor per (part, range) -- see the cursors below; their top bit is the mark, so not for a row of 2^31 products)
+            slots[slot].ok = ok ? (range_cursors && P < 0x80000000ull ? 3u : 1u) : 0u;
             slots[slot].direct = direct ? 1u : 0u;
             if (!direct) atomicAdd(&ctr->n_spilled, 1u);
         }
@@ -826,7 +829,8 @@ __global__ __launch_bounds__(TK_BLOCK) void k_big_plan(const uint64_t *__restric
         }
         if (ok && !direct) {
             // spilled: the counts of every part become its cursors.  Layout of the row's slice: RANGE major (a range task reads one
-            // contiguous slice), inside a range PART major, inside (range, part) by bucket -- the products a part sends to a range
+            // contiguous slice), inside a range PART major, inside (range, part) in the order the scatter's waves arrive (by bucket
+            // when the row keeps a cursor per bucket: `marks` below) -- the products a part sends to a range
             // form ONE run, and the runs of consecutive parts (which one workgroup of k_big_scatter writes one after the other) are
             // neighbours: a hub row with 10^6 products has ~500 ranges but 1024 buckets, so the runs are twice as long as
             // with one run per (bucket, part)
@@ -849,6 +853,10 @@ __global__ __launch_bounds__(TK_BLOCK) void k_big_plan(const uint64_t *__restric
                 if (r < NR) base[r] = pre[rfirst[r]];
             }
             __syncthreads();   // (pre is read above; from here on it is the second buffer of the loop)
+            // One cursor per (part, RANGE), kept at the range's first bucket; the other buckets of the range hold a mark and the number
+            // of that bucket.  Nothing reads a run bucket by bucket, and a workgroup of the scatter that appends to ~P / lim runs
+            // instead of up to 1024 keeps that many fewer half-written lines open in its L2.
+            const bool marks = range_cursors && pre[NB] < 0x80000000u;
             for (uint32_t k = 0; k < pc; ++k) {
                 if (parts[pb + k].slot == BX_NOPART) break;
                 // e[b] = products of the part before bucket b (k_big_hist), e[NB] = all of them: in LDS for the reads at the range
@@ -867,6 +875,12 @@ __global__ __launch_bounds__(TK_BLOCK) void k_big_plan(const uint64_t *__restric
                 c.y = base[rng[1]] + h.y - e[rf[1]];
                 c.z = base[rng[2]] + h.z - e[rf[2]];
                 c.w = base[rng[3]] + h.w - e[rf[3]];
+                if (marks) {
+                    if (rf[0] != (uint32_t)tid * 4u + 0u) c.x = BX_MARK | rf[0];
+                    if (rf[1] != (uint32_t)tid * 4u + 1u) c.y = BX_MARK | rf[1];
+                    if (rf[2] != (uint32_t)tid * 4u + 2u) c.z = BX_MARK | rf[2];
+                    if (rf[3] != (uint32_t)tid * 4u + 3u) c.w = BX_MARK | rf[3];
+                }
                 *hp = c;
                 __syncthreads();
 #pragma unroll
@@ -974,11 +988,16 @@ __global__ __launch_bounds__(TK_BLOCK) void k_big_scatter(const double *__restri
         }
         __syncthreads();
         const uint64_t sb = sl.scr_base;
+        const bool marks = (sl.ok & 2u) != 0;
         flat_walk<TK_BLOCK, TK_EPT, 1, true, U>(s_re, s_a0, 1u, e_count, eb0, elen, aval, bidx, bval, scratch, hdr,
                                                 [&](uint32_t(&col)[U], uint32_t(&plr)[U], double(&v)[U], uint32_t(&pp)[U]) {
 #pragma unroll
                                                     for (int u = 0; u < U; ++u) {
-                                                        const uint32_t bk = plr[u] != LR_NONE ? (col[u] - kmin) >> wshift : 0xFFFFFFFFu;
+                                                        uint32_t bk = plr[u] != LR_NONE ? (col[u] - kmin) >> wshift : 0xFFFFFFFFu;
+                                                        if (marks && bk != 0xFFFFFFFFu) {   // (the marks never change; a cursor stays below 2^31)
+                                                            const uint32_t x = cur[bk];
+                                                            if (x & BX_MARK) bk = x & (uint32_t)(NB - 1);
+                                                        }
                                                         bool head;
                                                         uint32_t len, hl;
                                                         const bool runs = wave_runs(bk, head, len, hl);
@@ -990,7 +1009,11 @@ __global__ __launch_bounds__(TK_BLOCK) void k_big_scatter(const double *__restri
                                                         if (head && bk != 0xFFFFFFFFu) pbase = atomicAdd(&cur[bk], len);
                                                         if (runs) pbase = (uint32_t)__shfl((int)pbase, (int)hl);
                                                         if (plr[u] != LR_NONE) {
+#ifdef SPADA_SCATTER_SEQ   // measurement build only (scripts/dev/scatter_seq.sh): the stores in walk order -- coalesced, and wrong
+                                                            const uint32_t p = pt.p_begin + pp[u] + 0u * pbase;
+#else
                                                             const uint32_t p = pbase + ((threadIdx.x & 63) - hl);
+#endif
                                                             // (plain stores: the runs of a range are completed in the caches;
                                                             // non-temporal ones made the stage 1.4 - 2 x slower)
                                                             scr_col[sb + p] = col[u];
@@ -1001,6 +1024,9 @@ __global__ __launch_bounds__(TK_BLOCK) void k_big_scatter(const double *__restri
                                                 });
         __syncthreads();
     }
+#ifdef SPADA_SCATTER_SEQ
+    if (threadIdx.x == 0 && blockIdx.x == 0) atomicOr((uint32_t *)&ctr->abort_flag, 128u);   // nothing may read this scratch
+#endif
 }
 
 // ---- 3. the cut: rows -> tasks in output order ---------------------------------------------------------------------------

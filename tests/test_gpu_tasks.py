@@ -471,6 +471,38 @@ def test_cut_table_switch_gives_the_same_product():
             os.environ["SPADA_CUT_TABLE"] = old
 
 
+def test_scatter_cursor_layouts_give_the_same_product():
+    """Spilled rows: one scatter cursor per (part, range) (default: k_big_plan leaves marks in the other buckets of a range) and one per
+    (part, bucket) (SPADA_RANGE_CURSORS=0) give the same C, through both entry points and both accumulators (the sort-merge tasks
+    read the same scratch slices): R-MAT 14, whose hub rows are spilled."""
+    import os
+    import spada_sim_amd as S
+    m = S.generate(S.GEN_RMAT, 14, 16, 4)
+    a = to_oracle(m)
+    ref = oracle.spgemm_sortmerge(a, a)
+    old = os.environ.get("SPADA_RANGE_CURSORS")
+    try:
+        for flag in ("0", "1"):
+            os.environ["SPADA_RANGE_CURSORS"] = flag
+            for acc in (S.ACC_LDS_HASH, S.ACC_SORT_MERGE):
+                eng = S.Engine(accumulator=acc)
+                try:
+                    c = eng.spgemm(m, m)
+                    assert eng.stats()["spill_rows"] > 0
+                    assert_parity(c, ref, a, a, RTOL)
+                    if acc == S.ACC_LDS_HASH:
+                        c1, st = fused(eng, m, m)
+                        assert st["spill_rows"] > 0
+                        assert_parity(c1, ref, a, a, RTOL)
+                finally:
+                    eng.close()
+    finally:
+        if old is None:
+            os.environ.pop("SPADA_RANGE_CURSORS", None)
+        else:
+            os.environ["SPADA_RANGE_CURSORS"] = old
+
+
 @pytest.mark.parametrize("run", [6, 10, 11])
 def test_many_displaced_blocks_take_the_cluster_fix(engine, run):
     """Batches of ~90 short rows, each with two runs of `run` ADJACENT 32-column blocks and a far column that stretches the row's span

@@ -35,6 +35,15 @@ __device__ inline void group_sync()
     }
 }
 
+// Workgroup barrier that orders LDS accesses only: loads from and stores to global memory that are in flight stay in flight
+// (__syncthreads() is a fence over all address spaces and may wait for them).
+__device__ inline void lds_barrier()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 // Sum over the group.  `hdr` is a per-workgroup LDS word used when the group spans several waves.
 template <int G>
 __device__ inline uint32_t group_sum(uint32_t v, uint32_t *hdr)

@@ -338,6 +338,7 @@ __global__ __launch_bounds__(256) void k_row_class(const uint64_t *__restrict__ 
 constexpr uint32_t LB_PAUSE_MAX = 2;   // a task polls its status word with a pause that grows by this many steps (0 .. 12: within 1 %)
 constexpr uint32_t BX_PART = 8192;   // products per part of a BIG row (4 K / 16 K / 32 K: within 3 % on web and R-MAT 16 / 18)
 constexpr uint32_t BX_NOPART = 0xFFFFFFFFu;
+constexpr uint32_t PLAN_UNROLL = 4;   // part records of a row whose histograms k_big_plan has in flight together
 constexpr uint32_t BX_MARK = 0x80000000u;   // a cursor word of k_big_plan that names the bucket holding the cursor instead (k_big_scatter)
 constexpr uint32_t BX_RUN = 8;   // consecutive part records per workgroup (k_big_scatter)
 struct BigPart {
@@ -442,13 +443,21 @@ __global__ __launch_bounds__(256) void k_big_parts(const uint64_t *__restrict__ 
         if (!fits) continue;
         uint32_t carry = 0, nstart = 0;   // products / parts before this step
         uint32_t prev_win = 0xFFFFFFFFu;  // window of the entry before this step (none: the first entry starts a part)
+        uint32_t nlen[BP_EPL];   // the lengths of the step after this one: loaded a step ahead (a hub row is a hundred dependent steps of one wave)
+#pragma unroll
+        for (int i = 0; i < BP_EPL; ++i) nlen[i] = a0 + (uint64_t)lane * BP_EPL + i < a1 ? elen[a0 + (uint64_t)lane * BP_EPL + i] : 0u;
         for (uint64_t q0 = a0; q0 < a1; q0 += 64 * BP_EPL) {
             const uint64_t q = q0 + (uint64_t)lane * BP_EPL;
             uint32_t len[BP_EPL], sum = 0;
 #pragma unroll
             for (int i = 0; i < BP_EPL; ++i) {
-                len[i] = q + i < a1 ? elen[q + i] : 0u;
+                len[i] = nlen[i];
                 sum += len[i];
+            }
+            if (q0 + 64 * BP_EPL < a1) {
+                const uint64_t qn = q + 64 * BP_EPL;
+#pragma unroll
+                for (int i = 0; i < BP_EPL; ++i) nlen[i] = qn + i < a1 ? elen[qn + i] : 0u;
             }
             uint32_t inc = sum;
 #pragma unroll
@@ -614,22 +623,38 @@ __global__ __launch_bounds__(TK_BLOCK) void k_big_plan(const uint64_t *__restric
         const uint32_t row = big_rows[slot];
         const uint32_t kmin = row_kmin[row], kmax = row_kmax[row], wshift = big_wshift(kmin, kmax);
         const uint32_t pb = slots[slot].part_begin, pc = slots[slot].part_count;
+        uint32_t nreal = 0;   // parts of the row (uniform over the workgroup)
         {   // products of the row before every bucket = the sum of the parts' prefixes (k_big_hist); the bucket counts are its differences
+            // (a hub row of R-MAT 22 has 500 parts and ONE workgroup: the records are taken PLAN_UNROLL at a time, their loads in
+            // flight together -- a round trip per part made this loop, and the one over the cursors below, as long as the histogram
+            // kernel of the whole chunk)
             uint4 acc = make_uint4(0u, 0u, 0u, 0u);
-            uint32_t k = 0;
-            for (; k < pc; ++k) {
-                if (parts[pb + k].slot == BX_NOPART) break;   // (uniform; the records of a row are its parts, then sentinels)
-                const uint4 h = ((const uint4 *)(part_hist + (size_t)(pb + k) * NB))[tid];
-                acc.x += h.x;
-                acc.y += h.y;
-                acc.z += h.z;
-                acc.w += h.w;
+            bool done = false;
+            for (uint32_t k = 0; k < pc && !done; k += PLAN_UNROLL) {
+                uint32_t sl[PLAN_UNROLL];
+                uint4 h[PLAN_UNROLL];
+#pragma unroll
+                for (uint32_t i = 0; i < PLAN_UNROLL; ++i) sl[i] = k + i < pc ? parts[pb + k + i].slot : BX_NOPART;
+#pragma unroll
+                for (uint32_t i = 0; i < PLAN_UNROLL; ++i)   // (the records of the row exist up to pc; those behind its last part are read and dropped)
+                    h[i] = k + i < pc ? ((const uint4 *)(part_hist + (size_t)(pb + k + i) * NB))[tid] : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+                for (uint32_t i = 0; i < PLAN_UNROLL; ++i) {
+                    done = done || sl[i] == BX_NOPART;   // (uniform; the records of a row are its parts, then sentinels)
+                    if (!done) {
+                        acc.x += h[i].x;
+                        acc.y += h[i].y;
+                        acc.z += h[i].z;
+                        acc.w += h[i].w;
+                        ++nreal;
+                    }
+                }
             }
             pre[tid * 4 + 0] = acc.x;
             pre[tid * 4 + 1] = acc.y;
             pre[tid * 4 + 2] = acc.z;
             pre[tid * 4 + 3] = acc.w;
-            if (tid == 0) pre[NB] = parts[pb + k].p_begin;   // (the record behind the last part: products before it = all of the row)
+            if (tid == 0) pre[NB] = parts[pb + nreal].p_begin;   // (the record behind the last part: products before it = all of the row)
         }
         __syncthreads();
 #pragma unroll
@@ -857,19 +882,30 @@ __global__ __launch_bounds__(TK_BLOCK) void k_big_plan(const uint64_t *__restric
             // of that bucket.  Nothing reads a run bucket by bucket, and a workgroup of the scatter that appends to ~P / lim runs
             // instead of up to 1024 keeps that many fewer half-written lines open in its L2.
             const bool marks = range_cursors && pre[NB] < 0x80000000u;
-            for (uint32_t k = 0; k < pc; ++k) {
-                if (parts[pb + k].slot == BX_NOPART) break;
+            // (the next part's counts are loaded while this one's cursors are formed; the barriers order LDS only: lds_barrier)
+            uint4 hn = make_uint4(0u, 0u, 0u, 0u);
+            uint32_t dn = 0;
+            if (nreal) {
+                hn = ((const uint4 *)(part_hist + (size_t)pb * NB))[tid];
+                if (tid == 0) dn = parts[pb + 1].p_begin - parts[pb].p_begin;
+            }
+            for (uint32_t k = 0; k < nreal; ++k) {
                 // e[b] = products of the part before bucket b (k_big_hist), e[NB] = all of them: in LDS for the reads at the range
                 // starts; two buffers in turn, so that the next part may be written while the range bases take this one in
                 uint32_t *e = (k & 1u) ? pre : aux;
                 uint4 *hp = (uint4 *)(part_hist + (size_t)(pb + k) * NB) + tid;
-                const uint4 h = *hp;
+                const uint4 h = hn;
+                const uint32_t dk = dn;
+                if (k + 1 < nreal) {
+                    hn = hp[NB / 4];
+                    if (tid == 0) dn = parts[pb + k + 2].p_begin - parts[pb + k + 1].p_begin;
+                }
                 e[tid * 4 + 0] = h.x;
                 e[tid * 4 + 1] = h.y;
                 e[tid * 4 + 2] = h.z;
                 e[tid * 4 + 3] = h.w;
-                if (tid == 0) e[NB] = parts[pb + k + 1].p_begin - parts[pb + k].p_begin;
-                __syncthreads();
+                if (tid == 0) e[NB] = dk;
+                lds_barrier();
                 uint4 c;
                 c.x = base[rng[0]] + h.x - e[rf[0]];
                 c.y = base[rng[1]] + h.y - e[rf[1]];
@@ -882,7 +918,7 @@ __global__ __launch_bounds__(TK_BLOCK) void k_big_plan(const uint64_t *__restric
                     if (rf[3] != (uint32_t)tid * 4u + 3u) c.w = BX_MARK | rf[3];
                 }
                 *hp = c;
-                __syncthreads();
+                lds_barrier();
 #pragma unroll
                 for (int j = 0; j < BPT; ++j) {
                     const uint32_t r = tid * BPT + j;

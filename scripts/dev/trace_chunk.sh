@@ -1,23 +1,15 @@
 #!/bin/bash
-# development aid (GPU box): scripts/dev/trace_chunk.sh "<library variants>" <chunk>  -- rocprofv3 kernel trace of one chunk of R-MAT 22
-# (scripts/probe_chunks.py 22 69 <chunk>) per variant library: per-kernel totals
+# development aid (GPU box): scripts/dev/trace_chunk.sh <chunk> ... -- kernel durations (rocprofv3 --kernel-trace) of the symbolic + numeric calls on chunks of R-MAT 22
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
-CH=${2:-34}
-mkdir -p $REPO/gpurun_out/trace; cd /tmp && export TMPDIR=/tmp
-for v in $1; do
-export SPADA_LIB_PATH=$REPO/spada_sim_amd/lib/libspada_$v.so
-rm -rf $REPO/gpurun_out/trace/chunk_$v
-timeout 400 rocprofv3 --kernel-trace --output-format csv -d $REPO/gpurun_out/trace/chunk_$v -o kt -- python3 $REPO/scripts/probe_chunks.py 22 69 $CH > $REPO/gpurun_out/trace/chunk_$v.log 2>&1
+OUT=$REPO/gpurun_out/r05/trace_chunk
+mkdir -p $OUT; cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --output-format csv -d $OUT -o t -- python3 $REPO/scripts/probe_chunks.py 22 69 "$@" > $OUT/log.txt 2>&1
 python3 - <<PY
-import csv, glob, collections
-f = glob.glob("$REPO/gpurun_out/trace/chunk_$v/**/*kernel_trace.csv", recursive=True)[0]
-agg = collections.defaultdict(list)
-for r in csv.DictReader(open(f)):
+import csv, collections
+d = collections.defaultdict(list)
+for r in csv.DictReader(open("$OUT/t_kernel_trace.csv")):
     n = r["Kernel_Name"].split("(")[0].replace("spada::", "").replace("void ", "")
-    agg[n].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
-print("== $v chunk $CH")
-for n, v in sorted(agg.items(), key=lambda x: -sum(x[1]))[:16]:
-    v2 = sorted(v)
-    print(f"{n[:44]:44s} n={len(v):4d} median {v2[len(v2)//2]:9.1f} us  min {v2[0]:9.1f}  total {sum(v):10.1f}")
+    d[n].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+for n, v in sorted(d.items(), key=lambda kv: -max(kv[1])):
+    if max(v) > 20: print("%-34s launches %3d  us per launch: %s" % (n[:34], len(v), " ".join("%.0f" % x for x in v if x > 5)))
 PY
-done

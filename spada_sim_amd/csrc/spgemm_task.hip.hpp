@@ -961,7 +961,10 @@ __global__ __launch_bounds__(256) void k_big_cuts(const uint32_t *__restrict__ b
         for (int k = 0; k < BX_CUT_ITEM / 256; ++k) {
             const uint64_t pr = (uint64_t)item.y * BX_CUT_ITEM + (uint32_t)k * 256u + threadIdx.x;
             if (pr < pairs) {
-                const uint32_t ri = (uint32_t)(pr / E), e = (uint32_t)(pr - (uint64_t)ri * E);
+                // pairs numbered ENTRY major: the lanes of a wave search ONE B row (or a few) for neighbouring ranges -- the same
+                // probes at the first steps, the same few lines at the last, where range-major numbering sent every lane to a row
+                // of its own (the table itself stays range major: a task reads rows ri and ri + 1 of it along its entries)
+                const uint32_t e = (uint32_t)(pr / m), ri = (uint32_t)(pr - (uint64_t)e * m);
                 const uint32_t lo = tmp[tb + ri].col_lo;
                 const uint64_t b0 = eb0[d0.src + e];
                 const uint32_t len = elen[d0.src + e];
@@ -975,7 +978,11 @@ __global__ __launch_bounds__(256) void k_big_cuts(const uint32_t *__restrict__ b
                         n = h;
                     }
                 }
-                cuts[sl.cut_base + pr] = l;
+                // (one 4-byte store per pair at a stride of E words.  Measured, kernel alone on R-MAT 16 / 18: 434 / 3308 us; with the table
+                // written in the order of the searches -- coalesced, wrong -- 320 / 1990 us; with the B rows staged in LDS, the searches there
+                // and the results through an LDS tile in the table's order, items of 1024 pairs: R-MAT 18 -10 % on the phase, R-MAT 16 and
+                // the web input +10 ... 20 % -- the per-item staging costs rows of a few hundred pairs more than it saves: not kept)
+                cuts[sl.cut_base + (uint64_t)ri * E + e] = l;
                 if (ri + 1 == m) cuts[sl.cut_base + pairs + e] = len;
             }
         }

@@ -524,11 +524,11 @@ def main():
         traffic, traffic_src = load_traffic(args.workload)
         cls_names = ["empty", "copy (one A entry)", "small", "solo", "big (column-range tasks)"]
         kernels = [
-            {"kernel": "k_entry_stats + k_row_class (B-row descriptors, products per row, row classes)", "ms": ms["ms_row_stats"]},
+            {"kernel": "k_entry_stats + k_row_class_cut (B-row descriptors, products per row, row classes, the tiles cut into batches)", "ms": ms["ms_row_stats"]},
             {"kernel": "k_big_parts/hist/plan on the engine stream (big rows: parts, column histograms, ranges; the scatter of spilled rows and the cut table too when they are not forked to the side streams)",
              "ms": ms["ms_big_expand"], "products": st["cls_prod"][4] if "cls_prod" in st else None,
              "spilled_products": st.get("scratch_products"), "spilled_rows": st.get("spill_rows")},
-            {"kernel": "from the plan's end to the task kernel's start: k_cut1/2/3 (task list) and, next to them on the side streams, k_big_scatter and k_big_cuts",
+            {"kernel": "from the plan's end to the task kernel's start: k_cut3 (task list) and, next to it on the side streams, k_big_scatter and k_big_cuts",
              "ms": ms["ms_cut"]},
         ]
         two_phase = not (ms["ms_fused_call"] > 0)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """What the task kernel spends per ROW CLASS (GPU box; verdict r4 item 3): C = A' * A on the webbase-1M surrogate where A' keeps the
-rows of ONE class of A (COPY / SMALL / SOLO / BIG, the classes of k_row_class) and all other rows are empty.  The product's rows of the
+rows of ONE class of A (COPY / SMALL / SOLO / BIG, the classes of k_row_class_cut) and all other rows are empty.  The product's rows of the
 kept class are exactly the rows the full product has, computed by the same tasks minus the packing with rows of other classes.
 Prints per class: rows, products, nnz(C), tasks, the task kernel's time (best of 6, HIP events) and ns per 1000 products; with
 --pmc-friendly it only runs every class once (for a rocprofv3 --pmc pass around it)."""

@@ -280,7 +280,18 @@ __global__ __launch_bounds__(256) void k_move_rows(const uint64_t *__restrict__ 
 float tev_ms(spada_ctx *c, int a, int b)
 {
     float ms = 0;
-    if (hipEventElapsedTime(&ms, c->tev[a], c->tev[b]) != hipSuccess) return 0.f;
+    hipError_t e = hipEventElapsedTime(&ms, c->tev[a], c->tev[b]);
+    if (e == hipErrorNotReady) {
+        // the end of a run is seen through the sequence number k_export_counters writes into host memory (task_pipeline): the kernel
+        // behind the event has finished by then, but the runtime may not have taken the event's own completion in yet (seen once in a
+        // few hundred calls: the interval came back as 0 and a caller's rate as a division by zero)
+        (void)hipGetLastError();
+        if (hipEventSynchronize(c->tev[b]) == hipSuccess) e = hipEventElapsedTime(&ms, c->tev[a], c->tev[b]);
+    }
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return 0.f;
+    }
     return ms;
 }
 
@@ -460,16 +471,13 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
                                c->row_kmin.as<uint32_t>(), c->row_kmax.as<uint32_t>(),
                                c->accumulator == SPADA_ACC_SORT_MERGE ? (uint32_t)TK_SOLO_MAX : TK_LIMIT_HI, dc, g,
                                c->accumulator == SPADA_ACC_SORT_MERGE ? (TaskArgs *)nullptr : c->t_args.as<TaskArgs>());
-            if (c->expect_no_big)   // (row classes and the tiles' cut in one kernel: nothing of the BIG-row stage is expected in between)
-                hipLaunchKernelGGL(k_row_class_cut, dim3(ntiles), dim3(256), 0, s, a->ptr, c->r0, n, rmax, c->t_rowP.as<unsigned long long>(),
-                                   c->row_kmin.as<uint32_t>(), c->row_kmax.as<uint32_t>(), c->row_nprod.as<uint32_t>(), c->row_bin.as<uint8_t>(),
-                                   c->row_cl.as<uint32_t>(), c->row_rec.as<RowRec>(), c->t_rowm.as<uint32_t>(), c->t_big.as<uint32_t>(), dc,
-                                   c->t_tiles.as<uint32_t>(), c->t_rowt.as<uint32_t>(), c->row_binfo.as<uint32_t>());
-            else
-            hipLaunchKernelGGL(k_row_class, dim3(std::min<uint32_t>((n + 255) / 256, c->n_cu * 8)), dim3(256), 0, s, a->ptr, c->r0,
-                               n, rmax, c->t_rowP.as<unsigned long long>(), c->row_kmin.as<uint32_t>(), c->row_kmax.as<uint32_t>(),
-                               c->row_nprod.as<uint32_t>(), c->row_bin.as<uint8_t>(), c->row_cl.as<uint32_t>(),
-                               c->row_rec.as<RowRec>(), c->t_rowm.as<uint32_t>(), c->t_big.as<uint32_t>(), dc);
+            // row classes and the tiles' cut in one kernel (a workgroup per tile of 1024 rows).  A BIG row starts no task there: its
+            // range tasks are added to its row's and its tile's counts by k_big_plan (round 5; before, the cut was a kernel of its own
+            // behind the BIG-row stage -- 29 us + a launch gap on the critical path of the web input, for work that needs nothing of that stage)
+            hipLaunchKernelGGL(k_row_class_cut, dim3(ntiles), dim3(256), 0, s, a->ptr, c->r0, n, rmax, c->t_rowP.as<unsigned long long>(),
+                               c->row_kmin.as<uint32_t>(), c->row_kmax.as<uint32_t>(), c->row_nprod.as<uint32_t>(), c->row_bin.as<uint8_t>(),
+                               c->row_cl.as<uint32_t>(), c->row_rec.as<RowRec>(), c->t_rowm.as<uint32_t>(), c->t_big.as<uint32_t>(), dc,
+                               c->t_tiles.as<uint32_t>(), c->t_rowt.as<uint32_t>(), c->row_binfo.as<uint32_t>());
             HIP_TRY(hipGetLastError());
         }
         if (c->phase_timing) HIP_TRY(hipEventRecord(c->tev[1], s));
@@ -493,7 +501,8 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
                                c->t_parthist.as<uint32_t>(), c->t_rowm.as<uint32_t>(), c->t_rowtmp.as<uint32_t>(),
                                c->t_tmp.as<TaskDesc>(), cap_tmp, c->t_slots.as<BigSlot>(), c->t_cap_scr, c->cut_table ? c->t_cap_cuts : 0ull,
                                mode == MODE_FUSED ? c->cut_factor16 : 16u * (uint32_t)BX_DIRECT_FACTOR,
-                               c->t_cutitems.as<uint2>(), cap_cut_items, c->range_cursors ? 1u : 0u, dc);
+                               c->t_cutitems.as<uint2>(), cap_cut_items, c->range_cursors ? 1u : 0u, c->t_rowt.as<uint32_t>(),
+                               c->t_tiles.as<uint32_t>(), dc);
             // the scatter of the spilled rows and the cut table of the direct rows run NEXT to the cut (side streams): the cut needs the
             // range descriptors k_big_plan wrote -- not the scratch, not the cuts; the task kernel waits for all three.  Each fork is
             // taken only if the previous run of this context had work for it (a fork / join pair costs ~10 us and hides nothing when
@@ -532,10 +541,6 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
         }
         if (c->phase_timing) HIP_TRY(hipEventRecord(c->tev[2], s));
         if (n) {
-            if (!no_big)   // (else: k_row_class_cut has cut the tiles)
-            hipLaunchKernelGGL(k_cut1, dim3(ntiles), dim3(256), 0, s, c->row_cl.as<uint32_t>(), c->row_nprod.as<uint32_t>(),
-                               c->row_rec.as<RowRec>(), c->t_rowm.as<uint32_t>(), n, rmax, dc, c->t_tiles.as<uint32_t>(), c->t_rowt.as<uint32_t>(),
-                               c->row_binfo.as<uint32_t>());
             const bool fold = ntiles <= CUT_FOLD_TILES;
             if (!fold) hipLaunchKernelGGL(k_cut2, dim3(1), dim3(256), 0, s, c->t_tiles.as<uint32_t>(), ntiles, cap_tasks, dc);
             // (few tiles -- a row chunk of a streamed product: several workgroups per tile copy its range descriptors)
@@ -597,7 +602,7 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
         TaskCounters &h = *c->h_tctr;
         h.a_nnz = 0;
         for (int k = 0; k < N_CLS; ++k) h.cls_rows[k] = h.cls_prod[k] = 0;
-        for (int sl = 0; sl < CLS_SLOTS; ++sl) {   // (k_row_class leaves its statistics spread over the slots)
+        for (int sl = 0; sl < CLS_SLOTS; ++sl) {   // (k_row_class_cut leaves its statistics spread over the slots)
             for (int k = 0; k < N_CLS; ++k) {
                 h.cls_rows[k] += h.cls_part[sl][k];
                 h.cls_prod[k] += h.cls_part[sl][N_CLS + k];

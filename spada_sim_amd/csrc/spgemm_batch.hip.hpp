@@ -7,7 +7,7 @@
 // (simulator.rs:86-111), the sort by column (simulator.rs:143-171), the sum of equal columns (simulator.rs:199-230) and the
 // result assembly (simulator.rs:1034-1062: columns ascending and unique, explicit zeros kept).
 //
-// Shape of a batch (k_cut1, batch_info): R <= 128 consecutive rows, E <= 512 A entries (contiguous: the entries of consecutive
+// Shape of a batch (k_row_class_cut, batch_info): R <= 128 consecutive rows, E <= 512 A entries (contiguous: the entries of consecutive
 // rows are), P <= 2048 products of which at most `limit` are hashed; the rest belong to COPY rows (one A entry: C_i = a * B_k is
 // already ascending and needs no accumulator).  Stages:
 //   prologue   the descriptor carries R, E, P and the first A entry: the entry loads (B-row begin / length, A value, row of the
@@ -36,7 +36,7 @@
 //   attempt    quadratically with a linear home-slot mapping: a lane that is displaced by BT_PROBE_MAX slots gives up, the task
 //              counts its products in 256 bins of the rows' spans and starts over with home slots in proportion to the bins'
 //              products (still monotone in (row, column))
-// DENSE (k_cut1 / the range's bounds decide): the blocks between the first and the last column of every hashed row, added up over
+// DENSE (k_row_class_cut / the range's bounds decide): the blocks between the first and the last column of every hashed row, added up over
 // the rows, fit the table one slot per block: no keys at all (meshes, banded matrices, narrow column ranges).
 // The DIRECT RANGE tasks of BIG rows (columns [col_lo, col_hi] of one row; the row's entries are narrowed to the range by the cut
 // table k_big_cuts has left: B rows are ascending) and the single-pass SPILLED ranges whose blocks fit (products read from the

@@ -17,7 +17,7 @@
 //                            which that costs more than a spill (thousands of entries, hundreds of ranges: R-MAT hubs) have their
 //                            products scattered into HBM scratch range by range (k_big_scatter, the "spill" of rows whose
 //                            accumulator does not fit LDS)
-//   task list            ->  k_cut1/2/3: consecutive non-BIG rows are cut into batches of <= limit products; tasks are numbered in
+//   task list            ->  k_row_class_cut, (k_cut2), k_cut3: consecutive non-BIG rows are cut into batches of <= limit products; tasks are numbered in
 //                            output order (row, then column range)
 //   k_task               ->  persistent workgroups of 512 threads take tasks by ticket.  A task expands its products into registers,
 //                            accumulates them in the LDS block table of spgemm_batch.hip.hpp (3072 slots keyed by 32-column blocks,
@@ -107,7 +107,7 @@ struct TaskCounters {   // (a multiple of 8 bytes: k_init clears it in 8-byte wo
     unsigned long long dbgh[3][24];
     unsigned long long dbgs[2048][2][16];  // (per workgroup: no contended atomics in the measurement) tasks that published late (> 30 000 ticks) | all: tasks, products, entries, rows, displaced, outputs, second attempts, dense, range, ticks ticket -> task start, -> gathers arrived, -> publication, tasks in the kernel's last 1000  // per task kind: [0..19] histogram of the cycles from ticket to publish (4096-cycle bins), [20] sum, [21] tasks, [22] max
 #endif
-    // statistics of k_row_class, spread over CLS_SLOTS lines (workgroup b adds to slot b % CLS_SLOTS; the host sums them): rows per
+    // statistics of k_row_class_cut, spread over CLS_SLOTS lines (workgroup b adds to slot b % CLS_SLOTS; the host sums them): rows per
     // class [0 .. 4], products per class [5 .. 9], A entries [10].  One hot word takes ~90 atomics per microsecond: with the
     // sums in one place the kernel had to run on one workgroup per CU (29 us for a million rows, a third of its memory rate)
     unsigned long long cls_part[64][16];
@@ -146,7 +146,7 @@ __device__ inline bool task_is_batch(const TaskDesc &td)
     return td.kind == TASK_BATCH || (td.kind == TASK_RANGE_DIRECT && (td.first >> 1) <= BT_EMAX && td.np <= BT_PMAX) || task_spill_dense(td);
 }
 
-// what a task needs to know about a row, in one 16-byte load (written by k_row_class)
+// what a task needs to know about a row, in one 16-byte load (written by k_row_class_cut)
 struct __attribute__((aligned(16))) RowRec {
     uint32_t kmin, kmax;   // first / last column that can occur in the row of C
     uint32_t nprod;        // products (saturated at 2^32 - 1)
@@ -169,8 +169,8 @@ __device__ inline uint8_t row_class(uint64_t P, uint32_t L, uint32_t rmax, uint3
 // the matrix).  Entries of one row are adjacent lanes: a segmented wave scan adds them up, and the last lane of every run adds the
 // run to the row's totals (row_P, row_kmin, row_kmax, preset to 0 / max / 0) with one device atomic each -- ~1 atomic triple per
 // row, none of them contended.
-// k_row_class: one lane per row: class, statistics, the list of BIG rows -- and the row's accumulators put back to their presets
-// for the next run (nobody reads them after this kernel), so that no clearing kernel stands at the head of a run.
+// k_row_class_cut (section 3): one lane per row: class, statistics, the list of BIG rows, and the cut of the row's tile.  (The row's
+// accumulators are put back to their presets for the next run by k_preset_rows, behind the end of the run where nobody waits.)
 // (Measured and not kept, round 5: both kernels as ONE, a workgroup per tile of 1024 rows walking the tile's entries with the row
 // totals in LDS -- no device atomics, no accumulators in HBM: correct, and 4.5 x SLOWER on the web input (0.297 against 0.066 ms): the
 // entries of a tile range from 600 to 67 000, and a matrix with few rows (R-MAT 16: 64 tiles) does not fill the GPU at all.  The
@@ -254,67 +254,7 @@ __global__ __launch_bounds__(256) void k_entry_stats(const uint64_t *__restrict_
     }
 }
 
-__global__ __launch_bounds__(256) void k_row_class(const uint64_t *__restrict__ aptr, uint64_t r0, uint32_t nrows, uint32_t rmax,
-                                                   const unsigned long long *__restrict__ row_P, const uint32_t *__restrict__ row_kmin,
-                                                   const uint32_t *__restrict__ row_kmax, uint32_t *__restrict__ row_nprod,
-                                                   uint8_t *__restrict__ row_cls, uint32_t *__restrict__ row_cl,
-                                                   RowRec *__restrict__ row_rec, uint32_t *__restrict__ row_m,
-                                                   uint32_t *__restrict__ big_rows, TaskCounters *__restrict__ ctr)
-{
-    const uint32_t lim = ctr->prod_limit;
-    __shared__ unsigned long long s_rows[N_CLS], s_prod[N_CLS], s_tot;
-    if (threadIdx.x < N_CLS) s_rows[threadIdx.x] = s_prod[threadIdx.x] = 0;
-    if (threadIdx.x == 0) s_tot = 0;
-    __syncthreads();
-    const int lane = threadIdx.x & 63;
-    unsigned long long c_rows[N_CLS] = {0, 0, 0, 0, 0}, c_prod[N_CLS] = {0, 0, 0, 0, 0}, tot_l = 0;
-    for (uint32_t tile = blockIdx.x * 256; tile < nrows; tile += gridDim.x * 256) {
-        const uint32_t i = tile + threadIdx.x;
-        uint8_t cls = CLS_EMPTY;
-        if (i < nrows) {
-            const unsigned long long P = row_P[i];
-            const uint32_t L = (uint32_t)(aptr[r0 + i + 1] - aptr[r0 + i]);
-            cls = row_class(P, L, rmax, lim);
-            const uint32_t P32 = P > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)P;
-            row_nprod[i] = P32;
-            row_cls[i] = cls;
-            row_cl[i] = (uint32_t)cls | (min(L, 0x1FFFFFFFu) << 3);   // class and length in one word (the cut)
-            row_rec[i] = RowRec{row_kmin[i], row_kmax[i], P32, (uint32_t)cls};
-            row_m[i] = 0;
-#pragma unroll
-            for (int k = 0; k < N_CLS; ++k) {   // (a run-time index would push the counters out of the registers)
-                c_rows[k] += cls == k ? 1ull : 0ull;
-                c_prod[k] += cls == k ? P : 0ull;
-            }
-            tot_l += L;
-        }
-        // BIG rows: one global atomic per wave
-        const unsigned long long bm = __ballot(i < nrows && cls == CLS_BIG);
-        if (bm) {
-            uint32_t base = 0;
-            if (lane == __ffsll((long long)bm) - 1) base = atomicAdd(&ctr->n_big, (uint32_t)__popcll(bm));
-            base = __shfl(base, __ffsll((long long)bm) - 1);
-            if (i < nrows && cls == CLS_BIG) big_rows[base + (uint32_t)__popcll(bm & ((1ull << lane) - 1ull))] = i;
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < N_CLS; ++k) {
-        const unsigned long long r = wave_sum_u64(c_rows[k]), p = wave_sum_u64(c_prod[k]);
-        if (lane == 0 && r) {
-            atomicAdd(&s_rows[k], r);
-            atomicAdd(&s_prod[k], p);
-        }
-    }
-    const unsigned long long wl = wave_sum_u64(tot_l);
-    if (lane == 0 && wl) atomicAdd(&s_tot, wl);
-    __syncthreads();
-    unsigned long long *part = ctr->cls_part[blockIdx.x % CLS_SLOTS];
-    if (threadIdx.x < N_CLS && s_rows[threadIdx.x]) {
-        atomicAdd(&part[threadIdx.x], s_rows[threadIdx.x]);
-        atomicAdd(&part[N_CLS + threadIdx.x], s_prod[threadIdx.x]);
-    }
-    if (threadIdx.x == 0 && s_tot) atomicAdd(&part[2 * N_CLS], s_tot);
-}
+// (the row classes: k_row_class_cut, with the cut of the tiles -- section 3)
 
 // ---- 2. BIG rows: histogram, column ranges, spill of the largest rows into HBM scratch --------------------------------------
 // A BIG row (more products than one task's table takes) becomes column-RANGE tasks.  It is first cut into PARTS of ~BX_PART
@@ -337,6 +277,8 @@ __global__ __launch_bounds__(256) void k_row_class(const uint64_t *__restrict__ 
 // k_cut3 copies the range descriptors into the task list in row order.
 constexpr uint32_t LB_PAUSE_MAX = 2;   // a task polls its status word with a pause that grows by this many steps (0 .. 12: within 1 %)
 constexpr uint32_t BX_PART = 8192;   // products per part of a BIG row (4 K / 16 K / 32 K: within 3 % on web and R-MAT 16 / 18)
+constexpr int CUT_ITEMS = 4, CUT_TILE = 256 * CUT_ITEMS;   // (tiles of 1024 rows: 2048 leaves too few workgroups on the smaller inputs,
+                                                           // 512 cuts too many batches at tile borders -- +11 % tasks on the stencil input)
 constexpr uint32_t BX_NOPART = 0xFFFFFFFFu;
 constexpr uint32_t PLAN_UNROLL = 4;   // part records of a row whose histograms k_big_plan has in flight together
 constexpr uint32_t BX_MARK = 0x80000000u;   // a cursor word of k_big_plan that names the bucket holding the cursor instead (k_big_scatter)
@@ -604,6 +546,7 @@ __global__ __launch_bounds__(TK_BLOCK) void k_big_plan(const uint64_t *__restric
                                                        const uint32_t *__restrict__ row_tmp, TaskDesc *__restrict__ tmp, uint32_t tmp_cap,
                                                        BigSlot *__restrict__ slots, uint64_t scr_cap, uint64_t cut_cap, uint32_t cut_factor16,
                                                        uint2 *__restrict__ cut_items, uint64_t cut_item_cap, uint32_t range_cursors,
+                                                       uint32_t *__restrict__ row_t, uint32_t *__restrict__ tile_tasks,
                                                        TaskCounters *__restrict__ ctr)
 {
     const uint32_t lim = ctr->prod_limit;
@@ -808,6 +751,10 @@ __global__ __launch_bounds__(TK_BLOCK) void k_big_plan(const uint64_t *__restric
             hdr[45] = ok ? 1u : 0u;
             if (!ok) atomicOr(&ctr->abort_flag, 1u);
             row_m[row] = m;
+            // (the tiles were cut before this kernel ran -- k_row_class_cut, where a BIG row starts no task yet: its range tasks join
+            // the row's and the tile's counts here, one atomic per BIG row spread over the tiles)
+            row_t[row] = m;
+            atomicAdd(&tile_tasks[row / (uint32_t)CUT_TILE], m);
             slots[slot].scr_base = sb;
             slots[slot].cut_base = cb;
             // (bit 1: ONE cursor per (part, range) -- see the cursors below; their top bit is the mark, so not for a row of 2^31 products)
@@ -1081,8 +1028,6 @@ __global__ __launch_bounds__(TK_BLOCK) void k_big_scatter(const double *__restri
 // after a batch that starts at row i) is found for all rows in parallel by binary search over the tile's prefix sums; the
 // starts are what the walks along nxt reach (pointer doubling; batches do not cross tiles).
 constexpr uint32_t CUT_FOLD_TILES = 2048;   // (k_cut3 adds up the tile counts itself up to here: O(tiles^2) words read in all)
-constexpr int CUT_ITEMS = 4, CUT_TILE = 256 * CUT_ITEMS;   // (tiles of 1024 rows: 2048 leaves too few workgroups on the smaller inputs,
-                                                           // 512 cuts too many batches at tile borders -- +11 % tasks on the stencil input)
 
 __device__ inline uint32_t block_scan_excl_u32(uint32_t v, uint32_t *s_w /*[4]*/, uint32_t *total)
 {
@@ -1289,32 +1234,11 @@ __device__ inline uint32_t cut_tile(const uint32_t *__restrict__ row_cl, const u
     return block_scan_excl_u32(local, L.s_w, tile_total);
 }
 
-// k_cut1: tasks started by every row -> row_t (0: none; BIG rows: their range tasks; else 1) and the tile totals
-__global__ __launch_bounds__(256) void k_cut1(const uint32_t *__restrict__ row_cl, const uint32_t *__restrict__ row_nprod,
-                                              const RowRec *__restrict__ row_rec,
-                                              const uint32_t *__restrict__ row_m, uint32_t n, uint32_t rmax,
-                                              const TaskCounters *__restrict__ ctr, uint32_t *__restrict__ tile_tasks,
-                                              uint32_t *__restrict__ row_t, uint32_t *__restrict__ row_binfo)
-{
-    const uint32_t lim = ctr->prod_limit;
-    __shared__ CutLds L;
-    CutRow cr;
-    uint32_t tot, binfo[CUT_ITEMS];
-    (void)cut_tile(row_cl, row_nprod, row_rec, row_m, n, rmax, lim, L, cr, &tot, binfo);
-    if (threadIdx.x == 0) tile_tasks[blockIdx.x] = tot;
-    const uint32_t base = blockIdx.x * CUT_TILE + threadIdx.x * CUT_ITEMS;
-#pragma unroll
-    for (int j = 0; j < CUT_ITEMS; ++j)
-        if (base + j < n) {
-            row_t[base + j] = cr.t[j];
-            row_binfo[base + j] = binfo[j];
-        }
-}
-
-// k_row_class and k_cut1 as ONE kernel, a workgroup per tile of CUT_TILE rows -- for the runs that expect no BIG row (spada_engine.hip:
-// the run before on the context found none): the cut of a tile then needs nothing that the BIG-row kernels write, and a launch, its
-// drain and the re-read of the row words are a twentieth of a step of the mesh inputs.  Should the rows have BIG ones after all, they
-// are listed and counted as in k_row_class and the engine repeats the run the long way.
+// k_row_class_cut: the class of every row (by its products P_i and its length), the list of the BIG rows, the statistics -- and the cut of
+// its tile of CUT_TILE rows: tasks started by every row -> row_t (0: none, else 1) and the tile's total.  A BIG row starts no task HERE:
+// k_big_plan, which knows its ranges, adds them to row_t and to the tile's total (through round 4 the classes and the cut were two
+// kernels with the BIG-row stage between them: a launch, its drain and the re-read of the row words on the critical path of every call,
+// for a cut that needs nothing the BIG-row kernels write).  (statistics spread over CLS_SLOTS lines: the host sums them)
 __global__ __launch_bounds__(256) void k_row_class_cut(const uint64_t *__restrict__ aptr, uint64_t r0, uint32_t nrows, uint32_t rmax,
                                                        const unsigned long long *__restrict__ row_P, const uint32_t *__restrict__ row_kmin,
                                                        const uint32_t *__restrict__ row_kmax, uint32_t *__restrict__ row_nprod,
@@ -1354,7 +1278,7 @@ __global__ __launch_bounds__(256) void k_row_class_cut(const uint64_t *__restric
             tot_l += L_;
         }
         const unsigned long long bm = __ballot(i < nrows && cls == CLS_BIG);
-        if (bm) {   // (not expected: listed for the count that sends the engine the long way)
+        if (bm) {   // BIG rows: one global atomic per wave
             uint32_t base = 0;
             if (lane == __ffsll((long long)bm) - 1) base = atomicAdd(&ctr->n_big, (uint32_t)__popcll(bm));
             base = __shfl(base, __ffsll((long long)bm) - 1);
@@ -1431,7 +1355,7 @@ __global__ __launch_bounds__(256) void k_cut3(const uint8_t *__restrict__ row_cl
     // the run is stopped here -- flag 64: the task kernel returns at once -- before any task can walk a scratch slice nobody filled)
     if (!scatter_launched && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && ctr->n_spilled != 0) atomicOr(&ctr->abort_flag, 64u);
     // first task of the tile.  Up to CUT_FOLD_TILES tiles every workgroup adds up the counts of the tiles before its own itself (a
-    // few KB of L2-resident words) and the one-workgroup scan kernel between k_cut1 and k_cut3 is not launched: one launch and its
+    // few KB of L2-resident words) and the one-workgroup scan kernel in front of k_cut3 is not launched: one launch and its
     // gap less on the critical path of every call (~7 us; what matters once a GPU holds an eighth of the rows).  tile_first keeps the
     // result for k_pos4.
     uint32_t first;
@@ -1568,7 +1492,7 @@ struct TaskArgs {
     const uint8_t *row_cls;
     const uint32_t *row_kmin, *row_kmax, *row_nprod;
     const uint32_t *arow;           // row of every A entry (spada_dev_csr::rowid)
-    const RowRec *row_rec;          // per row: column bounds, products, class (k_row_class)
+    const RowRec *row_rec;          // per row: column bounds, products, class (k_row_class_cut)
     const TaskDesc *tasks;
     const uint32_t *scr_col;
     const double *scr_val;
@@ -1669,7 +1593,7 @@ __global__ __launch_bounds__(256) void k_pos3(const TaskDesc *__restrict__ tasks
 }
 
 // The batch of row r is task  tile_tasks[tile of r] + (tasks started by the tile's rows up to and including r) - 1  (batches do
-// not cross the cut's tiles; row_t and tile_tasks are what k_cut1 / k_cut2 left).
+// not cross the cut's tiles; row_t and tile_tasks are what k_row_class_cut / k_big_plan / k_cut2 left).
 __global__ __launch_bounds__(256) void k_pos4(const uint8_t *__restrict__ row_cls, const uint32_t *__restrict__ row_t,
                                               const uint32_t *__restrict__ tile_tasks, uint32_t n, const uint64_t *__restrict__ range_out,
                                               const TaskCounters *__restrict__ ctr, uint64_t *__restrict__ cptr)

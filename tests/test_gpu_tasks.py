@@ -222,6 +222,26 @@ def test_phase_timing_switch():
         eng.close()
 
 
+def test_call_intervals_are_never_lost():
+    """The host learns of a run's end from a sequence number the last kernel writes into pinned memory -- possibly before the runtime
+    has taken in the completion of the event records in front of that kernel.  The intervals of spada_stats must be there all the
+    same (an interval that came back as 0.0 once in a few hundred calls made a caller's rate a division by zero): 3000 calls of the
+    one-pass entry point on device-resident operands, every one with a positive call and task-kernel time."""
+    import spada_sim_amd as S
+    m = S.generate(S.GEN_UNIFORM, 20000, 6, 9)
+    eng = S.Engine()
+    try:
+        d = eng.upload(m)
+        cap = S.count_products(m, m, 0, m.shape[0])
+        for call in range(3000):
+            eng.fused_owned(d, d, 0, m.shape[0], cap)
+            st = eng.stats()
+            assert st["ms_fused_call"] > 0 and st["ms_task"] > 0, (call, st["ms_fused_call"], st["ms_task"])
+        eng.free(d)
+    finally:
+        eng.close()
+
+
 def test_workspace_growth_reruns(engine):
     """A fresh context sizes its workspaces (part records, range descriptors, scratch, task list) from the counters of the runs
     that overflowed them and runs the pipeline again: the part records first, then whatever the plan behind them needs."""

@@ -121,8 +121,8 @@ def main():
     ap.add_argument("--chunk-consumer", choices=("none", "checksum"), default="none",
                     help="chunked steps: what reads a finished chunk of C before it is dropped -- nothing (default: the engine's calls alone, "
                          "as for the workloads whose C fits: nobody reads C there either) or a torch reduction over its values inside the "
-                         "timed step (rounds 2 - 4 and profiles/r05_bench_rmat22_1gpu_checksum.json: 8 bytes per output read once more, and "
-                         "the engine's own scatter phase runs 0.15 - 0.25 s per step slower behind it)")
+                         "timed step (rounds 2 - 4 and profiles/r05_bench_rmat22_1gpu_checksum.json: 8 bytes per output read once more, "
+                         "0.10 s of R-MAT 22's step)")
     ap.add_argument("--chunk-products", type=float, default=0,
                     help="stream C in A-row chunks of about this many products (0 = automatic: chunk when the product "
                          "count of a rank exceeds 3e9, i.e. when C would not fit next to the inputs)")

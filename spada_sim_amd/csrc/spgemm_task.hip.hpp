@@ -280,6 +280,10 @@ constexpr uint32_t BX_PART = 8192;   // products per part of a BIG row (4 K / 16
 constexpr int CUT_ITEMS = 4, CUT_TILE = 256 * CUT_ITEMS;   // (tiles of 1024 rows: 2048 leaves too few workgroups on the smaller inputs,
                                                            // 512 cuts too many batches at tile borders -- +11 % tasks on the stencil input)
 constexpr uint32_t BX_NOPART = 0xFFFFFFFFu;
+#ifndef HIST_BY_ENTRY
+#define HIST_BY_ENTRY 1
+#endif
+constexpr uint32_t HIST_ENTRY_MAX = 64, HIST_ENTRY_LEN = 256;   // k_big_hist: parts of at most .. entries of at least .. products on average are walked entry by entry
 constexpr uint32_t PLAN_UNROLL = 4;   // part records of a row whose histograms k_big_plan has in flight together
 constexpr uint32_t BX_MARK = 0x80000000u;   // a cursor word of k_big_plan that names the bucket holding the cursor instead (k_big_scatter)
 constexpr uint32_t BX_RUN = 8;   // consecutive part records per workgroup (k_big_scatter)
@@ -503,18 +507,49 @@ __global__ __launch_bounds__(TK_BLOCK) void k_big_hist(const uint32_t *__restric
             s_re[1] = e_count;
             s_a0[0] = pt.e_begin;
         }
+        // A part of FEW LONG entries (a hub row of an R-MAT graph: 92 % of its products come from B rows of 1000 columns and more) is
+        // walked entry by entry, the workgroup striding along each B row: no owner lookup per product (the flat walk's bitmaps and
+        // entry records: 50 VALU + 24 SALU instructions per 64 products against ~25 here).  Other parts: the flat walk.
+        const uint32_t p_count = parts[pi + 1].p_begin - pt.p_begin;   // (the record behind a row's last part holds all its products)
+        const bool by_entry = HIST_BY_ENTRY && e_count <= HIST_ENTRY_MAX && (uint64_t)e_count * HIST_ENTRY_LEN <= p_count;
+        uint64_t *s_eb = (uint64_t *)scratch;
+        uint32_t *s_el = (uint32_t *)(s_eb + HIST_ENTRY_MAX);
+        if (by_entry && (uint32_t)tid < e_count) {
+            s_eb[tid] = eb0[pt.e_begin + tid];
+            s_el[tid] = elen[pt.e_begin + tid];
+        }
         __syncthreads();
+        auto count = [&](uint32_t col, bool on) {
+            const uint32_t bk = on ? (col - kmin) >> wshift : 0xFFFFFFFFu;
+            bool head;
+            uint32_t len, hl;
+            if (!wave_runs(bk, head, len, hl)) len = 1u;   // (every lane its own run)
+            if (head && bk != 0xFFFFFFFFu) atomicAdd(&cnt[bk], len);
+        };
+        if (by_entry) {
+            for (uint32_t i = 0; i < e_count; ++i) {
+                const uint64_t b0 = s_eb[i];
+                const uint32_t ln = s_el[i];   // (uniform)
+                uint32_t j = 0;
+                for (; j + 4u * TK_BLOCK <= ln; j += 4u * TK_BLOCK) {   // four loads in flight
+                    uint32_t c[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) c[u] = bidx[b0 + j + (uint32_t)u * TK_BLOCK + tid];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) count(c[u], true);
+                }
+                for (; j < ln; j += TK_BLOCK) {
+                    const bool on = j + tid < ln;
+                    count(on ? bidx[b0 + j + tid] : 0u, on);
+                }
+            }
+        } else {
         flat_walk<TK_BLOCK, TK_EPT, 1, false, U>(s_re, s_a0, 1u, e_count, eb0, elen, nullptr, bidx, nullptr, scratch, hdr,
                                                  [&](uint32_t(&col)[U], uint32_t(&plr)[U], double(&)[U], uint32_t(&)[U]) {
 #pragma unroll
-                                                     for (int u = 0; u < U; ++u) {
-                                                         const uint32_t bk = plr[u] != LR_NONE ? (col[u] - kmin) >> wshift : 0xFFFFFFFFu;
-                                                         bool head;
-                                                         uint32_t len, hl;
-                                                         if (!wave_runs(bk, head, len, hl)) len = 1u;   // (every lane its own run)
-                                                         if (head && bk != 0xFFFFFFFFu) atomicAdd(&cnt[bk], len);
-                                                     }
+                                                     for (int u = 0; u < U; ++u) count(col[u], plr[u] != LR_NONE);
                                                  });
+        }
         __syncthreads();
         // stored as EXCLUSIVE PREFIXES over the buckets (the part's products before every bucket): the sums over the parts that
         // k_big_plan forms are then the row's prefixes, and the cursors of a part need no scan in its serial loop over the parts

@@ -121,6 +121,8 @@ struct spada_ctx {
     // The device counters exist twice.  A pipeline run finds its set cleared: the set of the run BEFORE the last one is cleared behind
     // the end of every run, where nobody waits for it (the last run's set stays as it is: the numeric call reads its task count)
     int ctr_idx = 0;
+    uint64_t last_nprod_big = 0;      // products in BIG rows of the previous pipeline run (chooses the part size of the next one)
+    uint32_t part_shift = 0;          // (SPADA_PART_SHIFT: log2 of the products per part, 0 = by the rule above)
     bool range_cursors = true;        // the scatter appends per (part, range), not per (part, bucket) (SPADA_RANGE_CURSORS=0: measurements)
     uint32_t scatter_wgs = 8;         // workgroups of k_big_scatter per CU (SPADA_SCATTER_WGS: measurements)
     // one pass or two phases inside spada_dev_spgemm_fused: measured per input (spada_dev_spgemm_fused; SPADA_AUTO=0: always one pass)
@@ -488,9 +490,12 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
         bool scatter_launched = false;
         if (n && !no_big) {
             uint32_t *seq = c->accumulator == SPADA_ACC_SORT_MERGE ? c->t_scrseq.as<uint32_t>() : (uint32_t *)nullptr;
+            // parts of 64 K products instead of 8 K when the call before had a billion products in BIG rows (a chunk of R-MAT 22: hub rows
+            // of thousands of parts, and ONE workgroup of k_big_plan walks a row's parts): any size is correct, the guess only costs time
+            const uint32_t psh = c->part_shift ? c->part_shift : (c->last_nprod_big >= (1ull << 30) ? BX_PART_SHIFT_HUGE : BX_PART_SHIFT);
             hipLaunchKernelGGL(k_big_parts, dim3(c->n_cu * 2), dim3(256), 0, s, a->ptr, c->elen.as<uint32_t>(), c->r0,
                                c->t_big.as<uint32_t>(), c->row_nprod.as<uint32_t>(), c->row_kmin.as<uint32_t>(),
-                               c->row_kmax.as<uint32_t>(), c->accumulator == SPADA_ACC_SORT_MERGE ? 0u : 1u, c->t_parts.as<BigPart>(), cap_parts,
+                               c->row_kmax.as<uint32_t>(), c->accumulator == SPADA_ACC_SORT_MERGE ? 0u : 1u, psh, c->t_parts.as<BigPart>(), cap_parts,
                                c->t_rowtmp.as<uint32_t>(), cap_tmp, c->t_slots.as<BigSlot>(), dc);
             hipLaunchKernelGGL(k_big_hist, dim3(c->n_cu * BH_GRID), dim3(TK_BLOCK), BX_WALK_LDS, s, b->idx, c->eb0.as<uint64_t>(),
                                c->elen.as<uint32_t>(), c->t_big.as<uint32_t>(), c->row_kmin.as<uint32_t>(),
@@ -526,7 +531,7 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
     hipLaunchKernelGGL(k_big_scatter, dim3(c->n_cu * c->scatter_wgs), dim3(TK_BLOCK), BX_WALK_LDS, side2 ? c->stream2 : s, a->val, b->idx, b->val,
                                c->eb0.as<uint64_t>(), c->elen.as<uint32_t>(), c->t_big.as<uint32_t>(), c->row_kmin.as<uint32_t>(),
                                c->row_kmax.as<uint32_t>(), c->t_parts.as<BigPart>(), c->t_parthist.as<uint32_t>(),
-                               c->t_slots.as<BigSlot>(), c->t_scrcol.as<uint32_t>(), c->t_scrval.as<double>(), seq, dc);
+                               c->t_slots.as<BigSlot>(), c->t_scrcol.as<uint32_t>(), c->t_scrval.as<double>(), seq, psh, dc);
             if (side2) HIP_TRY(hipEventRecord(c->ev_join, c->stream2));
             if (c->cut_table)
                 hipLaunchKernelGGL(k_big_cuts, dim3(c->n_cu * 8), dim3(256), 0, side3 ? c->stream3 : (c->side_mode == 1 ? s3 : s), b->idx, c->eb0.as<uint64_t>(),
@@ -612,6 +617,7 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
         h.nprod = 0;
         for (int k = 0; k < N_CLS; ++k) h.nprod += h.cls_prod[k];
         h.nprod_big = h.cls_prod[CLS_BIG];
+        c->last_nprod_big = h.nprod_big;
         c->last_spilled = h.n_spilled;
         uint64_t cut_most = 0;   // (the fullest arena sets the size)
         uint64_t items_most = 0;
@@ -811,6 +817,7 @@ int spada_create(const spada_options *opts, spada_ctx **out)
     c->scanner_ok = -1;   // (the one-pass kernel of the other accumulator has its own occupancy)
     if (const char *e = getenv("SPADA_SCATTER_WGS")) c->scatter_wgs = (uint32_t)std::max(atoi(e), 1);
     if (const char *e = getenv("SPADA_RANGE_CURSORS")) c->range_cursors = atoi(e) != 0;
+    if (const char *e = getenv("SPADA_PART_SHIFT")) c->part_shift = (uint32_t)std::min(std::max(atoi(e), 10), 20);
     if (const char *e = getenv("SPADA_SIDE")) c->side_mode = atoi(e);
     if (const char *e = getenv("SPADA_AUTO")) c->auto_pipeline = atoi(e) != 0;
     if (const char *e = getenv("SPADA_EXPORT")) c->export_poll = atoi(e) != 0;

@@ -276,7 +276,8 @@ __global__ __launch_bounds__(256) void k_entry_stats(const uint64_t *__restrict_
 //                 cursor: afterwards the scratch slice of every range is contiguous
 // k_cut3 copies the range descriptors into the task list in row order.
 constexpr uint32_t LB_PAUSE_MAX = 2;   // a task polls its status word with a pause that grows by this many steps (0 .. 12: within 1 %)
-constexpr uint32_t BX_PART = 8192;   // products per part of a BIG row (4 K / 16 K / 32 K: within 3 % on web and R-MAT 16 / 18)
+constexpr uint32_t BX_PART_SHIFT = 13, BX_PART_SHIFT_HUGE = 16;   // products per part of a BIG row: 8192 (4 K / 16 K / 32 K: within 3 % on R-MAT 16, + 5 % on web);
+                                                                  // 64 K when the call before on the context had a billion products in BIG rows (spada_engine.hip)
 constexpr int CUT_ITEMS = 4, CUT_TILE = 256 * CUT_ITEMS;   // (tiles of 1024 rows: 2048 leaves too few workgroups on the smaller inputs,
                                                            // 512 cuts too many batches at tile borders -- +11 % tasks on the stencil input)
 constexpr uint32_t BX_NOPART = 0xFFFFFFFFu;
@@ -325,7 +326,8 @@ __host__ __device__ inline uint32_t big_max_ranges(uint32_t P, uint32_t lim, boo
 __global__ __launch_bounds__(256) void k_big_parts(const uint64_t *__restrict__ aptr, const uint32_t *__restrict__ elen, uint64_t r0,
                                                    const uint32_t *__restrict__ big_rows, const uint32_t *__restrict__ row_nprod,
                                                    const uint32_t *__restrict__ row_kmin, const uint32_t *__restrict__ row_kmax,
-                                                   uint32_t allow_sub, BigPart *__restrict__ parts, uint32_t part_cap,
+                                                   uint32_t allow_sub, uint32_t psh /* log2 of the products per part */,
+                                                   BigPart *__restrict__ parts, uint32_t part_cap,
                                                    uint32_t *__restrict__ row_tmp, uint32_t tmp_cap, BigSlot *__restrict__ slots,
                                                    TaskCounters *__restrict__ ctr)
 {
@@ -342,7 +344,7 @@ __global__ __launch_bounds__(256) void k_big_parts(const uint64_t *__restrict__ 
             const bool have = lane < BP_ROWS && sl < nbig;
             const uint32_t P = have ? row_nprod[big_rows[sl]] : 0u;
             const bool good = have && P != 0xFFFFFFFFu;
-            const uint32_t np = good ? P / BX_PART + 2u : 0u, nt = good ? big_max_ranges(P, lim, wide_row(big_rows[sl])) : 0u;
+            const uint32_t np = good ? (P >> psh) + 2u : 0u, nt = good ? big_max_ranges(P, lim, wide_row(big_rows[sl])) : 0u;
             uint32_t ip = np, it = nt;
 #pragma unroll
             for (int o = 1; o < BP_ROWS; o <<= 1) {
@@ -375,9 +377,9 @@ __global__ __launch_bounds__(256) void k_big_parts(const uint64_t *__restrict__ 
             continue;
         }
         const uint64_t a0 = aptr[r0 + row], a1 = aptr[r0 + row + 1];
-        // every window [w BX_PART, (w + 1) BX_PART) of the running product count that contains the first product of some entry
+        // every window [w 2^psh, (w + 1) 2^psh) of the running product count that contains the first product of some entry
         // starts a part: at most `ub` of them (an entry with an empty B row may sit at prefix P itself)
-        const uint32_t ub = P / BX_PART + 1;
+        const uint32_t ub = (P >> psh) + 1;
         const uint32_t base = s_pbase[rr], tbase = s_tbase[rr];
         const bool fits = (unsigned long long)base + ub + 1 <= part_cap;
         if (lane == 0) {
@@ -413,14 +415,14 @@ __global__ __launch_bounds__(256) void k_big_parts(const uint64_t *__restrict__ 
             }
             uint32_t ex = carry + inc - sum;
             // window of the last entry of the lane before (lanes past the end repeat the last window: no new start there)
-            const uint32_t my_last = (ex + sum - len[BP_EPL - 1]) / BX_PART;   // (entries past the end have length 0)
+            const uint32_t my_last = (ex + sum - len[BP_EPL - 1]) >> psh;   // (entries past the end have length 0)
             uint32_t pw = __shfl_up(my_last, 1);
             if (lane == 0) pw = prev_win;
             uint32_t w[BP_EPL], exi[BP_EPL], cnt = 0;
 #pragma unroll
             for (int i = 0; i < BP_EPL; ++i) {
                 exi[i] = ex;
-                w[i] = ex / BX_PART;
+                w[i] = ex >> psh;
                 ex += len[i];
             }
             uint32_t startmask = 0, p = pw;
@@ -978,7 +980,7 @@ __global__ __launch_bounds__(TK_BLOCK) void k_big_scatter(const double *__restri
                                                           const BigPart *__restrict__ parts, const uint32_t *__restrict__ part_hist,
                                                           const BigSlot *__restrict__ slots, uint32_t *__restrict__ scr_col,
                                                           double *__restrict__ scr_val, uint32_t *__restrict__ scr_seq /* may be null */,
-                                                          const TaskCounters *__restrict__ ctr)
+                                                          uint32_t psh, const TaskCounters *__restrict__ ctr)
 {
     constexpr int NB = BX_NB, U = FLAT_U;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -995,7 +997,7 @@ __global__ __launch_bounds__(TK_BLOCK) void k_big_scatter(const double *__restri
     // (measured: giving every XCD a contiguous eighth of the records, so that neighbouring runs meet in one L2, is 3 - 8 % SLOWER)
     // (runs only when many rows are spilled: the parts of a few dozen rows -- the web input's rows with more than 512 entries --
     // are better spread over as many workgroups than done eight in a row by one)
-    const uint32_t run = ctr->n_spilled > gridDim.x / 8u ? BX_RUN : 1u;
+    const uint32_t run = ctr->n_spilled > gridDim.x / 8u ? max(BX_RUN >> (psh - BX_PART_SHIFT), 1u) : 1u;   // (~64 K products per run)
     for (uint32_t pi0 = blockIdx.x * run; pi0 < nparts; pi0 += gridDim.x * run)
     for (uint32_t pi = pi0; pi < min(pi0 + run, nparts); ++pi) {
         const BigPart pt = parts[pi];

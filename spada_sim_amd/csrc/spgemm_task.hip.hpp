@@ -83,6 +83,7 @@ static_assert(sizeof(TaskDesc) == 48, "three 16-byte words (load_task)");
 constexpr uint32_t TASK_BATCH = 1, TASK_RANGE = 2, TASK_RANGE_DIRECT = 3;   // (DIRECT: the products are taken from B, not from the scratch)
 
 // device counters of one pipeline run (zeroed at its start)
+constexpr uint32_t SCATTER_NQ = 16;
 struct TaskCounters {   // (a multiple of 8 bytes: k_init clears it in 8-byte words)
     unsigned long long nprod, a_nnz, nprod_big;       // of the row range
     unsigned long long scratch_cursor;                // products handed out in the scratch arrays
@@ -103,6 +104,8 @@ struct TaskCounters {   // (a multiple of 8 bytes: k_init clears it in 8-byte wo
     uint32_t ticket[2 * TK_NQ * 32];  // TK_NQ ticket counters, one per 128-byte line (a single hot word sustains ~88 atomics / us); the second half: k_task_range
     uint32_t n_legacy;                // tasks of the older range path (their numbers: TaskArgs::legacy)
     uint32_t scanner_leavers;         // one-pass mode: workgroups that left the scanner's CU to it (at most SCANNER_LEAVERS_MAX)
+    uint32_t scatter_next[SCATTER_NQ * 32];   // k_big_scatter: runs of parts by ticket (direct rows' parts cost nothing, spilled ones a walk), SCATTER_NQ
+                                              // counters on a 128-byte line each: queue q hands out the runs q, q + NQ, q + 2 NQ, ...
 #if SPADA_TASK_DBG
     unsigned long long dbgh[3][24];
     unsigned long long dbgs[2048][2][16];  // (per workgroup: no contended atomics in the measurement) tasks that published late (> 30 000 ticks) | all: tasks, products, entries, rows, displaced, outputs, second attempts, dense, range, ticks ticket -> task start, -> gathers arrived, -> publication, tasks in the kernel's last 1000  // per task kind: [0..19] histogram of the cycles from ticket to publish (4096-cycle bins), [20] sum, [21] tasks, [22] max
@@ -998,7 +1001,15 @@ __global__ __launch_bounds__(TK_BLOCK) void k_big_scatter(const double *__restri
     // (runs only when many rows are spilled: the parts of a few dozen rows -- the web input's rows with more than 512 entries --
     // are better spread over as many workgroups than done eight in a row by one)
     const uint32_t run = ctr->n_spilled > gridDim.x / 8u ? max(BX_RUN >> (psh - BX_PART_SHIFT), 1u) : 1u;   // (~64 K products per run)
-    for (uint32_t pi0 = blockIdx.x * run; pi0 < nparts; pi0 += gridDim.x * run)
+    // (the runs are handed out by ticket: the parts of direct rows are skipped at once, those of spilled rows are a walk of tens of
+    // thousands of products -- a fixed stride left the workgroups whose runs held mostly direct rows idle at the end)
+    __shared__ uint32_t s_run0;
+    for (;;) {
+    __syncthreads();
+    if (tid == 0) s_run0 = atomicAdd((uint32_t *)&ctr->scatter_next[(blockIdx.x % SCATTER_NQ) * 32u], 1u) * SCATTER_NQ + blockIdx.x % SCATTER_NQ;
+    __syncthreads();
+    if ((unsigned long long)s_run0 * run >= nparts) break;
+    const uint32_t pi0 = s_run0 * run;
     for (uint32_t pi = pi0; pi < min(pi0 + run, nparts); ++pi) {
         const BigPart pt = parts[pi];
         if (pt.slot == BX_NOPART) continue;   // (uniform over the workgroup, like the next one)
@@ -1050,6 +1061,7 @@ __global__ __launch_bounds__(TK_BLOCK) void k_big_scatter(const double *__restri
                                                     }
                                                 });
         __syncthreads();
+    }
     }
 #ifdef SPADA_SCATTER_SEQ
     if (threadIdx.x == 0 && blockIdx.x == 0) atomicOr((uint32_t *)&ctr->abort_flag, 128u);   // nothing may read this scratch

@@ -291,9 +291,11 @@ __device__ inline BatchHead batch_prologue(const ARGS &g, const TaskDesc &td, ui
 
 // `next()` -- called once, by all threads, where the task has nothing left to do but wait for its position and store: takes the
 // next ticket and runs the next task's prologue
-template <int MODE, bool DENSE, bool SPILL = false, class ARGS, class NEXT>
+// `early()` -- called once, by all threads, where the products have arrived and the task turns to LDS for a long while: the modes
+// without a chain take the next ticket here (the atomic's round trip lies under the insertion; see k_task)
+template <int MODE, bool DENSE, bool SPILL = false, class ARGS, class NEXT, class EARLY>
 __device__ inline void batch_main(const ARGS &g, const TaskDesc &td, uint32_t t, uint32_t ntasks, unsigned char *smem,
-                                  uint32_t *dbg_ph /* LDS: SPADA_TASK_DBG builds */, const BatchHead hd, NEXT &&next)
+                                  uint32_t *dbg_ph /* LDS: SPADA_TASK_DBG builds */, const BatchHead hd, NEXT &&next, EARLY &&early)
 {
     constexpr bool VALUES = MODE != MODE_COUNT;
     constexpr uint32_t T = BT_T;
@@ -440,6 +442,7 @@ __device__ inline void batch_main(const ARGS &g, const TaskDesc &td, uint32_t t,
         }
         if (SPADA_TASK_DBG) dbg_t_gath = (uint32_t)__builtin_amdgcn_s_memtime() + (col[0] & 0u);
         BSTOP(2, col[0] ^ col[1] ^ col[2] ^ col[3] ^ lrc[0] ^ lrc[1] ^ lrc[2] ^ lrc[3] ^ (uint32_t)__double2loint(r_v[0] + r_v[1] + r_v[2] + r_v[3]));
+        early();
         // The home slot of a block is a LINEAR function of its column inside the row's span: when the columns cluster -- the rows of
         // an R-MAT graph: a third of a row's blocks on a twentieth of its span -- the blocks of a cluster share a few home slots and
         // linear probing pays for it quadratically (such tasks took 60 - 100 us to count their outputs, and a thousand tasks of the

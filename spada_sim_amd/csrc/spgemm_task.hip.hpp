@@ -2416,9 +2416,22 @@ __global__ __launch_bounds__(TKW, TASK_WAVES) void k_task(const TaskArgs *__rest
         TaskDesc td2{};
         BatchHead hd2{0u, 0u, 0u, 0u};
         bool bt2 = false;
+        // The modes without a chain take the next ticket EARLY -- where the task's products have arrived and it works in LDS for
+        // thousands of ticks (`early`, called by the batch task): the atomic's round trip, a third of the dependent chain ticket ->
+        // descriptor -> row / entry loads in front of every task, lies under the insertion.  (With the chain a ticket taken before
+        // the task is done holds up every task behind it: comment above.  Issued any earlier, the atomic would stand in front of the
+        // task's own loads in the in-order return queue.)
+        uint32_t tk_early = 0;
+        bool have_early = false;
+        auto early = [&]() {
+            if constexpr (MODE != MODE_FUSED) {
+                if (threadIdx.x == 0) tk_early = atomicAdd(my_ticket, 1u);
+                have_early = true;
+            }
+        };
         auto next = [&]() {
             __syncthreads();   // (the ticket word of the task before has been read by everyone; this task's outputs are complete in LDS)
-            if (threadIdx.x == 0) hdr[50] = g.task_lo + atomicAdd(my_ticket, 1u) * TK_NQ + task_queue();
+            if (threadIdx.x == 0) hdr[50] = g.task_lo + (have_early ? tk_early : atomicAdd(my_ticket, 1u)) * TK_NQ + task_queue();
             __syncthreads();
             t2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)hdr[50]);
             if (SPADA_TASK_DBG && threadIdx.x == 0) dbg_ph[16] = (uint32_t)__builtin_amdgcn_s_memtime();
@@ -2430,9 +2443,9 @@ __global__ __launch_bounds__(TKW, TASK_WAVES) void k_task(const TaskArgs *__rest
         };
         if (bt) {
             const int v = task_variant(td);
-            if (v == 2) batch_main<MODE, true, true>(g, td, t, ntasks, smem, dbg_ph, hd, next);
-            else if (v == 1) batch_main<MODE, true>(g, td, t, ntasks, smem, dbg_ph, hd, next);
-            else batch_main<MODE, false>(g, td, t, ntasks, smem, dbg_ph, hd, next);
+            if (v == 2) batch_main<MODE, true, true>(g, td, t, ntasks, smem, dbg_ph, hd, next, early);
+            else if (v == 1) batch_main<MODE, true>(g, td, t, ntasks, smem, dbg_ph, hd, next, early);
+            else batch_main<MODE, false>(g, td, t, ntasks, smem, dbg_ph, hd, next, early);
         } else {
             if constexpr (MODE == MODE_FUSED) {
                 range_task<MODE, NOUT>(gp_, t, ntasks);

@@ -523,6 +523,39 @@ def test_scatter_cursor_layouts_give_the_same_product():
             os.environ["SPADA_RANGE_CURSORS"] = old
 
 
+def test_part_sizes_give_the_same_product():
+    """The parts of a BIG row are 8 K products by default and 64 K on calls whose predecessor had a billion products in BIG rows;
+    any size is correct.  SPADA_PART_SHIFT forces 1 K and 64 K parts on R-MAT 14 (hub rows: spilled, walked entry by entry where a
+    part is a few long B rows, their scatter runs handed out by ticket): both entry points and both accumulators give the oracle's
+    product, and the two-phase contract gives it again on the same context (the second call's guesses come from the first)."""
+    import os
+    import spada_sim_amd as S
+    m = S.generate(S.GEN_RMAT, 14, 16, 4)
+    a = to_oracle(m)
+    ref = oracle.spgemm_sortmerge(a, a)
+    old = os.environ.get("SPADA_PART_SHIFT")
+    try:
+        for shift in ("10", "16"):
+            os.environ["SPADA_PART_SHIFT"] = shift
+            for acc in (S.ACC_LDS_HASH, S.ACC_SORT_MERGE):
+                eng = S.Engine(accumulator=acc)
+                try:
+                    for _ in range(2):
+                        c = eng.spgemm(m, m)
+                        assert eng.stats()["spill_rows"] > 0
+                        assert_parity(c, ref, a, a, RTOL)
+                    if acc == S.ACC_LDS_HASH:
+                        c1, st = fused(eng, m, m)
+                        assert_parity(c1, ref, a, a, RTOL)
+                finally:
+                    eng.close()
+    finally:
+        if old is None:
+            os.environ.pop("SPADA_PART_SHIFT", None)
+        else:
+            os.environ["SPADA_PART_SHIFT"] = old
+
+
 @pytest.mark.parametrize("run", [6, 10, 11])
 def test_many_displaced_blocks_take_the_cluster_fix(engine, run):
     """Batches of ~90 short rows, each with two runs of `run` ADJACENT 32-column blocks and a far column that stretches the row's span

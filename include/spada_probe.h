@@ -1,0 +1,27 @@
+/*
+ * spada_probe.h -- MEASUREMENT entry points of libspada_spgemm.so.  Not part of the drop-in boundary (include/spada_ffi.h): nothing a
+ * caller of the engine needs, no counterpart in the reference.  They exist so that the figures in profiles/ can be reproduced with
+ * one call (scripts/probe_floor.py).
+ */
+#ifndef SPADA_PROBE_H
+#define SPADA_PROBE_H
+
+#include "spada_ffi.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* The floor under the task kernel: expand + scale only over the task list the context's LAST pipeline run has left (call
+ * spada_dev_spgemm_fused or _symbolic first), static task assignment, descriptors and entry records prefetched a task ahead, no
+ * ticket, no chain, no accumulator.  write = 0: the products are folded into a word nobody reads; write = 1: 12 bytes per product
+ * stored to a scratch buffer of the probe's own (tasks x 2048 entries).  wgs_per_cu: workgroups of 512 threads per CU (1 .. 4).
+ * reps launches are timed with HIP events on the engine stream; *ms_best / *ms_mean are per launch.  *tasks_skipped = tasks of the
+ * older range path, which the probe leaves out. */
+int spada_dev_probe_floor(spada_ctx *ctx, int write, uint32_t wgs_per_cu, uint32_t reps, double *ms_best, double *ms_mean,
+                          uint64_t *tasks, uint64_t *tasks_skipped);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -16,6 +16,8 @@
 
 #include "spada_internal.hpp"
 #include "spgemm_task.hip.hpp"
+#include "spgemm_probe.hip.hpp"
+#include "spada_probe.h"
 
 using namespace spada;
 
@@ -1338,6 +1340,61 @@ int spada_spgemm_numeric(spada_ctx *c, uint64_t *c_indptr, uint64_t *c_indices, 
         dv = c->un_val.p;
     }
     return spada_dev_download_c(c, dp, di, dv, c->nrows, c->nnz_c, c_indptr, c_indices, c_data);
+}
+
+// measurement only (include/spada_probe.h): the expand-only floor over the task list of the last pipeline run
+int spada_dev_probe_floor(spada_ctx *c, int write, uint32_t wgs_per_cu, uint32_t reps, double *ms_best, double *ms_mean, uint64_t *tasks,
+                          uint64_t *tasks_skipped)
+{
+    if (!c) return fail(SPADA_ERR_STATE, "spada_dev_probe_floor: no engine context (no GPU?)");
+    if (!c->A || !c->nrows || !c->h_tctr || !c->h_tctr->ntasks || c->accumulator == SPADA_ACC_SORT_MERGE)
+        return fail(SPADA_ERR_STATE, "spada_dev_probe_floor: no task list (run the one-pass or the symbolic pipeline of the hash accumulator first)");
+    if (!ms_best || !ms_mean || !reps) return fail(SPADA_ERR_INVALID, "spada_dev_probe_floor: null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    HIP_TRY(hipStreamSynchronize(s));
+    const uint32_t nt = c->h_tctr->ntasks;
+    uint32_t *o_idx = nullptr;
+    double *o_val = nullptr;
+    unsigned long long *sink = nullptr;
+    HIP_TRY(hipMalloc((void **)&sink, 64));
+    if (write) {
+        if (hipMalloc((void **)&o_idx, (size_t)nt * BT_PMAX * 4) != hipSuccess || hipMalloc((void **)&o_val, (size_t)nt * BT_PMAX * 8) != hipSuccess) {
+            (void)hipFree(o_idx);
+            (void)hipFree(sink);
+            return fail(SPADA_ERR_OOM, "spada_dev_probe_floor: no room for %u tasks x 2048 products", nt);
+        }
+    }
+    HIP_TRY(hipFuncSetAttribute((const void *)k_floor<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLOOR_LDS));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_floor<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FLOOR_LDS));
+    const uint32_t grid = c->n_cu * std::min<uint32_t>(std::max<uint32_t>(wgs_per_cu, 1u), 4u);
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    double best = 1e30, sum = 0;
+    for (uint32_t r = 0; r < reps + 1; ++r) {   // (the first launch is a warm-up)
+        HIP_TRY(hipEventRecord(e0, s));
+        if (write) hipLaunchKernelGGL(k_floor<1>, dim3(grid), dim3(TKW), FLOOR_LDS, s, (const TaskArgs *)c->t_args.as<TaskArgs>(), o_idx, o_val, sink);
+        else hipLaunchKernelGGL(k_floor<0>, dim3(grid), dim3(TKW), FLOOR_LDS, s, (const TaskArgs *)c->t_args.as<TaskArgs>(), o_idx, o_val, sink);
+        HIP_TRY(hipEventRecord(e1, s));
+        HIP_TRY(hipEventSynchronize(e1));
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+        if (r) {
+            best = std::min<double>(best, ms);
+            sum += ms;
+        }
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(o_idx);
+    (void)hipFree(o_val);
+    (void)hipFree(sink);
+    *ms_best = best;
+    *ms_mean = sum / reps;
+    if (tasks) *tasks = nt;
+    if (tasks_skipped) *tasks_skipped = c->h_tctr->n_legacy;
+    return SPADA_OK;
 }
 
 int spada_set_phase_timing(spada_ctx *c, int enabled)

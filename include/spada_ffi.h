@@ -49,7 +49,7 @@
 extern "C" {
 #endif
 
-#define SPADA_ABI_VERSION 4
+#define SPADA_ABI_VERSION 5
 
 enum spada_status {
     SPADA_OK = 0,
@@ -114,6 +114,13 @@ typedef struct spada_stats {
     uint64_t pipeline_runs;   /* > 1 when a workspace had to grow and the pipeline was run again (first call of a context) */
     uint64_t workspace_bytes; /* device scratch owned by the context */
     uint64_t task_product_limit; /* products one task hashes at most: 2040 (lds_hash) / 1536 (sort_merge) */
+    /* ABI 5 */
+    uint64_t chain_fallbacks; /* pipeline runs of the last call that gave themselves up on the one-pass chain (a wait that exceeded
+                                 SPADA_CHAIN_TIMEOUT_MS: the call then fails with SPADA_ERR_HIP instead of holding the GPU) */
+    uint64_t pipeline_kind;   /* what spada_dev_spgemm_fused ran: 0 one pass, 1 count + positions + numeric into the caller's buffers (most
+                                 products in BIG rows, or tasks that need the older range path) */
+    double ms_wall_call;      /* host wall-clock time of the last spada_dev_spgemm_symbolic / _numeric / _fused call, everything included
+                                 (workspace growth, repeated pipeline runs, the wait for the result) */
 } spada_stats;
 
 typedef struct spada_ctx spada_ctx;          /* engine context: one GPU, one stream, scratch */

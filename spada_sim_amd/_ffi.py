@@ -41,7 +41,8 @@ class Stats(ctypes.Structure):
                 ("ms_row_stats", ctypes.c_double), ("ms_big_expand", ctypes.c_double), ("ms_cut", ctypes.c_double),
                 ("ms_task", ctypes.c_double), ("cls_rows", u64 * 8), ("cls_prod", u64 * 8), ("n_tasks", u64),
                 ("multi_pass_tasks", u64), ("scratch_products", u64), ("spill_rows", u64), ("pipeline_runs", u64),
-                ("workspace_bytes", u64), ("task_product_limit", u64)]
+                ("workspace_bytes", u64), ("task_product_limit", u64), ("chain_fallbacks", u64), ("pipeline_kind", u64),
+                ("ms_wall_call", ctypes.c_double)]
 
     def as_dict(self):
         d = {}

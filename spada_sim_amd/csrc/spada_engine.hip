@@ -7,6 +7,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -40,6 +41,9 @@ struct spada_dev_csr {
     uint2 *rext = nullptr;       // first / last column of every row (0xFFFFFFFF / 0 for an empty one): what a product row can reach at most
                                  // is known from ONE 8-byte gather per A entry instead of two gathers from random lines of B.indices
     uint32_t *rowmap = nullptr;  // reordered matrices (-p): row i holds original row rowmap[i] (storage.rs:156-157 row_remap)
+    // what the two derived arrays cost at upload (not part of any SpGEMM call's time; reported by bench.py as upload_aux_ms):
+    double aux_host_ms = 0;      // rowid built on the host + its copy to the device (wall)
+    double aux_dev_ms = 0;       // k_row_extents (HIP events)
 };
 
 namespace {
@@ -127,13 +131,24 @@ struct spada_ctx {
     uint32_t part_shift = 0;          // (SPADA_PART_SHIFT: log2 of the products per part, 0 = by the rule above)
     bool range_cursors = true;        // the scatter appends per (part, range), not per (part, bucket) (SPADA_RANGE_CURSORS=0: measurements)
     uint32_t scatter_wgs = 8;         // workgroups of k_big_scatter per CU (SPADA_SCATTER_WGS: measurements)
-    // one pass or two phases inside spada_dev_spgemm_fused: measured per input (spada_dev_spgemm_fused; SPADA_AUTO=0: always one pass)
-    bool auto_pipeline = true, at_two = false;
+    // one pass or two phases inside spada_dev_spgemm_fused: by RULE (more than half of the products in BIG rows -> count + numeric), applied
+    // on the first call already (the run reads its row statistics back once, behind the row classes: task_pipeline, mid-run read);
+    // SPADA_AUTO=0: always one pass; SPADA_AUTO=measure: round 5's three-call measurement per input (at_*)
+    int auto_mode = 1;                // 0 off, 1 rule, 2 measure
+    bool at_two = false;
     int at_phase = 0;
-    uint64_t at_sig = 0;
+    uint64_t at_sig = 0;              // operands + row range of the last spada_dev_spgemm_fused call
     double at_ms_fused = 0;
+    bool rule_known = false, rule_two = false;   // the rule's answer for at_sig (from the statistics of the last run on it)
+    bool ws_sized = false;            // the data-dependent workspaces have been sized from a run's row statistics (else: the first run reads them back mid-run)
+    bool counters_dirty = false;      // a run left between the flip of the counter sets and the clearing kernel behind it
     bool expect_no_spill = false;     // ... spilled no row: k_big_scatter is left out (k_cut3 stops the run if the plan spills one after all)
     bool expect_no_big = false;       // the last pipeline run of this context found no BIG row (the next one does not launch their kernels)
+    // a wait on the one-pass chain that lasts longer than this (wall-clock ticks of the device) gives the run up: the call returns
+    // SPADA_ERR_HIP instead of holding the GPU for ever (SPADA_CHAIN_TIMEOUT_MS, default 2000; chain_gave_up in spgemm_task.hip.hpp)
+    unsigned long long chain_limit = 0;
+    int wall_khz = 100000;
+    uint32_t test_stall_task = 0xFFFFFFFFu;   // (tests, SPADA_TEST_STALL_TASK: a task of the one-pass kernel that never publishes its count)
     int side_mode = 2;                // (SPADA_SIDE: 0 no side streams, 1 scatter and cut table on one, 2 on one each -- measurements)
     bool shadow = true;               // (SPADA_SHADOW=0: the clearing at the head of every run instead of behind the one before -- measurements)
     uint64_t rows_preset = 0;         // rows whose accumulators (row_P, row_kmin, row_kmax) hold their presets: every run puts back what it used
@@ -186,6 +201,7 @@ int dev_row_extents(spada_ctx *c, spada_dev_csr *d)
     return SPADA_OK;
 }
 
+float tev_ms(spada_ctx *c, int a, int b);
 int dev_upload(spada_ctx *c, const spada_csr_view *m, spada_dev_csr **out)
 {
     if (m->cols >= 0xFFFFFFFFull)
@@ -198,8 +214,10 @@ int dev_upload(spada_ctx *c, const spada_csr_view *m, spada_dev_csr **out)
     d->nnz = m->nnz;
     std::vector<uint32_t> idx32(m->nnz), rid32(m->nnz);
     for (uint64_t q = 0; q < m->nnz; ++q) idx32[q] = (uint32_t)m->indices[q];
+    const auto t_aux = std::chrono::steady_clock::now();
     for (uint64_t r = 0; r < m->rows; ++r)
         for (uint64_t q = m->indptr[r]; q < m->indptr[r + 1]; ++q) rid32[q] = (uint32_t)r;
+    d->aux_host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_aux).count();
     HIP_TRY(hipMalloc((void **)&d->ptr, (m->rows + 1) * 8));
     if (hipMalloc((void **)&d->idx, std::max<uint64_t>(m->nnz, 1) * 4) != hipSuccess ||
         hipMalloc((void **)&d->val, std::max<uint64_t>(m->nnz, 1) * 8) != hipSuccess ||
@@ -212,10 +230,17 @@ int dev_upload(spada_ctx *c, const spada_csr_view *m, spada_dev_csr **out)
         if (m->nnz) {
             HIP_TRY(hipMemcpyAsync(d->idx, idx32.data(), m->nnz * 4, hipMemcpyHostToDevice, c->stream));
             HIP_TRY(hipMemcpyAsync(d->val, m->data, m->nnz * 8, hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            const auto t_rid = std::chrono::steady_clock::now();
             HIP_TRY(hipMemcpyAsync(d->rowid, rid32.data(), m->nnz * 4, hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            d->aux_host_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_rid).count();
         }
+        HIP_TRY(hipEventRecord(c->tev[0], c->stream));
         if (int rc2 = dev_row_extents(c, d.get())) return rc2;
+        HIP_TRY(hipEventRecord(c->tev[1], c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
+        d->aux_dev_ms = tev_ms(c, 0, 1);
         return SPADA_OK;
     };
     if (int rc = copy_in()) {
@@ -373,6 +398,9 @@ TaskArgs task_args(spada_ctx *c, uint64_t *cptr, uint32_t *d_idx, double *d_val,
     g.capacity = capacity;
     g.task_lo = 0;
     g.task_hi = 0xFFFFFFFFu;
+    g.stall_task = c->test_stall_task;
+    g.pad_stall = 0;
+    g.chain_limit = c->chain_limit;
     return g;
 }
 
@@ -380,8 +408,14 @@ TaskArgs task_args(spada_ctx *c, uint64_t *cptr, uint32_t *d_idx, double *d_val,
 // (cptr / d_idx / d_val = the caller's buffers).  Nothing is read back before the end; workspaces whose size depends on the
 // data (tasks, range descriptors, scratch) keep their capacity from earlier calls, the kernels refuse to overrun them, and one
 // more run with the sizes they report follows when that happened.
-int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, double *d_val, uint64_t capacity)
+// `by_rule` (one-pass entry point, first call on an input): the run reads its row statistics back ONCE, behind the row classes, and goes on
+// as MODE_FUSED or -- more than half of the products in BIG rows -- as MODE_COUNT into the context's own C.indptr; *mode_ran says which.
+// The same read sizes the data-dependent workspaces of a context's first run (tasks, range descriptors, parts, cut table, scratch), which
+// would otherwise find them too small, stop and run again.
+int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, double *d_val, uint64_t capacity, bool by_rule = false,
+                  int *mode_ran = nullptr)
 {
+    uint64_t *const cptr_caller = cptr;
     c->chunk_timing_open = false;   // (a numeric phase in pieces whose caller waited on the pieces' events never closed its interval: tev[0 .. 4] are this run's now)
     const spada_dev_csr *a = c->A, *b = c->B;
     const uint32_t n = c->nrows;
@@ -425,7 +459,11 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
         c->t_cap_parts = std::min<uint64_t>(std::max<uint64_t>(a->nnz / 128, 2048), 32768);   // (4 KB of bucket counts each)
     }
     c->stats.pipeline_runs = 0;
-    for (int attempt = 0; attempt < 4; ++attempt) {
+    uint64_t cap_cut_items = 0;
+    uint32_t cap_tasks = 0, cap_tmp = 0, cap_parts = 0;
+    // the workspaces whose size depends on the data, at the capacities the context has learnt so far
+    const auto ensure_ws = [&]() -> int {
+        int rc;
         c->t_cap_tasks = std::max<uint64_t>(c->t_cap_tasks, (uint64_t)n / 4 + 4096);
         if ((rc = c->t_tasks.ensure(c->t_cap_tasks * sizeof(TaskDesc), false, s, &c->ws_bytes))) return rc;
         if ((rc = c->t_status.ensure(c->t_cap_tasks * 8 * ST_STRIDE, false, s, &c->ws_bytes))) return rc;
@@ -437,25 +475,70 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
         if ((rc = c->t_scrval.ensure(c->t_cap_scr * 8, false, s, &c->ws_bytes))) return rc;
         if ((rc = c->t_cuts.ensure(c->t_cap_cuts * 4, false, s, &c->ws_bytes))) return rc;
         // (at most one partly filled item per row; an arena that rows of few words each crowd reports its items, and the retry takes them)
-        const uint64_t cap_cut_items = std::max<uint64_t>(c->t_cap_cuts / BX_CUT_ITEM + (uint64_t)n + 16 * BX_ARENAS, c->t_cap_cutitems);
+        cap_cut_items = std::max<uint64_t>(c->t_cap_cuts / BX_CUT_ITEM + (uint64_t)n + 16 * BX_ARENAS, c->t_cap_cutitems);
         if ((rc = c->t_cutitems.ensure(cap_cut_items * sizeof(uint2), false, s, &c->ws_bytes))) return rc;
         if (c->accumulator == SPADA_ACC_SORT_MERGE && (rc = c->t_scrseq.ensure(c->t_cap_scr * 4, false, s, &c->ws_bytes))) return rc;
         if ((rc = c->t_parts.ensure(c->t_cap_parts * sizeof(BigPart), false, s, &c->ws_bytes))) return rc;
         if ((rc = c->t_parthist.ensure(c->t_cap_parts * BX_NB * 4, false, s, &c->ws_bytes))) return rc;
         // capacities the kernels may rely on (DevBuf over-allocates; use what was asked for)
-        const uint32_t cap_tasks = (uint32_t)std::min<uint64_t>(c->t_cap_tasks, 0xFFFFFFF0u);
-        const uint32_t cap_tmp = (uint32_t)std::min<uint64_t>(c->t_cap_tmp, 0xFFFFFFF0u);
-        const uint32_t cap_parts = (uint32_t)std::min<uint64_t>(c->t_cap_parts, 0xFFFFFFF0u);
+        cap_tasks = (uint32_t)std::min<uint64_t>(c->t_cap_tasks, 0xFFFFFFF0u);
+        cap_tmp = (uint32_t)std::min<uint64_t>(c->t_cap_tmp, 0xFFFFFFF0u);
+        cap_parts = (uint32_t)std::min<uint64_t>(c->t_cap_parts, 0xFFFFFFF0u);
+        return SPADA_OK;
+    };
+    // the end of a run (and the mid-run read): the counters written into pinned host memory, then a sequence number the host polls
+    const auto export_and_wait = [&](TaskCounters *dc) -> int {
+        if (c->export_poll) {
+            hipLaunchKernelGGL(k_export_counters, dim3(1), dim3(256), 0, s, (const TaskCounters *)dc, c->h_tctr, c->h_seq, ++c->seq);
+            HIP_TRY(hipGetLastError());
+            // (the stream is asked now and then: a kernel that faulted never writes the number)
+            for (unsigned spins = 0; __atomic_load_n(c->h_seq, __ATOMIC_ACQUIRE) != c->seq; ++spins) {
+                __builtin_ia32_pause();
+                if ((spins & 0xFFFu) == 0xFFFu) {
+                    const hipError_t q = hipStreamQuery(s);
+                    if (q == hipSuccess) break;
+                    if (q != hipErrorNotReady) return fail(SPADA_ERR_HIP, "task pipeline: %s", hipGetErrorString(q));
+                }
+            }
+            if (__atomic_load_n(c->h_seq, __ATOMIC_ACQUIRE) != c->seq) HIP_TRY(hipStreamSynchronize(s));
+        } else {
+            HIP_TRY(hipMemcpyAsync(c->h_tctr, dc, sizeof(TaskCounters), hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipEventRecord(c->ev_done, s));
+            HIP_TRY(hipEventSynchronize(c->ev_done));
+        }
+        return SPADA_OK;
+    };
+    // (k_row_class_cut leaves its statistics spread over the slots)
+    const auto sum_class_slots = [&](TaskCounters &h, unsigned long long (&extra)[4]) {
+        h.a_nnz = 0;
+        for (int k = 0; k < N_CLS; ++k) h.cls_rows[k] = h.cls_prod[k] = 0;
+        for (auto &x : extra) x = 0;
+        for (int sl = 0; sl < CLS_SLOTS; ++sl) {
+            for (int k = 0; k < N_CLS; ++k) {
+                h.cls_rows[k] += h.cls_part[sl][k];
+                h.cls_prod[k] += h.cls_part[sl][N_CLS + k];
+            }
+            h.a_nnz += h.cls_part[sl][2 * N_CLS];
+            for (int k = 0; k < 4; ++k) extra[k] += h.cls_part[sl][11 + k];
+        }
+        h.nprod = 0;
+        for (int k = 0; k < N_CLS; ++k) h.nprod += h.cls_prod[k];
+        h.nprod_big = h.cls_prod[CLS_BIG];
+    };
+    bool mid_read = n && (by_rule || !c->ws_sized) && c->accumulator != SPADA_ACC_SORT_MERGE;
+    for (int attempt = 0; attempt < 4; ++attempt) {
+        if ((rc = ensure_ws())) return rc;
         ++c->stats.pipeline_runs;
         c->join2 = c->join3 = false;
         HIP_TRY(hipEventRecord(c->tev[0], s));
         static_assert(sizeof(TaskCounters) % 8 == 0, "k_clear_counters clears the counters in 8-byte words");
         c->ctr_idx ^= 1;   // (the set the run before the last one used: cleared behind the last run)
         TaskCounters *dc = dev_counters(c);
-        if (!c->shadow) {
+        if (!c->shadow || c->counters_dirty) {   // (dirty: an earlier run left through an error between this flip and the clearing kernel behind it)
             hipLaunchKernelGGL(k_clear_counters, dim3(8), dim3(256), 0, s, dc);
-            c->rows_preset = 0;
+            if (!c->shadow) c->rows_preset = 0;
         }
+        c->counters_dirty = true;
         if (c->rows_preset < n) {   // (the first run of a context, or one over more rows than any before it; else the run before has seen to it)
             hipLaunchKernelGGL(k_preset_rows, dim3(c->n_cu * 4), dim3(256), 0, s, c->t_rowP.as<unsigned long long>(), c->row_kmin.as<uint32_t>(),
                                c->row_kmax.as<uint32_t>(), (uint64_t)n);
@@ -464,7 +547,7 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
         const uint64_t preset_before = c->rows_preset;
         c->rows_preset = 0;   // (in use from here on; put back behind the run, below -- an error in between leaves them marked as unknown)
         // (the arguments of the task kernel -- all of them known here -- travel with the first kernel of the run: see k_task_args)
-        const TaskArgs g = task_args(c, cptr, d_idx, d_val, capacity);
+        TaskArgs g = task_args(c, cptr, d_idx, d_val, capacity);
         if (n) {
             // (products a task hashes at most: since the table of the batch tasks is keyed by BLOCKS of columns it never gets full, and
             // the fullest tasks win on every input: 2040 / 1920 / 1792 / 1536 -> web 0.826 / 0.844 / 0.882 / 0.965 ms, R-MAT 16 4.81 /
@@ -484,10 +567,46 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
                                c->t_tiles.as<uint32_t>(), c->t_rowt.as<uint32_t>(), c->row_binfo.as<uint32_t>());
             HIP_TRY(hipGetLastError());
         }
+        bool no_big_known = false;
+        if (mid_read) {
+            // THE MID-RUN READ (first run of a context, first call of the one-pass entry point on an input): one host round trip (~15 us)
+            // behind the row classes -- classes, products per class, BIG rows and the estimates of k_row_class_cut.  It chooses the
+            // pipeline by the rule, sizes the workspaces so that this run need not be thrown away, and knows whether there are BIG rows
+            mid_read = false;
+            if ((rc = export_and_wait(dc))) return rc;
+            TaskCounters &hm = *c->h_tctr;
+            unsigned long long ex[4];
+            sum_class_slots(hm, ex);
+            if (by_rule) {
+                const bool two = hm.nprod_big * 2 > hm.nprod;
+                mode = two ? MODE_COUNT : MODE_FUSED;
+                cptr = two ? c->cptr.as<uint64_t>() : cptr_caller;
+                trace(2, "  rule: %llu of %llu products in BIG rows -> %s", (unsigned long long)hm.nprod_big, (unsigned long long)hm.nprod,
+                      two ? "count + numeric" : "one pass");
+            }
+            c->last_nprod_big = hm.nprod_big;   // (the part size of THIS run)
+            no_big_known = true;
+            c->expect_no_big = hm.n_big == 0;
+            const uint32_t psh_m = c->part_shift ? c->part_shift : (hm.nprod_big >= (1ull << 30) ? BX_PART_SHIFT_HUGE : BX_PART_SHIFT);
+            const uint64_t est_ranges = ex[1], est_cut_words = ex[2], spill_sure = ex[3];
+            c->t_cap_tasks = std::max<uint64_t>(c->t_cap_tasks, ex[0] + est_ranges + 1024);
+            c->t_cap_tmp = std::max<uint64_t>(c->t_cap_tmp, est_ranges + 1024);
+            c->t_cap_parts = std::max<uint64_t>(c->t_cap_parts, (hm.nprod_big >> psh_m) + 2ull * hm.n_big + 256);
+            if (c->cut_table) c->t_cap_cuts = std::max<uint64_t>(c->t_cap_cuts, est_cut_words + est_cut_words / 2 + (64u << 10) * BX_ARENAS);
+            // (the spilled products: the rows with more than BT_EMAX entries for sure, of the others what the plan decides -- a guess; the
+            // run is repeated with the exact figure if it is too small)
+            c->t_cap_scr = std::max<uint64_t>(c->t_cap_scr, spill_sure + spill_sure / 8 + std::min<uint64_t>(hm.nprod_big - std::min<uint64_t>(spill_sure, hm.nprod_big), 16ull << 20) + 1024);
+            if ((rc = ensure_ws())) return rc;
+            g = task_args(c, cptr, d_idx, d_val, capacity);   // (buffers may have moved, the mode may have changed)
+            launch_task_args(c, g);
+            c->ws_sized = true;
+        }
         if (c->phase_timing) HIP_TRY(hipEventRecord(c->tev[1], s));
         // A run whose predecessor on this context found no BIG row does not launch the five BIG-row kernels (each costs a launch and a
         // drain -- together a tenth of a step of the mesh inputs -- to find an empty list).  The guess is checked at the end of the run:
         // if the row classes did find BIG rows, the run is thrown away and repeated with the kernels (never twice in a row)
+        // (behind a mid-run read it is no guess)
+        (void)no_big_known;
         const bool no_big = c->expect_no_big;
         bool scatter_launched = false;
         if (n && !no_big) {
@@ -592,6 +711,7 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
                                   c->row_kmax.as<uint32_t>(), (uint64_t)n);
         c->rows_preset = c->shadow ? preset_before : 0;
         HIP_TRY(hipGetLastError());
+        if (c->shadow) c->counters_dirty = false;   // (the other set's clearing is queued)
         if (c->export_poll) {
             // (the stream is asked now and then: a kernel that faulted never writes the number)
             for (unsigned spins = 0; __atomic_load_n(c->h_seq, __ATOMIC_ACQUIRE) != c->seq; ++spins) {
@@ -607,18 +727,10 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
             HIP_TRY(hipEventSynchronize(c->ev_done));
         }
         TaskCounters &h = *c->h_tctr;
-        h.a_nnz = 0;
-        for (int k = 0; k < N_CLS; ++k) h.cls_rows[k] = h.cls_prod[k] = 0;
-        for (int sl = 0; sl < CLS_SLOTS; ++sl) {   // (k_row_class_cut leaves its statistics spread over the slots)
-            for (int k = 0; k < N_CLS; ++k) {
-                h.cls_rows[k] += h.cls_part[sl][k];
-                h.cls_prod[k] += h.cls_part[sl][N_CLS + k];
-            }
-            h.a_nnz += h.cls_part[sl][2 * N_CLS];
+        {
+            unsigned long long ex[4];
+            sum_class_slots(h, ex);
         }
-        h.nprod = 0;
-        for (int k = 0; k < N_CLS; ++k) h.nprod += h.cls_prod[k];
-        h.nprod_big = h.cls_prod[CLS_BIG];
         c->last_nprod_big = h.nprod_big;
         c->last_spilled = h.n_spilled;
         uint64_t cut_most = 0;   // (the fullest arena sets the size)
@@ -628,6 +740,11 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
             items_most = std::max<uint64_t>(items_most, h.cut_arena[a2][1]);
         }
         c->last_cuts = cut_most;
+        if (h.abort_flag & ABORT_CHAIN) {   // a wait on the one-pass chain ran into its limit (chain_gave_up): the kernel has drained, nothing of the run is valid
+            ++c->stats.chain_fallbacks;
+            return fail(SPADA_ERR_HIP, "task pipeline: the one-pass chain made no progress for %.0f ms (a predecessor never published its count): run given up",
+                        (double)c->chain_limit / (double)c->wall_khz);
+        }
         if (h.abort_flag & 64u) {   // rows were spilled in a run without the scatter kernel (stopped before the task kernel): again, with it
             c->expect_no_spill = false;
             h.abort_flag &= ~64u;
@@ -737,6 +854,7 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
     } else {
         st.ms_fused_call = tev_ms(c, 0, 4);
     }
+    if (mode_ran) *mode_ran = mode;
     trace(1, "%s rows [%llu, %llu): %llu products -> %llu nnz(C), %u tasks, %.3f ms on the device (%llu pipeline run%s)",
           mode == MODE_COUNT ? "symbolic" : "one-pass", (unsigned long long)c->r0, (unsigned long long)(c->r0 + n),
           (unsigned long long)h.nprod, (unsigned long long)c->nnz_c, h.ntasks, tev_ms(c, 0, 4), (unsigned long long)st.pipeline_runs,
@@ -821,12 +939,21 @@ int spada_create(const spada_options *opts, spada_ctx **out)
     if (const char *e = getenv("SPADA_RANGE_CURSORS")) c->range_cursors = atoi(e) != 0;
     if (const char *e = getenv("SPADA_PART_SHIFT")) c->part_shift = (uint32_t)std::min(std::max(atoi(e), 10), 20);
     if (const char *e = getenv("SPADA_SIDE")) c->side_mode = atoi(e);
-    if (const char *e = getenv("SPADA_AUTO")) c->auto_pipeline = atoi(e) != 0;
+    if (const char *e = getenv("SPADA_AUTO")) c->auto_mode = !std::strcmp(e, "measure") ? 2 : (atoi(e) != 0 ? 1 : 0);
     if (const char *e = getenv("SPADA_EXPORT")) c->export_poll = atoi(e) != 0;
     if (const char *e = getenv("SPADA_SHADOW")) c->shadow = atoi(e) != 0;
     if (const char *e = getenv("SPADA_TASK_WGS")) c->task_wgs = (uint32_t)std::min(std::max(atoi(e), 1), TASK_WAVES / 2);
     if (const char *e = getenv("SPADA_CUT_TABLE")) c->cut_table = atoi(e) != 0;
     if (const char *e = getenv("SPADA_CUT_FACTOR16")) c->cut_factor16 = (uint32_t)atoi(e);
+    if (const char *e = getenv("SPADA_TEST_STALL_TASK")) c->test_stall_task = (uint32_t)atoi(e);
+    {
+        int khz = 0;   // (wall_clock64() ticks per millisecond: 100 MHz on this part)
+        if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0) khz = 100000;
+        double ms = 2000.0;
+        if (const char *e = getenv("SPADA_CHAIN_TIMEOUT_MS")) ms = std::max(atof(e), 1.0);
+        c->chain_limit = (unsigned long long)(ms * (double)khz);
+        c->wall_khz = khz;
+    }
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
     HIP_TRY(hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
@@ -904,6 +1031,9 @@ void spada_dev_csr_free(spada_ctx *c, spada_dev_csr *m)
         (void)hipSetDevice(c->device);
         (void)hipStreamSynchronize(c->stream);
         if (c->A == m || c->B == m) c->have_symbolic = false;
+        c->at_sig = 0;   // (what the one-pass entry point remembers of an input is keyed on the operands' addresses: a new matrix may get this one's)
+        c->at_phase = 0;
+        c->rule_known = false;
     }
     dev_free(m);
 }
@@ -1021,9 +1151,15 @@ int spada_dev_csr_rowmap(spada_ctx *c, const spada_dev_csr *a_reordered, uint64_
     return SPADA_OK;
 }
 
+static double wall_ms_since(const std::chrono::steady_clock::time_point &t0)
+{
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+
 int spada_dev_spgemm_symbolic(spada_ctx *c, const spada_dev_csr *a, const spada_dev_csr *b, uint64_t row_begin,
                               uint64_t row_end, uint64_t *nnz_c)
 {
+    const auto t_wall = std::chrono::steady_clock::now();
     if (!c) return fail(SPADA_ERR_STATE, "spada_dev_spgemm_symbolic: no engine context (no GPU?)");
     if (!a || !b || !nnz_c) return fail(SPADA_ERR_INVALID, "spada_dev_spgemm_symbolic: null argument");
     if (a->cols != b->rows)
@@ -1042,6 +1178,7 @@ int spada_dev_spgemm_symbolic(spada_ctx *c, const spada_dev_csr *a, const spada_
     if (rc_t) return rc_t;
     *nnz_c = c->nnz_c;
     c->have_symbolic = true;
+    c->stats.ms_wall_call = wall_ms_since(t_wall);
     return SPADA_OK;
 }
 
@@ -1052,7 +1189,10 @@ int spada_dev_spgemm_numeric(spada_ctx *c, void *d_c_indptr, void *d_c_indices, 
     if (!d_c_indptr || (c->nnz_c && (!d_c_indices || !d_c_data)))
         return fail(SPADA_ERR_INVALID, "spada_dev_spgemm_numeric: null output pointer");
     HIP_TRY(hipSetDevice(c->device));
-    return task_numeric(c, (uint64_t *)d_c_indptr, (uint32_t *)d_c_indices, (double *)d_c_data);
+    const auto t_wall = std::chrono::steady_clock::now();
+    const int rc = task_numeric(c, (uint64_t *)d_c_indptr, (uint32_t *)d_c_indices, (double *)d_c_data);
+    c->stats.ms_wall_call = wall_ms_since(t_wall);
+    return rc;
 }
 
 int spada_dev_spgemm_numeric_plan(spada_ctx *c, uint32_t chunks, uint64_t *chunk_pos)
@@ -1155,21 +1295,27 @@ int spada_dev_spgemm_fused(spada_ctx *c, const spada_dev_csr *a, const spada_dev
     c->nnz_c = 0;
     std::memset(&c->stats, 0, sizeof c->stats);
     // WHICH PIPELINE.  The one-pass pipeline (counts exchanged through the chain while the rows are computed) wins where the tasks are
-    // alike -- web graphs, meshes: 1.0 against 1.4 ms on the web input -- and loses where many range tasks take the older path inside the
-    // task kernel and a thousand tasks of the chain wait for each of them: R-MAT 16 6.2 against 5.7 ms, R-MAT 18 50 against 43 ms for
-    // count + positions + numeric.  So a context MEASURES: the first call on an input (operands, row range) whose products are mostly
-    // in BIG rows runs one pass, the second the two-phase pipeline into the same caller buffers, and from the third on the faster of
-    // the two runs.  The result is the same either way; spada_stats says what ran (ms_symbolic_call > 0 next to ms_fused_call).
+    // alike -- web graphs, meshes: 1.0 against 1.4 ms on the web input -- and loses where most products lie in BIG rows, whose range tasks
+    // hold up a thousand tasks of the chain each: R-MAT 16 6.2 against 5.7 ms, R-MAT 18 50 against 43 ms for count + positions + numeric
+    // into the same caller buffers.  Round 5 MEASURED per input over three calls (kept: SPADA_AUTO=measure); both inputs it ever fired
+    // on chose two phases, and the reference's usage is one execute() per process (main.rs:93) -- so the choice is now a RULE that holds on
+    // the first call: more than half of the products in BIG rows -> count + numeric.  The first call on an input (operands, row range)
+    // reads the row statistics back once behind the row classes (task_pipeline, mid-run read: ~15 us) and goes on in the right mode; later
+    // calls on the same input know the answer.  The result is the same either way; spada_stats::pipeline_kind says what ran.
+    const auto t_wall = std::chrono::steady_clock::now();
     const uint64_t sig = (uint64_t)(uintptr_t)a * 0x9E3779B97F4A7C15ull ^ (uint64_t)(uintptr_t)b * 0xC2B2AE3D27D4EB4Full ^ row_begin * 0x165667B19E3779F9ull ^
                          row_end * 0x27D4EB2F165667C5ull ^ a->nnz ^ (b->nnz << 20);
     if (sig != c->at_sig) {
         c->at_sig = sig;
         c->at_phase = 0;
+        c->rule_known = false;
     }
-    const bool two = c->auto_pipeline && (c->at_phase == 1 || (c->at_phase == 2 && c->at_two));
-    if (two) {
-        int rc2 = task_pipeline(c, MODE_COUNT, nullptr, nullptr, nullptr, 0);
-        if (rc2) return rc2;
+    // count + positions + numeric into the caller's buffers; `counted`: the counting pipeline of this call has run already
+    const auto two_phase = [&](bool counted) -> int {
+        if (!counted) {
+            const int rc2 = task_pipeline(c, MODE_COUNT, nullptr, nullptr, nullptr, 0);
+            if (rc2) return rc2;
+        }
         *nnz_c = c->nnz_c;
         if (c->nnz_c > capacity) {
             HIP_TRY(hipMemcpyAsync(d_c_indptr, c->cptr.p, ((size_t)c->nrows + 1) * 8, hipMemcpyDeviceToDevice, c->stream));
@@ -1179,34 +1325,70 @@ int spada_dev_spgemm_fused(spada_ctx *c, const spada_dev_csr *a, const spada_dev
                         (unsigned long long)capacity);
         }
         const double ms_sym = c->stats.ms_symbolic_call, ms_count_task = c->stats.ms_task;
-        if ((rc2 = task_numeric(c, (uint64_t *)d_c_indptr, (uint32_t *)d_c_indices, (double *)d_c_data))) return rc2;
+        const int rc2 = task_numeric(c, (uint64_t *)d_c_indptr, (uint32_t *)d_c_indices, (double *)d_c_data);
+        if (rc2) return rc2;
         c->stats.ms_fused_call = ms_sym + c->stats.ms_numeric_call;
         c->stats.ms_task = ms_count_task + c->stats.ms_numeric_call;   // (the two task kernels of the call)
-        if (c->at_phase == 1) {
-            c->at_two = c->stats.ms_fused_call < c->at_ms_fused;
-            c->at_phase = 2;
-            trace(1, "one pass %.3f ms, two-phase pipeline %.3f ms on this input: %s from here on", c->at_ms_fused, c->stats.ms_fused_call,
-                  c->at_two ? "two phases" : "one pass");
+        c->stats.pipeline_kind = 1;
+        return SPADA_OK;
+    };
+    const auto one_pass_done = [&]() -> int {
+        *nnz_c = c->nnz_c;
+        if (c->h_tctr->cap_overflow) {
+            // C.indptr is complete: keep it, so that a numeric call into large enough buffers can follow
+            HIP_TRY(hipMemcpyAsync(c->cptr.p, d_c_indptr, ((size_t)c->nrows + 1) * 8, hipMemcpyDeviceToDevice, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            c->have_symbolic = true;    // task list, scratch and range offsets are those of a finished symbolic phase
+            return fail(SPADA_ERR_CAPACITY, "nnz(C) = %llu exceeds the capacity of %llu entries", (unsigned long long)c->nnz_c,
+                        (unsigned long long)capacity);
         }
         return SPADA_OK;
+    };
+    int rc;
+    if (c->auto_mode == 2) {
+        // round 5's measurement: first call one pass, second (candidates only) two phases, then the faster of the two
+        if (c->at_phase == 1 || (c->at_phase == 2 && c->at_two)) {
+            rc = two_phase(false);
+            if (rc == SPADA_OK || rc == SPADA_ERR_CAPACITY) {
+                if (rc == SPADA_OK && c->at_phase == 1) {
+                    c->at_two = c->stats.ms_fused_call < c->at_ms_fused;
+                    c->at_phase = 2;
+                    trace(1, "one pass %.3f ms, two-phase pipeline %.3f ms on this input: %s from here on", c->at_ms_fused, c->stats.ms_fused_call,
+                          c->at_two ? "two phases" : "one pass");
+                }
+                c->stats.ms_wall_call = wall_ms_since(t_wall);
+                return rc;
+            }
+            // (the measurement must never turn a working call into a failing one -- e.g. a workspace only the two-phase
+            // pipeline needs that cannot be allocated: this input stays with one pass, which is tried right away)
+            c->at_phase = 2;
+            c->at_two = false;
+            spada::clear_error();
+        }
+        if ((rc = task_pipeline(c, MODE_FUSED, (uint64_t *)d_c_indptr, (uint32_t *)d_c_indices, (double *)d_c_data, capacity))) return rc;
+        rc = one_pass_done();
+        if (rc == SPADA_OK && c->at_phase == 0) {   // (a candidate for the comparison only if most products lie in BIG rows)
+            c->at_ms_fused = c->stats.ms_fused_call;
+            c->at_two = false;
+            c->at_phase = c->stats.cls_prod[CLS_BIG] * 2 > c->stats.nprod ? 1 : 2;
+        }
+        c->stats.ms_wall_call = wall_ms_since(t_wall);
+        return rc;
     }
-    int rc = task_pipeline(c, MODE_FUSED, (uint64_t *)d_c_indptr, (uint32_t *)d_c_indices, (double *)d_c_data, capacity);
-    if (rc) return rc;
-    *nnz_c = c->nnz_c;
-    if (c->h_tctr->cap_overflow) {
-        // C.indptr is complete: keep it, so that a numeric call into large enough buffers can follow
-        HIP_TRY(hipMemcpyAsync(c->cptr.p, d_c_indptr, ((size_t)c->nrows + 1) * 8, hipMemcpyDeviceToDevice, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        c->have_symbolic = true;    // task list, scratch and range offsets are those of a finished symbolic phase
-        return fail(SPADA_ERR_CAPACITY, "nnz(C) = %llu exceeds the capacity of %llu entries", (unsigned long long)c->nnz_c,
-                    (unsigned long long)capacity);
+    if (c->auto_mode == 1 && c->accumulator != SPADA_ACC_SORT_MERGE && c->rule_known && c->rule_two) {
+        rc = two_phase(false);
+    } else {
+        const bool ask = c->auto_mode == 1 && c->accumulator != SPADA_ACC_SORT_MERGE && !c->rule_known && c->nrows;
+        int ran = MODE_FUSED;
+        if ((rc = task_pipeline(c, MODE_FUSED, (uint64_t *)d_c_indptr, (uint32_t *)d_c_indices, (double *)d_c_data, capacity, ask, &ran))) return rc;
+        rc = ran == MODE_COUNT ? two_phase(true) : one_pass_done();
     }
-    if (c->at_phase == 0) {   // (a candidate for the comparison only if most products lie in BIG rows: the others stay with one pass)
-        c->at_ms_fused = c->stats.ms_fused_call;
-        c->at_two = false;
-        c->at_phase = c->auto_pipeline && c->stats.cls_prod[CLS_BIG] * 2 > c->stats.nprod ? 1 : 2;
+    if (c->auto_mode == 1) {   // (the statistics of the run that just finished: what the next call on this input goes by)
+        c->rule_known = true;
+        c->rule_two = c->stats.cls_prod[CLS_BIG] * 2 > c->stats.nprod;
     }
-    return SPADA_OK;
+    c->stats.ms_wall_call = wall_ms_since(t_wall);
+    return rc;
 }
 
 int spada_dev_spgemm_fused_owned(spada_ctx *c, const spada_dev_csr *a, const spada_dev_csr *b, uint64_t row_begin,
@@ -1340,6 +1522,16 @@ int spada_spgemm_numeric(spada_ctx *c, uint64_t *c_indptr, uint64_t *c_indices, 
         dv = c->un_val.p;
     }
     return spada_dev_download_c(c, dp, di, dv, c->nrows, c->nnz_c, c_indptr, c_indices, c_data);
+}
+
+// measurement only (include/spada_probe.h): what the derived arrays of a device CSR cost at upload
+int spada_dev_csr_aux_cost(const spada_dev_csr *m, double *host_ms, double *device_ms, uint64_t *bytes)
+{
+    if (!m || !host_ms || !device_ms) return fail(SPADA_ERR_INVALID, "spada_dev_csr_aux_cost: null argument");
+    *host_ms = m->aux_host_ms;
+    *device_ms = m->aux_dev_ms;
+    if (bytes) *bytes = m->nnz * 4 + m->rows * 8;
+    return SPADA_OK;
 }
 
 // measurement only (include/spada_probe.h): the expand-only floor over the task list of the last pipeline run

@@ -111,7 +111,9 @@ struct TaskCounters {   // (a multiple of 8 bytes: k_init clears it in 8-byte wo
     unsigned long long dbgs[2048][2][16];  // (per workgroup: no contended atomics in the measurement) tasks that published late (> 30 000 ticks) | all: tasks, products, entries, rows, displaced, outputs, second attempts, dense, range, ticks ticket -> task start, -> gathers arrived, -> publication, tasks in the kernel's last 1000  // per task kind: [0..19] histogram of the cycles from ticket to publish (4096-cycle bins), [20] sum, [21] tasks, [22] max
 #endif
     // statistics of k_row_class_cut, spread over CLS_SLOTS lines (workgroup b adds to slot b % CLS_SLOTS; the host sums them): rows per
-    // class [0 .. 4], products per class [5 .. 9], A entries [10].  One hot word takes ~90 atomics per microsecond: with the
+    // class [0 .. 4], products per class [5 .. 9], A entries [10]; what the first run of a context sizes its workspaces from
+    // (task_pipeline, mid-run read): batch tasks [11], an upper estimate of the BIG rows' range tasks [12] and cut-table words [13],
+    // products of the BIG rows that are spilled whatever the plan finds [14].  One hot word takes ~90 atomics per microsecond: with the
     // sums in one place the kernel had to run on one workgroup per CU (29 us for a million rows, a third of its memory rate)
     unsigned long long cls_part[64][16];
     unsigned long long dbg[16];  // SPADA_TASK_DBG builds: [0] cycles in the chain, [1] look-back windows, [2] spin retries, [3] cycles
@@ -1288,6 +1290,9 @@ __device__ inline uint32_t cut_tile(const uint32_t *__restrict__ row_cl, const u
 // k_big_plan, which knows its ranges, adds them to row_t and to the tile's total (through round 4 the classes and the cut were two
 // kernels with the BIG-row stage between them: a launch, its drain and the re-read of the row words on the critical path of every call,
 // for a cut that needs nothing the BIG-row kernels write).  (statistics spread over CLS_SLOTS lines: the host sums them)
+// (estimates for the first run's workspaces: a BIG row of P products becomes at most 2 P / limit + 2 ranges -- the plan packs buckets
+// greedily, two neighbouring ranges together exceed the limit -- plus the column sub-ranges of heavy buckets on very wide matrices)
+__device__ inline unsigned long long est_ranges(unsigned long long P, uint32_t lim) { return 2ull * P / lim + P / BT_PMAX + 2ull; }
 __global__ __launch_bounds__(256) void k_row_class_cut(const uint64_t *__restrict__ aptr, uint64_t r0, uint32_t nrows, uint32_t rmax,
                                                        const unsigned long long *__restrict__ row_P, const uint32_t *__restrict__ row_kmin,
                                                        const uint32_t *__restrict__ row_kmax, uint32_t *__restrict__ row_nprod,
@@ -1298,10 +1303,11 @@ __global__ __launch_bounds__(256) void k_row_class_cut(const uint64_t *__restric
                                                        uint32_t *__restrict__ row_binfo)
 {
     const uint32_t lim = ctr->prod_limit;
-    __shared__ unsigned long long s_rows[N_CLS], s_prod[N_CLS], s_tot;
+    __shared__ unsigned long long s_rows[N_CLS], s_prod[N_CLS], s_tot, s_est[3];
     __shared__ CutLds L;
     if (threadIdx.x < N_CLS) s_rows[threadIdx.x] = s_prod[threadIdx.x] = 0;
     if (threadIdx.x == 0) s_tot = 0;
+    if (threadIdx.x < 3) s_est[threadIdx.x] = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63;
     unsigned long long c_rows[N_CLS] = {0, 0, 0, 0, 0}, c_prod[N_CLS] = {0, 0, 0, 0, 0}, tot_l = 0;
@@ -1325,6 +1331,12 @@ __global__ __launch_bounds__(256) void k_row_class_cut(const uint64_t *__restric
                 c_prod[k] += cls == k ? P : 0ull;
             }
             tot_l += L_;
+            if (cls == CLS_BIG) {   // (few rows: LDS atomics of their own)
+                const unsigned long long m_est = est_ranges(P, lim);
+                atomicAdd(&s_est[0], m_est);
+                if (L_ <= BT_EMAX) atomicAdd(&s_est[1], (m_est + 1ull) * L_);
+                else atomicAdd(&s_est[2], P);
+            }
         }
         const unsigned long long bm = __ballot(i < nrows && cls == CLS_BIG);
         if (bm) {   // BIG rows: one global atomic per wave
@@ -1354,7 +1366,11 @@ __global__ __launch_bounds__(256) void k_row_class_cut(const uint64_t *__restric
     CutRow cr;
     uint32_t tot, binfo[CUT_ITEMS];
     (void)cut_tile(row_cl, row_nprod, row_rec, row_m, nrows, rmax, lim, L, cr, &tot, binfo);
-    if (threadIdx.x == 0) tile_tasks[blockIdx.x] = tot;
+    if (threadIdx.x == 0) {
+        tile_tasks[blockIdx.x] = tot;
+        if (tot) atomicAdd(&part[11], (unsigned long long)tot);
+    }
+    if (threadIdx.x < 3 && s_est[threadIdx.x]) atomicAdd(&part[12 + threadIdx.x], s_est[threadIdx.x]);
     const uint32_t base = blockIdx.x * CUT_TILE + threadIdx.x * CUT_ITEMS;
 #pragma unroll
     for (int j = 0; j < CUT_ITEMS; ++j)
@@ -1558,6 +1574,9 @@ struct TaskArgs {
     double *c_val;
     uint64_t capacity;              // FUSED: entries the caller's C buffers hold
     uint32_t task_lo, task_hi;      // tasks [task_lo, min(task_hi, all)) are run (NUMERIC in chunks; otherwise 0, 0xFFFFFFFF)
+    uint32_t stall_task;            // tests only (SPADA_TEST_STALL_TASK): this task never publishes its count -- the chain stops there (0xFFFFFFFF: none)
+    uint32_t pad_stall;
+    unsigned long long chain_limit; // one-pass mode: wall-clock ticks a wait on the chain may last before the run gives itself up (flag 128)
 };
 
 // ---- positions after a COUNT run: exclusive scan of the tasks' counts (left in range_out by the task kernel) ---------------------
@@ -1719,6 +1738,21 @@ __device__ inline uint32_t task_queue() { return blockIdx.x % (uint32_t)TK_NQ; }
 // host decides (launch_task: occupancy x CUs must be at least 4 TK_NQ, TaskArgs::scanner); a device whose CUs are masked or held by
 // other kernels below that walks back per task as before.
 __device__ inline bool chain_has_scanner(uint32_t host_says) { return host_says != 0u && gridDim.x >= 2u * (uint32_t)TK_NQ; }
+// A wait on the chain is BOUNDED (MI355X_MICROARCH.md, correctness boundaries: "bound every spin").  The chain is live as long as every
+// ticket queue has a resident workgroup (k_task); should that ever fail -- CUs taken away under the kernel, a fault in a predecessor -- a
+// waiter that has spun for `limit` wall-clock ticks (seconds: nothing legitimate waits that long, a task waits for tasks that started
+// before it) raises flag 128, every waiter looks at the flag now and then and gives up, the kernel drains and the call returns an error
+// instead of holding the GPU for ever.
+constexpr uint32_t ABORT_CHAIN = 128u;
+__device__ inline bool chain_gave_up(TaskCounters *ctr, unsigned long long t0, unsigned long long limit)
+{
+    if (__hip_atomic_load(&ctr->abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & ABORT_CHAIN) return true;
+    if (limit && wall_clock64() - t0 > limit) {
+        atomicOr(&ctr->abort_flag, ABORT_CHAIN);
+        return true;
+    }
+    return false;
+}
 __device__ inline void chain_publish(unsigned long long *status, uint32_t t, unsigned long long count, uint32_t scanner)
 {
     if (threadIdx.x == 0)
@@ -1727,12 +1761,14 @@ __device__ inline void chain_publish(unsigned long long *status, uint32_t t, uns
 }
 
 // the scanner (first wave of workgroup 0, one-pass mode): tasks [t_lo, t_end) in order
-__device__ inline void chain_scanner(unsigned long long *status, uint32_t t_lo, uint32_t t_end)
+__device__ inline void chain_scanner(unsigned long long *status, uint32_t t_lo, uint32_t t_end, TaskCounters *ctr, unsigned long long limit)
 {
     if (threadIdx.x >= 64) return;
     const uint32_t lane = threadIdx.x;
     unsigned long long run = 0;   // counts of the tasks before `next`
     uint32_t next = t_lo;
+    uint32_t idle = 0;
+    unsigned long long t_idle = 0;
     while (next < t_end) {
         unsigned long long sv[SCAN_WIN];
 #pragma unroll
@@ -1769,12 +1805,18 @@ __device__ inline void chain_scanner(unsigned long long *status, uint32_t t_lo, 
             open = lead == 64u;
         }
         next += adv;
-        if (!adv) __builtin_amdgcn_s_sleep(2);   // (a pause that grows to 2 / 8 / 32 steps, or none at all: within the run-to-run noise)
+        if (!adv) {
+            __builtin_amdgcn_s_sleep(2);   // (a pause that grows to 2 / 8 / 32 steps, or none at all: within the run-to-run noise)
+            if (idle == 0) t_idle = wall_clock64();
+            if ((++idle & 255u) == 0u && chain_gave_up(ctr, t_idle, limit)) return;   // (uniform: one wave, the same loads in every lane)
+        } else {
+            idle = 0;
+        }
     }
 }
 
 __device__ inline unsigned long long chain_lookback(unsigned long long *status, uint32_t t, unsigned long long count, uint32_t *hdr,
-                                                    TaskCounters *ctr, uint32_t scanner)
+                                                    TaskCounters *ctr, uint32_t scanner, unsigned long long limit)
 {
     const int tid = threadIdx.x, lane = tid & 63;
     unsigned long long dbg_win = 0, dbg_spin = 0;
@@ -1782,13 +1824,20 @@ __device__ inline unsigned long long chain_lookback(unsigned long long *status, 
     // wait for the scanner to turn this task's own count into the inclusive prefix (one lane, one word)
     if (tid == 0) {
         unsigned long long s;
-        uint32_t pause = 0;
+        uint32_t pause = 0, spins = 0;
+        unsigned long long t_wait = 0;
         for (;;) {
             s = __hip_atomic_load(&status[(size_t)t * ST_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if ((s & ST_MASK) == ST_INC) break;
             __builtin_amdgcn_s_sleep(2);
             if (pause < LB_PAUSE_MAX) ++pause;
             for (uint32_t z = 0; z < pause; ++z) __builtin_amdgcn_s_sleep(4);
+            if (spins == 0) t_wait = wall_clock64();
+            if ((++spins & 255u) == 0u && chain_gave_up(ctr, t_wait, limit)) {   // (the run is given up: any position inside the buffers will do)
+                s = ST_INC | count;
+                hdr[51] = 1u;   // (the workgroup leaves the task loop: k_task)
+                break;
+            }
         }
         const unsigned long long excl = (s & ~ST_MASK) - count;
         hdr[48] = (uint32_t)excl;
@@ -1823,16 +1872,27 @@ __device__ inline unsigned long long chain_lookback(unsigned long long *status, 
                     // growing pause: a thousand workgroups re-reading whole windows would slow down the very tasks they wait for
                     const int who = __ffsll((long long)(m_empty & relevant)) - 1;
                     unsigned long long spins = 0;
+                    bool gave_up = false;
                     if (lane == who) {
                         uint32_t pause = 0;
+                        unsigned long long t_wait = 0;
                         while ((__hip_atomic_load(&status[idx * ST_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & ST_MASK) == 0) {
+                            if (spins == 0) t_wait = wall_clock64();
                             ++spins;
                             __builtin_amdgcn_s_sleep(8);
                             if (pause < LB_PAUSE_MAX) ++pause;
                             for (uint32_t z = 0; z < pause; ++z) __builtin_amdgcn_s_sleep(16);
+                            if ((spins & 255ull) == 0ull && chain_gave_up(ctr, t_wait, limit)) {
+                                gave_up = true;
+                                break;
+                            }
                         }
                     }
                     dbg_spin += __shfl(spins, who);
+                    if (__ballot(gave_up)) {   // (the run is given up: any position will do)
+                        if (lane == 0) hdr[51] = 1u;
+                        break;
+                    }
                     continue;
                 }
                 unsigned long long v = lane <= first_inc ? (s & ~ST_MASK) : 0ull;
@@ -1868,6 +1928,7 @@ __device__ inline void task_publish(const G &g, uint32_t t, unsigned long long c
     if constexpr (MODE == MODE_COUNT) {
         if (threadIdx.x == 0) g.range_out[t] = count;
     } else {
+        if (t == g.stall_task) return;   // (tests: a predecessor that never publishes)
         chain_publish(g.status, t, count, g.scanner);
     }
 }
@@ -1875,7 +1936,7 @@ template <int MODE, class G>
 __device__ inline unsigned long long task_position(const G &g, uint32_t t, unsigned long long count, uint32_t *hdr)
 {
     if constexpr (MODE == MODE_COUNT) return 0ull;
-    else return chain_lookback(g.status, t, count, hdr, g.ctr, g.scanner);
+    else return chain_lookback(g.status, t, count, hdr, g.ctr, g.scanner, g.chain_limit);
 }
 
 // Ordered emission of the table (all waves): every occupied slot -> bucket = boff[lr] + floor((col - kmin) * n / span), monotone
@@ -2358,7 +2419,7 @@ __global__ __launch_bounds__(TKW, TASK_WAVES) void k_task(const TaskArgs *__rest
         if (blockIdx.x == 0) {
             if (tid == 0) __hip_atomic_store(&g.ctr->scanner_cu, me, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __builtin_amdgcn_s_setprio(3);
-            chain_scanner(g.status, g.task_lo, task_end);
+            chain_scanner(g.status, g.task_lo, task_end, g.ctr, g.chain_limit);
             return;
         }
         {
@@ -2381,9 +2442,16 @@ __global__ __launch_bounds__(TKW, TASK_WAVES) void k_task(const TaskArgs *__rest
     // all hold smaller, hence finished, tasks and are free to take it: no cycle of waiting workgroups can form as long as
     // every queue has a resident workgroup, which a grid of at least TK_NQ workgroups dispatched in order guarantees.
     uint32_t *my_ticket = &g.ctr->ticket[(task_queue()) * 32];
-    // (a static round-robin assignment instead of tickets: web -1 %, R-MAT 16 -6.5 %, and it needs every workgroup of the grid resident at
-    // once -- two one-pass kernels of two contexts on one GPU would deadlock each other; not adopted: profiles/r04_experiments.txt)
-    if (tid == 0) hdr[50] = g.task_lo + atomicAdd(my_ticket, 1u) * TK_NQ + task_queue();
+    // (STATIC assignment instead of tickets -- worker w of G takes tasks w, w + G, ...: round 4 measured it at -1 % (web) / -6.5 % (R-MAT 16)
+    // and did not adopt it, because the chain is then live only while EVERY workgroup of the grid is resident.  Round 6 built it with
+    // what it was supposed to make possible -- the next task is known, so its whole prologue runs under the wait for the position / under
+    // the stores -- and a bounded wait as the safety net: one-pass web 0.766 against 0.769 ms, cop20k_A 0.554 / 0.562, R-MAT 16 4.16 / 3.50;
+    // the modes without a chain LOSE 12 % (web count 0.466 against 0.411, numeric 0.738 against 0.658: tickets balance the tail, a fixed
+    // share does not).  Hiding two of a task's three dependent round trips buys nothing: profiles/r06_experiments.txt section 2.)
+    if (tid == 0) {
+        hdr[50] = g.task_lo + atomicAdd(my_ticket, 1u) * TK_NQ + task_queue();
+        hdr[51] = 0u;
+    }
     if (SPADA_TASK_DBG && tid < 32) ((uint32_t *)(smem + task_dbg_off()))[tid] = 0u;
     __syncthreads();
     // (t is uniform: the descriptor is a scalar load, what is derived from it lives in scalar registers)
@@ -2456,6 +2524,7 @@ __global__ __launch_bounds__(TKW, TASK_WAVES) void k_task(const TaskArgs *__rest
         td = td2;
         hd = hd2;
         bt = bt2;
+        if (MODE == MODE_FUSED && hdr[51]) break;   // (uniform; a wait on the chain ran into its limit -- chain_gave_up: the run is lost, the workgroup leaves)
     }
     if (SPADA_TASK_DBG && tid == 0) {
         const uint32_t *d = (const uint32_t *)(smem + task_dbg_off());
@@ -2591,7 +2660,7 @@ __global__ __launch_bounds__(TK_BLOCK, 3) void k_task_sm(const TaskArgs g)
     const uint32_t ntasks = g.ctr->ntasks, task_end = min(ntasks, g.task_hi);
     if (g.ctr->abort_flag) return;
     if (chain_has_scanner(g.scanner) && MODE == MODE_FUSED && blockIdx.x == 0) {   // the chain's scanner (see k_task)
-        chain_scanner(g.status, g.task_lo, task_end);
+        chain_scanner(g.status, g.task_lo, task_end, g.ctr, g.chain_limit);
         return;
     }
     const uint32_t colmask = g.colbits >= 32 ? 0xFFFFFFFFu : ((1u << g.colbits) - 1u);

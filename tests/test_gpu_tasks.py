@@ -669,38 +669,111 @@ def test_a_run_that_expected_no_spilled_rows_is_stopped_and_repeated():
         eng.close()
 
 
-def test_one_pass_entry_point_measures_both_pipelines_on_big_row_inputs():
-    """spada_dev_spgemm_fused on an input whose products lie mostly in BIG rows: the first call runs one pass, the second the count +
-    numeric pipeline into the same caller buffers (stats: ms_symbolic_call > 0 next to ms_fused_call), later calls the faster of the
-    two; every call returns the oracle's product.  Inputs without that profile never leave the one-pass pipeline."""
+@pytest.mark.gpu
+def test_one_pass_entry_point_chooses_its_pipeline_by_rule_on_the_first_call():
+    """spada_dev_spgemm_fused on an input whose products lie mostly in BIG rows runs count + numeric into the caller's buffers -- on
+    the FIRST call of a fresh context already (the run reads its row statistics back once and goes on in the right mode;
+    stats: pipeline_kind = 1, ms_symbolic_call > 0 next to ms_fused_call) -- and one pass on every other input; every call returns
+    the oracle's product.  SPADA_AUTO=0 keeps one pass everywhere, SPADA_AUTO=measure is round 5's three-call comparison."""
     import spada_sim_amd as S
     hubs = S.generate(S.GEN_RMAT, 13, 16, 11)
     flat = S.generate(S.GEN_UNIFORM, 4000, 5, 3)
+    ref = oracle.spgemm_sortmerge(to_oracle(hubs), to_oracle(hubs))
+    cap = S.count_products(hubs, hubs, 0, hubs.shape[0])
     eng = S.Engine()
     try:
-        ref = oracle.spgemm_sortmerge(to_oracle(hubs), to_oracle(hubs))
         d = eng.upload(hubs)
-        cap = S.count_products(hubs, hubs, 0, hubs.shape[0])
-        seen_two = 0
-        for call in range(4):
+        for call in range(3):
             p, i, v, nnz = eng.fused_owned(d, d, 0, hubs.shape[0], cap)
             st = eng.stats()
-            assert st["ms_fused_call"] > 0 and st["ms_fused_call"] >= st["ms_task"] > 0
-            if call == 0:
-                assert st["cls_prod"][4] * 2 > st["nprod"] and st["ms_symbolic_call"] == 0
-            if call == 1:
-                assert st["ms_symbolic_call"] > 0
-            seen_two += st["ms_symbolic_call"] > 0
+            assert st["cls_prod"][4] * 2 > st["nprod"]
+            assert st["pipeline_kind"] == 1 and st["ms_symbolic_call"] > 0, (call, st["pipeline_kind"])
+            assert st["ms_fused_call"] > 0 and st["ms_fused_call"] >= st["ms_task"] > 0 and st["ms_wall_call"] > 0
             c = eng.download(p, i, v, hubs.shape[0], nnz, hubs.shape[1])
             assert_parity(c, ref, to_oracle(hubs), to_oracle(hubs), RTOL)
-        assert seen_two >= 1
-        with pytest.raises(S.SpadaError):                    # capacity too small, whichever pipeline runs by now
+        with pytest.raises(S.SpadaError):                    # capacity too small
             eng.fused_owned(d, d, 0, hubs.shape[0], max(ref.nnz // 3, 1))
         eng.free(d)
-        d2 = eng.upload(flat)
+        d2 = eng.upload(flat)                                # another input on the same context: one pass from its first call
         for call in range(3):
             eng.fused_owned(d2, d2, 0, flat.shape[0], S.count_products(flat, flat, 0, flat.shape[0]))
-            assert eng.stats()["ms_symbolic_call"] == 0
+            st = eng.stats()
+            assert st["pipeline_kind"] == 0 and st["ms_symbolic_call"] == 0
         eng.free(d2)
+    finally:
+        eng.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("auto", ["0", "measure"])
+def test_one_pass_entry_point_switches(auto, monkeypatch):
+    """SPADA_AUTO=0: one pass whatever the input; SPADA_AUTO=measure: first call one pass, second count + numeric, then the faster."""
+    import spada_sim_amd as S
+    monkeypatch.setenv("SPADA_AUTO", auto)
+    hubs = S.generate(S.GEN_RMAT, 13, 16, 11)
+    ref = oracle.spgemm_sortmerge(to_oracle(hubs), to_oracle(hubs))
+    cap = S.count_products(hubs, hubs, 0, hubs.shape[0])
+    eng = S.Engine()
+    try:
+        d = eng.upload(hubs)
+        kinds = []
+        for call in range(4):
+            p, i, v, nnz = eng.fused_owned(d, d, 0, hubs.shape[0], cap)
+            kinds.append(eng.stats()["pipeline_kind"])
+            c = eng.download(p, i, v, hubs.shape[0], nnz, hubs.shape[1])
+            assert_parity(c, ref, to_oracle(hubs), to_oracle(hubs), RTOL)
+        if auto == "0":
+            assert kinds == [0, 0, 0, 0]
+        else:
+            assert kinds[0] == 0 and kinds[1] == 1
+        eng.free(d)
+    finally:
+        eng.close()
+
+
+@pytest.mark.gpu
+def test_the_first_call_of_a_context_is_one_pipeline_run():
+    """A fresh context sizes its data-dependent workspaces from the row statistics it reads back behind the row classes: the first
+    call on the web and mesh surrogates no longer finds a workspace too small, stops and runs again (pipeline_runs == 1)."""
+    import spada_sim_amd as S
+    for kind, seed in ((S.GEN_WEBBASE_LIKE, 12347), (S.GEN_COP20K_LIKE, 12346), (S.GEN_MC2DEPI_LIKE, 12349)):
+        m = S.generate(kind, 0, 0, seed)
+        cap = S.count_products(m, m, 0, m.shape[0])
+        eng = S.Engine()
+        try:
+            d = eng.upload(m)
+            _, _, _, nnz1 = eng.fused_owned(d, d, 0, m.shape[0], cap)
+            st1 = eng.stats()
+            assert st1["pipeline_runs"] == 1, (kind, st1["pipeline_runs"])
+            _, _, _, nnz2 = eng.fused_owned(d, d, 0, m.shape[0], cap)
+            assert nnz1 == nnz2 and eng.stats()["pipeline_runs"] == 1
+            eng.free(d)
+        finally:
+            eng.close()
+
+
+@pytest.mark.gpu
+def test_a_stalled_chain_gives_up_instead_of_hanging(monkeypatch):
+    """Every wait on the one-pass chain is bounded (chain_gave_up): with a task that never publishes its count (test hook) the call
+    returns SPADA_ERR_HIP after SPADA_CHAIN_TIMEOUT_MS instead of holding the GPU; a context without the hook computes the product."""
+    import spada_sim_amd as S
+    a = S.generate(S.GEN_UNIFORM, 60000, 6, 5)
+    ref = oracle.spgemm_sortmerge(to_oracle(a), to_oracle(a))
+    monkeypatch.setenv("SPADA_TEST_STALL_TASK", "7")
+    monkeypatch.setenv("SPADA_CHAIN_TIMEOUT_MS", "200")
+    monkeypatch.setenv("SPADA_AUTO", "0")
+    eng = S.Engine()
+    try:
+        with pytest.raises(S.SpadaError) as ei:
+            eng.spgemm_fused(a, a)
+        assert "no progress" in str(ei.value)
+    finally:
+        eng.close()
+    monkeypatch.delenv("SPADA_TEST_STALL_TASK")
+    monkeypatch.delenv("SPADA_CHAIN_TIMEOUT_MS")
+    eng = S.Engine()
+    try:
+        c = eng.spgemm_fused(a, a)
+        assert_parity(c, ref, to_oracle(a), to_oracle(a), RTOL)
     finally:
         eng.close()

@@ -33,7 +33,7 @@ def test_library_exports_every_symbol_of_the_header():
     for name in sorted(declared):
         assert hasattr(L, name), f"{name} declared in include/*.h but not exported"
     assert declared == set(_ffi.SIGNATURES), declared ^ set(_ffi.SIGNATURES)
-    assert _ffi.lib().spada_abi_version() == 4
+    assert _ffi.lib().spada_abi_version() == 5
 
 
 def test_comm_library_exports_every_symbol_of_its_header():
@@ -116,7 +116,7 @@ def test_comm_plan_places_every_segment(nranks, chunks):
 def test_struct_layouts_match_the_header():
     assert ctypes.sizeof(_ffi.CsrView) == 48
     assert ctypes.sizeof(_ffi.Options) == 16
-    assert ctypes.sizeof(_ffi.Stats) == 7 * 8 + 7 * 8 + 2 * 8 * 8 + 7 * 8
+    assert ctypes.sizeof(_ffi.Stats) == 7 * 8 + 7 * 8 + 2 * 8 * 8 + 7 * 8 + 3 * 8
     # and against the C compiler's view of include/spada_ffi.h
     import subprocess, tempfile
     with tempfile.TemporaryDirectory() as d:

@@ -117,7 +117,7 @@ struct spada_ctx {
     DevBuf eb0, elen;
     DevBuf t_tmp, t_tasks, t_status, t_rangeout, t_scrcol, t_scrval, t_scrseq, t_ctr, t_args, t_cuts, t_cutitems, t_legacy;
     DevBuf t_possum;                                          // COUNT mode: sums of the tasks' counts per tile
-    DevBuf t_parts, t_parthist, t_slots;                      // BIG rows: parts, bucket counts (then cursors) per part, row records
+    DevBuf t_parts, t_parthist, t_slots, t_spillparts;        // BIG rows: parts, bucket counts (then cursors) per part, row records, the spilled rows' parts
     DevBuf own_idx, own_val, own_ptr, wide_idx;
     uint64_t t_cap_tmp = 0, t_cap_tasks = 0, t_cap_scr = 0, t_cap_parts = 0, t_cap_cuts = 0, t_cap_cutitems = 0;
     uint32_t prod_limit = TK_SOLO_MAX;   // capacities the kernels may rely on
@@ -149,7 +149,8 @@ struct spada_ctx {
     unsigned long long chain_limit = 0;
     int wall_khz = 100000;
     uint32_t test_stall_task = 0xFFFFFFFFu;   // (tests, SPADA_TEST_STALL_TASK: a task of the one-pass kernel that never publishes its count)
-    int side_mode = 2;                // (SPADA_SIDE: 0 no side streams, 1 scatter and cut table on one, 2 on one each -- measurements)
+    int side_mode = 3;                // 3: scatter, cut table and task list in ONE launch behind the plan (k_after_plan).  (SPADA_SIDE, measurements --
+                                      // rounds 3 - 5: 0 three launches on the engine stream, 1 scatter and cut table on one side stream, 2 on one each)
     bool shadow = true;               // (SPADA_SHADOW=0: the clearing at the head of every run instead of behind the one before -- measurements)
     uint64_t rows_preset = 0;         // rows whose accumulators (row_P, row_kmin, row_kmax) hold their presets: every run puts back what it used
     hipEvent_t ev_done = nullptr;     // the counters of a run have reached the host
@@ -331,7 +332,7 @@ void launch_task_args(spada_ctx *c, const TaskArgs &g)
     if (c->accumulator != SPADA_ACC_SORT_MERGE) hipLaunchKernelGGL(k_task_args, dim3(1), dim3(64), 0, c->stream, g, c->t_args.as<TaskArgs>());
 }
 template <int MODE>
-void launch_task(spada_ctx *c, const TaskArgs &g)
+void launch_task(spada_ctx *c, const TaskArgs &g, bool with_range_kernel = true)
 {
     if (c->accumulator == SPADA_ACC_SORT_MERGE)
         hipLaunchKernelGGL(k_task_sm<MODE>, dim3(c->n_cu * 3), dim3(TK_BLOCK), task_sm_lds(), c->stream, g);
@@ -343,9 +344,11 @@ void launch_task(spada_ctx *c, const TaskArgs &g)
         // (NEXT to the first kernel on a side stream instead of behind it -- separate tickets, nothing shared: R-MAT 22 chunks and the
         // two-phase R-MAT 16 / 18 within +-1 %, profiles/r05_experiments.txt section 21: the first kernel holds all the LDS of every
         // CU while it has tasks, so only its tail could overlap, and that tail is short)
+        // (a numeric call knows from the symbolic run's counters whether there are such tasks at all)
         if constexpr (MODE != MODE_FUSED)
-            hipLaunchKernelGGL((k_task_range<MODE, TK_NOUT>), dim3(c->n_cu * 4), dim3(TK_BLOCK), task_lds(), c->stream,
-                               (const TaskArgs *)c->t_args.as<TaskArgs>());
+            if (with_range_kernel)
+                hipLaunchKernelGGL((k_task_range<MODE, TK_NOUT>), dim3(c->n_cu * 4), dim3(TK_BLOCK), task_lds(), c->stream,
+                                   (const TaskArgs *)c->t_args.as<TaskArgs>());
     }
 }
 
@@ -480,6 +483,7 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
         if (c->accumulator == SPADA_ACC_SORT_MERGE && (rc = c->t_scrseq.ensure(c->t_cap_scr * 4, false, s, &c->ws_bytes))) return rc;
         if ((rc = c->t_parts.ensure(c->t_cap_parts * sizeof(BigPart), false, s, &c->ws_bytes))) return rc;
         if ((rc = c->t_parthist.ensure(c->t_cap_parts * BX_NB * 4, false, s, &c->ws_bytes))) return rc;
+        if ((rc = c->t_spillparts.ensure(c->t_cap_parts * 4, false, s, &c->ws_bytes))) return rc;
         // capacities the kernels may rely on (DevBuf over-allocates; use what was asked for)
         cap_tasks = (uint32_t)std::min<uint64_t>(c->t_cap_tasks, 0xFFFFFFF0u);
         cap_tmp = (uint32_t)std::min<uint64_t>(c->t_cap_tmp, 0xFFFFFFF0u);
@@ -628,13 +632,15 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
                                c->t_tmp.as<TaskDesc>(), cap_tmp, c->t_slots.as<BigSlot>(), c->t_cap_scr, c->cut_table ? c->t_cap_cuts : 0ull,
                                mode == MODE_FUSED ? c->cut_factor16 : 16u * (uint32_t)BX_DIRECT_FACTOR,
                                c->t_cutitems.as<uint2>(), cap_cut_items, c->range_cursors ? 1u : 0u, c->t_rowt.as<uint32_t>(),
-                               c->t_tiles.as<uint32_t>(), dc);
+                               c->t_tiles.as<uint32_t>(), c->t_spillparts.as<uint32_t>(), dc);
             // the scatter of the spilled rows and the cut table of the direct rows run NEXT to the cut (side streams): the cut needs the
             // range descriptors k_big_plan wrote -- not the scratch, not the cuts; the task kernel waits for all three.  Each fork is
             // taken only if the previous run of this context had work for it (a fork / join pair costs ~10 us and hides nothing when
             // its kernel finds nothing to do); the two are decided separately
             // (the cut table alone is not worth its fork and join -- cop20k_A, no spilled row: 0.737 ms per call with the fork, 0.723 without --
             // next to a scatter it is: web 1.02 - 1.04 ms without side streams, 1.01 with)
+            scatter_launched = !c->expect_no_spill;
+            if (c->side_mode != 3) {
             bool side2 = c->last_spilled != 0, side3 = c->cut_table && c->last_cuts != 0 && c->last_spilled != 0;
             hipStream_t s3 = c->stream3;
             if (c->side_mode == 0) side2 = side3 = false;
@@ -647,12 +653,11 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
             if (side2) HIP_TRY(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
             if (side3) HIP_TRY(hipStreamWaitEvent(c->stream3, c->ev_fork, 0));
             // (left out when the run before on this context spilled no row: guarded by k_cut3, verified at the end of the run)
-            scatter_launched = !c->expect_no_spill;
             if (scatter_launched)
     hipLaunchKernelGGL(k_big_scatter, dim3(c->n_cu * c->scatter_wgs), dim3(TK_BLOCK), BX_WALK_LDS, side2 ? c->stream2 : s, a->val, b->idx, b->val,
                                c->eb0.as<uint64_t>(), c->elen.as<uint32_t>(), c->t_big.as<uint32_t>(), c->row_kmin.as<uint32_t>(),
                                c->row_kmax.as<uint32_t>(), c->t_parts.as<BigPart>(), c->t_parthist.as<uint32_t>(),
-                               c->t_slots.as<BigSlot>(), c->t_scrcol.as<uint32_t>(), c->t_scrval.as<double>(), seq, psh, dc);
+                               c->t_slots.as<BigSlot>(), c->t_scrcol.as<uint32_t>(), c->t_scrval.as<double>(), seq, psh, c->t_spillparts.as<uint32_t>(), dc);
             if (side2) HIP_TRY(hipEventRecord(c->ev_join, c->stream2));
             if (c->cut_table)
                 hipLaunchKernelGGL(k_big_cuts, dim3(c->n_cu * 8), dim3(256), 0, side3 ? c->stream3 : (c->side_mode == 1 ? s3 : s), b->idx, c->eb0.as<uint64_t>(),
@@ -664,6 +669,8 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
             if (c->side_mode == 1 && side2) HIP_TRY(hipEventRecord(c->ev_join, c->stream2));   // (behind the cut table as well)
             c->join2 = side2;
             c->join3 = side3;
+            }
+            HIP_TRY(hipGetLastError());
         }
         if (c->phase_timing) HIP_TRY(hipEventRecord(c->tev[2], s));
         if (n) {
@@ -671,7 +678,54 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
             if (!fold) hipLaunchKernelGGL(k_cut2, dim3(1), dim3(256), 0, s, c->t_tiles.as<uint32_t>(), ntiles, cap_tasks, dc);
             // (few tiles -- a row chunk of a streamed product: several workgroups per tile copy its range descriptors)
             const uint32_t cut_sub = std::min<uint32_t>(16u, std::max<uint32_t>(1u, 1024u / std::max<uint32_t>(ntiles, 1u)));
-            hipLaunchKernelGGL(k_cut3, dim3(ntiles, cut_sub), dim3(256), 0, s, c->row_bin.as<uint8_t>(), c->t_rowt.as<uint32_t>(),
+            if (c->side_mode == 3) {
+                // scatter of the spilled rows + cut table of the direct rows + task list: ONE launch (k_after_plan)
+                AfterPlanArgs ap{};
+                const bool big = !no_big;
+                ap.aval = a->val;
+                ap.bval = b->val;
+                ap.bidx = b->idx;
+                ap.eb0 = c->eb0.as<uint64_t>();
+                ap.elen = c->elen.as<uint32_t>();
+                ap.big_rows = c->t_big.as<uint32_t>();
+                ap.row_kmin = c->row_kmin.as<uint32_t>();
+                ap.row_kmax = c->row_kmax.as<uint32_t>();
+                ap.parts = c->t_parts.as<BigPart>();
+                ap.part_hist = c->t_parthist.as<uint32_t>();
+                ap.slots = c->t_slots.as<BigSlot>();
+                ap.scr_col = c->t_scrcol.as<uint32_t>();
+                ap.scr_val = c->t_scrval.as<double>();
+                ap.scr_seq = c->accumulator == SPADA_ACC_SORT_MERGE ? c->t_scrseq.as<uint32_t>() : (uint32_t *)nullptr;
+                ap.spill_parts = c->t_spillparts.as<uint32_t>();
+                ap.psh = c->part_shift ? c->part_shift : (c->last_nprod_big >= (1ull << 30) ? BX_PART_SHIFT_HUGE : BX_PART_SHIFT);
+                ap.n_scatter = big && scatter_launched ? c->n_cu * c->scatter_wgs : 0u;
+                ap.row_m = c->t_rowm.as<uint32_t>();
+                ap.row_tmp = c->t_rowtmp.as<uint32_t>();
+                ap.tmp = c->t_tmp.as<TaskDesc>();
+                ap.items = c->t_cutitems.as<uint2>();
+                ap.item_cap = cap_cut_items;
+                ap.cuts = c->t_cuts.as<uint32_t>();
+                ap.n_cuts = big && c->cut_table ? c->n_cu * 8u : 0u;
+                ap.row_cls = c->row_bin.as<uint8_t>();
+                ap.row_t = c->t_rowt.as<uint32_t>();
+                ap.row_binfo = c->row_binfo.as<uint32_t>();
+                ap.aptr = a->ptr;
+                ap.r0 = c->r0;
+                ap.n = n;
+                ap.task_cap = cap_tasks;
+                ap.fold = fold ? 1u : 0u;
+                ap.scatter_launched = scatter_launched ? 1u : 0u;
+                ap.ntiles = ntiles;
+                ap.cut_sub = cut_sub;
+                ap.tile_tasks = c->t_tiles.as<uint32_t>();
+                ap.tile_first = c->t_tiles.as<uint32_t>() + ntiles + 2;
+                ap.legacy = c->t_legacy.as<uint32_t>();
+                ap.tasks = c->t_tasks.as<TaskDesc>();
+                ap.status = c->t_status.as<unsigned long long>();
+                ap.ctr = dc;
+                hipLaunchKernelGGL(k_after_plan, dim3(ap.n_scatter + ap.n_cuts + ntiles * cut_sub), dim3(256), AFTER_PLAN_LDS, s, ap);
+            } else
+            hipLaunchKernelGGL(k_cut3, dim3(ntiles, cut_sub), dim3(256), sizeof(CutLds), s, c->row_bin.as<uint8_t>(), c->t_rowt.as<uint32_t>(),
                                c->row_binfo.as<uint32_t>(), a->ptr, c->r0, c->t_rowtmp.as<uint32_t>(), n, c->t_tiles.as<uint32_t>(),
                                c->t_tmp.as<TaskDesc>(), c->t_tasks.as<TaskDesc>(), cap_tasks, fold ? 1u : 0u,
                                c->t_tiles.as<uint32_t>() + ntiles + 2, c->t_legacy.as<uint32_t>(), c->t_status.as<unsigned long long>(), scatter_launched ? 1u : 0u, dc);
@@ -872,13 +926,24 @@ int task_numeric(spada_ctx *c, uint64_t *d_ptr, uint32_t *d_idx, double *d_val)
     c->chunk_timing_open = false;
     hipStream_t s = c->stream;
     HIP_TRY(hipEventRecord(c->tev[0], s));
-    HIP_TRY(hipMemcpyAsync(d_ptr, c->cptr.p, ((size_t)c->nrows + 1) * 8, hipMemcpyDeviceToDevice, s));
-    HIP_TRY(hipMemsetAsync(dev_counters(c)->ticket, 0, sizeof(TaskCounters::ticket), s));
-    if (c->nrows) {
+    if (c->nrows && c->accumulator != SPADA_ACC_SORT_MERGE) {
+        // arguments, tickets and the caller's C.indptr in one launch (k_numeric_head); the range kernel only if the symbolic run left it tasks
         const TaskArgs g = task_args(c, c->cptr.as<uint64_t>(), d_idx, d_val, c->nnz_c);
-        launch_task_args(c, g);
-        launch_task<MODE_NUMERIC>(c, g);
+        const uint64_t n_ptr = (uint64_t)c->nrows + 1;
+        hipLaunchKernelGGL(k_numeric_head, dim3((unsigned)std::min<uint64_t>((n_ptr + 255) / 256, (uint64_t)c->n_cu * 8)), dim3(256), 0, s, g,
+                           c->t_args.as<TaskArgs>(), dev_counters(c)->ticket, (uint32_t)(sizeof(TaskCounters::ticket) / 4), c->cptr.as<uint64_t>(),
+                           d_ptr, n_ptr);
+        launch_task<MODE_NUMERIC>(c, g, c->h_tctr->n_legacy != 0);
         HIP_TRY(hipGetLastError());
+    } else {
+        HIP_TRY(hipMemcpyAsync(d_ptr, c->cptr.p, ((size_t)c->nrows + 1) * 8, hipMemcpyDeviceToDevice, s));
+        HIP_TRY(hipMemsetAsync(dev_counters(c)->ticket, 0, sizeof(TaskCounters::ticket), s));
+        if (c->nrows) {
+            const TaskArgs g = task_args(c, c->cptr.as<uint64_t>(), d_idx, d_val, c->nnz_c);
+            launch_task_args(c, g);
+            launch_task<MODE_NUMERIC>(c, g);
+            HIP_TRY(hipGetLastError());
+        }
     }
     HIP_TRY(hipEventRecord(c->tev[4], s));
     HIP_TRY(hipStreamSynchronize(s));
@@ -976,6 +1041,7 @@ int spada_create(const spada_options *opts, spada_ctx **out)
     if ((rc = allow_lds(k_task_sm<MODE_NUMERIC>, task_sm_lds()))) return rc;
     if ((rc = allow_lds(k_task_sm<MODE_FUSED>, task_sm_lds()))) return rc;
     if ((rc = allow_lds(k_big_hist, BX_WALK_LDS)) || (rc = allow_lds(k_big_scatter, BX_WALK_LDS)) || (rc = allow_lds(k_big_plan, BX_PLAN_LDS))) return rc;
+    if ((rc = allow_lds(k_after_plan, AFTER_PLAN_LDS)) || (rc = allow_lds(k_cut3, sizeof(CutLds)))) return rc;
     *out = c.release();
     return SPADA_OK;
 }
@@ -995,7 +1061,7 @@ void spada_destroy(spada_ctx *c)
     c->un_val.release();
     for (DevBuf *b : {&c->row_cl, &c->row_rec, &c->row_binfo, &c->row_nprod, &c->row_bin, &c->row_kmin, &c->row_kmax, &c->cptr, &c->t_rowP, &c->t_rowm, &c->t_rowt, &c->t_rowtmp,
                       &c->t_big, &c->t_tiles, &c->eb0, &c->elen, &c->t_tmp, &c->t_tasks, &c->t_status, &c->t_rangeout, &c->t_possum, &c->t_scrcol,
-                      &c->t_scrval, &c->t_scrseq, &c->t_ctr, &c->t_args, &c->t_cuts, &c->t_cutitems, &c->t_legacy, &c->t_parts, &c->t_parthist, &c->t_slots, &c->own_idx, &c->own_val, &c->own_ptr, &c->wide_idx})
+                      &c->t_scrval, &c->t_scrseq, &c->t_ctr, &c->t_args, &c->t_cuts, &c->t_cutitems, &c->t_legacy, &c->t_parts, &c->t_parthist, &c->t_slots, &c->t_spillparts, &c->own_idx, &c->own_val, &c->own_ptr, &c->wide_idx})
         b->release();
     if (c->h_tctr) (void)hipHostFree(c->h_tctr);
     if (c->h_seq) (void)hipHostFree(c->h_seq);

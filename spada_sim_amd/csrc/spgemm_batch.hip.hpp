@@ -140,7 +140,6 @@ __device__ inline BatchHead batch_prologue(const ARGS &g, const TaskDesc &td, ui
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
     asm volatile("; BT_MARK p0" ::: "memory");
-    static_assert(!SPILL || DENSE, "spilled ranges take the dense path only");
     constexpr bool spill = SPILL;
     const bool range = td.kind != TASK_BATCH;
     const uint32_t rb = td.row, R = range ? 1u : (td.np & 0xFFu), E = spill ? 0u : range ? (td.first >> 1) : ((td.np >> 8) & 0x3FFu),

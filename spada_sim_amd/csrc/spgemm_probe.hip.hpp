@@ -36,7 +36,7 @@ __global__ __launch_bounds__(TKW, 8) void k_floor(const TaskArgs *__restrict__ g
     };
     auto usable = [](const TaskDesc &d) { return task_is_batch(d); };
     auto entries_of = [](const TaskDesc &d) -> uint32_t {
-        if (task_spill_dense(d)) return 0u;
+        if (task_spill_batch(d)) return 0u;
         return d.kind == TASK_BATCH ? ((d.np >> 8) & 0x3FFu) : (d.first >> 1);
     };
     auto issue_entries = [&](const TaskDesc &d) -> Ent {
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(TKW, 8) void k_floor(const TaskArgs *__restrict__ g
         EntryRecNum *w_ent = (EntryRecNum *)buf;
         uint32_t *bm32 = (uint32_t *)(buf + (size_t)BT_EMAX * 16);
         const unsigned long long *bm64 = (const unsigned long long *)bm32;
-        const bool ok = usable(td), spill = task_spill_dense(td);
+        const bool ok = usable(td), spill = task_spill_batch(td);
         const uint32_t E = entries_of(td);
         // entries numbered densely, and their products (the entry loads of this task were issued an iteration ago)
         if (tid < 64u) bm32[tid] = 0u;

@@ -94,7 +94,7 @@ struct TaskCounters {   // (a multiple of 8 bytes: k_init clears it in 8-byte wo
     unsigned long long nnz_c;                         // written by the last task (COUNT / FUSED)
     unsigned long long cls_rows[N_CLS], cls_prod[N_CLS];
     uint32_t n_big, tmp_cursor, ntasks, n_parts;
-    uint32_t n_spilled, pad_spilled;                  // BIG rows whose products go through the scratch arrays
+    uint32_t n_spilled, n_spill_parts;                // BIG rows whose products go through the scratch arrays; their parts (the list k_big_scatter walks)
     uint32_t prod_limit, pad_limit;                   // products a task hashes at most (set by k_entry_stats from its argument)
     uint32_t abort_flag;                              // a workspace was too small: results invalid, sizes below say what is needed
     uint32_t cap_overflow;                            // FUSED: nnz(C) exceeded the caller's capacity (C.indptr is complete)
@@ -141,14 +141,17 @@ static_assert(BT_EMAX == (uint32_t)TKW * TKW_EPT && BT_PMAX == 4u * TKW && TK_LI
 // most one chunk of entries and at most as many products as the registers hold (a heavy histogram bucket -- many products on few
 // columns -- may have more), or a single-pass spilled range that fits the registers and whose blocks fit the
 // table slot for slot
+// (a single-pass spilled range whose products fit the registers: its slice holds exactly its products.  Round 6: whatever its column
+// span -- a range wider than the table's 3072 blocks goes through the HASHED instantiation, as a direct range of that width does; until
+// round 5 those took the older range path: 283 tasks of the web input, a kernel of their own in the modes without a chain)
+__device__ inline bool task_spill_batch(const TaskDesc &td) { return td.kind == TASK_RANGE && !(td.first & 2u) && td.np <= BT_PMAX; }
 __device__ inline bool task_spill_dense(const TaskDesc &td)
 {
-    return td.kind == TASK_RANGE && !(td.first & 2u) && td.np <= BT_PMAX &&
-           (td.col_hi >> BT_DSHIFT) - (td.col_lo >> BT_DSHIFT) < BT_T;   // (slots of 32 columns)
+    return task_spill_batch(td) && (td.col_hi >> BT_DSHIFT) - (td.col_lo >> BT_DSHIFT) < BT_T;   // (slots of 32 columns)
 }
 __device__ inline bool task_is_batch(const TaskDesc &td)
 {
-    return td.kind == TASK_BATCH || (td.kind == TASK_RANGE_DIRECT && (td.first >> 1) <= BT_EMAX && td.np <= BT_PMAX) || task_spill_dense(td);
+    return td.kind == TASK_BATCH || (td.kind == TASK_RANGE_DIRECT && (td.first >> 1) <= BT_EMAX && td.np <= BT_PMAX) || task_spill_batch(td);
 }
 
 // what a task needs to know about a row, in one 16-byte load (written by k_row_class_cut)
@@ -589,6 +592,7 @@ __global__ __launch_bounds__(TK_BLOCK) void k_big_plan(const uint64_t *__restric
                                                        BigSlot *__restrict__ slots, uint64_t scr_cap, uint64_t cut_cap, uint32_t cut_factor16,
                                                        uint2 *__restrict__ cut_items, uint64_t cut_item_cap, uint32_t range_cursors,
                                                        uint32_t *__restrict__ row_t, uint32_t *__restrict__ tile_tasks,
+                                                       uint32_t *__restrict__ spill_parts /* the part records of the spilled rows: what k_big_scatter walks */,
                                                        TaskCounters *__restrict__ ctr)
 {
     const uint32_t lim = ctr->prod_limit;
@@ -802,9 +806,14 @@ __global__ __launch_bounds__(TK_BLOCK) void k_big_plan(const uint64_t *__restric
             // (bit 1: ONE cursor per (part, range) -- see the cursors below; their top bit is the mark, so not for a row of 2^31 products)
             slots[slot].ok = ok ? (range_cursors && P < 0x80000000ull ? 3u : 1u) : 0u;
             slots[slot].direct = direct ? 1u : 0u;
-            if (!direct) atomicAdd(&ctr->n_spilled, 1u);
+            if (!direct) {
+                atomicAdd(&ctr->n_spilled, 1u);
+                hdr[57] = atomicAdd(&ctr->n_spill_parts, nreal);   // (the row's parts join the scatter's list: its workgroups take nothing else)
+            }
         }
         __syncthreads();
+        if (hdr[46] == 0u)   // (spilled; the list has room for every part record: both are sized by the parts' capacity)
+            for (uint32_t i = tid; i < nreal; i += TK_BLOCK) spill_parts[hdr[57] + i] = pb + i;
         const uint32_t tb = hdr[42];
         const uint64_t sb = ((uint64_t)hdr[44] << 32) | hdr[43], cb = ((uint64_t)hdr[52] << 32) | hdr[51];
         const bool ok = hdr[45] != 0, direct = hdr[46] != 0, has_cuts = hdr[53] != 0;
@@ -925,6 +934,103 @@ __global__ __launch_bounds__(TK_BLOCK) void k_big_plan(const uint64_t *__restric
 // k_big_plan, so that a hub row with hundreds of ranges is searched by hundreds of workgroups.  A direct range task then reads its entries' narrowed B rows (rows ri and
 // ri + 1) in the same round trip as the entries themselves: the dozen dependent search steps that made the range tasks the slowest
 // to publish their counts -- and every task behind them in the chain wait -- are done here, in parallel and before the task kernel.
+// (bx of gx: the workgroup's number among those that build the table -- a launch of its own, or a share of k_after_plan's grid)
+__device__ inline void big_cuts_body(const uint32_t *__restrict__ bidx, const uint64_t *__restrict__ eb0,
+                                     const uint32_t *__restrict__ elen, const uint32_t *__restrict__ big_rows,
+                                     const uint32_t *__restrict__ row_m, const uint32_t *__restrict__ row_tmp,
+                                     const BigSlot *__restrict__ slots, const TaskDesc *__restrict__ tmp,
+                                     const uint2 *__restrict__ items, uint64_t item_cap, uint32_t *__restrict__ cuts,
+                                     const TaskCounters *__restrict__ ctr, uint32_t bx, uint32_t gx)
+{
+    if (ctr->abort_flag) return;
+    unsigned long long most = 0;
+    for (uint32_t a = 0; a < BX_ARENAS; ++a) most = max(most, ctr->cut_arena[a][1]);
+    const unsigned long long icap = item_cap / BX_ARENAS;
+    // (TWO work items per turn of a workgroup, their searches in lock step: a search is a chain of dependent loads -- a dozen round trips --
+    // and the kernel is bound by their latency, not by their number: two chains in flight per thread.  Round 6, next to the single launch behind
+    // the plan, where this job is the longest of the three)
+    for (unsigned long long x0 = bx; x0 < most * BX_ARENAS; x0 += 2ull * gx) {
+        bool on[2][BX_CUT_ITEM / 256];
+        uint32_t lo[2][BX_CUT_ITEM / 256], l[2][BX_CUT_ITEM / 256], nn[2][BX_CUT_ITEM / 256], len_[2][BX_CUT_ITEM / 256];
+        uint64_t b0[2][BX_CUT_ITEM / 256], dst[2][BX_CUT_ITEM / 256], dst_end[2][BX_CUT_ITEM / 256];
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const unsigned long long x = x0 + (unsigned long long)it * gx;
+            const uint32_t arena = (uint32_t)(x % BX_ARENAS);
+            const unsigned long long k = x / BX_ARENAS;
+            const bool have = x < most * BX_ARENAS && k < ctr->cut_arena[arena][1];
+            uint2 item = make_uint2(0u, 0u);
+            if (have) item = items[arena * icap + k];   // (row of the BIG-row list, number of the item in the row)
+            const BigSlot sl = slots[item.x];
+            const uint32_t row = big_rows[item.x], m = have ? row_m[row] : 0u, tb = row_tmp[row];
+            const TaskDesc d0 = tmp[tb];
+            const uint32_t E = d0.first >> 1;
+            const uint64_t pairs = (uint64_t)m * E;
+#pragma unroll
+            for (int kk = 0; kk < BX_CUT_ITEM / 256; ++kk) {
+                const uint64_t pr = (uint64_t)item.y * BX_CUT_ITEM + (uint32_t)kk * 256u + threadIdx.x;
+                on[it][kk] = have && pr < pairs;
+                lo[it][kk] = 0u;
+                l[it][kk] = 0u;
+                nn[it][kk] = 0u;
+                len_[it][kk] = 0u;
+                b0[it][kk] = 0ull;
+                dst[it][kk] = dst_end[it][kk] = ~0ull;
+                if (on[it][kk]) {
+                    // pairs numbered ENTRY major: the lanes of a wave search ONE B row (or a few) for neighbouring ranges -- the same
+                    // probes at the first steps, the same few lines at the last, where range-major numbering sent every lane to a row
+                    // of its own (the table itself stays range major: a task reads rows ri and ri + 1 of it along its entries)
+                    const uint32_t e = (uint32_t)(pr / m), ri = (uint32_t)(pr - (uint64_t)e * m);
+                    lo[it][kk] = tmp[tb + ri].col_lo;
+                    b0[it][kk] = eb0[d0.src + e];
+                    len_[it][kk] = nn[it][kk] = elen[d0.src + e];
+                    dst[it][kk] = sl.cut_base + (uint64_t)ri * E + e;
+                    if (ri + 1 == m) dst_end[it][kk] = sl.cut_base + pairs + e;
+                }
+            }
+        }
+        for (;;) {   // (all searches of the thread in lock step: the loads of a step are independent)
+            bool any = false;
+            uint32_t c[2][BX_CUT_ITEM / 256];
+#pragma unroll
+            for (int it = 0; it < 2; ++it)
+#pragma unroll
+                for (int kk = 0; kk < BX_CUT_ITEM / 256; ++kk) {
+                    c[it][kk] = 0u;
+                    if (nn[it][kk]) {
+                        any = true;
+                        c[it][kk] = bidx[b0[it][kk] + l[it][kk] + (nn[it][kk] >> 1)];
+                    }
+                }
+            if (!any) break;
+#pragma unroll
+            for (int it = 0; it < 2; ++it)
+#pragma unroll
+                for (int kk = 0; kk < BX_CUT_ITEM / 256; ++kk)
+                    if (nn[it][kk]) {
+                        const uint32_t h = nn[it][kk] >> 1;
+                        if (c[it][kk] < lo[it][kk]) {
+                            l[it][kk] += h + 1;
+                            nn[it][kk] -= h + 1;
+                        } else {
+                            nn[it][kk] = h;
+                        }
+                    }
+        }
+        // (one 4-byte store per pair at a stride of E words.  Measured, kernel alone on R-MAT 16 / 18: 434 / 3308 us; with the table
+        // written in the order of the searches -- coalesced, wrong -- 320 / 1990 us; with the B rows staged in LDS, the searches there
+        // and the results through an LDS tile in the table's order, items of 1024 pairs: R-MAT 18 -10 % on the phase, R-MAT 16 and
+        // the web input +10 ... 20 % -- the per-item staging costs rows of a few hundred pairs more than it saves: not kept)
+#pragma unroll
+        for (int it = 0; it < 2; ++it)
+#pragma unroll
+            for (int kk = 0; kk < BX_CUT_ITEM / 256; ++kk)
+                if (on[it][kk]) {
+                    cuts[dst[it][kk]] = l[it][kk];
+                    if (dst_end[it][kk] != ~0ull) cuts[dst_end[it][kk]] = len_[it][kk];
+                }
+    }
+}
 __global__ __launch_bounds__(256) void k_big_cuts(const uint32_t *__restrict__ bidx, const uint64_t *__restrict__ eb0,
                                                   const uint32_t *__restrict__ elen, const uint32_t *__restrict__ big_rows,
                                                   const uint32_t *__restrict__ row_m, const uint32_t *__restrict__ row_tmp,
@@ -932,60 +1038,17 @@ __global__ __launch_bounds__(256) void k_big_cuts(const uint32_t *__restrict__ b
                                                   const uint2 *__restrict__ items, uint64_t item_cap, uint32_t *__restrict__ cuts,
                                                   const TaskCounters *__restrict__ ctr)
 {
-    if (ctr->abort_flag) return;
-    unsigned long long most = 0;
-    for (uint32_t a = 0; a < BX_ARENAS; ++a) most = max(most, ctr->cut_arena[a][1]);
-    const unsigned long long icap = item_cap / BX_ARENAS;
-    for (unsigned long long x = blockIdx.x; x < most * BX_ARENAS; x += gridDim.x) {
-        const uint32_t arena = (uint32_t)(x % BX_ARENAS);
-        const unsigned long long k = x / BX_ARENAS;
-        if (k >= ctr->cut_arena[arena][1]) continue;
-        const uint2 item = items[arena * icap + k];   // (row of the BIG-row list, number of the item in the row)
-        const BigSlot sl = slots[item.x];
-        const uint32_t row = big_rows[item.x], m = row_m[row], tb = row_tmp[row];
-        const TaskDesc d0 = tmp[tb];
-        const uint32_t E = d0.first >> 1;
-        const uint64_t pairs = (uint64_t)m * E;
-#pragma unroll
-        for (int k = 0; k < BX_CUT_ITEM / 256; ++k) {
-            const uint64_t pr = (uint64_t)item.y * BX_CUT_ITEM + (uint32_t)k * 256u + threadIdx.x;
-            if (pr < pairs) {
-                // pairs numbered ENTRY major: the lanes of a wave search ONE B row (or a few) for neighbouring ranges -- the same
-                // probes at the first steps, the same few lines at the last, where range-major numbering sent every lane to a row
-                // of its own (the table itself stays range major: a task reads rows ri and ri + 1 of it along its entries)
-                const uint32_t e = (uint32_t)(pr / m), ri = (uint32_t)(pr - (uint64_t)e * m);
-                const uint32_t lo = tmp[tb + ri].col_lo;
-                const uint64_t b0 = eb0[d0.src + e];
-                const uint32_t len = elen[d0.src + e];
-                uint32_t l = 0, n = len;
-                while (n) {
-                    const uint32_t h = n >> 1;
-                    if (bidx[b0 + l + h] < lo) {
-                        l += h + 1;
-                        n -= h + 1;
-                    } else {
-                        n = h;
-                    }
-                }
-                // (one 4-byte store per pair at a stride of E words.  Measured, kernel alone on R-MAT 16 / 18: 434 / 3308 us; with the table
-                // written in the order of the searches -- coalesced, wrong -- 320 / 1990 us; with the B rows staged in LDS, the searches there
-                // and the results through an LDS tile in the table's order, items of 1024 pairs: R-MAT 18 -10 % on the phase, R-MAT 16 and
-                // the web input +10 ... 20 % -- the per-item staging costs rows of a few hundred pairs more than it saves: not kept)
-                cuts[sl.cut_base + (uint64_t)ri * E + e] = l;
-                if (ri + 1 == m) cuts[sl.cut_base + pairs + e] = len;
-            }
-        }
-    }
+    big_cuts_body(bidx, eb0, elen, big_rows, row_m, row_tmp, slots, tmp, items, item_cap, cuts, ctr, blockIdx.x, gridDim.x);
 }
 
-__global__ __launch_bounds__(TK_BLOCK) void k_big_scatter(const double *__restrict__ aval, const uint32_t *__restrict__ bidx,
-                                                          const double *__restrict__ bval, const uint64_t *__restrict__ eb0,
-                                                          const uint32_t *__restrict__ elen, const uint32_t *__restrict__ big_rows,
-                                                          const uint32_t *__restrict__ row_kmin, const uint32_t *__restrict__ row_kmax,
-                                                          const BigPart *__restrict__ parts, const uint32_t *__restrict__ part_hist,
-                                                          const BigSlot *__restrict__ slots, uint32_t *__restrict__ scr_col,
-                                                          double *__restrict__ scr_val, uint32_t *__restrict__ scr_seq /* may be null */,
-                                                          uint32_t psh, const TaskCounters *__restrict__ ctr)
+__device__ inline void big_scatter_body(const double *__restrict__ aval, const uint32_t *__restrict__ bidx,
+                                        const double *__restrict__ bval, const uint64_t *__restrict__ eb0,
+                                        const uint32_t *__restrict__ elen, const uint32_t *__restrict__ big_rows,
+                                        const uint32_t *__restrict__ row_kmin, const uint32_t *__restrict__ row_kmax,
+                                        const BigPart *__restrict__ parts, const uint32_t *__restrict__ part_hist,
+                                        const BigSlot *__restrict__ slots, uint32_t *__restrict__ scr_col,
+                                        double *__restrict__ scr_val, uint32_t *__restrict__ scr_seq /* may be null */,
+                                        uint32_t psh, const uint32_t *__restrict__ spill_parts, TaskCounters *__restrict__ ctr, uint32_t bx, uint32_t gx)
 {
     constexpr int NB = BX_NB, U = FLAT_U;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -996,23 +1059,27 @@ __global__ __launch_bounds__(TK_BLOCK) void k_big_scatter(const double *__restri
     unsigned char *scratch = (unsigned char *)(s_a0 + 2);
     const int tid = threadIdx.x;
     if (ctr->abort_flag || ctr->n_spilled == 0) return;
-    const uint32_t nparts = ctr->n_parts;
+    // (round 6: the tickets run over the list of the SPILLED rows' parts k_big_plan has left -- on the web input 120 of 4 000 part records:
+    // a workgroup no longer spends its first tickets on the records of direct rows.  Neighbouring entries of the list are neighbouring
+    // parts of one row, as before)
+    const uint32_t nparts = ctr->n_spill_parts;
     // a workgroup takes BX_RUN consecutive records: the parts of one row (or of neighbouring rows), whose scattered stores fall into
     // the same lines of the row's scratch slice, go through one CU and one L2 one after the other
     // (measured: giving every XCD a contiguous eighth of the records, so that neighbouring runs meet in one L2, is 3 - 8 % SLOWER)
     // (runs only when many rows are spilled: the parts of a few dozen rows -- the web input's rows with more than 512 entries --
     // are better spread over as many workgroups than done eight in a row by one)
-    const uint32_t run = ctr->n_spilled > gridDim.x / 8u ? max(BX_RUN >> (psh - BX_PART_SHIFT), 1u) : 1u;   // (~64 K products per run)
+    const uint32_t run = ctr->n_spilled > gx / 8u ? max(BX_RUN >> (psh - BX_PART_SHIFT), 1u) : 1u;   // (~64 K products per run)
     // (the runs are handed out by ticket: the parts of direct rows are skipped at once, those of spilled rows are a walk of tens of
     // thousands of products -- a fixed stride left the workgroups whose runs held mostly direct rows idle at the end)
     __shared__ uint32_t s_run0;
     for (;;) {
     __syncthreads();
-    if (tid == 0) s_run0 = atomicAdd((uint32_t *)&ctr->scatter_next[(blockIdx.x % SCATTER_NQ) * 32u], 1u) * SCATTER_NQ + blockIdx.x % SCATTER_NQ;
+    if (tid == 0) s_run0 = atomicAdd(&ctr->scatter_next[(bx % SCATTER_NQ) * 32u], 1u) * SCATTER_NQ + bx % SCATTER_NQ;
     __syncthreads();
     if ((unsigned long long)s_run0 * run >= nparts) break;
     const uint32_t pi0 = s_run0 * run;
-    for (uint32_t pi = pi0; pi < min(pi0 + run, nparts); ++pi) {
+    for (uint32_t li = pi0; li < min(pi0 + run, nparts); ++li) {
+        const uint32_t pi = spill_parts[li];
         const BigPart pt = parts[pi];
         if (pt.slot == BX_NOPART) continue;   // (uniform over the workgroup, like the next one)
         const BigSlot sl = slots[pt.slot];
@@ -1066,8 +1133,21 @@ __global__ __launch_bounds__(TK_BLOCK) void k_big_scatter(const double *__restri
     }
     }
 #ifdef SPADA_SCATTER_SEQ
-    if (threadIdx.x == 0 && blockIdx.x == 0) atomicOr((uint32_t *)&ctr->abort_flag, 128u);   // nothing may read this scratch
+    if (threadIdx.x == 0 && bx == 0) atomicOr(&ctr->abort_flag, 256u);   // nothing may read this scratch
 #endif
+}
+// (`ctr` is written -- the runs' tickets: not const)
+__global__ __launch_bounds__(TK_BLOCK) void k_big_scatter(const double *__restrict__ aval, const uint32_t *__restrict__ bidx,
+                                                          const double *__restrict__ bval, const uint64_t *__restrict__ eb0,
+                                                          const uint32_t *__restrict__ elen, const uint32_t *__restrict__ big_rows,
+                                                          const uint32_t *__restrict__ row_kmin, const uint32_t *__restrict__ row_kmax,
+                                                          const BigPart *__restrict__ parts, const uint32_t *__restrict__ part_hist,
+                                                          const BigSlot *__restrict__ slots, uint32_t *__restrict__ scr_col,
+                                                          double *__restrict__ scr_val, uint32_t *__restrict__ scr_seq /* may be null */,
+                                                          uint32_t psh, const uint32_t *__restrict__ spill_parts, TaskCounters *__restrict__ ctr)
+{
+    big_scatter_body(aval, bidx, bval, eb0, elen, big_rows, row_kmin, row_kmax, parts, part_hist, slots, scr_col, scr_val, scr_seq, psh, spill_parts, ctr,
+                     blockIdx.x, gridDim.x);
 }
 
 // ---- 3. the cut: rows -> tasks in output order ---------------------------------------------------------------------------
@@ -1405,20 +1485,22 @@ __global__ __launch_bounds__(256) void k_cut2(uint32_t *__restrict__ tile_tasks,
 // k_cut3: task descriptors at their final place: tile offset + prefix of row_t inside the tile.  gridDim.y workgroups share a tile:
 // each works out the tile's layout, workgroup y = 0 writes the batch tasks, and the range descriptors of the tile's BIG rows are
 // copied by all of them (a chunk of R-MAT 22: 95 tiles with 11 000 descriptors each -- 4.5 ms on 95 workgroups)
-__global__ __launch_bounds__(256) void k_cut3(const uint8_t *__restrict__ row_cls, const uint32_t *__restrict__ row_t,
-                                              const uint32_t *__restrict__ row_binfo, const uint64_t *__restrict__ aptr, uint64_t r0,
-                                              const uint32_t *__restrict__ row_tmp, uint32_t n,
-                                              uint32_t *__restrict__ tile_tasks, const TaskDesc *__restrict__ tmp,
-                                              TaskDesc *__restrict__ tasks, uint32_t task_cap, uint32_t fold /* no k_cut2 has run */,
-                                              uint32_t *__restrict__ tile_first, uint32_t *__restrict__ legacy,
-                                              unsigned long long *__restrict__ status /* the chain's status words: cleared with the task they belong to */,
-                                              uint32_t scatter_launched, TaskCounters *__restrict__ ctr)
+// (tile bx of gx, share by of gy of the tile: blockIdx / gridDim of a launch of its own, or a share of k_after_plan's grid)
+__device__ inline void cut3_body(const uint8_t *__restrict__ row_cls, const uint32_t *__restrict__ row_t,
+                                 const uint32_t *__restrict__ row_binfo, const uint64_t *__restrict__ aptr, uint64_t r0,
+                                 const uint32_t *__restrict__ row_tmp, uint32_t n,
+                                 uint32_t *__restrict__ tile_tasks, const TaskDesc *__restrict__ tmp,
+                                 TaskDesc *__restrict__ tasks, uint32_t task_cap, uint32_t fold /* no k_cut2 has run */,
+                                 uint32_t *__restrict__ tile_first, uint32_t *__restrict__ legacy,
+                                 unsigned long long *__restrict__ status /* the chain's status words: cleared with the task they belong to */,
+                                 uint32_t scatter_launched, TaskCounters *__restrict__ ctr, uint32_t bx, uint32_t gx, uint32_t by, uint32_t gy)
 {
-    __shared__ CutLds L;
-    const bool lead_wg = blockIdx.y == 0;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    CutLds &L = *reinterpret_cast<CutLds *>(smem);
+    const bool lead_wg = by == 0;
     // (the engine leaves k_big_scatter out when the context's previous run spilled no row; should the plan of THIS run have spilled some,
     // the run is stopped here -- flag 64: the task kernel returns at once -- before any task can walk a scratch slice nobody filled)
-    if (!scatter_launched && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && ctr->n_spilled != 0) atomicOr(&ctr->abort_flag, 64u);
+    if (!scatter_launched && bx == 0 && by == 0 && threadIdx.x == 0 && ctr->n_spilled != 0) atomicOr(&ctr->abort_flag, 64u);
     // first task of the tile.  Up to CUT_FOLD_TILES tiles every workgroup adds up the counts of the tiles before its own itself (a
     // few KB of L2-resident words) and the one-workgroup scan kernel in front of k_cut3 is not launched: one launch and its
     // gap less on the critical path of every call (~7 us; what matters once a GPU holds an eighth of the rows).  tile_first keeps the
@@ -1426,28 +1508,28 @@ __global__ __launch_bounds__(256) void k_cut3(const uint8_t *__restrict__ row_cl
     uint32_t first;
     if (fold) {
         uint32_t mine = 0;
-        for (uint32_t i = threadIdx.x; i < blockIdx.x; i += 256) mine += tile_tasks[i];
+        for (uint32_t i = threadIdx.x; i < bx; i += 256) mine += tile_tasks[i];
         uint32_t before;
         (void)block_scan_excl_u32(mine, L.s_w, &before);
         first = before;
         __syncthreads();
         if (threadIdx.x == 0 && lead_wg) {
-            tile_first[blockIdx.x] = first;
-            if (blockIdx.x == gridDim.x - 1) {
-                const uint32_t all = first + tile_tasks[blockIdx.x];
+            tile_first[bx] = first;
+            if (bx == gx - 1) {
+                const uint32_t all = first + tile_tasks[bx];
                 ctr->ntasks = all;
                 ctr->need_tasks = all;
                 if (all > task_cap) atomicOr(&ctr->abort_flag, 2u);
             }
         }
     } else {
-        first = tile_tasks[blockIdx.x];
-        if (threadIdx.x == 0 && lead_wg) tile_first[blockIdx.x] = first;
+        first = tile_tasks[bx];
+        if (threadIdx.x == 0 && lead_wg) tile_first[bx] = first;
     }
     CutRow cr;
     uint32_t tot, local = 0;
     {
-        const uint32_t b = blockIdx.x * CUT_TILE + threadIdx.x * CUT_ITEMS;
+        const uint32_t b = bx * CUT_TILE + threadIdx.x * CUT_ITEMS;
 #pragma unroll
         for (int j = 0; j < CUT_ITEMS; ++j) {
             cr.t[j] = b + j < n ? row_t[b + j] : 0u;
@@ -1464,7 +1546,7 @@ __global__ __launch_bounds__(256) void k_cut3(const uint8_t *__restrict__ row_cl
     __syncthreads();
     uint32_t kbn = block_scan_excl_u32(mybig, L.s_w, &nb);
     if (ctr->abort_flag & ~2u) return;   // a workspace overflowed upstream: nothing below may be trusted (every write is bounded by task_cap)
-    const uint32_t base = blockIdx.x * CUT_TILE + threadIdx.x * CUT_ITEMS;
+    const uint32_t base = bx * CUT_TILE + threadIdx.x * CUT_ITEMS;
     uint32_t kb[CUT_ITEMS], idxb[CUT_ITEMS];
 #pragma unroll
     for (int j = 0; j < CUT_ITEMS; ++j) {
@@ -1512,7 +1594,7 @@ __global__ __launch_bounds__(256) void k_cut3(const uint8_t *__restrict__ row_cl
         M += tot2;
         __syncthreads();
     }
-    for (uint32_t q = blockIdx.y * 256u + threadIdx.x; q < M; q += 256u * gridDim.y) {
+    for (uint32_t q = by * 256u + threadIdx.x; q < M; q += 256u * gy) {
         uint32_t lo = 0, hi = nb - 1;
         while (lo < hi) {
             const uint32_t mid = (lo + hi + 1) >> 1;
@@ -1538,6 +1620,75 @@ __global__ __launch_bounds__(256) void k_cut3(const uint8_t *__restrict__ row_cl
             if (leg) legacy[lb + (uint32_t)__popcll(lm & ((1ull << ln) - 1ull))] = b_first[lo] + off;
         }
     }
+}
+
+__global__ __launch_bounds__(256) void k_cut3(const uint8_t *__restrict__ row_cls, const uint32_t *__restrict__ row_t,
+                                              const uint32_t *__restrict__ row_binfo, const uint64_t *__restrict__ aptr, uint64_t r0,
+                                              const uint32_t *__restrict__ row_tmp, uint32_t n,
+                                              uint32_t *__restrict__ tile_tasks, const TaskDesc *__restrict__ tmp,
+                                              TaskDesc *__restrict__ tasks, uint32_t task_cap, uint32_t fold,
+                                              uint32_t *__restrict__ tile_first, uint32_t *__restrict__ legacy,
+                                              unsigned long long *__restrict__ status, uint32_t scatter_launched, TaskCounters *__restrict__ ctr)
+{
+    cut3_body(row_cls, row_t, row_binfo, aptr, r0, row_tmp, n, tile_tasks, tmp, tasks, task_cap, fold, tile_first, legacy, status, scatter_launched, ctr,
+              blockIdx.x, gridDim.x, blockIdx.y, gridDim.y);
+}
+
+// ONE launch behind the plan (round 6).  The three jobs between k_big_plan and the task kernel need nothing of each other -- the scatter
+// of the spilled rows fills the scratch slices, the cut table narrows the direct rows' entries, k_cut3 writes the task list (it reads the
+// plan's range descriptors only) -- and the task kernel needs all three.  Until round 5 they were three kernels on three streams: two
+// fork / join event pairs (~30 us of the 82 us between the plan's end and the task kernel's start on the web input, whose longest branch
+// alone takes 40) and 5 000 mostly idle workgroups of three grids turning over on the same CUs.  Now: one grid whose workgroups take
+// scatter runs (by ticket), cut-table items or tiles of the cut by their number -- scatter first: its workgroups walk the longest.
+struct AfterPlanArgs {
+    // scatter
+    const double *aval, *bval;
+    const uint32_t *bidx;
+    const uint64_t *eb0;
+    const uint32_t *elen, *big_rows, *row_kmin, *row_kmax;
+    const BigPart *parts;
+    const uint32_t *part_hist;
+    const BigSlot *slots;
+    uint32_t *scr_col;
+    double *scr_val;
+    uint32_t *scr_seq;
+    const uint32_t *spill_parts;
+    uint32_t psh, n_scatter;     // workgroups that scatter (0: the scatter is left out of this run)
+    // cut table
+    const uint32_t *row_m, *row_tmp;
+    const TaskDesc *tmp;
+    const uint2 *items;
+    uint64_t item_cap;
+    uint32_t *cuts;
+    uint32_t n_cuts, pad0;       // workgroups that build the cut table (0: none)
+    // task list
+    const uint8_t *row_cls;
+    const uint32_t *row_t, *row_binfo;
+    const uint64_t *aptr;
+    uint64_t r0;
+    uint32_t n, task_cap, fold, scatter_launched, ntiles, cut_sub;
+    uint32_t *tile_tasks, *tile_first, *legacy;
+    TaskDesc *tasks;
+    unsigned long long *status;
+    TaskCounters *ctr;
+};
+constexpr size_t AFTER_PLAN_LDS = BX_WALK_LDS > sizeof(CutLds) ? BX_WALK_LDS : sizeof(CutLds);
+__global__ __launch_bounds__(256) void k_after_plan(const AfterPlanArgs a)
+{
+    uint32_t b = blockIdx.x;
+    if (b < a.n_scatter) {
+        big_scatter_body(a.aval, a.bidx, a.bval, a.eb0, a.elen, a.big_rows, a.row_kmin, a.row_kmax, a.parts, a.part_hist, a.slots, a.scr_col, a.scr_val,
+                         a.scr_seq, a.psh, a.spill_parts, a.ctr, b, a.n_scatter);
+        return;
+    }
+    b -= a.n_scatter;
+    if (b < a.n_cuts) {
+        big_cuts_body(a.bidx, a.eb0, a.elen, a.big_rows, a.row_m, a.row_tmp, a.slots, a.tmp, a.items, a.item_cap, a.cuts, a.ctr, b, a.n_cuts);
+        return;
+    }
+    b -= a.n_cuts;
+    cut3_body(a.row_cls, a.row_t, a.row_binfo, a.aptr, a.r0, a.row_tmp, a.n, a.tile_tasks, a.tmp, a.tasks, a.task_cap, a.fold, a.tile_first, a.legacy,
+              a.status, a.scatter_launched, a.ctr, b % a.ntiles, a.ntiles, b / a.ntiles, a.cut_sub);
 }
 
 // ---- 4. the task kernel ------------------------------------------------------------------------------------------------
@@ -2370,7 +2521,7 @@ __device__ __attribute__((noinline)) void range_task(const TaskArgs *gp_, uint32
 // hashed row fit the table slot for slot
 __device__ inline int task_variant(const TaskDesc &d)
 {
-    if (task_spill_dense(d)) return 2;
+    if (task_spill_batch(d)) return task_spill_dense(d) ? 2 : 3;
     const bool dense = (d.kind == TASK_BATCH ? (d.np & BINFO_DENSE) != 0
                                                                 : (d.col_hi >> BT_DSHIFT) - (d.col_lo >> BT_DSHIFT) < BT_T);
     return dense ? 1 : 0;
@@ -2387,6 +2538,7 @@ __device__ __attribute__((noinline)) BatchHead task_prologue(const TaskArgs *gp_
     const TaskDesc td = load_task(g.tasks, t);
     if (!task_is_batch(td)) return BatchHead{0u, 0u, 0u, 0u};
     const int v = task_variant(td);
+    if (v == 3) return batch_prologue<MODE, false, true>(g, td, t, smem);
     if (v == 2) return batch_prologue<MODE, true, true>(g, td, t, smem);
     if (v == 1) return batch_prologue<MODE, true>(g, td, t, smem);
     return batch_prologue<MODE, false>(g, td, t, smem);
@@ -2398,6 +2550,18 @@ __device__ __attribute__((noinline)) BatchHead task_prologue(const TaskArgs *gp_
 __global__ void k_task_args(const TaskArgs g, TaskArgs *__restrict__ dst)
 {
     if (threadIdx.x == 0) *dst = g;
+}
+// the head of a numeric call in ONE launch: the task kernel's arguments, the ticket counters put back to zero, and C.indptr copied into the
+// caller's buffer (until round 5: a copy command, a fill command and k_task_args -- ~30 us of commands and gaps in front of the task kernel)
+__global__ __launch_bounds__(256) void k_numeric_head(const TaskArgs g, TaskArgs *__restrict__ dst, uint32_t *__restrict__ ticket, uint32_t n_ticket,
+                                                      const uint64_t *__restrict__ cptr, uint64_t *__restrict__ cptr_out, uint64_t n_ptr)
+{
+    if (blockIdx.x == 0) {
+        if (threadIdx.x == 0) *dst = g;
+        for (uint32_t i = threadIdx.x; i < n_ticket; i += 256) ticket[i] = 0u;
+    }
+    if (cptr_out)
+        for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n_ptr; i += (uint64_t)gridDim.x * 256) cptr_out[i] = cptr[i];
 }
 constexpr int TASK_WAVES = 8;   // waves per SIMD the task kernel is compiled for (HIP: second argument of __launch_bounds__): 8 = 64 VGPRs
 template <int MODE, int NOUT>
@@ -2511,7 +2675,8 @@ __global__ __launch_bounds__(TKW, TASK_WAVES) void k_task(const TaskArgs *__rest
         };
         if (bt) {
             const int v = task_variant(td);
-            if (v == 2) batch_main<MODE, true, true>(g, td, t, ntasks, smem, dbg_ph, hd, next, early);
+            if (v == 3) batch_main<MODE, false, true>(g, td, t, ntasks, smem, dbg_ph, hd, next, early);
+            else if (v == 2) batch_main<MODE, true, true>(g, td, t, ntasks, smem, dbg_ph, hd, next, early);
             else if (v == 1) batch_main<MODE, true>(g, td, t, ntasks, smem, dbg_ph, hd, next, early);
             else batch_main<MODE, false>(g, td, t, ntasks, smem, dbg_ph, hd, next, early);
         } else {

@@ -292,20 +292,22 @@ def main():
             # and are reused from step to step
             if "c_ptr" not in out_bufs:
                 out_bufs["c_ptr"] = torch.empty(r1 - r0 + 1, dtype=torch.int64, device=dev)
-                out_bufs["buf"] = torch.empty(max(cap, 1) * 12, dtype=torch.uint8, device=dev)
+                voff = (max(cap, 1) * 8 + 255) // 256 * 256       # (the index part starts on a 256-byte boundary, like the value part)
+                out_bufs["buf"] = torch.empty(voff + max(cap, 1) * 4, dtype=torch.uint8, device=dev)
                 # (the views and their device pointers are taken once as well: three tensor operations per step are ~10 us of
                 # interpreter time that no caller of the C ABI spends)
                 out_bufs["c_val"] = out_bufs["buf"][:max(cap, 1) * 8].view(torch.float64)
-                out_bufs["c_idx"] = out_bufs["buf"][max(cap, 1) * 8:].view(torch.int32)
+                out_bufs["c_idx"] = out_bufs["buf"][voff:].view(torch.int32)
                 out_bufs["ptrs"] = (out_bufs["c_ptr"].data_ptr(), out_bufs["c_idx"].data_ptr(), out_bufs["c_val"].data_ptr())
             c_ptr, c_idx, c_val = out_bufs["c_ptr"], out_bufs["c_idx"], out_bufs["c_val"]
             nnz = eng.fused(da, da, r0, r1, *out_bufs["ptrs"], cap)
         else:
             c_ptr = torch.empty(r1 - r0 + 1, dtype=torch.int64, device=dev)
             nnz = eng.symbolic(da, da, r0, r1)
-            buf = torch.empty(max(nnz, 1) * 12, dtype=torch.uint8, device=dev)
+            voff = (max(nnz, 1) * 8 + 255) // 256 * 256
+            buf = torch.empty(voff + max(nnz, 1) * 4, dtype=torch.uint8, device=dev)
             c_val = buf[:max(nnz, 1) * 8].view(torch.float64)
-            c_idx = buf[max(nnz, 1) * 8:].view(torch.int32)
+            c_idx = buf[voff:].view(torch.int32)
             eng.numeric(c_ptr.data_ptr(), c_idx.data_ptr(), c_val.data_ptr())     # returns after its stream has drained
         st = eng.stats()
         if world > 1:
@@ -523,10 +525,11 @@ def main():
                 e2 = S.Engine(device=local_rank)
                 d2 = e2.upload(a)
                 p2 = torch.empty(rows + 1, dtype=torch.int64, device=dev)
-                b2 = torch.empty(max(cap, 1) * 12, dtype=torch.uint8, device=dev)
+                voff = (max(cap, 1) * 8 + 255) // 256 * 256
+                b2 = torch.empty(voff + max(cap, 1) * 4, dtype=torch.uint8, device=dev)
                 torch.cuda.synchronize()
                 ts = time.perf_counter()
-                e2.fused(d2, d2, 0, rows, p2.data_ptr(), b2[max(cap, 1) * 8:].data_ptr(), b2.data_ptr(), cap)
+                e2.fused(d2, d2, 0, rows, p2.data_ptr(), b2[voff:].data_ptr(), b2.data_ptr(), cap)
                 wall = (time.perf_counter() - ts) * 1e3
                 s2 = e2.stats()
                 fc.append({"ms_wall": wall, "ms_device_last_run": s2["ms_fused_call"], "pipeline_runs": s2["pipeline_runs"],
@@ -561,8 +564,9 @@ def main():
                 c_ptr = torch.empty(r1 - r0 + 1, dtype=torch.int64, device=dev)
                 n_ = eng.symbolic(da, da, r0, r1)
                 ms_sym = eng.stats_raw().ms_symbolic_call
-                buf = torch.empty(max(n_, 1) * 12, dtype=torch.uint8, device=dev)
-                eng.numeric(c_ptr.data_ptr(), buf[max(n_, 1) * 8:].data_ptr(), buf.data_ptr())
+                voff = (max(n_, 1) * 8 + 255) // 256 * 256
+                buf = torch.empty(voff + max(n_, 1) * 4, dtype=torch.uint8, device=dev)
+                eng.numeric(c_ptr.data_ptr(), buf[voff:].data_ptr(), buf.data_ptr())
                 dev_c += ms_sym + eng.stats_raw().ms_numeric_call
             torch.cuda.synchronize()
             extra["contract_ms_per_step"] = (time.perf_counter() - tcs) / KC * 1e3

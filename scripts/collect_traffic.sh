@@ -6,15 +6,15 @@
 # FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KiB.
 set -e
 WL=${1:-webbase-1M}
-TAG=${2:-r05}
+TAG=${2:-r06}
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/traffic_$WL
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 CMD="python3 $REPO/bench.py --steps 10 --warmup 2 --no-cpu-baseline --workload $WL"
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o p -- $CMD > $OUT/fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -o p -- $CMD > $OUT/write.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o p -- $CMD > $OUT/stats.log 2>&1
+timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o p -- $CMD > $OUT/fetch.log 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -o p -- $CMD > $OUT/write.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o p -- $CMD > $OUT/stats.log 2>&1
 cp $OUT/stats/p_kernel_stats.csv $OUT/${TAG}_${WL}_kernel_stats.csv
 # the launches of the one-pass task kernel one by one (the summary's average includes the aborted run of the first call)
 python3 - <<PY

@@ -4,7 +4,7 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 WL=${1:-webbase-1M}
 OUT=$REPO/gpurun_out/r06/timeline_$WL
 mkdir -p $OUT; cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d $OUT -o t -- python3 $REPO/bench.py --steps 6 --warmup 3 --no-cpu-baseline --workload $WL > $OUT/log.txt 2>&1
+timeout 200 rocprofv3 --kernel-trace --output-format csv -d $OUT -o t -- python3 $REPO/bench.py --steps 6 --warmup 3 --no-cpu-baseline --workload $WL > $OUT/log.txt 2>&1
 python3 - <<PY
 import csv, glob
 f = glob.glob("$OUT/**/*kernel_trace.csv", recursive=True)[0]

@@ -723,7 +723,11 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
                 ap.tasks = c->t_tasks.as<TaskDesc>();
                 ap.status = c->t_status.as<unsigned long long>();
                 ap.ctr = dc;
-                hipLaunchKernelGGL(k_after_plan, dim3(ap.n_scatter + ap.n_cuts + ntiles * cut_sub), dim3(256), AFTER_PLAN_LDS, s, ap);
+                // (the scatter's variant by what the context's previous run spilled: LIGHT = 64 registers, eight workgroups per CU)
+                if (c->ws_sized && c->last_spilled <= 256u)
+                    hipLaunchKernelGGL(k_after_plan<true>, dim3(ap.n_scatter + ap.n_cuts + ntiles * cut_sub), dim3(256), AFTER_PLAN_LDS, s, ap);
+                else
+                    hipLaunchKernelGGL(k_after_plan<false>, dim3(ap.n_scatter + ap.n_cuts + ntiles * cut_sub), dim3(256), AFTER_PLAN_LDS, s, ap);
             } else
             hipLaunchKernelGGL(k_cut3, dim3(ntiles, cut_sub), dim3(256), sizeof(CutLds), s, c->row_bin.as<uint8_t>(), c->t_rowt.as<uint32_t>(),
                                c->row_binfo.as<uint32_t>(), a->ptr, c->r0, c->t_rowtmp.as<uint32_t>(), n, c->t_tiles.as<uint32_t>(),
@@ -1041,7 +1045,7 @@ int spada_create(const spada_options *opts, spada_ctx **out)
     if ((rc = allow_lds(k_task_sm<MODE_NUMERIC>, task_sm_lds()))) return rc;
     if ((rc = allow_lds(k_task_sm<MODE_FUSED>, task_sm_lds()))) return rc;
     if ((rc = allow_lds(k_big_hist, BX_WALK_LDS)) || (rc = allow_lds(k_big_scatter, BX_WALK_LDS)) || (rc = allow_lds(k_big_plan, BX_PLAN_LDS))) return rc;
-    if ((rc = allow_lds(k_after_plan, AFTER_PLAN_LDS)) || (rc = allow_lds(k_cut3, sizeof(CutLds)))) return rc;
+    if ((rc = allow_lds(k_after_plan<true>, AFTER_PLAN_LDS)) || (rc = allow_lds(k_after_plan<false>, AFTER_PLAN_LDS)) || (rc = allow_lds(k_cut3, sizeof(CutLds)))) return rc;
     *out = c.release();
     return SPADA_OK;
 }

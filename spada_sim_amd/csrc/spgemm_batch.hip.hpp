@@ -949,7 +949,10 @@ __device__ inline void batch_main(const ARGS &g, const TaskDesc &td, uint32_t t,
     // line of C.indices (and on a 256-byte boundary of C.data): a non-temporal store does not wait in the L2 for its neighbours, and a
     // piece that straddles one more line than it fills wrote 1.18 x the bytes of C (WRITE_SIZE, round 3)
     {
-        const uint32_t shift = (uint32_t)base & 31u;
+        // (by the ADDRESS of the slice in C.indices, not by its number: a caller's index buffer need not start on a line -- bench.py's
+        // followed its value buffer at 48 bytes past one until round 6, and every wave's piece straddled two lines: 684 MB written
+        // against 656 MB into aligned buffers)
+        const uint32_t shift = (uint32_t)(((unsigned long long)(uintptr_t)g.c_idx >> 2) + base) & 31u;
         for (uint32_t j = tid; j < ((SPADA_ABLATE & 8) ? 0u : total + shift); j += BW) {
             if (j >= shift) {
                 const uint32_t i = j - shift;

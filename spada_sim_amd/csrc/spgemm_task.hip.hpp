@@ -43,6 +43,10 @@ constexpr int TASK_PRIO = 3;
 #ifndef SPADA_TASK_DBG
 #define SPADA_TASK_DBG 0   /* 1 (scripts/build_dbg.sh): phase cycle counters of k_task, printed to stderr */
 #endif
+#ifndef SPADA_WA_PROBE
+#define SPADA_WA_PROBE 0   /* measurement builds, WRONG RESULTS (scripts/dev/write_amp.sh: where the one-pass kernel's extra HBM writes come from):
+                              1 the tasks of the older range path are not run | 2 no chain: no status word is stored or read, task t stores at t * 1500 */
+#endif
 
 namespace spada {
 
@@ -1041,6 +1045,7 @@ __global__ __launch_bounds__(256) void k_big_cuts(const uint32_t *__restrict__ b
     big_cuts_body(bidx, eb0, elen, big_rows, row_m, row_tmp, slots, tmp, items, item_cap, cuts, ctr, blockIdx.x, gridDim.x);
 }
 
+template <int U = FLAT_U>
 __device__ inline void big_scatter_body(const double *__restrict__ aval, const uint32_t *__restrict__ bidx,
                                         const double *__restrict__ bval, const uint64_t *__restrict__ eb0,
                                         const uint32_t *__restrict__ elen, const uint32_t *__restrict__ big_rows,
@@ -1050,7 +1055,7 @@ __device__ inline void big_scatter_body(const double *__restrict__ aval, const u
                                         double *__restrict__ scr_val, uint32_t *__restrict__ scr_seq /* may be null */,
                                         uint32_t psh, const uint32_t *__restrict__ spill_parts, TaskCounters *__restrict__ ctr, uint32_t bx, uint32_t gx)
 {
-    constexpr int NB = BX_NB, U = FLAT_U;
+    constexpr int NB = BX_NB;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *hdr = (uint32_t *)smem;
     uint32_t *cur = (uint32_t *)(smem + 256);
@@ -1673,11 +1678,16 @@ struct AfterPlanArgs {
     TaskCounters *ctr;
 };
 constexpr size_t AFTER_PLAN_LDS = BX_WALK_LDS > sizeof(CutLds) ? BX_WALK_LDS : sizeof(CutLds);
-__global__ __launch_bounds__(256) void k_after_plan(const AfterPlanArgs a)
+// LIGHT: compiled for 64 registers (eight workgroups of 256 threads per CU instead of five; the scatter's walk with two product segments in
+// flight per thread instead of four) -- for runs whose scatter has little to do (the engine's guess from the context's previous run: the web
+// input's 29 spilled rows; a wrong guess costs time only).  The launch is bound by its workgroups' latencies times the slots the CUs have:
+// 5 073 workgroups of the web input in 1 280 slots (85 registers: the walk) against 2 048.
+template <bool LIGHT>
+__global__ __launch_bounds__(256, LIGHT ? 8 : 4) void k_after_plan(const AfterPlanArgs a)
 {
     uint32_t b = blockIdx.x;
     if (b < a.n_scatter) {
-        big_scatter_body(a.aval, a.bidx, a.bval, a.eb0, a.elen, a.big_rows, a.row_kmin, a.row_kmax, a.parts, a.part_hist, a.slots, a.scr_col, a.scr_val,
+        big_scatter_body<LIGHT ? 2 : FLAT_U>(a.aval, a.bidx, a.bval, a.eb0, a.elen, a.big_rows, a.row_kmin, a.row_kmax, a.parts, a.part_hist, a.slots, a.scr_col, a.scr_val,
                          a.scr_seq, a.psh, a.spill_parts, a.ctr, b, a.n_scatter);
         return;
     }
@@ -2080,6 +2090,7 @@ __device__ inline void task_publish(const G &g, uint32_t t, unsigned long long c
         if (threadIdx.x == 0) g.range_out[t] = count;
     } else {
         if (t == g.stall_task) return;   // (tests: a predecessor that never publishes)
+        if (SPADA_WA_PROBE & 2) return;
         chain_publish(g.status, t, count, g.scanner);
     }
 }
@@ -2087,7 +2098,10 @@ template <int MODE, class G>
 __device__ inline unsigned long long task_position(const G &g, uint32_t t, unsigned long long count, uint32_t *hdr)
 {
     if constexpr (MODE == MODE_COUNT) return 0ull;
-    else return chain_lookback(g.status, t, count, hdr, g.ctr, g.scanner, g.chain_limit);
+    else if (SPADA_WA_PROBE & 2) {
+        __syncthreads();
+        return (unsigned long long)t * 1500ull;
+    } else return chain_lookback(g.status, t, count, hdr, g.ctr, g.scanner, g.chain_limit);
 }
 
 // Ordered emission of the table (all waves): every occupied slot -> bucket = boff[lr] + floor((col - kmin) * n / span), monotone
@@ -2583,6 +2597,7 @@ __global__ __launch_bounds__(TKW, TASK_WAVES) void k_task(const TaskArgs *__rest
         if (blockIdx.x == 0) {
             if (tid == 0) __hip_atomic_store(&g.ctr->scanner_cu, me, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __builtin_amdgcn_s_setprio(3);
+            if (SPADA_WA_PROBE & 2) return;
             chain_scanner(g.status, g.task_lo, task_end, g.ctr, g.chain_limit);
             return;
         }
@@ -2681,7 +2696,8 @@ __global__ __launch_bounds__(TKW, TASK_WAVES) void k_task(const TaskArgs *__rest
             else batch_main<MODE, false>(g, td, t, ntasks, smem, dbg_ph, hd, next, early);
         } else {
             if constexpr (MODE == MODE_FUSED) {
-                range_task<MODE, NOUT>(gp_, t, ntasks);
+                if (!(SPADA_WA_PROBE & 1)) range_task<MODE, NOUT>(gp_, t, ntasks);
+                else task_publish<MODE>(g, t, 0ull);   // (the chain goes on without the task's outputs)
             }   // (the modes without a chain: k_task_range takes these tasks)
             next();
         }

@@ -233,7 +233,7 @@ __device__ inline bool wave_runs(uint32_t key, bool &head, uint32_t &len, uint32
 // LDS of k_big_hist / k_big_scatter: 256 B hdr | cnt u32[NB] | s_re u32[4], s_a0 u64[2] | walk scratch
 constexpr size_t BX_WALK_LDS = 256 + (size_t)BX_NB * 4 + 32 + flat_walk_bytes<TK_BLOCK, TK_EPT, true>() + 16;
 
-__global__ __launch_bounds__(TK_BLOCK) void k_big_hist(const uint32_t *__restrict__ bidx, const uint64_t *__restrict__ eb0,
+__global__ __launch_bounds__(TK_BLOCK, 8) void k_big_hist(const uint32_t *__restrict__ bidx, const uint64_t *__restrict__ eb0,
                                                        const uint32_t *__restrict__ elen, const uint32_t *__restrict__ big_rows,
                                                        const uint32_t *__restrict__ row_kmin, const uint32_t *__restrict__ row_kmax,
                                                        const BigPart *__restrict__ parts, uint32_t *__restrict__ part_hist,
@@ -328,7 +328,7 @@ static_assert(BX_NB == 4 * TK_BLOCK, "a thread owns four consecutive buckets (on
 // -- rows with few ranges (web graphs, meshes) go direct, rows with thousands of entries and hundreds of ranges (R-MAT hubs) are
 // spilled.  `allow_direct` = 0 spills every row (the sort-merge accumulator numbers the products of a slice in scratch order).
 constexpr uint32_t BX_DIRECT_FACTOR = 8, BX_DIRECT_MAX_SEARCH = 4096;
-__global__ __launch_bounds__(TK_BLOCK) void k_big_plan(const uint64_t *__restrict__ aptr, uint64_t r0, uint32_t nrows_call, uint32_t allow_direct,
+__global__ __launch_bounds__(TK_BLOCK, 8) void k_big_plan(const uint64_t *__restrict__ aptr, uint64_t r0, uint32_t nrows_call, uint32_t allow_direct,
                                                        const uint32_t *__restrict__ big_rows, const uint32_t *__restrict__ row_kmin,
                                                        const uint32_t *__restrict__ row_kmax, const BigPart *__restrict__ parts,
                                                        uint32_t *__restrict__ part_hist, uint32_t *__restrict__ row_m,

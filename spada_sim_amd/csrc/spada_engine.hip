@@ -556,7 +556,7 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
             // (products a task hashes at most: since the table of the batch tasks is keyed by BLOCKS of columns it never gets full, and
             // the fullest tasks win on every input: 2040 / 1920 / 1792 / 1536 -> web 0.826 / 0.844 / 0.882 / 0.965 ms, R-MAT 16 4.81 /
             // 5.00 / 5.22 / 5.98 ms in round 3; rounds 1 - 2 sampled the products / outputs ratio to choose between 1920 and 2040)
-            const uint32_t gent = (uint32_t)std::min<uint64_t>((a->nnz + 255) / 256 + 1, (uint64_t)c->n_cu * 8 * 4);
+            const uint32_t gent = (uint32_t)std::min<uint64_t>((a->nnz + 256 * ENTRY_STATS_U - 1) / (256 * ENTRY_STATS_U) + 1, (uint64_t)c->n_cu * 8 * 4);
             hipLaunchKernelGGL(k_entry_stats<TaskArgs>, dim3(gent), dim3(256), 0, s, a->ptr, a->idx, a->rowid, b->ptr, b->rext, c->r0, n,
                                c->eb0.as<uint64_t>(), c->elen.as<uint32_t>(), c->t_rowP.as<unsigned long long>(),
                                c->row_kmin.as<uint32_t>(), c->row_kmax.as<uint32_t>(),

@@ -568,7 +568,7 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
             hipLaunchKernelGGL(k_row_class_cut, dim3(ntiles), dim3(256), 0, s, a->ptr, c->r0, n, rmax, c->t_rowP.as<unsigned long long>(),
                                c->row_kmin.as<uint32_t>(), c->row_kmax.as<uint32_t>(), c->row_nprod.as<uint32_t>(), c->row_bin.as<uint8_t>(),
                                c->row_cl.as<uint32_t>(), c->row_rec.as<RowRec>(), c->t_rowm.as<uint32_t>(), c->t_big.as<uint32_t>(), dc,
-                               c->t_tiles.as<uint32_t>(), c->t_rowt.as<uint32_t>(), c->row_binfo.as<uint32_t>());
+                               c->t_tiles.as<uint32_t>(), c->t_rowt.as<uint32_t>(), c->row_binfo.as<uint32_t>(), mid_read ? 1u : 0u);
             HIP_TRY(hipGetLastError());
         }
         bool no_big_known = false;
@@ -678,8 +678,9 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
             if (!fold) hipLaunchKernelGGL(k_cut2, dim3(1), dim3(256), 0, s, c->t_tiles.as<uint32_t>(), ntiles, cap_tasks, dc);
             // (few tiles -- a row chunk of a streamed product: several workgroups per tile copy its range descriptors)
             const uint32_t cut_sub = std::min<uint32_t>(16u, std::max<uint32_t>(1u, 1024u / std::max<uint32_t>(ntiles, 1u)));
-            if (c->side_mode == 3) {
-                // scatter of the spilled rows + cut table of the direct rows + task list: ONE launch (k_after_plan)
+            if (c->side_mode == 3 && !no_big) {
+                // scatter of the spilled rows + cut table of the direct rows + task list: ONE launch (k_after_plan); a run without BIG rows
+                // has the task list alone: k_cut3 as it is (a smaller argument block: 1 us on inputs whose whole call takes 150)
                 AfterPlanArgs ap{};
                 const bool big = !no_big;
                 ap.aval = a->val;

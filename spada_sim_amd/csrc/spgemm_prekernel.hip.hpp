@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void k_preset_rows(unsigned long long *__restr
     }
 }
 
-constexpr int ENTRY_STATS_U = 2;   // segments of 64 entries per wave and turn (the engine sizes the grid by it)
+constexpr int ENTRY_STATS_U = 1;   // segments of 64 entries per wave and turn (the engine sizes the grid by it)
 template <class ARGS>
 __global__ __launch_bounds__(256) void k_entry_stats(const uint64_t *__restrict__ aptr, const uint32_t *__restrict__ aidx,
                                                      const uint32_t *__restrict__ arow, const uint64_t *__restrict__ bptr,
@@ -61,68 +61,43 @@ __global__ __launch_bounds__(256) void k_entry_stats(const uint64_t *__restrict_
     }
     const uint64_t e0 = aptr[r0], e1 = aptr[r0 + nrows];
     const int lane = threadIdx.x & 63;
-    // (round 6: ES_U segments of 64 entries per wave and turn, their loads in flight together, and the extent of the selected B row loaded
-    // NEXT to its indptr pair instead of behind it -- an empty row's extent is (max, 0), the identity of the min / max below: the kernel is a
-    // chain of dependent gathers (A.indices -> B.indptr -> extent), three round trips per turn before, two now, over twice the entries)
-    constexpr int ES_U = ENTRY_STATS_U;
-    for (uint64_t q0 = e0 + ((uint64_t)blockIdx.x * 256 + (threadIdx.x & ~63)) * ES_U; q0 < e1; q0 += (uint64_t)gridDim.x * 256 * ES_U) {
-        uint32_t row[ES_U], mn[ES_U], mx[ES_U], kk[ES_U];
-        unsigned long long len[ES_U];
-        uint64_t b0[ES_U], b1[ES_U];
-        uint2 ex[ES_U];
-#pragma unroll
-        for (int u = 0; u < ES_U; ++u) {
-            const uint64_t q = q0 + (uint64_t)u * 64 + lane;
-            row[u] = 0xFFFFFFFFu;
-            kk[u] = 0u;
-            if (q < e1) {
-                kk[u] = aidx[q];
-                row[u] = arow[q] - (uint32_t)r0;
+    // (round 6 measured TWO segments of 64 entries per wave and turn with the extent loaded beside the indptr pair -- one dependent round trip
+    // less, twice the loads in flight: level on the web input, 2 us SLOWER on the small ones (half the workgroups): not kept)
+    for (uint64_t q0 = e0 + (uint64_t)blockIdx.x * 256 + (threadIdx.x & ~63); q0 < e1; q0 += (uint64_t)gridDim.x * 256) {
+        const uint64_t q = q0 + lane;
+        uint32_t row = 0xFFFFFFFFu, mn = 0xFFFFFFFFu, mx = 0;
+        unsigned long long len = 0;
+        if (q < e1) {
+            const uint32_t k = aidx[q];
+            row = arow[q] - (uint32_t)r0;
+            const uint64_t b0 = bptr[k], b1 = bptr[k + 1];
+            eb0[q] = b0;
+            len = b1 - b0;
+            elen[q] = (uint32_t)len;
+            if (b1 > b0) {   // (first / last column of the selected B row: one 8-byte gather, spada_dev_csr::rext)
+                const uint2 ex = bext[k];
+                mn = ex.x;
+                mx = ex.y;
             }
         }
+        // segmented inclusive scan over runs of equal row
 #pragma unroll
-        for (int u = 0; u < ES_U; ++u) {
-            const uint64_t q = q0 + (uint64_t)u * 64 + lane;
-            b0[u] = b1[u] = 0ull;
-            ex[u] = make_uint2(0xFFFFFFFFu, 0u);
-            if (q < e1) {
-                b0[u] = bptr[kk[u]];
-                b1[u] = bptr[kk[u] + 1];
-                ex[u] = bext[kk[u]];   // (first / last column of the selected B row: one 8-byte gather, spada_dev_csr::rext)
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t r2 = __shfl_up(row, o);
+            const unsigned long long l2 = __shfl_up(len, o);
+            const uint32_t n2 = __shfl_up(mn, o), x2 = __shfl_up(mx, o);
+            if (lane >= o && r2 == row) {
+                len += l2;
+                mn = min(mn, n2);
+                mx = max(mx, x2);
             }
         }
-#pragma unroll
-        for (int u = 0; u < ES_U; ++u) {
-            const uint64_t q = q0 + (uint64_t)u * 64 + lane;
-            len[u] = b1[u] - b0[u];
-            mn[u] = ex[u].x;
-            mx[u] = ex[u].y;
-            if (q < e1) {
-                eb0[q] = b0[u];
-                elen[q] = (uint32_t)len[u];
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < ES_U; ++u) {
-            // segmented inclusive scan over runs of equal row
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const uint32_t r2 = __shfl_up(row[u], o);
-                const unsigned long long l2 = __shfl_up(len[u], o);
-                const uint32_t n2 = __shfl_up(mn[u], o), x2 = __shfl_up(mx[u], o);
-                if (lane >= o && r2 == row[u]) {
-                    len[u] += l2;
-                    mn[u] = min(mn[u], n2);
-                    mx[u] = max(mx[u], x2);
-                }
-            }
-            const uint32_t rnext = __shfl_down(row[u], 1);
-            const bool tail = row[u] != 0xFFFFFFFFu && (lane == 63 || rnext != row[u]);
-            if (tail && len[u]) {
-                atomicAdd(&row_P[row[u]], len[u]);
-                atomicMin(&row_kmin[row[u]], mn[u]);
-                atomicMax(&row_kmax[row[u]], mx[u]);
-            }
+        const uint32_t rnext = __shfl_down(row, 1);
+        const bool tail = row != 0xFFFFFFFFu && (lane == 63 || rnext != row);
+        if (tail && len) {
+            atomicAdd(&row_P[row], len);
+            atomicMin(&row_kmin[row], mn);
+            atomicMax(&row_kmax[row], mx);
         }
     }
 }
@@ -360,7 +335,7 @@ __global__ __launch_bounds__(256) void k_row_class_cut(const uint64_t *__restric
                                                        RowRec *__restrict__ row_rec, uint32_t *__restrict__ row_m,
                                                        uint32_t *__restrict__ big_rows, TaskCounters *__restrict__ ctr,
                                                        uint32_t *__restrict__ tile_tasks, uint32_t *__restrict__ row_t,
-                                                       uint32_t *__restrict__ row_binfo)
+                                                       uint32_t *__restrict__ row_binfo, uint32_t want_est /* the run reads its statistics back mid-run: slots 11 - 14 */)
 {
     const uint32_t lim = ctr->prod_limit;
     __shared__ unsigned long long s_rows[N_CLS], s_prod[N_CLS], s_tot, s_est[3];
@@ -428,9 +403,9 @@ __global__ __launch_bounds__(256) void k_row_class_cut(const uint64_t *__restric
     (void)cut_tile(row_cl, row_nprod, row_rec, row_m, nrows, rmax, lim, L, cr, &tot, binfo);
     if (threadIdx.x == 0) {
         tile_tasks[blockIdx.x] = tot;
-        if (tot) atomicAdd(&part[11], (unsigned long long)tot);
+        if (want_est && tot) atomicAdd(&part[11], (unsigned long long)tot);
     }
-    if (threadIdx.x < 3 && s_est[threadIdx.x]) atomicAdd(&part[12 + threadIdx.x], s_est[threadIdx.x]);
+    if (want_est && threadIdx.x < 3 && s_est[threadIdx.x]) atomicAdd(&part[12 + threadIdx.x], s_est[threadIdx.x]);
     const uint32_t base = blockIdx.x * CUT_TILE + threadIdx.x * CUT_ITEMS;
 #pragma unroll
     for (int j = 0; j < CUT_ITEMS; ++j)

@@ -182,7 +182,6 @@ __device__ inline unsigned long long chain_lookback(unsigned long long *status, 
             if (spins == 0) t_wait = wall_clock64();
             if ((++spins & 255u) == 0u && chain_gave_up(ctr, t_wait, limit)) {   // (the run is given up: any position inside the buffers will do)
                 s = ST_INC | count;
-                hdr[51] = 1u;   // (the workgroup leaves the task loop: k_task)
                 break;
             }
         }
@@ -236,10 +235,7 @@ __device__ inline unsigned long long chain_lookback(unsigned long long *status, 
                         }
                     }
                     dbg_spin += __shfl(spins, who);
-                    if (__ballot(gave_up)) {   // (the run is given up: any position will do)
-                        if (lane == 0) hdr[51] = 1u;
-                        break;
-                    }
+                    if (__ballot(gave_up)) break;   // (the run is given up: any position will do)
                     continue;
                 }
                 unsigned long long v = lane <= first_inc ? (s & ~ST_MASK) : 0ull;
@@ -813,10 +809,7 @@ __global__ __launch_bounds__(TKW, TASK_WAVES) void k_task(const TaskArgs *__rest
     // the stores -- and a bounded wait as the safety net: one-pass web 0.766 against 0.769 ms, cop20k_A 0.554 / 0.562, R-MAT 16 4.16 / 3.50;
     // the modes without a chain LOSE 12 % (web count 0.466 against 0.411, numeric 0.738 against 0.658: tickets balance the tail, a fixed
     // share does not).  Hiding two of a task's three dependent round trips buys nothing: profiles/r06_experiments.txt section 2.)
-    if (tid == 0) {
-        hdr[50] = g.task_lo + atomicAdd(my_ticket, 1u) * TK_NQ + task_queue();
-        hdr[51] = 0u;
-    }
+    if (tid == 0) hdr[50] = g.task_lo + atomicAdd(my_ticket, 1u) * TK_NQ + task_queue();
     if (SPADA_TASK_DBG && tid < 32) ((uint32_t *)(smem + task_dbg_off()))[tid] = 0u;
     __syncthreads();
     // (t is uniform: the descriptor is a scalar load, what is derived from it lives in scalar registers)
@@ -891,7 +884,8 @@ __global__ __launch_bounds__(TKW, TASK_WAVES) void k_task(const TaskArgs *__rest
         td = td2;
         hd = hd2;
         bt = bt2;
-        if (MODE == MODE_FUSED && hdr[51]) break;   // (uniform; a wait on the chain ran into its limit -- chain_gave_up: the run is lost, the workgroup leaves)
+        // (behind a wait that gave itself up -- chain_gave_up -- the workgroup's remaining tasks each give up at their first look at the flag: no
+        // check here, where an LDS read per task would make the loop wait for the next task's scalar loads)
     }
     if (SPADA_TASK_DBG && tid == 0) {
         const uint32_t *d = (const uint32_t *)(smem + task_dbg_off());

@@ -48,6 +48,17 @@ struct spada_dev_csr {
 
 namespace {
 
+// (what the workspace allocations of the calling thread have cost so far: SPADA_TRACE=2 prints the share of a call)
+thread_local double g_alloc_ms = 0;
+thread_local unsigned g_alloc_calls = 0;
+struct AllocClock {
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    ~AllocClock()
+    {
+        g_alloc_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        ++g_alloc_calls;
+    }
+};
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
@@ -55,6 +66,7 @@ struct DevBuf {
     int ensure(size_t bytes, bool zero, hipStream_t s, size_t *accounted)
     {
         if (bytes <= cap) return SPADA_OK;
+        AllocClock clock_;
         if (p) {
             HIP_TRY(hipStreamSynchronize(s));
             HIP_TRY(hipFree(p));
@@ -419,6 +431,10 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
                   int *mode_ran = nullptr)
 {
     uint64_t *const cptr_caller = cptr;
+    // (SPADA_TRACE=2: where the host's time of a call goes -- marks in ms since the call entered the pipeline)
+    const auto t_enter = std::chrono::steady_clock::now();
+    double t_mark[6] = {0, 0, 0, 0, 0, 0};
+    const auto mark = [&](int k) { t_mark[k] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_enter).count(); };
     c->chunk_timing_open = false;   // (a numeric phase in pieces whose caller waited on the pieces' events never closed its interval: tev[0 .. 4] are this run's now)
     const spada_dev_csr *a = c->A, *b = c->B;
     const uint32_t n = c->nrows;
@@ -530,8 +546,11 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
         h.nprod_big = h.cls_prod[CLS_BIG];
     };
     bool mid_read = n && (by_rule || !c->ws_sized) && c->accumulator != SPADA_ACC_SORT_MERGE;
+    mark(0);   // per-row workspaces are there
     for (int attempt = 0; attempt < 4; ++attempt) {
-        if ((rc = ensure_ws())) return rc;
+        // (a run that reads its statistics back mid-run sizes these workspaces THERE: nothing in front of that point touches them, and
+        // allocating them at their defaults first only to free and allocate them again cost the first call of a context ~0.4 ms)
+        if (!mid_read && (rc = ensure_ws())) return rc;
         ++c->stats.pipeline_runs;
         c->join2 = c->join3 = false;
         HIP_TRY(hipEventRecord(c->tev[0], s));
@@ -577,7 +596,9 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
             // behind the row classes -- classes, products per class, BIG rows and the estimates of k_row_class_cut.  It chooses the
             // pipeline by the rule, sizes the workspaces so that this run need not be thrown away, and knows whether there are BIG rows
             mid_read = false;
+            mark(1);   // statistics kernels queued
             if ((rc = export_and_wait(dc))) return rc;
+            mark(2);   // statistics read back
             TaskCounters &hm = *c->h_tctr;
             unsigned long long ex[4];
             sum_class_slots(hm, ex);
@@ -593,17 +614,24 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
             c->expect_no_big = hm.n_big == 0;
             const uint32_t psh_m = c->part_shift ? c->part_shift : (hm.nprod_big >= (1ull << 30) ? BX_PART_SHIFT_HUGE : BX_PART_SHIFT);
             const uint64_t est_ranges = ex[1], est_cut_words = ex[2], spill_sure = ex[3];
+            if (!c->ws_sized) {   // (a context's first run: the defaults above are guesses for a run that cannot read -- these are figures)
+                c->t_cap_tasks = c->t_cap_tmp = c->t_cap_parts = 0;
+                c->t_cap_cuts = c->t_cap_scr = 1u << 16;
+            }
             c->t_cap_tasks = std::max<uint64_t>(c->t_cap_tasks, ex[0] + est_ranges + 1024);
             c->t_cap_tmp = std::max<uint64_t>(c->t_cap_tmp, est_ranges + 1024);
             c->t_cap_parts = std::max<uint64_t>(c->t_cap_parts, (hm.nprod_big >> psh_m) + 2ull * hm.n_big + 256);
             if (c->cut_table) c->t_cap_cuts = std::max<uint64_t>(c->t_cap_cuts, est_cut_words + est_cut_words / 2 + (64u << 10) * BX_ARENAS);
             // (the spilled products: the rows with more than BT_EMAX entries for sure, of the others what the plan decides -- a guess; the
             // run is repeated with the exact figure if it is too small)
-            c->t_cap_scr = std::max<uint64_t>(c->t_cap_scr, spill_sure + spill_sure / 8 + std::min<uint64_t>(hm.nprod_big - std::min<uint64_t>(spill_sure, hm.nprod_big), 16ull << 20) + 1024);
+            // (kept small on purpose: fresh device memory is cleared by the driver before a kernel may touch it -- ~12 ms per GB on this part, which
+            // is what a context's first call consists of: 18 - 27 ms of the web input's with 205 MB of scratch guessed for 12 MB needed)
+            c->t_cap_scr = std::max<uint64_t>(c->t_cap_scr, spill_sure + spill_sure / 8 + std::min<uint64_t>(hm.nprod_big - std::min<uint64_t>(spill_sure, hm.nprod_big), 1ull << 20) + 1024);
             if ((rc = ensure_ws())) return rc;
             g = task_args(c, cptr, d_idx, d_val, capacity);   // (buffers may have moved, the mode may have changed)
             launch_task_args(c, g);
             c->ws_sized = true;
+            mark(3);   // data-dependent workspaces are there
         }
         if (c->phase_timing) HIP_TRY(hipEventRecord(c->tev[1], s));
         // A run whose predecessor on this context found no BIG row does not launch the five BIG-row kernels (each costs a launch and a
@@ -770,6 +798,7 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
                                   c->row_kmax.as<uint32_t>(), (uint64_t)n);
         c->rows_preset = c->shadow ? preset_before : 0;
         HIP_TRY(hipGetLastError());
+        mark(4);   // everything queued
         if (c->shadow) c->counters_dirty = false;   // (the other set's clearing is queued)
         if (c->export_poll) {
             // (the stream is asked now and then: a kernel that faulted never writes the number)
@@ -914,6 +943,10 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
         st.ms_fused_call = tev_ms(c, 0, 4);
     }
     if (mode_ran) *mode_ran = mode;
+    mark(5);
+    trace(2, "  host clock of the call, ms since it entered the pipeline: per-row workspaces %.3f | statistics queued %.3f | read back %.3f | workspaces sized %.3f | "
+          "last run queued %.3f | result seen %.3f; workspace allocations of this thread so far: %.3f ms in %u calls", t_mark[0], t_mark[1], t_mark[2], t_mark[3],
+          t_mark[4], t_mark[5], g_alloc_ms, g_alloc_calls);
     trace(1, "%s rows [%llu, %llu): %llu products -> %llu nnz(C), %u tasks, %.3f ms on the device (%llu pipeline run%s)",
           mode == MODE_COUNT ? "symbolic" : "one-pass", (unsigned long long)c->r0, (unsigned long long)(c->r0 + n),
           (unsigned long long)h.nprod, (unsigned long long)c->nnz_c, h.ntasks, tev_ms(c, 0, 4), (unsigned long long)st.pipeline_runs,

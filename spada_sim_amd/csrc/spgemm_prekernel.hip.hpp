@@ -325,9 +325,13 @@ __device__ inline uint32_t cut_tile(const uint32_t *__restrict__ row_cl, const u
 // k_big_plan, which knows its ranges, adds them to row_t and to the tile's total (through round 4 the classes and the cut were two
 // kernels with the BIG-row stage between them: a launch, its drain and the re-read of the row words on the critical path of every call,
 // for a cut that needs nothing the BIG-row kernels write).  (statistics spread over CLS_SLOTS lines: the host sums them)
-// (estimates for the first run's workspaces: a BIG row of P products becomes at most 2 P / limit + 2 ranges -- the plan packs buckets
-// greedily, two neighbouring ranges together exceed the limit -- plus the column sub-ranges of heavy buckets on very wide matrices)
-__device__ inline unsigned long long est_ranges(unsigned long long P, uint32_t lim) { return 2ull * P / lim + P / BT_PMAX + 2ull; }
+// (estimates for the first run's workspaces)
+__device__ inline unsigned long long est_ranges(unsigned long long P, uint32_t lim, uint32_t kmin, uint32_t kmax)
+{
+    // (exactly the descriptors k_big_parts sets aside for the row: big_max_ranges)
+    const uint32_t P32 = P > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)P;
+    return big_max_ranges(P32, lim, (1ull << big_wshift(kmin, kmax)) > (unsigned long long)TK_NOUT);
+}
 __global__ __launch_bounds__(256) void k_row_class_cut(const uint64_t *__restrict__ aptr, uint64_t r0, uint32_t nrows, uint32_t rmax,
                                                        const unsigned long long *__restrict__ row_P, const uint32_t *__restrict__ row_kmin,
                                                        const uint32_t *__restrict__ row_kmax, uint32_t *__restrict__ row_nprod,
@@ -367,7 +371,7 @@ __global__ __launch_bounds__(256) void k_row_class_cut(const uint64_t *__restric
             }
             tot_l += L_;
             if (cls == CLS_BIG) {   // (few rows: LDS atomics of their own)
-                const unsigned long long m_est = est_ranges(P, lim);
+                const unsigned long long m_est = est_ranges(P, lim, row_kmin[i], row_kmax[i]);
                 atomicAdd(&s_est[0], m_est);
                 if (L_ <= BT_EMAX) atomicAdd(&s_est[1], (m_est + 1ull) * L_);
                 else atomicAdd(&s_est[2], P);

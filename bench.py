@@ -541,9 +541,9 @@ def main():
                     fn.restype, fn.argtypes = ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
                                                              ctypes.POINTER(ctypes.c_uint64)]
                     if fn(d2, ctypes.byref(hm), ctypes.byref(dm), ctypes.byref(nb)) == 0:
-                        extra["upload_aux_ms"] = {"host_rowid_build_and_copy": hm.value, "device_row_extents_kernel": dm.value, "bytes": nb.value,
-                                                  "note": "rowid (4 B x nnz) and rext (8 B x rows) are derived at upload, outside every timed region; "
-                                                          "k_entry_stats reads them"}
+                        extra["upload_aux_ms"] = {"host": hm.value, "device_row_ids_and_extents_kernels": dm.value, "bytes": nb.value,
+                                                  "note": "rowid (4 B x nnz) and rext (8 B x rows) are derived on the device at upload, outside every "
+                                                          "timed region; k_entry_stats reads them"}
                 e2.free(d2)
                 e2.close()
                 del p2, b2

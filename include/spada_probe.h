@@ -22,8 +22,8 @@ int spada_dev_probe_floor(spada_ctx *ctx, int write, uint32_t wgs_per_cu, uint32
                           uint64_t *tasks, uint64_t *tasks_skipped);
 
 /* What spada_dev_csr_upload spent on the two arrays it derives from the matrix and keeps with it -- `rowid` (row of every entry, 4 B x
- * nnz: built on the host, copied) and `rext` (first / last column of every row, 8 B x rows: one small kernel): input pre-processing
- * that no SpGEMM call's time contains.  host_ms = wall time of building and copying rowid, device_ms = the kernel by HIP events. */
+ * nnz) and `rext` (first / last column of every row, 8 B x rows): input pre-processing that no SpGEMM call's time contains.  Both are
+ * built on the device (two small kernels: device_ms by HIP events); host_ms is 0 since round 6 (rounds 2 - 5 built rowid on the host). */
 int spada_dev_csr_aux_cost(const spada_dev_csr *m, double *host_ms, double *device_ms, uint64_t *bytes);
 
 #ifdef __cplusplus

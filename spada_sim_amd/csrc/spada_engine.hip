@@ -42,8 +42,8 @@ struct spada_dev_csr {
                                  // is known from ONE 8-byte gather per A entry instead of two gathers from random lines of B.indices
     uint32_t *rowmap = nullptr;  // reordered matrices (-p): row i holds original row rowmap[i] (storage.rs:156-157 row_remap)
     // what the two derived arrays cost at upload (not part of any SpGEMM call's time; reported by bench.py as upload_aux_ms):
-    double aux_host_ms = 0;      // rowid built on the host + its copy to the device (wall)
-    double aux_dev_ms = 0;       // k_row_extents (HIP events)
+    double aux_host_ms = 0;      // (rounds 2 - 5: rowid built on the host + its copy, 5 ms for the web input; since round 6 both arrays are built on the device: 0)
+    double aux_dev_ms = 0;       // k_row_ids + k_row_extents (HIP events)
 };
 
 namespace {
@@ -206,6 +206,24 @@ __global__ void k_row_extents(const uint64_t *__restrict__ ptr, const uint32_t *
         ext[i] = b1 > b0 ? make_uint2(idx[b0], idx[b1 - 1]) : make_uint2(0xFFFFFFFFu, 0u);
     }
 }
+// row of every entry of a device CSR: entry q belongs to the last row whose indptr is <= q (a binary search per entry over an indptr that
+// stays in the caches; until round 5 the array was built by a host loop over all entries and copied: 5 ms + 12 MB of the web input's upload)
+__global__ void k_row_ids(const uint64_t *__restrict__ ptr, uint64_t rows, uint64_t nnz, uint32_t *__restrict__ rowid)
+{
+    for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < nnz; q += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t lo = 0, n = rows;   // first row in [0, rows] with ptr[row] > q, minus one
+        while (n) {
+            const uint64_t h = n >> 1;
+            if (ptr[lo + h] <= q) {
+                lo += h + 1;
+                n -= h + 1;
+            } else {
+                n = h;
+            }
+        }
+        rowid[q] = (uint32_t)(lo - 1);
+    }
+}
 int dev_row_extents(spada_ctx *c, spada_dev_csr *d)
 {
     HIP_TRY(hipMalloc((void **)&d->rext, std::max<uint64_t>(d->rows, 1) * sizeof(uint2)));
@@ -225,12 +243,8 @@ int dev_upload(spada_ctx *c, const spada_csr_view *m, spada_dev_csr **out)
     d->rows = m->rows;
     d->cols = m->cols;
     d->nnz = m->nnz;
-    std::vector<uint32_t> idx32(m->nnz), rid32(m->nnz);
+    std::vector<uint32_t> idx32(m->nnz);
     for (uint64_t q = 0; q < m->nnz; ++q) idx32[q] = (uint32_t)m->indices[q];
-    const auto t_aux = std::chrono::steady_clock::now();
-    for (uint64_t r = 0; r < m->rows; ++r)
-        for (uint64_t q = m->indptr[r]; q < m->indptr[r + 1]; ++q) rid32[q] = (uint32_t)r;
-    d->aux_host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_aux).count();
     HIP_TRY(hipMalloc((void **)&d->ptr, (m->rows + 1) * 8));
     if (hipMalloc((void **)&d->idx, std::max<uint64_t>(m->nnz, 1) * 4) != hipSuccess ||
         hipMalloc((void **)&d->val, std::max<uint64_t>(m->nnz, 1) * 8) != hipSuccess ||
@@ -243,13 +257,11 @@ int dev_upload(spada_ctx *c, const spada_csr_view *m, spada_dev_csr **out)
         if (m->nnz) {
             HIP_TRY(hipMemcpyAsync(d->idx, idx32.data(), m->nnz * 4, hipMemcpyHostToDevice, c->stream));
             HIP_TRY(hipMemcpyAsync(d->val, m->data, m->nnz * 8, hipMemcpyHostToDevice, c->stream));
-            HIP_TRY(hipStreamSynchronize(c->stream));
-            const auto t_rid = std::chrono::steady_clock::now();
-            HIP_TRY(hipMemcpyAsync(d->rowid, rid32.data(), m->nnz * 4, hipMemcpyHostToDevice, c->stream));
-            HIP_TRY(hipStreamSynchronize(c->stream));
-            d->aux_host_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_rid).count();
         }
         HIP_TRY(hipEventRecord(c->tev[0], c->stream));
+        if (m->nnz)
+            hipLaunchKernelGGL(k_row_ids, dim3((unsigned)std::min<uint64_t>((m->nnz + 255) / 256, 8192)), dim3(256), 0, c->stream, d->ptr, (uint64_t)m->rows, (uint64_t)m->nnz,
+                               d->rowid);
         if (int rc2 = dev_row_extents(c, d.get())) return rc2;
         HIP_TRY(hipEventRecord(c->tev[1], c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));

@@ -36,6 +36,18 @@ def test_library_exports_every_symbol_of_the_header():
     assert _ffi.lib().spada_abi_version() == 5
 
 
+def test_probe_header_symbols_are_exported():
+    """include/spada_probe.h (measurement entry points: not part of the drop-in boundary, not in the binding) against libspada_spgemm.so."""
+    hdr = open(os.path.join(ROOT, "include", "spada_probe.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(spada_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == {"spada_dev_probe_floor", "spada_dev_csr_aux_cost"}, declared
+    L = ctypes.CDLL(_ffi.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(L, name), f"{name} declared in include/spada_probe.h but not exported"
+    assert not (declared & set(_ffi.SIGNATURES))      # (the product binding does not carry them)
+
+
 def test_comm_library_exports_every_symbol_of_its_header():
     """include/spada_comm.h (RCCL exchange) against libspada_comm.so and the binding; no collective is called here."""
     hdr = open(os.path.join(ROOT, "include", "spada_comm.h")).read()

@@ -658,7 +658,7 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
             // parts of 64 K products instead of 8 K when the call before had a billion products in BIG rows (a chunk of R-MAT 22: hub rows
             // of thousands of parts, and ONE workgroup of k_big_plan walks a row's parts): any size is correct, the guess only costs time
             const uint32_t psh = c->part_shift ? c->part_shift : (c->last_nprod_big >= (1ull << 30) ? BX_PART_SHIFT_HUGE : BX_PART_SHIFT);
-            hipLaunchKernelGGL(k_big_parts, dim3(c->n_cu * 2), dim3(256), 0, s, a->ptr, c->elen.as<uint32_t>(), c->r0,
+            hipLaunchKernelGGL(k_big_parts, dim3(c->n_cu * 2), dim3(BP_ROWS * 64), 0, s, a->ptr, c->elen.as<uint32_t>(), c->r0,
                                c->t_big.as<uint32_t>(), c->row_nprod.as<uint32_t>(), c->row_kmin.as<uint32_t>(),
                                c->row_kmax.as<uint32_t>(), c->accumulator == SPADA_ACC_SORT_MERGE ? 0u : 1u, psh, c->t_parts.as<BigPart>(), cap_parts,
                                c->t_rowtmp.as<uint32_t>(), cap_tmp, c->t_slots.as<BigSlot>(), dc);

@@ -75,7 +75,7 @@ __host__ __device__ inline uint32_t big_max_ranges(uint32_t P, uint32_t lim, boo
     return 2u * (P / lim) + 2u * (P / (lim + 1u)) + 3u + (wide ? (BX_SUB_MAX - 1u) * (P / lim) : 0u);
 }
 
-__global__ __launch_bounds__(256) void k_big_parts(const uint64_t *__restrict__ aptr, const uint32_t *__restrict__ elen, uint64_t r0,
+__global__ __launch_bounds__(BP_ROWS * 64) void k_big_parts(const uint64_t *__restrict__ aptr, const uint32_t *__restrict__ elen, uint64_t r0,
                                                    const uint32_t *__restrict__ big_rows, const uint32_t *__restrict__ row_nprod,
                                                    const uint32_t *__restrict__ row_kmin, const uint32_t *__restrict__ row_kmax,
                                                    uint32_t allow_sub, uint32_t psh /* log2 of the products per part */,
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void k_big_parts(const uint64_t *__restrict__ 
             }
         }
         __syncthreads();
-        for (int rr = wave; rr < BP_ROWS; rr += 4) {
+        for (int rr = wave; rr < BP_ROWS; rr += (int)(blockDim.x >> 6)) {   // (one wave per row of the round: sixteen waves since round 6, a row's walk is a chain of dependent steps)
         const uint32_t slot = s0 + rr;
         if (slot >= nbig) break;
         const uint32_t row = big_rows[slot];

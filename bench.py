@@ -635,6 +635,10 @@ def main():
             "verified": None if verified is None else bool(verified.get("ok")),
             "verification": verified,
             "c_alloc": "reused" if one_pass and comm is None and (world == 1 or chunk_bounds is not None) else "per_step",
+            # what one timed step consists of, as a key round-to-round comparisons can check (rounds 2 - 4 timed the chunked R-MAT 22 step
+            # with the checksum of every chunk inside it; since round 5 the default leaves the chunks unread)
+            "step_definition": ("chunked:" + ("one_pass" if one_pass else "two_phase") + ":consumer=" + args.chunk_consumer) if chunk_bounds is not None
+                               else ("one_pass" if one_pass else "two_phase") + (":exchange=" + str(exchange) if world > 1 else ""),
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,

@@ -576,7 +576,7 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
         c->counters_dirty = true;
         if (c->rows_preset < n) {   // (the first run of a context, or one over more rows than any before it; else the run before has seen to it)
             hipLaunchKernelGGL(k_preset_rows, dim3(c->n_cu * 4), dim3(256), 0, s, c->t_rowP.as<unsigned long long>(), c->row_kmin.as<uint32_t>(),
-                               c->row_kmax.as<uint32_t>(), (uint64_t)n);
+                               c->row_kmax.as<uint32_t>(), (uint64_t)n, (TaskCounters *)nullptr);
             c->rows_preset = n;
         }
         const uint64_t preset_before = c->rows_preset;
@@ -805,9 +805,10 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
             HIP_TRY(hipEventRecord(c->ev_done, s));
         }
         // behind the end of the run, where nobody waits: the other set of counters and the per-row accumulators for the run after this one
-        if (c->shadow) hipLaunchKernelGGL(k_clear_counters, dim3(8), dim3(256), 0, s, c->t_ctr.as<TaskCounters>() + (c->ctr_idx ^ 1));
-        if (n && c->shadow) hipLaunchKernelGGL(k_preset_rows, dim3(c->n_cu * 4), dim3(256), 0, s, c->t_rowP.as<unsigned long long>(), c->row_kmin.as<uint32_t>(),
-                                  c->row_kmax.as<uint32_t>(), (uint64_t)n);
+        if (n && c->shadow)
+            hipLaunchKernelGGL(k_preset_rows, dim3(c->n_cu * 4), dim3(256), 0, s, c->t_rowP.as<unsigned long long>(), c->row_kmin.as<uint32_t>(),
+                               c->row_kmax.as<uint32_t>(), (uint64_t)n, c->t_ctr.as<TaskCounters>() + (c->ctr_idx ^ 1));
+        else if (c->shadow) hipLaunchKernelGGL(k_clear_counters, dim3(8), dim3(256), 0, s, c->t_ctr.as<TaskCounters>() + (c->ctr_idx ^ 1));
         c->rows_preset = c->shadow ? preset_before : 0;
         HIP_TRY(hipGetLastError());
         mark(4);   // everything queued

@@ -35,9 +35,12 @@ __global__ __launch_bounds__(256) void k_export_counters(const TaskCounters *__r
     if (threadIdx.x == 0) __hip_atomic_store(host_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 // (the first run of a context, and a run over more rows than any before it)
+// (behind a run the same launch clears the counter set the run after the next one will use -- `clr`: one launch fewer between two calls)
 __global__ __launch_bounds__(256) void k_preset_rows(unsigned long long *__restrict__ row_P, uint32_t *__restrict__ row_kmin,
-                                                     uint32_t *__restrict__ row_kmax, uint64_t n)
+                                                     uint32_t *__restrict__ row_kmax, uint64_t n, TaskCounters *__restrict__ clr)
 {
+    if (clr)
+        for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < sizeof(TaskCounters) / 8; i += gridDim.x * 256) ((unsigned long long *)clr)[i] = 0ull;
     for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
         row_P[i] = 0ull;
         row_kmin[i] = 0xFFFFFFFFu;

@@ -596,7 +596,7 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
             // row classes and the tiles' cut in one kernel (a workgroup per tile of 1024 rows).  A BIG row starts no task there: its
             // range tasks are added to its row's and its tile's counts by k_big_plan (round 5; before, the cut was a kernel of its own
             // behind the BIG-row stage -- 29 us + a launch gap on the critical path of the web input, for work that needs nothing of that stage)
-            hipLaunchKernelGGL(k_row_class_cut, dim3(ntiles), dim3(256), 0, s, a->ptr, c->r0, n, rmax, c->t_rowP.as<unsigned long long>(),
+            hipLaunchKernelGGL(k_row_class_cut, dim3(ntiles), dim3(CUT_TILE), 0, s, a->ptr, c->r0, n, rmax, c->t_rowP.as<unsigned long long>(),
                                c->row_kmin.as<uint32_t>(), c->row_kmax.as<uint32_t>(), c->row_nprod.as<uint32_t>(), c->row_bin.as<uint8_t>(),
                                c->row_cl.as<uint32_t>(), c->row_rec.as<RowRec>(), c->t_rowm.as<uint32_t>(), c->t_big.as<uint32_t>(), dc,
                                c->t_tiles.as<uint32_t>(), c->t_rowt.as<uint32_t>(), c->row_binfo.as<uint32_t>(), mid_read ? 1u : 0u);
@@ -934,6 +934,11 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
     for (int k = 0; k < 8; ++k) std::fprintf(stderr, " %llu", h.dbgh[0][4 + k]);
     std::fprintf(stderr, "\n");
 #endif
+    if (SPADA_PRE_DBG && h.dbg[15])
+        std::fprintf(stderr, "[pre dbg] k_row_class_cut, %llu workgroups, clock ticks each: row words loaded, classes, BIG list %.0f | sums %.0f | row words re-read %.0f | "
+                     "four scans %.0f | batch ends by binary search %.0f | pointer doubling %.0f | batch records, last scan %.0f | stores %.0f\n",
+                     h.dbg[15], (double)h.dbg[0] / h.dbg[15], (double)h.dbg[1] / h.dbg[15], (double)h.dbg[2] / h.dbg[15], (double)h.dbg[3] / h.dbg[15],
+                     (double)h.dbg[4] / h.dbg[15], (double)h.dbg[5] / h.dbg[15], (double)h.dbg[6] / h.dbg[15], (double)h.dbg[7] / h.dbg[15]);
     if (SPADA_TASK_DBG && h.dbg[5])
         std::fprintf(stderr, "[shape dbg] %llu tasks through the batch path: products %.0f, hashed outputs %.0f, blocks %.0f, displaced blocks %.1f, entries %.0f per task\n",
                      h.dbg[5], (double)h.dbg[0] / h.dbg[5], (double)h.dbg[1] / h.dbg[5], (double)h.dbg[2] / h.dbg[5], (double)h.dbg[3] / h.dbg[5],

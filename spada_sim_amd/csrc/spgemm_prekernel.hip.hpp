@@ -48,6 +48,22 @@ __global__ __launch_bounds__(256) void k_preset_rows(unsigned long long *__restr
     }
 }
 
+#ifndef SPADA_PRE_DBG
+#define SPADA_PRE_DBG 0   /* 1: phase clocks of k_row_class_cut (thread 0 of every workgroup), summed into TaskCounters::dbg, printed to stderr */
+#endif
+#if SPADA_PRE_DBG
+__device__ inline unsigned long long *pre_ticks()
+{
+    __shared__ unsigned long long s_pre_tick[16];
+    return s_pre_tick;
+}
+__device__ inline void pre_tick(int k)
+{
+    if (threadIdx.x == 0) pre_ticks()[k] = __builtin_amdgcn_s_memtime();
+}
+#else
+__device__ inline void pre_tick(int) {}
+#endif
 constexpr int ENTRY_STATS_U = 1;   // segments of 64 entries per wave and turn (the engine sizes the grid by it)
 template <class ARGS>
 __global__ __launch_bounds__(256) void k_entry_stats(const uint64_t *__restrict__ aptr, const uint32_t *__restrict__ aidx,
@@ -178,151 +194,6 @@ constexpr uint32_t BINFO_DENSE = 1u << 31;
 __host__ __device__ inline uint32_t batch_info(uint32_t R, uint32_t E, uint32_t P) { return R | (E << 8) | (P << 18); }
 static_assert(TK_RMAX <= 255 && BT_EMAX <= 1023 && BT_PMAX <= 4095, "batch_info fields");
 
-// tasks started by every row of the tile; returns the exclusive prefix of this thread's first row and the tile total.
-// A batch is a maximal run of non-BIG rows (greedy, in row order) with at most `lim` products to hash, at most BT_PMAX products in
-// all (hashed + copied: the task keeps them in registers), at most BT_EMAX A entries (one chunk of the walk) and at most `rmax`
-// rows.  binfo[j] (batch starts only) = batch_info(rows, entries, products) of the batch that starts at the thread's row j.
-__device__ inline uint32_t cut_tile(const uint32_t *__restrict__ row_cl, const uint32_t *__restrict__ row_nprod,
-                                    const RowRec *__restrict__ row_rec,
-                                    const uint32_t *__restrict__ row_m, uint32_t n, uint32_t rmax, uint32_t lim, CutLds &L,
-                                    CutRow &cr, uint32_t *tile_total, uint32_t (&binfo)[CUT_ITEMS])
-{
-    const uint32_t tile_base = blockIdx.x * CUT_TILE, base = tile_base + threadIdx.x * CUT_ITEMS;
-    const uint32_t cnt = min((uint32_t)CUT_TILE, n - tile_base);
-    uint8_t cls[CUT_ITEMS];
-    bool fat[CUT_ITEMS];   // EMPTY row with more entries than a chunk holds: a batch of its own that has nothing to do
-    uint32_t c[CUT_ITEMS], w[CUT_ITEMS], e[CUT_ITEMS], sp[CUT_ITEMS], sc = 0, sw = 0, se = 0, ss = 0;
-#pragma unroll
-    for (int j = 0; j < CUT_ITEMS; ++j) {
-        const uint32_t i = base + j;
-        const uint32_t cl = i < n ? row_cl[i] : (uint32_t)CLS_EMPTY;
-        RowRec rr{0u, 0u, 0u, (uint32_t)CLS_EMPTY};
-        if (i < n) rr = row_rec[i];   // (issued with the other loads of the row, not behind its class)
-        cls[j] = (uint8_t)(cl & 7u);
-        const uint32_t len = cl >> 3;
-        const uint32_t P = i < n ? row_nprod[i] : 0u;
-        fat[j] = cls[j] == CLS_EMPTY && len > BT_EMAX;
-        c[j] = (cls[j] == CLS_BIG || fat[j]) ? lim + 1 : ((cls[j] == CLS_SMALL || cls[j] == CLS_SOLO) ? P : 0u);
-        w[j] = cls[j] == CLS_COPY ? P : 0u;
-        e[j] = (cls[j] == CLS_BIG || fat[j]) ? 0u : len;
-        sp[j] = 0;
-        if ((cls[j] == CLS_SMALL || cls[j] == CLS_SOLO))   // blocks a table addressed by column would need for the row
-            sp[j] = min((rr.kmax >> BT_DSHIFT) - (rr.kmin >> BT_DSHIFT) + 1u, 2u * BT_T);
-        L.mark[threadIdx.x * CUT_ITEMS + j] = 0;
-        sc += c[j];
-        sw += w[j];
-        se += e[j];
-        ss += sp[j];
-    }
-    uint32_t tot;
-    uint32_t ec = block_scan_excl_u32(sc, L.s_w, &tot);
-    __syncthreads();
-    uint32_t ew = block_scan_excl_u32(sw, L.s_w, &tot);
-    __syncthreads();
-    uint32_t ee = block_scan_excl_u32(se, L.s_w, &tot);
-    __syncthreads();
-    uint32_t es = block_scan_excl_u32(ss, L.s_w, &tot);
-#pragma unroll
-    for (int j = 0; j < CUT_ITEMS; ++j) {
-        L.pc[threadIdx.x * CUT_ITEMS + j] = ec;
-        L.pw[threadIdx.x * CUT_ITEMS + j] = ew;
-        L.pe[threadIdx.x * CUT_ITEMS + j] = ee;
-        L.ps[threadIdx.x * CUT_ITEMS + j] = es;
-        ec += c[j];
-        ew += w[j];
-        ee += e[j];
-        es += sp[j];
-    }
-    if (threadIdx.x == 255) {
-        L.pc[CUT_TILE] = ec;
-        L.pw[CUT_TILE] = ew;
-        L.pe[CUT_TILE] = ee;
-        L.ps[CUT_TILE] = es;
-    }
-    __syncthreads();
-    // nxt[i]: largest j <= cnt with pc[j] - pc[i] <= lim, (pc + pw)[j] - (pc + pw)[i] <= BT_PMAX, pe[j] - pe[i] <= BT_EMAX, j - i <= rmax
-    // (j = i + 1 is always feasible: a row that is not BIG fits a batch by its class)
-#pragma unroll
-    for (int j = 0; j < CUT_ITEMS; ++j) {
-        const uint32_t li = threadIdx.x * CUT_ITEMS + j;
-        uint32_t nx = li + 1;
-        if (li < cnt && cls[j] != CLS_BIG) {
-            const uint32_t limc = L.pc[li] + lim, limp = L.pc[li] + L.pw[li] + BT_PMAX, lime = L.pe[li] + BT_EMAX;
-            uint32_t lo = li + 1, hi = min(cnt, li + rmax);   // invariant: lo is feasible
-            while (lo < hi) {
-                const uint32_t mid = (lo + hi + 1) >> 1;
-                if (L.pc[mid] <= limc && L.pc[mid] + L.pw[mid] <= limp && L.pe[mid] <= lime) lo = mid;
-                else hi = mid - 1;
-            }
-            nx = lo;
-        }
-        // (BIG rows and the end of the tile stop a walk: they point nowhere)
-        L.nxt[li] = (li < cnt && cls[j] != CLS_BIG && nx < cnt) ? nx : CUT_END;
-        // batch starts, to begin with: BIG rows (tasks of their own), and the first row of every run of non-BIG rows -- the tile's
-        // first row, or the row after a BIG row
-        if (li < cnt) L.mark[li] = (cls[j] == CLS_BIG || li == 0 || L.pc[li] - L.pc[li - 1] > lim) ? 1 : 0;
-    }
-    __syncthreads();
-    // ... then every row that a walk along nxt reaches from such a start.  Walked by pointer doubling (round k marks what lies
-    // 2^k hops behind a marked row, then squares the pointers): log2(tile) rounds for all runs at once, where one thread per run
-    // following the pointers took up to a tile's worth of dependent LDS reads (the cut of cop20k_A: 71 -> 30 us)
-    for (uint32_t span = 1; span < cnt; span <<= 1) {
-        uint32_t j1[CUT_ITEMS], j2[CUT_ITEMS];
-#pragma unroll
-        for (int j = 0; j < CUT_ITEMS; ++j) {
-            const uint32_t li = threadIdx.x * CUT_ITEMS + j;
-            j1[j] = li < cnt ? L.nxt[li] : CUT_END;
-            j2[j] = j1[j] != CUT_END ? L.nxt[j1[j]] : CUT_END;
-            if (j1[j] != CUT_END && L.mark[li]) L.mark[j1[j]] = 1;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < CUT_ITEMS; ++j) {
-            const uint32_t li = threadIdx.x * CUT_ITEMS + j;
-            if (li < cnt) L.nxt[li] = j2[j];
-        }
-        __syncthreads();
-    }
-    // where the batch that starts at a row ends: the next start behind it (or the end of the tile)
-    uint32_t nm[CUT_ITEMS];
-    {
-        uint32_t first = CUT_END;
-#pragma unroll
-        for (int j = CUT_ITEMS - 1; j >= 0; --j) {
-            const uint32_t li = threadIdx.x * CUT_ITEMS + j;
-            if (li < cnt && L.mark[li]) first = li;
-        }
-        uint32_t run = block_suffix_min_excl_u32(first, L.s_w);
-#pragma unroll
-        for (int j = CUT_ITEMS - 1; j >= 0; --j) {
-            const uint32_t li = threadIdx.x * CUT_ITEMS + j;
-            nm[j] = run == CUT_END ? cnt : run;
-            if (li < cnt && L.mark[li]) run = li;
-        }
-    }
-    uint32_t local = 0;
-#pragma unroll
-    for (int j = 0; j < CUT_ITEMS; ++j) {
-        const uint32_t i = base + j, li = threadIdx.x * CUT_ITEMS + j;
-        cr.t[j] = 0;
-        cr.kind[j] = 0;
-        binfo[j] = 0;
-        if (i < n && L.mark[li]) {
-            cr.kind[j] = cls[j] == CLS_BIG ? 2u : 1u;
-            cr.t[j] = cls[j] == CLS_BIG ? row_m[i] : 1u;
-            if (cls[j] != CLS_BIG) {
-                const uint32_t end = nm[j];
-                binfo[j] = fat[j] ? batch_info(1u, 0u, 0u)
-                                  : batch_info(end - li, L.pe[end] - L.pe[li], (L.pc[end] - L.pc[li]) + (L.pw[end] - L.pw[li]));
-                if (!fat[j] && L.pc[end] > L.pc[li] && L.ps[end] - L.ps[li] <= BT_T) binfo[j] |= BINFO_DENSE;
-            }
-        }
-        local += cr.t[j];
-    }
-    __syncthreads();
-    return block_scan_excl_u32(local, L.s_w, tile_total);
-}
-
 // k_row_class_cut: the class of every row (by its products P_i and its length), the list of the BIG rows, the statistics -- and the cut of
 // its tile of CUT_TILE rows: tasks started by every row -> row_t (0: none, else 1) and the tile's total.  A BIG row starts no task HERE:
 // k_big_plan, which knows its ranges, adds them to row_t and to the tile's total (through round 4 the classes and the cut were two
@@ -335,91 +206,219 @@ __device__ inline unsigned long long est_ranges(unsigned long long P, uint32_t l
     const uint32_t P32 = P > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)P;
     return big_max_ranges(P32, lim, (1ull << big_wshift(kmin, kmax)) > (unsigned long long)TK_NOUT);
 }
-__global__ __launch_bounds__(256) void k_row_class_cut(const uint64_t *__restrict__ aptr, uint64_t r0, uint32_t nrows, uint32_t rmax,
-                                                       const unsigned long long *__restrict__ row_P, const uint32_t *__restrict__ row_kmin,
-                                                       const uint32_t *__restrict__ row_kmax, uint32_t *__restrict__ row_nprod,
-                                                       uint8_t *__restrict__ row_cls, uint32_t *__restrict__ row_cl,
-                                                       RowRec *__restrict__ row_rec, uint32_t *__restrict__ row_m,
-                                                       uint32_t *__restrict__ big_rows, TaskCounters *__restrict__ ctr,
-                                                       uint32_t *__restrict__ tile_tasks, uint32_t *__restrict__ row_t,
-                                                       uint32_t *__restrict__ row_binfo, uint32_t want_est /* the run reads its statistics back mid-run: slots 11 - 14 */)
+constexpr int RCC_WAVES = CUT_TILE / 64;
+struct ClassCutLds {
+    uint4 pre[CUT_TILE + 1];    // exclusive prefix sums over the tile's rows: products to hash, products to copy, A entries, blocks of columns
+                                // between the first and last column of the hashed rows
+    uint32_t nxt[CUT_TILE];
+    uint8_t mark[CUT_TILE];
+    uint32_t slot[5][RCC_WAVES];   // the scans' wave totals (scan_part / scan_done)
+    uint32_t first[RCC_WAVES];     // first batch start of every wave
+    unsigned long long rows[N_CLS], prod[N_CLS], entries, est[3];
+    uint32_t nbig, big_base, live[2];
+};
+static_assert(RCC_WAVES == 16, "k_row_class_cut: one row per thread, sixteen waves");
+// ONE ROW PER THREAD, workgroups of CUT_TILE = 1024 threads.  Through round 5 (and most of round 6) a workgroup of 256 threads took four
+// rows per thread: the kernel is one workgroup's chain of dependent steps -- every tile is resident at once, the kernel takes as long as
+// its slowest workgroup -- and with one wave per SIMD every instruction of that chain waited for the one before it (phase clocks of a
+// build with SPADA_PRE_DBG: 56 k ticks per workgroup on mc2depi -- 23 of the kernel's 28 us -- of which 13 k in the four binary searches
+// of a thread and 10 k in the pointer doubling: neither got faster when the searches were interleaved or the row words passed through
+// LDS).  Sixteen waves do the same work four to a SIMD, and a row's values stay in its thread's registers from the classes to the cut.
+// The statistics are reduced on DPP inside the waves (eleven 64-bit shuffled reductions before); the BIG rows get their places in
+// the list from one device atomic per WORKGROUP whose answer is not needed before the kernel's end; the pointer doubling stops with the
+// round in which no pointer is left.
+__global__ __launch_bounds__(CUT_TILE) void k_row_class_cut(const uint64_t *__restrict__ aptr, uint64_t r0, uint32_t nrows, uint32_t rmax,
+                                                            const unsigned long long *__restrict__ row_P, const uint32_t *__restrict__ row_kmin,
+                                                            const uint32_t *__restrict__ row_kmax, uint32_t *__restrict__ row_nprod,
+                                                            uint8_t *__restrict__ row_cls, uint32_t *__restrict__ row_cl,
+                                                            RowRec *__restrict__ row_rec, uint32_t *__restrict__ row_m,
+                                                            uint32_t *__restrict__ big_rows, TaskCounters *__restrict__ ctr,
+                                                            uint32_t *__restrict__ tile_tasks, uint32_t *__restrict__ row_t,
+                                                            uint32_t *__restrict__ row_binfo, uint32_t want_est /* the run reads its statistics back mid-run: slots 11 - 14 */)
 {
+    pre_tick(0);
     const uint32_t lim = ctr->prod_limit;
-    __shared__ unsigned long long s_rows[N_CLS], s_prod[N_CLS], s_tot, s_est[3];
-    __shared__ CutLds L;
-    if (threadIdx.x < N_CLS) s_rows[threadIdx.x] = s_prod[threadIdx.x] = 0;
-    if (threadIdx.x == 0) s_tot = 0;
-    if (threadIdx.x < 3) s_est[threadIdx.x] = 0;
-    __syncthreads();
-    const int lane = threadIdx.x & 63;
-    unsigned long long c_rows[N_CLS] = {0, 0, 0, 0, 0}, c_prod[N_CLS] = {0, 0, 0, 0, 0}, tot_l = 0;
-#pragma unroll
-    for (int q = 0; q < CUT_ITEMS; ++q) {
-        const uint32_t i = blockIdx.x * CUT_TILE + (uint32_t)q * 256u + threadIdx.x;
-        uint8_t cls = CLS_EMPTY;
-        if (i < nrows) {
-            const unsigned long long P = row_P[i];
-            const uint32_t L_ = (uint32_t)(aptr[r0 + i + 1] - aptr[r0 + i]);
-            cls = row_class(P, L_, rmax, lim);
-            const uint32_t P32 = P > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)P;
-            row_nprod[i] = P32;
-            row_cls[i] = cls;
-            row_cl[i] = (uint32_t)cls | (min(L_, 0x1FFFFFFFu) << 3);
-            row_rec[i] = RowRec{row_kmin[i], row_kmax[i], P32, (uint32_t)cls};
-            row_m[i] = 0;
-#pragma unroll
-            for (int k = 0; k < N_CLS; ++k) {
-                c_rows[k] += cls == k ? 1ull : 0ull;
-                c_prod[k] += cls == k ? P : 0ull;
-            }
-            tot_l += L_;
-            if (cls == CLS_BIG) {   // (few rows: LDS atomics of their own)
-                const unsigned long long m_est = est_ranges(P, lim, row_kmin[i], row_kmax[i]);
-                atomicAdd(&s_est[0], m_est);
-                if (L_ <= BT_EMAX) atomicAdd(&s_est[1], (m_est + 1ull) * L_);
-                else atomicAdd(&s_est[2], P);
-            }
+    __shared__ ClassCutLds L;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t tile_base = blockIdx.x * CUT_TILE, cnt = min((uint32_t)CUT_TILE, nrows - tile_base);
+    const uint32_t li = tid, i = tile_base + li;
+    const bool in = li < cnt;
+    if (tid < N_CLS) L.rows[tid] = L.prod[tid] = 0;
+    if (tid < 3) L.est[tid] = 0;
+    if (tid == 0) {
+        L.entries = 0;
+        L.nbig = 0;
+        L.live[0] = L.live[1] = 0;
+    }
+    const unsigned long long P = in ? row_P[i] : 0ull;
+    const uint64_t a0 = in ? aptr[r0 + i] : 0ull, a1 = in ? aptr[r0 + i + 1] : 0ull;
+    const uint32_t kmin = in ? row_kmin[i] : 0u, kmax = in ? row_kmax[i] : 0u;
+    __syncthreads();   // (the LDS sums are cleared)
+    // ---- class, row words, statistics, the BIG rows counted ----
+    const uint32_t L_ = (uint32_t)(a1 - a0);
+    const uint8_t cls = in ? row_class(P, L_, rmax, lim) : (uint8_t)CLS_EMPTY;
+    const uint32_t P32 = P > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)P;
+    uint32_t big_loc = 0xFFFFFFFFu;
+    if (in) {
+        row_nprod[i] = P32;
+        row_cls[i] = cls;
+        row_cl[i] = (uint32_t)cls | (min(L_, 0x1FFFFFFFu) << 3);
+        row_rec[i] = RowRec{kmin, kmax, P32, (uint32_t)cls};
+        row_m[i] = 0;
+        if (cls == CLS_BIG) {   // (few rows: LDS atomics of their own)
+            const unsigned long long m_est = est_ranges(P, lim, kmin, kmax);
+            atomicAdd(&L.est[0], m_est);
+            if (L_ <= BT_EMAX) atomicAdd(&L.est[1], (m_est + 1ull) * L_);
+            else atomicAdd(&L.est[2], P);
+            atomicAdd(&L.prod[CLS_BIG], P);
         }
-        const unsigned long long bm = __ballot(i < nrows && cls == CLS_BIG);
-        if (bm) {   // BIG rows: one global atomic per wave
+        if (L_ > BT_EMAX) atomicAdd(&L.entries, (unsigned long long)L_);   // (BIG, or EMPTY with a long row: few)
+    }
+    {
+        // rows per class (COPY .. BIG: a byte each; EMPTY = the rest of the wave's rows), products of the classes a batch takes (at most
+        // BT_PMAX a row), entries of the rows a chunk holds: five 32-bit sums per wave
+        const unsigned long long inm = __ballot(in);
+        const uint32_t r4 = wave_scan_incl_u32(in && cls != CLS_EMPTY ? 1u << (8 * (cls - 1)) : 0u);
+        const uint32_t p1 = wave_scan_incl_u32(cls == CLS_COPY ? P32 : 0u), p2 = wave_scan_incl_u32(cls == CLS_SMALL ? P32 : 0u),
+                       p3 = wave_scan_incl_u32(cls == CLS_SOLO ? P32 : 0u), en = wave_scan_incl_u32(in && L_ <= BT_EMAX ? L_ : 0u);
+        if (lane == 63u && inm) {
+            const uint32_t nz = (r4 & 0xFFu) + ((r4 >> 8) & 0xFFu) + ((r4 >> 16) & 0xFFu) + (r4 >> 24);
+            const uint32_t ne = (uint32_t)__popcll(inm) - nz;
+            if (ne) atomicAdd(&L.rows[CLS_EMPTY], (unsigned long long)ne);
+#pragma unroll
+            for (int k = 1; k < N_CLS; ++k)
+                if ((r4 >> (8 * (k - 1))) & 0xFFu) atomicAdd(&L.rows[k], (unsigned long long)((r4 >> (8 * (k - 1))) & 0xFFu));
+            if (p1) atomicAdd(&L.prod[CLS_COPY], (unsigned long long)p1);
+            if (p2) atomicAdd(&L.prod[CLS_SMALL], (unsigned long long)p2);
+            if (p3) atomicAdd(&L.prod[CLS_SOLO], (unsigned long long)p3);
+            if (en) atomicAdd(&L.entries, (unsigned long long)en);
+        }
+        const unsigned long long bm = __ballot(in && cls == CLS_BIG);
+        if (bm) {   // BIG rows: places inside the workgroup's share of the list (one LDS atomic per wave)
             uint32_t base = 0;
-            if (lane == __ffsll((long long)bm) - 1) base = atomicAdd(&ctr->n_big, (uint32_t)__popcll(bm));
+            if (lane == (uint32_t)__ffsll((long long)bm) - 1u) base = atomicAdd(&L.nbig, (uint32_t)__popcll(bm));
             base = __shfl(base, __ffsll((long long)bm) - 1);
-            if (i < nrows && cls == CLS_BIG) big_rows[base + (uint32_t)__popcll(bm & ((1ull << lane) - 1ull))] = i;
+            if (in && cls == CLS_BIG) big_loc = base + (uint32_t)__popcll(bm & ((1ull << lane) - 1ull));
         }
     }
-#pragma unroll
-    for (int k = 0; k < N_CLS; ++k) {
-        const unsigned long long r = wave_sum_u64(c_rows[k]), p = wave_sum_u64(c_prod[k]);
-        if (lane == 0 && r) {
-            atomicAdd(&s_rows[k], r);
-            atomicAdd(&s_prod[k], p);
-        }
-    }
-    const unsigned long long wl = wave_sum_u64(tot_l);
-    if (lane == 0 && wl) atomicAdd(&s_tot, wl);
-    __syncthreads();   // (the tile's row words are written: the cut below reads them back)
+    pre_tick(1);
+    // what the cut needs of the row: products to hash (a BIG row, or an EMPTY row with more entries than a chunk holds -- `fat`: a batch
+    // of its own that has nothing to do -- closes every batch: lim + 1), products to copy, entries, blocks of columns a table addressed
+    // by column would need
+    const bool fat = cls == CLS_EMPTY && L_ > BT_EMAX, hashed = cls == CLS_SMALL || cls == CLS_SOLO;
+    uint4 v;
+    v.x = (cls == CLS_BIG || fat) ? lim + 1 : (hashed ? P32 : 0u);
+    v.y = cls == CLS_COPY ? P32 : 0u;
+    v.z = (cls == CLS_BIG || fat) ? 0u : min(L_, 0x1FFFFFFFu);
+    v.w = hashed ? min((kmax >> BT_DSHIFT) - (kmin >> BT_DSHIFT) + 1u, 2u * BT_T) : 0u;
+    const uint32_t ix = scan_part(v.x, L.slot[0], tid), iy = scan_part(v.y, L.slot[1], tid), iz = scan_part(v.z, L.slot[2], tid),
+                   iw = scan_part(v.w, L.slot[3], tid);
+    __syncthreads();
+    pre_tick(2);
+    // (the share of the BIG-row list: asked for here, needed at the kernel's end)
+    uint32_t big_base = 0;
+    if (tid == 0 && L.nbig) big_base = atomicAdd(&ctr->n_big, L.nbig);
     unsigned long long *part = ctr->cls_part[blockIdx.x % CLS_SLOTS];
-    if (threadIdx.x < N_CLS && s_rows[threadIdx.x]) {
-        atomicAdd(&part[threadIdx.x], s_rows[threadIdx.x]);
-        atomicAdd(&part[N_CLS + threadIdx.x], s_prod[threadIdx.x]);
+    if (tid < N_CLS && L.rows[tid]) {
+        atomicAdd(&part[tid], L.rows[tid]);
+        if (L.prod[tid]) atomicAdd(&part[N_CLS + tid], L.prod[tid]);
     }
-    if (threadIdx.x == 0 && s_tot) atomicAdd(&part[2 * N_CLS], s_tot);
-    CutRow cr;
-    uint32_t tot, binfo[CUT_ITEMS];
-    (void)cut_tile(row_cl, row_nprod, row_rec, row_m, nrows, rmax, lim, L, cr, &tot, binfo);
-    if (threadIdx.x == 0) {
+    if (tid == 64 && L.entries) atomicAdd(&part[2 * N_CLS], L.entries);
+    if (want_est && tid >= 128 && tid < 131 && L.est[tid - 128]) atomicAdd(&part[12 + tid - 128], L.est[tid - 128]);
+    uint4 me;   // exclusive prefix sums of the row
+    {
+        uint32_t tot;
+        me.x = scan_done<RCC_WAVES>(ix, v.x, L.slot[0], &tot, tid);
+        me.y = scan_done<RCC_WAVES>(iy, v.y, L.slot[1], &tot, tid);
+        me.z = scan_done<RCC_WAVES>(iz, v.z, L.slot[2], &tot, tid);
+        me.w = scan_done<RCC_WAVES>(iw, v.w, L.slot[3], &tot, tid);
+        L.pre[li] = me;
+        if (tid == CUT_TILE - 1) L.pre[CUT_TILE] = make_uint4(me.x + v.x, me.y + v.y, me.z + v.z, me.w + v.w);
+    }
+    pre_tick(3);
+    __syncthreads();
+    pre_tick(4);
+    // nxt[i]: largest j <= cnt with pc[j] - pc[i] <= lim, (pc + pw)[j] - (pc + pw)[i] <= BT_PMAX, pe[j] - pe[i] <= BT_EMAX, j - i <= rmax
+    // (j = i + 1 is always feasible: a row that is not BIG fits a batch by its class)
+    {
+        uint32_t nx = li + 1;
+        if (in && cls != CLS_BIG) {
+            const uint32_t limc = me.x + lim, limp = me.x + me.y + BT_PMAX, lime = me.z + BT_EMAX;
+            uint32_t lo = li + 1, hi = min(cnt, li + rmax);   // invariant: lo is feasible
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi + 1) >> 1;
+                const uint4 pm = L.pre[mid];
+                if (pm.x <= limc && pm.x + pm.y <= limp && pm.z <= lime) lo = mid;
+                else hi = mid - 1;
+            }
+            nx = lo;
+        }
+        // (BIG rows and the end of the tile stop a walk: they point nowhere)
+        L.nxt[li] = (in && cls != CLS_BIG && nx < cnt) ? nx : CUT_END;
+        // batch starts, to begin with: BIG rows (tasks of their own), and the first row of every run of non-BIG rows -- the tile's
+        // first row, or the row after a BIG row
+        const uint32_t c_prev = __shfl_up(v.x, 1);   // (lane 0: the row in front belongs to the wave before)
+        const uint32_t before = lane ? c_prev : (li ? me.x - L.pre[li - 1].x : 0u);
+        L.mark[li] = in && (cls == CLS_BIG || li == 0 || before > lim) ? 1 : 0;
+    }
+    __syncthreads();
+    pre_tick(5);
+    // ... then every row that a walk along nxt reaches from such a start.  Walked by pointer doubling (round k marks what lies
+    // 2^k hops behind a marked row, then squares the pointers): log2(batches of the tile) rounds for all runs at once, where one thread
+    // per run following the pointers took up to a tile's worth of dependent LDS reads (the cut of cop20k_A: 71 -> 30 us)
+    for (uint32_t span = 1, round = 0; span < cnt; span <<= 1, ++round) {
+        const uint32_t j1 = in ? L.nxt[li] : CUT_END;
+        const uint32_t j2 = j1 != CUT_END ? L.nxt[j1] : CUT_END;
+        if (j1 != CUT_END && L.mark[li]) L.mark[j1] = 1;
+        if (__ballot(j2 != CUT_END) && lane == 0) L.live[round & 1u] = 1u;
+        __syncthreads();
+        if (in) L.nxt[li] = j2;
+        if (tid == 0) L.live[(round & 1u) ^ 1u] = 0u;   // (the next round's flag: last read before the barrier above)
+        __syncthreads();
+        if (!L.live[round & 1u]) break;   // (no pointer is left: nothing more can be marked)
+    }
+    pre_tick(6);
+    // where the batch that starts at a row ends: the next start behind it (or the end of the tile)
+    const bool start = in && L.mark[li] != 0;
+    const unsigned long long sm = __ballot(start);
+    if (lane == 0) L.first[wave] = sm ? wave * 64u + (uint32_t)__ffsll((long long)sm) - 1u : CUT_END;
+    // (the tile's tasks: a BIG row starts none HERE -- k_big_plan adds its ranges)
+    const bool batch = start && cls != CLS_BIG;
+    const unsigned long long bq = __ballot(batch);
+    if (lane == 0) L.slot[4][wave] = (uint32_t)__popcll(bq);
+    if (tid == 0) L.big_base = big_base;   // (the device atomic's answer, asked for long ago)
+    __syncthreads();
+    uint32_t binfo = 0;
+    if (batch) {
+        const unsigned long long later = lane == 63u ? 0ull : sm & ~((2ull << lane) - 1ull);
+        uint32_t end = later ? wave * 64u + (uint32_t)__ffsll((long long)later) - 1u : CUT_END;
+        for (uint32_t k = wave + 1; k < (uint32_t)RCC_WAVES && end == CUT_END; ++k) end = L.first[k];
+        if (end == CUT_END) end = cnt;
+        const uint4 pe = L.pre[end];
+        binfo = fat ? batch_info(1u, 0u, 0u) : batch_info(end - li, pe.z - me.z, (pe.x - me.x) + (pe.y - me.y));
+        if (!fat && pe.x > me.x && pe.w - me.w <= BT_T) binfo |= BINFO_DENSE;
+    }
+    pre_tick(7);
+    if (tid == 0) {
+        uint32_t tot = 0;
+#pragma unroll
+        for (int k = 0; k < RCC_WAVES; ++k) tot += L.slot[4][k];
         tile_tasks[blockIdx.x] = tot;
         if (want_est && tot) atomicAdd(&part[11], (unsigned long long)tot);
     }
-    if (want_est && threadIdx.x < 3 && s_est[threadIdx.x]) atomicAdd(&part[12 + threadIdx.x], s_est[threadIdx.x]);
-    const uint32_t base = blockIdx.x * CUT_TILE + threadIdx.x * CUT_ITEMS;
-#pragma unroll
-    for (int j = 0; j < CUT_ITEMS; ++j)
-        if (base + j < nrows) {
-            row_t[base + j] = cr.t[j];
-            row_binfo[base + j] = binfo[j];
-        }
+    if (in) {
+        row_t[i] = batch ? 1u : 0u;
+        row_binfo[i] = binfo;
+    }
+    if (big_loc != 0xFFFFFFFFu) big_rows[L.big_base + big_loc] = i;
+#if SPADA_PRE_DBG
+    pre_tick(8);
+    if (threadIdx.x == 0) {
+        const unsigned long long *tk = pre_ticks();
+        for (int k = 0; k < 8; ++k) atomicAdd(&ctr->dbg[k], tk[k + 1] - tk[k]);
+        atomicAdd(&ctr->dbg[15], 1ull);
+    }
+#endif
 }
 
 // single workgroup: exclusive scan of the tile totals in place; total -> ctr->ntasks

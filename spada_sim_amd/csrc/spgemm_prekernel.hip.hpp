@@ -161,32 +161,13 @@ struct CutRow {
     uint32_t kind[CUT_ITEMS];   // 0 none, 1 batch start, 2 BIG
 };
 constexpr uint32_t CUT_END = 0xFFFFFFFFu;
+// (k_cut3's arrays over the tile's BIG rows; through round 5 the struct also held the prefix sums of the cut, which k_row_class_cut now keeps
+// in a struct of its own: 12 KB instead of 21.5 -- what every workgroup of k_after_plan's launch is given, eight to a CU instead of seven)
 struct CutLds {
-    uint32_t pc[CUT_TILE + 1], pw[CUT_TILE + 1], pe[CUT_TILE + 1];   // prefix sums: products to hash, products to copy, A entries
-    uint32_t ps[CUT_TILE + 1];                                       // ... blocks of columns between the first and last column of the hashed rows
+    uint32_t pc[CUT_TILE + 1], pw[CUT_TILE + 1];
     uint32_t nxt[CUT_TILE];
-    uint8_t mark[CUT_TILE];
     uint32_t s_w[4];
 };
-
-// exclusive suffix minimum across the workgroup (the minimum of v over the threads behind this one; none: 0xFFFFFFFF)
-__device__ inline uint32_t block_suffix_min_excl_u32(uint32_t v, uint32_t *s_w /*[4]*/)
-{
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    uint32_t inc = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t t = __shfl_down(inc, o);
-        if (lane + o < 64) inc = min(inc, t);
-    }
-    __syncthreads();
-    if (lane == 0) s_w[w] = inc;
-    __syncthreads();
-    uint32_t ex = __shfl_down(inc, 1);
-    if (lane == 63) ex = 0xFFFFFFFFu;
-    for (int k = w + 1; k < 4; ++k) ex = min(ex, s_w[k]);
-    return ex;
-}
 
 // batch descriptor word (TaskDesc::np of a TASK_BATCH): rows | A entries << 8 | products (hashed + copied) << 18 | DENSE << 31: the
 // column spans of its hashed rows, in blocks, fit the table one slot per block

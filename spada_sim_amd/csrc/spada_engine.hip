@@ -934,7 +934,13 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
     for (int k = 0; k < 8; ++k) std::fprintf(stderr, " %llu", h.dbgh[0][4 + k]);
     std::fprintf(stderr, "\n");
 #endif
-    if (SPADA_PRE_DBG && h.dbg[15])
+    if (SPADA_PRE_DBG == 2 && h.dbg[15])
+        std::fprintf(stderr, "[pre dbg] k_big_plan, %llu rows, clock ticks each: row words, part histograms summed %.0f | counts, forced starts %.0f | capacity by binary search %.0f | "
+                     "serial walk over the range starts %.0f | ranges numbered %.0f | descriptors counted %.0f | allocation (one thread, device atomics) %.0f | descriptors, cut items %.0f | "
+                     "cursors of a spilled row %.0f\n",
+                     h.dbg[15], (double)h.dbg[0] / h.dbg[15], (double)h.dbg[1] / h.dbg[15], (double)h.dbg[2] / h.dbg[15], (double)h.dbg[3] / h.dbg[15],
+                     (double)h.dbg[4] / h.dbg[15], (double)h.dbg[5] / h.dbg[15], (double)h.dbg[6] / h.dbg[15], (double)h.dbg[7] / h.dbg[15], (double)h.dbg[8] / h.dbg[15]);
+    if (SPADA_PRE_DBG == 1 && h.dbg[15])
         std::fprintf(stderr, "[pre dbg] k_row_class_cut, %llu workgroups, clock ticks each: row words loaded, classes, BIG list %.0f | sums %.0f | row words re-read %.0f | "
                      "four scans %.0f | batch ends by binary search %.0f | pointer doubling %.0f | batch records, last scan %.0f | stores %.0f\n",
                      h.dbg[15], (double)h.dbg[0] / h.dbg[15], (double)h.dbg[1] / h.dbg[15], (double)h.dbg[2] / h.dbg[15], (double)h.dbg[3] / h.dbg[15],

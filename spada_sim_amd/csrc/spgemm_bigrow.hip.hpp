@@ -37,6 +37,7 @@ constexpr uint32_t BX_NOPART = 0xFFFFFFFFu;
 #define HIST_BY_ENTRY 1
 #endif
 constexpr uint32_t HIST_ENTRY_MAX = 64, HIST_ENTRY_LEN = 256;   // k_big_hist: parts of at most .. entries of at least .. products on average are walked entry by entry
+constexpr uint32_t PLAN_WALK_MAX = 16;   // k_big_plan: rows of at most .. x limit products walk their ranges one after the other (a search by the whole workgroup per range)
 constexpr uint32_t PLAN_UNROLL = 4;   // part records of a row whose histograms k_big_plan has in flight together
 constexpr uint32_t BX_MARK = 0x80000000u;   // a cursor word of k_big_plan that names the bucket holding the cursor instead (k_big_scatter)
 constexpr uint32_t BX_RUN = 8;   // consecutive part records per workgroup (k_big_scatter)
@@ -353,9 +354,21 @@ __global__ __launch_bounds__(TK_BLOCK, 8) void k_big_plan(const uint64_t *__rest
     // the cursors, which have to be complete)
     if (ctr->abort_flag & ~1u) return;
     for (uint32_t slot = blockIdx.x; slot < nbig; slot += gridDim.x) {
+
+#if SPADA_PRE_DBG == 2
+        pre_tick(0);
+#endif
         const uint32_t row = big_rows[slot];
         const uint32_t kmin = row_kmin[row], kmax = row_kmax[row], wshift = big_wshift(kmin, kmax);
         const uint32_t pb = slots[slot].part_begin, pc = slots[slot].part_count;
+        // (what the allocating thread needs of the row, asked for here: behind the LDS stages these loads were a round trip of their own)
+        unsigned long long al_a0 = 0, al_a1 = 0;
+        uint32_t al_tb = 0;
+        if (tid == TK_BLOCK - 1) {
+            al_a0 = aptr[r0 + row];
+            al_a1 = aptr[r0 + row + 1];
+            al_tb = row_tmp[row];
+        }
         uint32_t nreal = 0;   // parts of the row (uniform over the workgroup)
         {   // products of the row before every bucket = the sum of the parts' prefixes (k_big_hist); the bucket counts are its differences
             // (a hub row of R-MAT 22 has 500 parts and ONE workgroup: the records are taken PLAN_UNROLL at a time, their loads in
@@ -390,62 +403,82 @@ __global__ __launch_bounds__(TK_BLOCK, 8) void k_big_plan(const uint64_t *__rest
             if (tid == 0) pre[NB] = parts[pb + nreal].p_begin;   // (the record behind the last part: products before it = all of the row)
         }
         __syncthreads();
-#pragma unroll
-        for (int k = 0; k < BPT; ++k) cnt[tid * BPT + k] = pre[tid * BPT + k + 1] - pre[tid * BPT + k];
-        __syncthreads();
-        // range starts: a heavy bucket is a range of its own; the light buckets between heavy ones are packed greedily, as many
-        // as fit one task's table (<= TK_SOLO_MAX products: a range is closed when the next bucket does not fit, so two consecutive
-        // ranges hold more than TK_SOLO_MAX products together).  Fuller ranges = fewer range tasks,
-        // fewer searches of the direct tasks, fewer hops of the chain.  Greedy packing is sequential, so it is done with jump
-        // pointers: nxt[b] = where the range that starts at b ends (capacity by binary search over the prefix sums, or the next
-        // forced start -- a heavy bucket or the bucket after one), all b in parallel; then one thread follows the pointers.
+#if SPADA_PRE_DBG == 2
+        pre_tick(1);
+#endif
+
+        // range starts: the buckets are packed greedily, as many as fit one task's table (<= lim products: a range is closed when the
+        // next bucket does not fit, so two consecutive ranges hold more than lim products together; a heavy bucket -- more than lim
+        // products -- fits nowhere and is a range of its own).  Fuller ranges = fewer range tasks, fewer searches of the direct tasks,
+        // fewer hops of the chain.  The range that starts at bucket b ends in front of the first bucket whose products no longer
+        // fit -- the first e >= b with pre[e + 1] - pre[b] > lim -- or behind b itself if b is heavy.  (Through round 5 the heavy
+        // buckets and their successors were also found as "forced" starts, by a scan of their own: redundant -- a heavy bucket
+        // closes the range in front of it by the capacity rule already.)
+        //   * a row of FEW ranges (at most PLAN_WALK_MAX * lim products: the BIG rows of web graphs and meshes) walks them one
+        //     after the other, every step a search by the whole workgroup -- each thread compares its four buckets' prefixes,
+        //     which it keeps in registers, one ballot per wave, one barrier;
+        //   * a row of many ranges (the hubs of an R-MAT graph) finds the end of the range that WOULD start at every bucket,
+        //     all buckets in parallel by binary search over the prefix sums, then one thread follows those pointers.
+        // (Phase clocks of round 6, web input, ticks per row: the forced starts 5.2 k, the 1024 binary searches -- four per
+        // thread, one after the other -- 10.0 k, the walk 0.8 k of the kernel's 32.6 k; the rows have five ranges.)
         {
-            uint32_t forced[BPT], fex[BPT];
-#pragma unroll
-            for (int k = 0; k < BPT; ++k) {
-                const int bk = tid * BPT + k;
-                forced[k] = (bk == 0 || cnt[bk] > lim || cnt[bk - (bk > 0)] > lim) ? 1u : 0u;
-            }
-            __syncthreads();   // (cnt is read above and reused for the pointers below)
-#pragma unroll
-            for (int k = 0; k < BPT; ++k) aux[tid * BPT + k] = forced[k];
-            __syncthreads();
-            block_exclusive_scan4_dpp(aux, hdr + 4);
-#pragma unroll
-            for (int k = 0; k < BPT; ++k) {
-                fex[k] = aux[tid * BPT + k];
-                if (forced[k]) rfirst[fex[k]] = tid * BPT + k;   // positions of the forced starts, ascending
-            }
-            if (tid == TK_BLOCK - 1) rfirst[fex[BPT - 1] + forced[BPT - 1]] = NB;
-            __syncthreads();
-#pragma unroll
-            for (int k = 0; k < BPT; ++k) {
-                const uint32_t bk = tid * BPT + k;
-                const uint32_t nf = rfirst[fex[k] + forced[k]];   // next forced start behind bk
-                // largest e with pre[e] - pre[bk] <= lim (pre[NB] = P)
-                const uint32_t plim = pre[bk] + lim;
-                uint32_t lo = bk + 1, n = NB - bk;   // e in [bk + 1, NB]: first e with pre[e] > lim, minus one ... searched as upper bound
-                while (n) {
-                    const uint32_t h = n >> 1;
-                    if (pre[lo + h] <= plim) {
-                        lo += h + 1;
-                        n -= h + 1;
-                    } else {
-                        n = h;
-                    }
-                }
-                // lo = first index in [bk + 1, NB + 1] whose prefix exceeds lim; the range [bk, lo - 1) fits
-                const uint32_t cap_end = max(lo - 1, bk + 1);
-                cnt[bk] = min(cap_end, nf);
-            }
-            __syncthreads();
 #pragma unroll
             for (int k = 0; k < BPT; ++k) aux[tid * BPT + k] = 0u;
-            __syncthreads();
-            if (tid == 0)
-                for (uint32_t bk = 0; bk < (uint32_t)NB; bk = cnt[bk]) aux[bk] = 1u;
+            if (pre[NB] <= PLAN_WALK_MAX * lim) {
+                uint32_t pv[BPT + 1];
+#pragma unroll
+                for (int k = 0; k <= BPT; ++k) pv[k] = pre[tid * BPT + k];
+                __syncthreads();   // (aux is cleared)
+                const uint32_t lane = (uint32_t)tid & 63u, wave = (uint32_t)tid >> 6;
+                uint32_t bk = 0, turn = 0;
+                while (bk < (uint32_t)NB) {   // (uniform)
+                    const uint32_t plim = pre[bk] + lim;
+                    uint32_t mine = 0xFFFFFFFFu;
+#pragma unroll
+                    for (int k = BPT - 1; k >= 0; --k)
+                        if ((uint32_t)(tid * BPT + k) >= bk && pv[k + 1] > plim) mine = (uint32_t)(tid * BPT + k);
+                    // (the threads hold the buckets in order: the lowest lane with a hit has the wave's first)
+                    const unsigned long long hit = __ballot(mine != 0xFFFFFFFFu);
+                    const uint32_t cand = hit ? (uint32_t)__shfl((int)mine, __ffsll((long long)hit) - 1) : (uint32_t)NB;
+                    uint32_t *wc = hdr + 32 + (turn & 1u) * 4u;   // (two sets in turn: one barrier per range)
+                    if (lane == 0) wc[wave] = cand;
+                    if (tid == 0) aux[bk] = 1u;
+                    __syncthreads();
+                    const uint32_t e = min(min(wc[0], wc[1]), min(wc[2], wc[3]));
+                    bk = max(e, bk + 1u);
+                    ++turn;
+                }
+            } else {
+                // (cnt: the pointers)
+#pragma unroll
+                for (int k = 0; k < BPT; ++k) {
+                    const uint32_t bk = tid * BPT + k;
+                    // largest e with pre[e] - pre[bk] <= lim (pre[NB] = P)
+                    const uint32_t plim = pre[bk] + lim;
+                    uint32_t lo = bk + 1, n = NB - bk;   // e in [bk + 1, NB]: first e with pre[e] > lim, minus one ... searched as upper bound
+                    while (n) {
+                        const uint32_t h = n >> 1;
+                        if (pre[lo + h] <= plim) {
+                            lo += h + 1;
+                            n -= h + 1;
+                        } else {
+                            n = h;
+                        }
+                    }
+                    // lo = first index in [bk + 1, NB + 1] whose prefix exceeds lim; the range [bk, lo - 1) fits
+                    cnt[bk] = max(lo - 1, bk + 1);
+                }
+                __syncthreads();
+                if (tid == 0)
+                    for (uint32_t bk = 0; bk < (uint32_t)NB; bk = cnt[bk]) aux[bk] = 1u;
+            }
             __syncthreads();
         }
+#if SPADA_PRE_DBG == 2
+        pre_tick(2);
+        pre_tick(3);
+        pre_tick(4);
+#endif
         uint32_t stf[BPT];
 #pragma unroll
         for (int k = 0; k < BPT; ++k) stf[k] = aux[tid * BPT + k];
@@ -460,6 +493,10 @@ __global__ __launch_bounds__(TK_BLOCK, 8) void k_big_plan(const uint64_t *__rest
             hdr[40] = NR;
         }
         __syncthreads();
+
+#if SPADA_PRE_DBG == 2
+        pre_tick(5);
+#endif
         const uint32_t NR = hdr[40];
         // non-empty ranges, compacted
         uint32_t nef[BPT];
@@ -497,10 +534,13 @@ __global__ __launch_bounds__(TK_BLOCK, 8) void k_big_plan(const uint64_t *__rest
                 if (pre[f1] - pre[f0] > lim && ((uint64_t)(f1 - f0) << wshift) > lim) hdr[47] = 1;
             }
         block_exclusive_scan4_dpp(aux, hdr + 4);
+#if SPADA_PRE_DBG == 2
+        pre_tick(6);
+#endif
         if (tid == TK_BLOCK - 1) {
             const uint32_t m = aux[NB - 1] + wgt[BPT - 1];
             const unsigned long long P = pre[NB];
-            const unsigned long long a0 = aptr[r0 + row], E = aptr[r0 + row + 1] - a0;
+            const unsigned long long a0 = al_a0, E = al_a1 - a0;
             hdr[48] = (uint32_t)min(E, 0x7FFFFFFFull);
             hdr[49] = (uint32_t)a0;
             hdr[50] = (uint32_t)(a0 >> 32);
@@ -508,7 +548,7 @@ __global__ __launch_bounds__(TK_BLOCK, 8) void k_big_plan(const uint64_t *__rest
             const unsigned long long steps = 1ull + (avg_len ? 31u - (uint32_t)__clz((int)avg_len) : 0u);   // of one binary search
             const bool direct = allow_direct && hdr[47] == 0 && (unsigned long long)m * E * steps <= (unsigned long long)BX_DIRECT_FACTOR * P &&
                                 E * steps <= BX_DIRECT_MAX_SEARCH && (E <= BX_DIRECT_EMAX || nrows_call < BX_DIRECT_ROWS);
-            const uint32_t tb = row_tmp[row];   // big_max_ranges(P) >= m records, allocated by k_big_parts
+            const uint32_t tb = al_tb;   // big_max_ranges(P) >= m records, allocated by k_big_parts
             const unsigned long long sb = direct ? 0ull : atomicAdd(&ctr->scratch_cursor, P);
             // the cut table of a direct row whose range tasks run through the batch stages: (ranges + 1) rows of one word per entry
             // -- if the row's searches are few enough for its products (cut_factor16 / 16 searches steps per product: the host's
@@ -541,6 +581,7 @@ __global__ __launch_bounds__(TK_BLOCK, 8) void k_big_plan(const uint64_t *__rest
             hdr[45] = ok ? 1u : 0u;
             if (!ok) atomicOr(&ctr->abort_flag, 1u);
             row_m[row] = m;
+            hdr[41] = m;
             // (the tiles were cut before this kernel ran -- k_row_class_cut, where a BIG row starts no task yet: its range tasks join
             // the row's and the tile's counts here, one atomic per BIG row spread over the tiles)
             row_t[row] = m;
@@ -556,12 +597,15 @@ __global__ __launch_bounds__(TK_BLOCK, 8) void k_big_plan(const uint64_t *__rest
             }
         }
         __syncthreads();
+#if SPADA_PRE_DBG == 2
+        pre_tick(7);
+#endif
         if (hdr[46] == 0u)   // (spilled; the list has room for every part record: both are sized by the parts' capacity)
             for (uint32_t i = tid; i < nreal; i += TK_BLOCK) spill_parts[hdr[57] + i] = pb + i;
         const uint32_t tb = hdr[42];
         const uint64_t sb = ((uint64_t)hdr[44] << 32) | hdr[43], cb = ((uint64_t)hdr[52] << 32) | hdr[51];
         const bool ok = hdr[45] != 0, direct = hdr[46] != 0, has_cuts = hdr[53] != 0;
-        const uint32_t m_row = row_m[row];
+        const uint32_t m_row = hdr[41];   // (not read back from row_m: a store and a load of the same word, a round trip through the L2)
         if (ok) {
 #pragma unroll
             for (int k = 0; k < BPT; ++k)
@@ -594,6 +638,10 @@ __global__ __launch_bounds__(TK_BLOCK, 8) void k_big_plan(const uint64_t *__rest
             const uint64_t ib = ((uint64_t)hdr[55] << 32) | hdr[54];
             for (uint32_t q = tid; q < hdr[56]; q += TK_BLOCK) cut_items[ib + q] = make_uint2(slot, q);
         }
+
+#if SPADA_PRE_DBG == 2
+        pre_tick(8);
+#endif
         if (ok && !direct) {
             // spilled: the counts of every part become its cursors.  Layout of the row's slice: RANGE major (a range task reads one
             // contiguous slice), inside a range PART major, inside (range, part) in the order the scatter's waves arrive (by bucket
@@ -669,6 +717,15 @@ __global__ __launch_bounds__(TK_BLOCK, 8) void k_big_plan(const uint64_t *__rest
             }
         }
         __syncthreads();
+#if SPADA_PRE_DBG == 2
+        pre_tick(9);
+        if (tid == 0 && (slot & 31u) == 0u) {   // (a sample of the rows: the report's own atomics share a line, and a channel, with the counters the kernel allocates from)
+            const unsigned long long *tk = pre_ticks();
+            for (int k = 0; k < 9; ++k) atomicAdd(&ctr->dbg[k], tk[k + 1] - tk[k]);
+            atomicAdd(&ctr->dbg[15], 1ull);
+        }
+        __syncthreads();
+#endif
     }
 }
 

@@ -147,6 +147,23 @@ __device__ inline uint8_t row_class(uint64_t P, uint32_t L, uint32_t rmax, uint3
     return CLS_BIG;
 }
 
+#ifndef SPADA_PRE_DBG
+#define SPADA_PRE_DBG 0   /* 1: phase clocks of k_row_class_cut, 2: of k_big_plan (thread 0 of every workgroup), summed into TaskCounters::dbg, printed to stderr */
+#endif
+#if SPADA_PRE_DBG
+__device__ inline unsigned long long *pre_ticks()
+{
+    __shared__ unsigned long long s_pre_tick[16];
+    return s_pre_tick;
+}
+__device__ inline void pre_tick(int k)
+{
+    if (threadIdx.x == 0) pre_ticks()[k] = __builtin_amdgcn_s_memtime();
+}
+#else
+__device__ inline void pre_tick(int) {}
+#endif
+
 // ---- 4. the task kernel ------------------------------------------------------------------------------------------------
 constexpr int MODE_COUNT = 0, MODE_NUMERIC = 1, MODE_FUSED = 2;
 constexpr unsigned long long ST_AGG = 1ull << 62, ST_INC = 2ull << 62, ST_MASK = 3ull << 62;

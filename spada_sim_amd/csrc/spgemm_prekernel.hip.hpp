@@ -48,22 +48,6 @@ __global__ __launch_bounds__(256) void k_preset_rows(unsigned long long *__restr
     }
 }
 
-#ifndef SPADA_PRE_DBG
-#define SPADA_PRE_DBG 0   /* 1: phase clocks of k_row_class_cut (thread 0 of every workgroup), summed into TaskCounters::dbg, printed to stderr */
-#endif
-#if SPADA_PRE_DBG
-__device__ inline unsigned long long *pre_ticks()
-{
-    __shared__ unsigned long long s_pre_tick[16];
-    return s_pre_tick;
-}
-__device__ inline void pre_tick(int k)
-{
-    if (threadIdx.x == 0) pre_ticks()[k] = __builtin_amdgcn_s_memtime();
-}
-#else
-__device__ inline void pre_tick(int) {}
-#endif
 constexpr int ENTRY_STATS_U = 1;   // segments of 64 entries per wave and turn (the engine sizes the grid by it)
 template <class ARGS>
 __global__ __launch_bounds__(256) void k_entry_stats(const uint64_t *__restrict__ aptr, const uint32_t *__restrict__ aidx,
@@ -392,7 +376,7 @@ __global__ __launch_bounds__(CUT_TILE) void k_row_class_cut(const uint64_t *__re
         row_binfo[i] = binfo;
     }
     if (big_loc != 0xFFFFFFFFu) big_rows[L.big_base + big_loc] = i;
-#if SPADA_PRE_DBG
+#if SPADA_PRE_DBG == 1
     pre_tick(8);
     if (threadIdx.x == 0) {
         const unsigned long long *tk = pre_ticks();

@@ -143,6 +143,14 @@ struct spada_ctx {
     uint32_t part_shift = 0;          // (SPADA_PART_SHIFT: log2 of the products per part, 0 = by the rule above)
     bool range_cursors = true;        // the scatter appends per (part, range), not per (part, bucket) (SPADA_RANGE_CURSORS=0: measurements)
     uint32_t scatter_wgs = 8;         // workgroups of k_big_scatter per CU (SPADA_SCATTER_WGS: measurements)
+    // placement of the scratch arrays (place_scratch): runs with a large scatter seen on the arrays as they are | the arrays the choice was made for
+    bool place_enabled = true;        // (SPADA_PLACE=0: the arrays stay where the first allocation put them)
+    unsigned long long place_min = 1ull << 27;   // scratch arrays of at least this many products: 1.5 GB (SPADA_PLACE_MIN: tests)
+    uint32_t place_after = 6;                    // ... after this many runs with a large scatter on them (SPADA_PLACE_AFTER: tests)
+    uint32_t place_runs = 0, place_tries = 0, place_blocks = 0;
+    unsigned long long last_scratch = 0;   // products the previous pipeline run scattered
+    const void *place_col = nullptr, *place_val = nullptr;
+    float place_ms_first = 0.f, place_ms_kept = 0.f;
     // one pass or two phases inside spada_dev_spgemm_fused: by RULE (more than half of the products in BIG rows -> count + numeric), applied
     // on the first call already (the run reads its row statistics back once, behind the row classes: task_pipeline, mid-run read);
     // SPADA_AUTO=0: always one pass; SPADA_AUTO=measure: round 5's three-call measurement per input (at_*)
@@ -431,6 +439,76 @@ TaskArgs task_args(spada_ctx *c, uint64_t *cptr, uint32_t *d_idx, double *d_val,
     return g;
 }
 
+// WHERE the scatter's two scratch arrays lie in physical memory decides between two regimes of the scatter phase a tenth apart (R-MAT 18: 7.9 or
+// 8.8 ms behind the plan; R-MAT 22: 0.78 or 1.00 s per step) -- constant for the life of the allocation, different from one allocation to the next,
+// and of the PAIR: moving either array alone changes it (profiles/r06_experiments.txt section 12).  A probe with the scatter's store pattern
+// (k_place_probe) tells the regimes apart in a few milliseconds.  So a context that keeps running large scatters on the same arrays -- six
+// runs: a one-off call does not pay for this -- tries other places for the column array (the smaller one): a new block is taken while the old one
+// is held, the pair is probed, the faster block is kept; at most PLACE_TRIES blocks, and no more once both regimes have been seen.  Rounds 2 - 5
+// reported the two regimes as a property of the process; it is a property of two allocations.
+constexpr uint32_t PLACE_TRIES = 4;
+static float place_probe_ms(spada_ctx *c, hipStream_t s, void *col, void *val, unsigned long long nprod)
+{
+    float best = 1e30f;
+    for (int rep = 0; rep < 3; ++rep) {
+        if (hipEventRecord(c->ev_fork, s) != hipSuccess) return -1.f;
+        hipLaunchKernelGGL(k_place_probe, dim3(4096), dim3(256), 0, s, (uint32_t *)col, (double *)val, nprod, 256u);
+        if (hipEventRecord(c->ev_join, s) != hipSuccess || hipEventSynchronize(c->ev_join) != hipSuccess) return -1.f;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, c->ev_fork, c->ev_join) != hipSuccess) return -1.f;
+        best = std::min(best, ms);
+    }
+    return best;
+}
+static void place_scratch(spada_ctx *c, hipStream_t s)
+{
+    if (!c->place_enabled || c->accumulator == SPADA_ACC_SORT_MERGE || !c->t_scrcol.p || !c->t_scrval.p) return;
+    if (c->place_col != c->t_scrcol.p || c->place_val != c->t_scrval.p) {   // (new arrays: the choice starts over)
+        c->place_col = c->t_scrcol.p;
+        c->place_val = c->t_scrval.p;
+        c->place_runs = c->place_tries = c->place_blocks = 0;
+        c->place_ms_first = c->place_ms_kept = 0.f;
+    }
+    const unsigned long long nprod = std::min<unsigned long long>(c->t_scrcol.cap / 4, c->t_scrval.cap / 8);
+    if (nprod < c->place_min || nprod < 64 || c->place_tries >= PLACE_TRIES) return;
+    if (c->last_scratch < c->place_min / 4 || ++c->place_runs < c->place_after) return;   // (the run before this one: did it scatter much?)
+    if (hipStreamSynchronize(s) != hipSuccess) return;
+    const auto t0 = std::chrono::steady_clock::now();
+    uint32_t tried = 0;
+    if (c->place_tries == 0) {
+        c->place_ms_first = c->place_ms_kept = place_probe_ms(c, s, c->t_scrcol.p, c->t_scrval.p, nprod);
+        if (c->place_ms_kept <= 0.f) {
+            c->place_tries = PLACE_TRIES;
+            return;
+        }
+    }
+    float slowest = c->place_ms_kept;
+    while (c->place_tries < PLACE_TRIES) {
+        ++c->place_tries;
+        ++c->place_blocks;
+        ++tried;
+        void *q = nullptr;
+        if (hipMalloc(&q, c->t_scrcol.cap) != hipSuccess) {   // (no room for a second block: stay)
+            (void)hipGetLastError();
+            c->place_tries = PLACE_TRIES;
+            break;
+        }
+        const float ms = place_probe_ms(c, s, q, c->t_scrval.p, nprod);
+        slowest = std::max(slowest, ms);
+        if (ms > 0.f && ms < c->place_ms_kept) {
+            (void)hipFree(c->t_scrcol.p);
+            c->t_scrcol.p = q;
+            c->place_ms_kept = ms;
+        } else {
+            (void)hipFree(q);
+        }
+        if (c->place_ms_kept < 0.88f * slowest) c->place_tries = PLACE_TRIES;   // (both regimes seen, the faster one kept)
+    }
+    c->place_col = c->t_scrcol.p;
+    trace(1, "scratch placement: probe %.2f ms where the arrays were, %.2f ms kept (%u other blocks of %.1f GB tried, %.0f ms)", c->place_ms_first, c->place_ms_kept,
+          tried, c->t_scrcol.cap / 1e9, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+}
+
 // Row statistics, BIG-row expansion, task list and the task kernel in MODE_COUNT (cptr = the context's C.indptr) or MODE_FUSED
 // (cptr / d_idx / d_val = the caller's buffers).  Nothing is read back before the end; workspaces whose size depends on the
 // data (tasks, range descriptors, scratch) keep their capacity from earlier calls, the kernels refuse to overrun them, and one
@@ -516,6 +594,7 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
         cap_tasks = (uint32_t)std::min<uint64_t>(c->t_cap_tasks, 0xFFFFFFF0u);
         cap_tmp = (uint32_t)std::min<uint64_t>(c->t_cap_tmp, 0xFFFFFFF0u);
         cap_parts = (uint32_t)std::min<uint64_t>(c->t_cap_parts, 0xFFFFFFF0u);
+        place_scratch(c, s);
         return SPADA_OK;
     };
     // the end of a run (and the mid-run read): the counters written into pinned host memory, then a sequence number the host polls
@@ -834,6 +913,7 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
         }
         c->last_nprod_big = h.nprod_big;
         c->last_spilled = h.n_spilled;
+        c->last_scratch = h.scratch_cursor;
         uint64_t cut_most = 0;   // (the fullest arena sets the size)
         uint64_t items_most = 0;
         for (uint32_t a2 = 0; a2 < BX_ARENAS; ++a2) {
@@ -1068,6 +1148,9 @@ int spada_create(const spada_options *opts, spada_ctx **out)
     if (const char *e = getenv("SPADA_SIDE")) c->side_mode = atoi(e);
     if (const char *e = getenv("SPADA_AUTO")) c->auto_mode = !std::strcmp(e, "measure") ? 2 : (atoi(e) != 0 ? 1 : 0);
     if (const char *e = getenv("SPADA_EXPORT")) c->export_poll = atoi(e) != 0;
+    if (const char *e = getenv("SPADA_PLACE")) c->place_enabled = atoi(e) != 0;
+    if (const char *e = getenv("SPADA_PLACE_MIN")) c->place_min = std::strtoull(e, nullptr, 10);
+    if (const char *e = getenv("SPADA_PLACE_AFTER")) c->place_after = (uint32_t)std::max(atoi(e), 1);
     if (const char *e = getenv("SPADA_SHADOW")) c->shadow = atoi(e) != 0;
     if (const char *e = getenv("SPADA_TASK_WGS")) c->task_wgs = (uint32_t)std::min(std::max(atoi(e), 1), TASK_WAVES / 2);
     if (const char *e = getenv("SPADA_CUT_TABLE")) c->cut_table = atoi(e) != 0;
@@ -1659,6 +1742,16 @@ int spada_dev_csr_aux_cost(const spada_dev_csr *m, double *host_ms, double *devi
     *host_ms = m->aux_host_ms;
     *device_ms = m->aux_dev_ms;
     if (bytes) *bytes = m->nnz * 4 + m->rows * 8;
+    return SPADA_OK;
+}
+
+// measurement only (include/spada_probe.h): what place_scratch has done on this context
+int spada_dev_scratch_placement(const spada_ctx *c, uint32_t *blocks_tried, float *probe_ms_first, float *probe_ms_kept)
+{
+    if (!c || !blocks_tried || !probe_ms_first || !probe_ms_kept) return fail(SPADA_ERR_INVALID, "spada_dev_scratch_placement: null argument");
+    *blocks_tried = c->place_blocks;
+    *probe_ms_first = c->place_ms_first;
+    *probe_ms_kept = c->place_ms_kept;
     return SPADA_OK;
 }
 

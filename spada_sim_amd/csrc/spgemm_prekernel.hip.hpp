@@ -48,6 +48,25 @@ __global__ __launch_bounds__(256) void k_preset_rows(unsigned long long *__restr
     }
 }
 
+// k_place_probe: the scatter's store pattern on the scratch arrays -- runs of 12 products (a 4-byte column and an 8-byte value at the same
+// product number) at scattered places, five runs per wave and turn.  What it takes depends on WHERE the two arrays lie in physical memory: 2.5 or 3.3 ms
+// on R-MAT 18's arrays, and the scatter phase of every run on those arrays takes 7.9 or 8.8 ms accordingly (spada_engine.hip, place_scratch).
+__global__ __launch_bounds__(256) void k_place_probe(uint32_t *__restrict__ col, double *__restrict__ val, unsigned long long nprod, uint32_t per_wave)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    unsigned long long x = ((unsigned long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 0x9E3779B97F4A7C15ull + 777ull;
+    for (uint32_t i = 0; i < per_wave; ++i) {
+        x ^= x >> 29;
+        x *= 0xBF58476D1CE4E5B9ull;
+        x ^= x >> 32;
+        const unsigned long long r = (x + (lane / 12u) * 0x51ED27ull * (x | 1ull)) % (nprod - 16ull) + lane % 12u;
+        if (lane < 60u) {
+            col[r] = (uint32_t)x;
+            val[r] = (double)i;
+        }
+    }
+}
+
 constexpr int ENTRY_STATS_U = 1;   // segments of 64 entries per wave and turn (the engine sizes the grid by it)
 template <class ARGS>
 __global__ __launch_bounds__(256) void k_entry_stats(const uint64_t *__restrict__ aptr, const uint32_t *__restrict__ aidx,

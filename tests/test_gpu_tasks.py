@@ -777,3 +777,41 @@ def test_a_stalled_chain_gives_up_instead_of_hanging(monkeypatch):
         assert_parity(c, ref, to_oracle(a), to_oracle(a), RTOL)
     finally:
         eng.close()
+
+
+@pytest.mark.gpu
+def test_moving_the_scratch_arrays_to_a_faster_place_keeps_the_product(monkeypatch):
+    """A context that keeps scattering into the same scratch arrays tries other places for the column array (place_scratch: where the two
+    arrays lie in physical memory decides between two regimes of the scatter, a tenth apart, and a probe with the scatter's store pattern
+    tells them apart).  With the thresholds lowered (test hooks) the choice is made on R-MAT 14's few megabytes after two runs: every call
+    before and after it gives the same C, through both entry points; SPADA_PLACE=0 leaves the arrays alone."""
+    import ctypes
+    import spada_sim_amd as S
+    from spada_sim_amd import _ffi
+    fn = _ffi.lib().spada_dev_scratch_placement
+    fn.restype = ctypes.c_int
+    fn.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
+    m = S.generate(S.GEN_RMAT, 14, 16, 4)
+    a = to_oracle(m)
+    ref = oracle.spgemm_sortmerge(a, a)
+    monkeypatch.setenv("SPADA_PLACE_MIN", "1024")
+    monkeypatch.setenv("SPADA_PLACE_AFTER", "2")
+    for place in ("1", "0"):
+        monkeypatch.setenv("SPADA_PLACE", place)
+        eng = S.Engine()
+        try:
+            for call in range(5):
+                if call % 2:
+                    c = eng.spgemm(m, m)
+                else:
+                    c, st = fused(eng, m, m)
+                    assert st["spill_rows"] > 0
+                assert_parity(c, ref, a, a, RTOL)
+            tried, first, kept = ctypes.c_uint32(0), ctypes.c_float(0), ctypes.c_float(0)
+            assert fn(eng._ctx, ctypes.byref(tried), ctypes.byref(first), ctypes.byref(kept)) == 0
+            if place == "1":
+                assert 1 <= tried.value <= 4 and 0 < kept.value <= first.value
+            else:
+                assert tried.value == 0
+        finally:
+            eng.close()

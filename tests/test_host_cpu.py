@@ -41,7 +41,7 @@ def test_probe_header_symbols_are_exported():
     hdr = open(os.path.join(ROOT, "include", "spada_probe.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
     declared = set(re.findall(r"\b(spada_[a-z0-9_]+)\s*\(", hdr))
-    assert declared == {"spada_dev_probe_floor", "spada_dev_csr_aux_cost"}, declared
+    assert declared == {"spada_dev_probe_floor", "spada_dev_csr_aux_cost", "spada_dev_scratch_placement"}, declared
     L = ctypes.CDLL(_ffi.LIB_PATH)
     for name in sorted(declared):
         assert hasattr(L, name), f"{name} declared in include/spada_probe.h but not exported"

@@ -483,6 +483,8 @@ static void place_scratch(spada_ctx *c, hipStream_t s)
         }
     }
     float slowest = c->place_ms_kept;
+    void *rejected[PLACE_TRIES];   // (held until the choice is made: a block given back at once is the first the next request is handed)
+    uint32_t n_rejected = 0;
     while (c->place_tries < PLACE_TRIES) {
         ++c->place_tries;
         ++c->place_blocks;
@@ -496,14 +498,15 @@ static void place_scratch(spada_ctx *c, hipStream_t s)
         const float ms = place_probe_ms(c, s, q, c->t_scrval.p, nprod);
         slowest = std::max(slowest, ms);
         if (ms > 0.f && ms < c->place_ms_kept) {
-            (void)hipFree(c->t_scrcol.p);
+            rejected[n_rejected++] = c->t_scrcol.p;
             c->t_scrcol.p = q;
             c->place_ms_kept = ms;
         } else {
-            (void)hipFree(q);
+            rejected[n_rejected++] = q;
         }
         if (c->place_ms_kept < 0.88f * slowest) c->place_tries = PLACE_TRIES;   // (both regimes seen, the faster one kept)
     }
+    for (uint32_t k = 0; k < n_rejected; ++k) (void)hipFree(rejected[k]);
     c->place_col = c->t_scrcol.p;
     trace(1, "scratch placement: probe %.2f ms where the arrays were, %.2f ms kept (%u other blocks of %.1f GB tried, %.0f ms)", c->place_ms_first, c->place_ms_kept,
           tried, c->t_scrcol.cap / 1e9, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());

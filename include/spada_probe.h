@@ -27,7 +27,7 @@ int spada_dev_probe_floor(spada_ctx *ctx, int write, uint32_t wgs_per_cu, uint32
 int spada_dev_csr_aux_cost(const spada_dev_csr *m, double *host_ms, double *device_ms, uint64_t *bytes);
 
 /* Where the scatter's scratch arrays lie (spada_engine.hip, place_scratch): a context that keeps scattering into the same two arrays probes
- * them with the scatter's store pattern and tries other places for the column array, keeping the fastest.  *blocks_tried = blocks probed
+ * them with the scatter's store pattern and tries other places for the column array (then, if none made a difference, for the value array), keeping the fastest.  *blocks_tried = blocks probed
  * besides the one the arrays started in (0: no choice was made -- arrays too small, too few runs, SPADA_PLACE=0); *probe_ms_first /
  * *probe_ms_kept = the probe's time where the arrays were / where they are now.  The two regimes are 2.5 and 3.3 ms apart on MI355X. */
 int spada_dev_scratch_placement(const spada_ctx *ctx, uint32_t *blocks_tried, float *probe_ms_first, float *probe_ms_kept);

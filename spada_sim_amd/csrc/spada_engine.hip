@@ -444,9 +444,15 @@ TaskArgs task_args(spada_ctx *c, uint64_t *cptr, uint32_t *d_idx, double *d_val,
 // and of the PAIR: moving either array alone changes it (profiles/r06_experiments.txt section 12).  A probe with the scatter's store pattern
 // (k_place_probe) tells the regimes apart in a few milliseconds.  So a context that keeps running large scatters on the same arrays -- six
 // runs: a one-off call does not pay for this -- tries other places for the column array (the smaller one): a new block is taken while the old one
-// is held, the pair is probed, the faster block is kept; at most PLACE_TRIES blocks, and no more once both regimes have been seen.  Rounds 2 - 5
+// is held, the pair is probed, the faster block is kept; at most PLACE_TRIES blocks, and no more once both regimes have been seen; if no column block
+// makes a difference, two blocks for the value array.  Rounds 2 - 5
 // reported the two regimes as a property of the process; it is a property of two allocations.
 constexpr uint32_t PLACE_TRIES = 4;
+// (the probe's work does not depend on the arrays' size: 2.3 - 2.6 ms on a well placed pair on MI355X, 2.9 - 3.4 on a badly placed one -- and an imperfect
+// proxy in between: a pair that probed at 2.62 ms scattered in the slower regime, pairs at 2.72 - 2.78 in the faster one.  A pair that probes under
+// PLACE_FAST_MS is left alone; a request for a block that takes longer than PLACE_SLOW_ALLOC_MS ends the search: one of 6.8 GB once took 2 s)
+constexpr float PLACE_FAST_MS = 2.5f;
+constexpr double PLACE_SLOW_ALLOC_MS = 150.0;
 static float place_probe_ms(spada_ctx *c, hipStream_t s, void *col, void *val, unsigned long long nprod)
 {
     float best = 1e30f;
@@ -477,12 +483,14 @@ static void place_scratch(spada_ctx *c, hipStream_t s)
     uint32_t tried = 0;
     if (c->place_tries == 0) {
         c->place_ms_first = c->place_ms_kept = place_probe_ms(c, s, c->t_scrcol.p, c->t_scrval.p, nprod);
-        if (c->place_ms_kept <= 0.f) {
+        if (c->place_ms_kept <= 0.f || c->place_ms_kept <= PLACE_FAST_MS) {
             c->place_tries = PLACE_TRIES;
+            trace(1, "scratch placement: probe %.2f ms where the arrays are: left alone", c->place_ms_kept);
             return;
         }
     }
     float slowest = c->place_ms_kept;
+    bool give_up = false;
     void *rejected[PLACE_TRIES];   // (held until the choice is made: a block given back at once is the first the next request is handed)
     uint32_t n_rejected = 0;
     while (c->place_tries < PLACE_TRIES) {
@@ -490,11 +498,13 @@ static void place_scratch(spada_ctx *c, hipStream_t s)
         ++c->place_blocks;
         ++tried;
         void *q = nullptr;
+        const auto ta = std::chrono::steady_clock::now();
         if (hipMalloc(&q, c->t_scrcol.cap) != hipSuccess) {   // (no room for a second block: stay)
             (void)hipGetLastError();
             c->place_tries = PLACE_TRIES;
             break;
         }
+        if (std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ta).count() > PLACE_SLOW_ALLOC_MS) give_up = true;
         const float ms = place_probe_ms(c, s, q, c->t_scrval.p, nprod);
         slowest = std::max(slowest, ms);
         if (ms > 0.f && ms < c->place_ms_kept) {
@@ -504,12 +514,42 @@ static void place_scratch(spada_ctx *c, hipStream_t s)
         } else {
             rejected[n_rejected++] = q;
         }
-        if (c->place_ms_kept < 0.88f * slowest) c->place_tries = PLACE_TRIES;   // (both regimes seen, the faster one kept)
+        if (c->place_ms_kept < 0.88f * slowest || c->place_ms_kept <= PLACE_FAST_MS || give_up) c->place_tries = PLACE_TRIES;   // (both regimes seen, the faster one kept)
     }
     for (uint32_t k = 0; k < n_rejected; ++k) (void)hipFree(rejected[k]);
+    n_rejected = 0;
+    // No column block made a difference: every pair was fast, or the VALUE array is what is badly placed (scripts/dev/place_offset_probe.hip: with
+    // some value blocks every column block probes at 3.35 - 3.41 ms).  Two other blocks for the value array tell.
+    uint32_t tried_val = 0;
+    if (!(c->place_ms_kept < 0.88f * slowest) && c->place_ms_kept > PLACE_FAST_MS && !give_up) {
+        for (; tried_val < 2u && !give_up; ) {
+            void *q = nullptr;
+            const auto ta = std::chrono::steady_clock::now();
+            if (hipMalloc(&q, c->t_scrval.cap) != hipSuccess) {
+                (void)hipGetLastError();
+                break;
+            }
+            if (std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ta).count() > PLACE_SLOW_ALLOC_MS) give_up = true;
+            ++tried_val;
+            ++c->place_blocks;
+            const float ms = place_probe_ms(c, s, c->t_scrcol.p, q, nprod);
+            slowest = std::max(slowest, ms);
+            if (ms > 0.f && ms < c->place_ms_kept) {
+                rejected[n_rejected++] = c->t_scrval.p;
+                c->t_scrval.p = q;
+                c->place_ms_kept = ms;
+            } else {
+                rejected[n_rejected++] = q;
+            }
+            if (c->place_ms_kept < 0.88f * slowest || c->place_ms_kept <= PLACE_FAST_MS) break;
+        }
+        for (uint32_t k = 0; k < n_rejected; ++k) (void)hipFree(rejected[k]);
+    }
     c->place_col = c->t_scrcol.p;
-    trace(1, "scratch placement: probe %.2f ms where the arrays were, %.2f ms kept (%u other blocks of %.1f GB tried, %.0f ms)", c->place_ms_first, c->place_ms_kept,
-          tried, c->t_scrcol.cap / 1e9, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    c->place_val = c->t_scrval.p;
+    trace(1, "scratch placement: probe %.2f ms where the arrays were, %.2f ms kept (%u other column blocks of %.1f GB, %u other value blocks tried, %.0f ms)",
+          c->place_ms_first, c->place_ms_kept, tried, c->t_scrcol.cap / 1e9, tried_val,
+          std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
 }
 
 // Row statistics, BIG-row expansion, task list and the task kernel in MODE_COUNT (cptr = the context's C.indptr) or MODE_FUSED

@@ -57,6 +57,25 @@ int main(int argc, char **argv)
         hipFree(c);
         hipFree(v);
     }
+    // (a2) does a pair's time change when the arrays are overwritten front to back?
+    for (int t = 0; t < 6; ++t) {
+        uint32_t *c;
+        double *v;
+        if (hipMalloc(&c, np * 4) != hipSuccess || hipMalloc(&v, np * 8) != hipSuccess) return 1;
+        const float p0 = probe(c, v, np);
+        hipMemset(c, 0, np * 4);
+        hipMemset(v, 0, np * 8);
+        hipDeviceSynchronize();
+        const float p1 = probe(c, v, np);
+        hipMemset(c, 0xFF, np * 4);
+        hipMemset(v, 0xFF, np * 8);
+        hipDeviceSynchronize();
+        const float p2 = probe(c, v, np);
+        const float p3 = probe(c, v, np);
+        printf("fresh pair %d: probe %.3f ms, after memset 0 %.3f, after memset 0xFF %.3f, again %.3f\n", t, p0, p1, p2, p3);
+        hipFree(c);
+        hipFree(v);
+    }
     // (b) one block, the value array X bytes behind the column array's end
     char *blk;
     if (hipMalloc(&blk, np * 12 + slack) != hipSuccess) return 1;

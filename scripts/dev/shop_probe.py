@@ -1,6 +1,7 @@
 """development aid (GPU box, library built with -DSPADA_SHOP_PROBE): does the scatter's regime follow the memory of one workspace?  R-MAT 18, the stage behind the
 plan (ms_cut) per one-pass call, with the workspaces named by SPADA_SHOP (bit mask: 1 scr_col, 2 scr_val, 4 part histograms, 8 parts, 16 range descriptors,
-32 cut table) moved to new memory before every call."""
+32 cut table, 64 tasks, 128 status words, 256 / 512 entry descriptors, 1024 row records, 2048 task counts, 4096 row accumulators) moved to new memory before
+every call.  Without SPADA_SHOP (any build): the placement the engine chooses itself (SPADA_TRACE=1 prints it)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import spada_sim_amd as S

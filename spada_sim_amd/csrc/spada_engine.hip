@@ -616,6 +616,23 @@ int task_pipeline(spada_ctx *c, int mode, uint64_t *cptr, uint32_t *d_idx, doubl
     // the workspaces whose size depends on the data, at the capacities the context has learnt so far
     const auto ensure_ws = [&]() -> int {
         int rc;
+#ifdef SPADA_SHOP_PROBE
+        // measurement (scripts/dev/shop_probe.py, shop_web.py; profiles/r06_experiments.txt section 12): the workspaces named by the bit mask SPADA_SHOP
+        // are moved to NEW memory before every run -- the new block is taken before the old one is given back, the contents are copied
+        if (const char *e = getenv("SPADA_SHOP")) {
+            const int mask = atoi(e);
+            DevBuf *const named[] = {&c->t_scrcol, &c->t_scrval, &c->t_parthist, &c->t_parts, &c->t_tmp, &c->t_cuts, &c->t_tasks, &c->t_status,
+                                     &c->eb0, &c->elen, &c->row_rec, &c->t_rangeout, &c->t_rowP};
+            for (int k = 0; k < (int)(sizeof named / sizeof named[0]); ++k) {
+                DevBuf &b = *named[k];
+                void *q = nullptr;
+                if (!(mask & (1 << k)) || !b.p || hipStreamSynchronize(s) != hipSuccess || hipMalloc(&q, b.cap) != hipSuccess) continue;
+                (void)hipMemcpy(q, b.p, b.cap, hipMemcpyDeviceToDevice);
+                (void)hipFree(b.p);
+                b.p = q;
+            }
+        }
+#endif
         c->t_cap_tasks = std::max<uint64_t>(c->t_cap_tasks, (uint64_t)n / 4 + 4096);
         if ((rc = c->t_tasks.ensure(c->t_cap_tasks * sizeof(TaskDesc), false, s, &c->ws_bytes))) return rc;
         if ((rc = c->t_status.ensure(c->t_cap_tasks * 8 * ST_STRIDE, false, s, &c->ws_bytes))) return rc;
